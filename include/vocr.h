@@ -1,0 +1,140 @@
+/*
+ * vocr.h — C-ABI of libvocr.so: the MI355X (gfx950) kernels behind VistaOCR's CnnOcrModel hot path.
+ *
+ * The reference (isi-vista/VistaOCR) is pure Python and has NO FFI of its own: every entry point below
+ * replaces a PyTorch/cuDNN/warp-ctc call that the reference makes from Python.  Each declaration cites the
+ * reference call site it stands in for (paths under /root/reference/).  INTEGRATION.md shows the ctypes
+ * binding a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers, ints, floats; `stream` is a hipStream_t passed as void*.
+ *   - every function returns 0 on success, a negative VOCR_E* code otherwise; vocr_last_error() returns a
+ *     thread-local message.  No C++ exception crosses the boundary.
+ *   - the caller owns every buffer; the library allocates nothing and never synchronises the stream.
+ *   - tensors are contiguous fp32 unless stated; images NCHW; sequences time-major [T,B,...].
+ */
+#ifndef VOCR_H
+#define VOCR_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VOCR_OK          0
+#define VOCR_EINVAL     -1   /* bad argument (shape, null pointer, unsupported size) */
+#define VOCR_ELAUNCH    -2   /* HIP launch error */
+#define VOCR_ENODEVICE  -3   /* no gfx950 device visible */
+
+const char* vocr_last_error(void);
+int  vocr_abi_version(void);
+/* number of visible HIP devices (>=0) or VOCR_ENODEVICE */
+int  vocr_device_count(void);
+
+/* ---- convolution: nn.Conv2d(k=3, pad=1) — src/models/cnnlstm.py:118,264 ------------------------------ */
+/* wpack_fwd[(ci*9+kh*3+kw)][co] = w[co][ci][kh][kw];  wpack_dgrad[(co*9+kh*3+kw)][ci] = w[co][ci][2-kh][2-kw] */
+int vocr_conv3x3_pack_weights(const float* w, float* wpack_fwd, float* wpack_dgrad, int cout, int cin, void* stream);
+/* y[n,co,h,w] = bias[co] + sum wpack[k][co] * x[n,ci,h+kh-1,w+kw-1]   (bias may be NULL).
+ * dgrad is the same call with x=dy, cin=Cout, wpack=wpack_dgrad, cout=Cin, bias=NULL. */
+int vocr_conv3x3_fwd(const float* x, const float* wpack, const float* bias, float* y,
+                     int n, int cin, int h, int w, int cout, void* stream);
+/* dw[co][ci][3][3] = sum_{n,h,w} dy[n,co,h,w] * x[n,ci,h+kh-1,w+kw-1];  workspace from *_workspace_bytes. */
+size_t vocr_conv3x3_wgrad_workspace_bytes(int n, int cin, int h, int w, int cout);
+int vocr_conv3x3_wgrad(const float* x, const float* dy, float* dw, void* workspace,
+                       int n, int cin, int h, int w, int cout, void* stream);
+/* per-channel sum over (n,h,w): conv bias gradient.  out[c] */
+int vocr_channel_sum(const float* x, float* out, int n, int c, int hw, void* stream);
+
+/* ---- BatchNorm2d + ReLU — src/models/cnnlstm.py:265-266 -------------------------------------------------- */
+/* training statistics: mean[c], invstd[c] (biased var, eps) and running-stat update (momentum, unbiased var).
+ * running_mean/var may be NULL.  workspace: 2*c*nchunk doubles, see vocr_bn_workspace_bytes. */
+size_t vocr_bn_workspace_bytes(int n, int c, int hw);
+int vocr_bn_train_stats(const float* y, int n, int c, int hw, float eps, float momentum,
+                        float* mean, float* invstd, float* running_mean, float* running_var,
+                        void* workspace, void* stream);
+/* eval: mean/invstd from running stats */
+int vocr_bn_eval_stats(const float* running_mean, const float* running_var, int c, float eps,
+                       float* mean, float* invstd, void* stream);
+/* out = relu((y-mean)*invstd*gamma + beta) */
+int vocr_bn_relu_apply(const float* y, const float* mean, const float* invstd, const float* gamma,
+                       const float* beta, float* out, int n, int c, int hw, void* stream);
+/* given da = dL/d(out): dgamma, dbeta and dy = dL/d(y) (training-mode batch-stat backward through ReLU) */
+int vocr_bn_relu_bwd(const float* da, const float* y, const float* mean, const float* invstd,
+                     const float* gamma, const float* beta, float* dy, float* dgamma, float* dbeta,
+                     int n, int c, int hw, void* workspace, void* stream);
+
+/* ---- FractionalMaxPool2d(2, output_ratio=(0.5,0.7)) — src/models/cnnlstm.py:127,130 --------------------- */
+/* samples[n][c][2] (u_w, u_h) as ATen's _random_samples; idx = flat h*W+w of the winner (int32) */
+int vocr_fracpool2x2_fwd(const float* x, const float* samples, float* out, int32_t* idx,
+                         int n, int c, int h, int w, int oh, int ow, void* stream);
+/* dx must be zero-filled by the caller; dx[idx] += dout */
+int vocr_fracpool2x2_bwd(const float* dout, const int32_t* idx, float* dx,
+                         int n, int c, int h, int w, int oh, int ow, void* stream);
+
+/* ---- rapid_ds tail: ReLU + MaxPool2d(2,2) — src/models/cnnlstm.py:119-120 -------------------------------- */
+int vocr_relu_maxpool2_fwd(const float* x, float* out, int32_t* idx, int n, int c, int h, int w, void* stream);
+int vocr_relu_maxpool2_bwd(const float* dout, const float* out, const int32_t* idx, float* dx,
+                           int n, int c, int h, int w, void* stream);
+
+/* ---- dense layers: bridge Linear+ReLU, LSTM input projections, prob Linear — cnnlstm.py:143-154,278,294 -- */
+/* C[M,N] (ldc) = op(A)[M,K] * op(B)[K,N] (+ bias[N]) (relu) — row-major.
+ * transa=0: A is [M,K] lda;  transa=1: A is stored [K,M] lda.   transb=0: B is [K,N] ldb;  transb=1: B is [N,K] ldb.
+ * accumulate!=0: C += result (split-K uses float atomics; C must hold the addend or zeros). */
+int vocr_gemm(int transa, int transb, int m, int n, int k,
+              const float* a, int lda, const float* b, int ldb, float* c, int ldc,
+              const float* bias, int relu, int accumulate, void* stream);
+/* out[N] = sum over M rows of x[M,N] (bias gradients) */
+int vocr_colsum(const float* x, float* out, int m, int n, void* stream);
+/* dz = (out > 0) ? dy : 0  (ReLU backward, elementwise) */
+int vocr_relu_bwd(const float* dy, const float* out, float* dz, size_t count, void* stream);
+/* bchw -> (w,b,c*h) and back — cnn_output.permute(3,0,1,2).contiguous(), cnnlstm.py:276 */
+int vocr_bchw_to_wbch(const float* x, float* out, int b, int c, int h, int w, void* stream);
+int vocr_wbch_to_bchw(const float* x, float* out, int b, int c, int h, int w, void* stream);
+/* out = x * mask (inter-layer LSTM dropout with an explicit, pre-scaled mask) */
+int vocr_mul(const float* x, const float* mask, float* out, size_t count, void* stream);
+/* out = x + y ; out = x * (*scalar) with the scalar read from device memory (no host sync) */
+int vocr_add(const float* x, const float* y, float* out, size_t count, void* stream);
+int vocr_scale_dev(const float* x, const float* scalar, float* out, size_t count, void* stream);
+/* mask[i] = (hash(seed,i) >= p) ? 1/(1-p) : 0 ; out = x*mask */
+int vocr_dropout_fwd(const float* x, float* out, float* mask, size_t count, float p, uint64_t seed, void* stream);
+
+/* ---- nn.LSTM recurrence on a packed, length-sorted batch — src/models/cnnlstm.py:148-149,288-290 ---------- */
+/* One direction pair of one layer.  xproj[dir][T][B][4H] = x W_ih^T + b_ih + b_hh (gate order i,f,g,o),
+ * whh_fwd / whh_rev [4H][H] (the two directions' weight_hh), lens[B] int32 (device, descending).  Outputs y[T][B][2H] (zeros past lens),
+ * gates[dir][T][B][4H] (post-activation i,f,g,o) and cell[dir][T][B][H] for backward.
+ * workspace: vocr_lstm_workspace_bytes.  Supports B <= 64, H % 16 == 0. */
+size_t vocr_lstm_workspace_bytes(int t, int b, int h);
+int vocr_lstm_fwd(const float* xproj, const float* whh_fwd, const float* whh_rev, const int32_t* lens, float* y,
+                  float* gates, float* cell, void* workspace, int t, int b, int h, void* stream);
+/* dy[T][B][2H] -> dgates[dir][T][B][4H] (gradient w.r.t. pre-activation gates = w.r.t. xproj). */
+int vocr_lstm_bwd(const float* dy, const float* whh_fwd, const float* whh_rev, const int32_t* lens, const float* gates,
+                  const float* cell, float* dgates, void* workspace, int t, int b, int h, void* stream);
+
+/* ---- CTC: warpctc_pytorch.CTCLoss — src/train_cnn_lstm.py:358,138 ------------------------------------------ */
+/* logits[T][B][V] pre-softmax, blank = 0.  labels flat int32 (device), label_offsets[B], label_lens[B],
+ * act_lens[B] (device int32).  nll[B] = -log p(labels|x); dlogits[T][B][V] = d(sum_b nll)/dlogits
+ * (zeros for t >= act_lens[b]).  max_label_len = max(label_lens) (host value, sizes the workspace). */
+size_t vocr_ctc_workspace_bytes(int t, int b, int v, int max_label_len);
+int vocr_ctc_loss_grad(const float* logits, const int32_t* labels, const int32_t* label_offsets,
+                       const int32_t* label_lens, const int32_t* act_lens, float* nll, float* dlogits,
+                       void* workspace, int t, int b, int v, int max_label_len, void* stream);
+
+/* ---- greedy decode: decode_without_lm / ArgmaxDecoder — cnnlstm.py:479-541, decoder.py:116-185 ------------ */
+/* per row of x[rows][v]: first index of the maximum and the maximum */
+int vocr_argmax_rows(const float* x, int32_t* idx, float* maxv, int rows, int v, void* stream);
+/* CTC best-path collapse on device.  canon[v] = smallest index with the same alphabet string (string
+ * comparison of the reference), thresh = 3/len(alphabet) applied to the raw maximum.
+ * out_labels[B][T], out_counts[B]. */
+int vocr_greedy_collapse(const int32_t* idx, const float* maxv, const int32_t* lens, const int32_t* canon,
+                         int32_t* out_labels, int32_t* out_counts, int t, int b, float thresh, void* stream);
+
+/* ---- optimiser: grad clamp + torch.optim.Adam — src/train_cnn_lstm.py:143-149,363 -------------------------- */
+/* g = clamp(g*grad_scale, -clamp, clamp) (+ wd*p); Adam(m, v); step is the 1-based step count. */
+int vocr_clamp_adam(float* p, const float* g, float* m, float* v, size_t count, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, float clamp, float grad_scale, int step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

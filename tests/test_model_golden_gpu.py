@@ -1,0 +1,202 @@
+"""GPU parity tests proper: the HIP path (through the C-ABI, via vistaocr_amd.CnnOcrModel / CTCLoss / decoder /
+train) against (a) the golden vectors captured from the imported reference and (b) the on-box oracle.
+
+Bar (BASELINE.json north_star): greedy-decoded integer label sequences bit-exact; CTC loss within 1e-3 relative."""
+import numpy as np
+import pytest
+import torch
+
+from tests import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+LOSS_RTOL = 1e-3          # the tolerance north_star states for the fp32 CTC loss
+LOGIT_ATOL = 2e-3         # fp32 logits, different summation order than oneDNN/ATen (goldens' margins are checked too)
+
+CASES = [("c1", "english"), ("c1_eval", "english"), ("varwidth", "english"), ("varwidth_train", "english"),
+         ("rds", "english"), ("arabic", "arabic"), ("h256", "english")]
+
+
+def _build(name, alpha):
+    import vistaocr_amd as va
+    g, hp, chars, sd_np, x, w, tgt, tl, (s1, s2) = gu.case_inputs(name, alpha)
+    al = va.Alphabet(chars, left_to_right=(alpha != "arabic"))
+    model = va.CnnOcrModel(alphabet=al, verbose=False, **hp)
+    assert next(model.parameters()).is_cuda, "model must sit on the GPU"
+    sd = model.state_dict()
+    for k, v in sd_np.items():
+        assert k in sd, k
+        sd[k] = torch.from_numpy(v)
+    model.load_state_dict(sd, strict=True)
+    model.pool_samples = [torch.from_numpy(s1), torch.from_numpy(s2)]
+    if str(g["mode"]) == "train":
+        model.train()
+        model.lstm.eval()          # same switch as the golden generator: BN batch stats, LSTM dropout off
+    else:
+        model.eval()
+    return g, hp, al, model, x, w, tgt, tl
+
+
+@pytest.mark.parametrize("name,alpha", CASES)
+def test_forward_loss_labels_vs_reference_goldens(name, alpha):
+    import vistaocr_amd as va
+    g, hp, al, model, x, w, tgt, tl = _build(name, alpha)
+    logits, lens = model(torch.from_numpy(x), torch.from_numpy(w))
+    assert lens.dtype == torch.int32 and not lens.is_cuda
+    assert lens.tolist() == g["lens"].tolist()
+    assert list(logits.shape) == g["logits_shape"].tolist()
+    lg = logits.detach().cpu().numpy()
+    if "logits" in g.files:
+        err = np.abs(lg - g["logits"])
+        T = lg.shape[0]
+        valid = np.arange(T)[:, None] < g["lens"][None, :]
+        assert float(err[valid].max()) < LOGIT_ATOL, "max logit error %.3e (margin of golden %.3e)" % (err[valid].max(), float(g["margin"]))
+    else:
+        assert float(np.abs(lg[:, :, :8] - g["logits_head"]).max()) < LOGIT_ATOL
+    loss = va.CTCLoss()(logits, torch.from_numpy(tgt), lens, torch.from_numpy(tl))
+    assert tuple(loss.shape) == (1,)
+    ref_loss = float(g["loss"][0])
+    assert abs(float(loss) - ref_loss) <= LOSS_RTOL * abs(ref_loss), (float(loss), ref_loss)
+    # integer label sequences: bit-exact
+    labels = model.decode_labels(logits, lens)
+    assert labels == gu.split_labels(g), "greedy label sequences differ from the reference"
+    assert model.decode_without_lm(logits, lens, uxxxx=True) == [str(s) for s in g["strings_uxxxx"]]
+    assert model.decode_without_lm(logits, lens, uxxxx=False) == [str(s) for s in g["strings_utf8"]]
+    assert va.ArgmaxDecoder(al).decode(logits, lens, uxxxx=True) == [str(s) for s in g["strings_uxxxx"]]
+    from vistaocr_amd.decoder import greedy_labels_device
+    assert greedy_labels_device(logits, lens, al) == gu.split_labels(g)
+
+    if str(g["mode"]) == "train":
+        loss.backward()
+        bad = []
+        for k, p in model.named_parameters():
+            ref = float(g["gnorm/" + k])
+            got = float(p.grad.double().norm())
+            conv_bias = k.startswith("cnn.") and k.endswith(".bias") and int(k.split(".")[1]) in (0, 3, 7, 10, 14, 17, 20)
+            if conv_bias:
+                continue      # exactly zero in exact arithmetic (bias before batch-stat BN): both sides are rounding noise
+            if abs(got - ref) > 5e-3 * ref + 1e-5:
+                bad.append((k, got, ref))
+            head = p.grad.reshape(-1)[:32].cpu().numpy()
+            if np.abs(head - g["ghead/" + k]).max() > 5e-3 * max(np.abs(g["ghead/" + k]).max(), ref / np.sqrt(p.numel())) + 1e-5:
+                bad.append((k + "[head]", float(np.abs(head - g["ghead/" + k]).max()), float(np.abs(g["ghead/" + k]).max())))
+        assert not bad, bad
+        for k in g.files:
+            if k.startswith("post/"):
+                got = model.state_dict()[k[5:]].cpu().numpy()
+                np.testing.assert_allclose(got, g[k], rtol=1e-4, atol=1e-5)
+        if "dlogits" in g.files:
+            # recompute dlogits alone
+            lg2 = logits.detach().clone().requires_grad_(True)
+            va.CTCLoss()(lg2, torch.from_numpy(tgt), lens, torch.from_numpy(tl)).backward()
+            np.testing.assert_allclose(lg2.grad.cpu().numpy(), g["dlogits"], rtol=2e-3, atol=2e-5)
+
+
+def test_train_two_steps_vs_reference():
+    """train() (src/train_cnn_lstm.py:131-150) twice: same summed losses, same post-Adam weights."""
+    import vistaocr_amd as va
+    from oracle import closed_form as cf
+    g = gu.load("train2")
+    chars = gu.alphabet_chars("english")
+    hp = dict(input_line_height=30, rds_line_height=30, lstm_input_dim=32, num_lstm_layers=2, num_lstm_hidden_units=48,
+              p_lstm_dropout=0.5, num_in_channels=1)
+    V = len(chars)
+    sd0 = cf.closed_form_state(hp, V)
+    model = va.CnnOcrModel(alphabet=va.Alphabet(chars, True), verbose=False, **hp)
+    sd = model.state_dict()
+    for k, v in sd0.items():
+        sd[k] = torch.from_numpy(v)
+    model.load_state_dict(sd)
+    model.train()
+    model.lstm.eval()
+    opt = va.FlatClampAdam(model.parameters(), lr=float(g["lr"]))
+    crit = va.CTCLoss()
+    B = len(g["widths"])
+    x, w, tgt, tl = cf.closed_form_batch(B, 1, 30, [int(v) for v in g["widths"]], V, [int(v) for v in g["labels_per_line"]], seed=1)
+    losses = []
+    for s in range(int(g["steps"])):
+        s1, s2 = cf.closed_form_pool_samples(B, seed=5 + s)
+        model.pool_samples = [torch.from_numpy(s1), torch.from_numpy(s2)]
+        losses.append(va.train((torch.from_numpy(x), torch.from_numpy(tgt), torch.from_numpy(w), torch.from_numpy(tl), {}),
+                               model, crit, opt))
+    np.testing.assert_allclose(losses, g["losses"], rtol=1e-3)
+    post = model.state_dict()
+    for k in sd0:
+        is_conv_bias = k.startswith("cnn.") and k.endswith(".bias") and int(k.split(".")[1]) in (0, 3, 7, 10, 14, 17, 20)
+        if is_conv_bias:
+            continue          # Adam turns their pure-noise gradients into +-lr steps on both sides
+        np.testing.assert_allclose(post[k].reshape(-1)[:32].cpu().numpy(), g["post_head/" + k], rtol=0, atol=3e-4, err_msg=k)
+        d = (post[k].cpu().double() - torch.from_numpy(sd0[k]).double()).norm().item()
+        np.testing.assert_allclose(d, float(g["delta_norm/" + k]), rtol=0.08, atol=1e-5, err_msg=k)
+
+
+def test_against_on_box_oracle_with_dropout_mask():
+    """Explicit inter-layer dropout masks (the train-mode path the goldens cannot capture): HIP vs oracle."""
+    import vistaocr_amd as va
+    from oracle import closed_form as cf
+    from oracle import vista_oracle as vo
+    g, hp, al, model, x, w, tgt, tl = _build("varwidth_train", "english")
+    _, _, _, sd_np, _, _, _, _, (s1, s2) = gu.case_inputs("varwidth_train")
+    T, B, H = 147, 4, hp["num_lstm_hidden_units"]
+    r = np.random.RandomState(3)
+    masks = [torch.from_numpy((r.uniform(size=(T, B, 2 * H)) >= 0.5).astype(np.float32) * 2.0) for _ in range(hp["num_lstm_layers"] - 1)]
+    sd = vo.state_from_numpy(sd_np)
+    lo, ln = vo.forward(sd, hp, torch.from_numpy(x), w, (torch.from_numpy(s1), torch.from_numpy(s2)), training=True,
+                        dropout_masks=masks)
+    loss_o = vo.ctc_criterion(lo, torch.from_numpy(tgt), ln, torch.from_numpy(tl))
+    loss_o.backward()
+    model.dropout_masks = masks
+    lg, lens = model(torch.from_numpy(x), torch.from_numpy(w))
+    loss = va.CTCLoss()(lg, torch.from_numpy(tgt), lens, torch.from_numpy(tl))
+    loss.backward()
+    assert lens.tolist() == ln.tolist()
+    assert abs(float(loss) - float(loss_o)) <= LOSS_RTOL * abs(float(loss_o))
+    assert model.decode_labels(lg, lens) == vo.greedy_decode(lo.detach(), ln, al.idx_to_char, uxxxx=True)[1]
+    for k, p in model.named_parameters():
+        ref = sd[k].grad
+        if k.startswith("cnn.") and k.endswith(".bias") and int(k.split(".")[1]) in (0, 3, 7, 10, 14, 17, 20):
+            continue
+        rn = float(ref.double().norm())
+        assert abs(float(p.grad.double().norm()) - rn) <= 5e-3 * rn + 1e-5, k
+
+
+def test_full_size_properties():
+    """BASELINE config (B=32, 30x600, 3xBiLSTM-512, V=96) — size-independent properties: lens = T(w) table,
+    padded frames give bias-only logits, loss is finite and equals the sum of per-sample losses, gradient of
+    padded frames is zero, a second identical step reproduces bit-identical logits (determinism)."""
+    import vistaocr_amd as va
+    al = va.english_alphabet()
+    torch.manual_seed(0)
+    model = va.CnnOcrModel(alphabet=al, verbose=False, input_line_height=30, rds_line_height=30, lstm_input_dim=128,
+                           num_lstm_layers=3, num_lstm_hidden_units=512, p_lstm_dropout=0.5)
+    model.train()
+    model.lstm.eval()
+    B = 32
+    widths = sorted([600 - 7 * i for i in range(B)], reverse=True)
+    x = torch.rand(B, 1, 30, 600)
+    for b in range(B):
+        x[b, :, :, widths[b]:] = 0
+    u = [torch.rand(B, 64, 2), torch.rand(B, 128, 2)]
+    model.pool_samples = u
+    tl = torch.full((B,), 20, dtype=torch.int32)
+    tgt = torch.randint(1, 96, (B * 20,), dtype=torch.int32)
+    logits, lens = model(x, torch.tensor(widths, dtype=torch.int32))
+    assert lens.tolist() == [int(np.floor(np.floor(w * 0.7) * 0.7)) for w in widths]
+    assert tuple(logits.shape) == (294, B, 96)
+    bias = model.state_dict()["prob_layer.0.bias"]
+    for b in (B - 1, B // 2):
+        pad = logits[int(lens[b]):, b]
+        assert pad.numel() > 0 and torch.equal(pad, bias.expand_as(pad)), "padded frames must be bias-only"
+    crit = va.CTCLoss()
+    loss = crit(logits, tgt, lens, tl)
+    assert torch.isfinite(loss).all()
+    per = sum(float(crit(logits[:, b:b + 1].contiguous(), tgt[20 * b:20 * b + 20], lens[b:b + 1], tl[b:b + 1])) for b in range(B))
+    assert abs(per - float(loss)) <= 1e-4 * abs(per)
+    lg = logits.detach().clone().requires_grad_(True)
+    crit(lg, tgt, lens, tl).backward()
+    assert float(lg.grad[int(lens[-1]):, -1].abs().max()) == 0.0
+    logits2, _ = model(x, torch.tensor(widths, dtype=torch.int32))
+    assert torch.equal(logits2, logits), "forward must be deterministic"
+    loss.backward()
+    g = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    assert torch.isfinite(g).all() and float(g.abs().max()) > 0

@@ -1,0 +1,273 @@
+"""GPU: every C-ABI operator against the same op on PyTorch-CPU (the arithmetic the reference delegates to),
+on seeded inputs sized so the CPU side finishes in seconds.  Integer outputs bit-exact; fp32 within the stated
+tolerance."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from vistaocr_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g) * 2 - 1) * scale
+
+
+def _close(a, b, rtol, atol, what=""):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    bad = err > tol
+    if bad.any():
+        i = int(torch.nonzero(bad.reshape(-1))[0])
+        raise AssertionError("%s: %d/%d mismatches, max abs err %.3e (ref scale %.3e); first @%d got %.6g want %.6g"
+                             % (what, int(bad.sum()), a.numel(), float(err.max()), float(b.abs().max()), i,
+                                float(a.reshape(-1)[i]), float(b.reshape(-1)[i])))
+
+
+@pytest.mark.parametrize("n,cin,h,w,cout", [(2, 1, 30, 70, 64), (2, 64, 15, 45, 64), (1, 64, 15, 97, 128), (2, 128, 7, 33, 256),
+                                            (1, 16, 9, 40, 64), (1, 3, 12, 31, 16)])
+def test_conv3x3_fwd_dgrad_wgrad(dev, n, cin, h, w, cout):
+    from vistaocr_amd import ops
+    x = _rand((n, cin, h, w), 1)
+    wt = _rand((cout, cin, 3, 3), 2, 0.2)
+    bias = _rand((cout,), 3)
+    dy = _rand((n, cout, h, w), 4)
+    xr = x.clone().requires_grad_(True)
+    wr = wt.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, bias, padding=1)
+    yr.backward(dy)
+    pf, pd = ops.conv3x3_pack(wt.to(dev))
+    y = ops.conv3x3_forward(x.to(dev), pf, bias.to(dev), cout)
+    _close(y, yr, 1e-4, 1e-4, "conv fwd")
+    dx = ops.conv3x3_forward(dy.to(dev), pd, None, cin)
+    _close(dx, xr.grad, 1e-4, 1e-4, "conv dgrad")
+    dw = ops.conv3x3_wgrad(x.to(dev), dy.to(dev))
+    _close(dw, wr.grad, 1e-4, 2e-4 * math.sqrt(n * h * w), "conv wgrad")
+    db = ops.channel_sum(dy.to(dev))
+    _close(db, dy.sum((0, 2, 3)), 1e-5, 1e-4, "channel_sum")
+
+
+@pytest.mark.parametrize("n,c,h,w", [(4, 64, 30, 50), (3, 128, 7, 33)])
+def test_conv_bn_relu_fn(dev, n, c, h, w):
+    from vistaocr_amd import ops
+    cin = 8
+    x = _rand((n, cin, h, w), 1)
+    wt = _rand((c, cin, 3, 3), 2, 0.3)
+    bias = _rand((c,), 3)
+    gamma = _rand((c,), 5) * 0.3 + 1.0
+    beta = _rand((c,), 6) * 0.2
+    rm, rv = _rand((c,), 7) * 0.1, _rand((c,), 8) * 0.2 + 1.0
+    da = _rand((n, c, h, w), 9)
+    for training in (True, False):
+        leaf = [t.clone().requires_grad_(True) for t in (x, wt, bias, gamma, beta)]
+        rm_r, rv_r = rm.clone(), rv.clone()
+        yr = F.relu(F.batch_norm(F.conv2d(leaf[0], leaf[1], leaf[2], padding=1), rm_r, rv_r, leaf[3], leaf[4],
+                                 training=training, momentum=0.1, eps=1e-5))
+        gl = [t.clone().to(dev).requires_grad_(True) for t in (x, wt, bias, gamma, beta)]
+        rm_g, rv_g = rm.clone().to(dev), rv.clone().to(dev)
+        y = ops.ConvBnReluFn.apply(gl[0], gl[1], gl[2], gl[3], gl[4], rm_g, rv_g, training, 1e-5, 0.1)
+        _close(y, yr, 1e-4, 2e-4, "conv-bn-relu fwd (training=%s)" % training)
+        if training:
+            _close(rm_g, rm_r, 1e-5, 1e-6, "running_mean")
+            _close(rv_g, rv_r, 1e-5, 1e-6, "running_var")
+            yr.backward(da)
+            y.backward(da.to(dev))
+            names = ["dx", "dw", "dbias", "dgamma", "dbeta"]
+            for nm, a, b in zip(names, gl, leaf):
+                if nm == "dbias":       # mathematically zero through batch-stat BN; both sides hold rounding noise
+                    assert float(a.grad.abs().max()) < 1e-2
+                    continue
+                _close(a.grad, b.grad, 2e-3, 2e-4 * float(b.grad.abs().max()) + 1e-5, nm)
+
+
+def test_fracpool_bit_exact(dev):
+    from vistaocr_amd import ops
+    for (n, c, h, w), seed in [((3, 5, 30, 600), 0), ((2, 7, 15, 420), 1), ((2, 4, 15, 47), 2), ((1, 3, 30, 15), 3)]:
+        x = _rand((n, c, h, w), seed)
+        x[0, 0, 2:4, 5:9] = 0.5
+        u = torch.rand(n, c, 2, generator=torch.Generator().manual_seed(seed + 10))
+        oh, ow = math.floor(h * 0.5), math.floor(w * 0.7)
+        xr = x.clone().requires_grad_(True)
+        ref, idx = F.fractional_max_pool2d(xr, 2, output_size=(oh, ow), _random_samples=u, return_indices=True)
+        xg = x.to(dev).requires_grad_(True)
+        out = ops.FracPoolFn.apply(xg, u.to(dev), oh, ow)
+        assert torch.equal(out.cpu(), ref), "fracpool values differ"
+        dout = _rand(ref.shape, seed + 20)
+        ref.backward(dout)
+        out.backward(dout.to(dev))
+        assert torch.equal(xg.grad.cpu(), xr.grad), "fracpool backward differs"
+
+
+def test_relu_maxpool(dev):
+    from vistaocr_amd import ops
+    x = _rand((2, 1, 60, 122), 0)
+    wt = _rand((16, 1, 3, 3), 1, 0.4)
+    b = _rand((16,), 2)
+    leaf = [t.clone().requires_grad_(True) for t in (x, wt, b)]
+    ref = F.max_pool2d(F.relu(F.conv2d(leaf[0], leaf[1], leaf[2], padding=1)), 2, stride=2)
+    gl = [t.clone().to(dev).requires_grad_(True) for t in (x, wt, b)]
+    out = ops.ConvReluPoolFn.apply(*gl)
+    _close(out, ref, 1e-5, 1e-5, "rds fwd")
+    do = _rand(ref.shape, 3)
+    ref.backward(do)
+    out.backward(do.to(dev))
+    for nm, a, r in zip(("dx", "dw", "db"), gl, leaf):
+        _close(a.grad, r.grad, 1e-4, 1e-4 * float(r.grad.abs().max()) + 1e-6, "rds " + nm)
+
+
+@pytest.mark.parametrize("m,n,k", [(100, 96, 1024), (9408, 128, 1792), (300, 2048, 128), (257, 166, 96), (64, 64, 4000), (1200, 384, 96)])
+def test_gemm_variants(dev, m, n, k):
+    from vistaocr_amd import ops
+    a = _rand((m, k), 1)
+    b = _rand((k, n), 2)
+    bias = _rand((n,), 3)
+    ref = a.double() @ b.double()
+    tol = 3e-6 * k
+    c = torch.empty(m, n, device=dev)
+    ops.gemm(0, 0, m, n, k, a.to(dev), k, b.to(dev), n, c, n)
+    _close(c, ref, 1e-5, tol, "gemm NN")
+    ops.gemm(0, 1, m, n, k, a.to(dev), k, b.t().contiguous().to(dev), k, c, n, bias=bias.to(dev), relu=True)
+    _close(c, torch.relu(ref + bias.double()), 1e-5, tol, "gemm NT bias relu")
+    ops.gemm(1, 0, m, n, k, a.t().contiguous().to(dev), m, b.to(dev), n, c, n)
+    _close(c, ref, 1e-5, tol, "gemm TN")
+    ops.gemm(1, 1, m, n, k, a.t().contiguous().to(dev), m, b.t().contiguous().to(dev), k, c, n)
+    _close(c, ref, 1e-5, tol, "gemm TT")
+    c0 = _rand((m, n), 4)
+    c = c0.clone().to(dev)
+    ops.gemm(0, 0, m, n, k, a.to(dev), k, b.to(dev), n, c, n, accumulate=True)
+    _close(c, ref + c0.double(), 1e-5, tol, "gemm accumulate")
+    _close(ops.colsum(a.to(dev)), a.double().sum(0), 1e-5, 1e-5 * m, "colsum")
+
+
+def test_permute_and_elementwise(dev):
+    from vistaocr_amd import ops
+    x = _rand((3, 16, 7, 37), 0)
+    xg = x.to(dev).requires_grad_(True)
+    out = ops.PermuteBchwToWbchFn.apply(xg)
+    ref = x.permute(3, 0, 1, 2).contiguous().view(-1, 16 * 7)
+    assert torch.equal(out.cpu(), ref)
+    g = _rand(ref.shape, 1)
+    out.backward(g.to(dev))
+    assert torch.equal(xg.grad.cpu(), g.view(37, 3, 16, 7).permute(1, 2, 3, 0).contiguous())
+    a = _rand((1000,), 2).to(dev)
+    o = ops.DropoutFn.apply(a, 0.5, 123)
+    frac = float((o == 0).float().mean())
+    assert 0.4 < frac < 0.6
+    kept = o != 0
+    assert torch.allclose(o[kept], a[kept] * 2)
+
+
+def _ref_bilstm(x, lens, params, H):
+    T, B, D = x.shape
+    m = torch.nn.LSTM(D, H, num_layers=1, bidirectional=True)
+    with torch.no_grad():
+        for name, p in zip(["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0", "weight_ih_l0_reverse",
+                            "weight_hh_l0_reverse", "bias_ih_l0_reverse", "bias_hh_l0_reverse"], params):
+            getattr(m, name).copy_(p)
+    packed = torch.nn.utils.rnn.pack_padded_sequence(x, lens)
+    out, _ = m(packed)
+    y, _ = torch.nn.utils.rnn.pad_packed_sequence(out)
+    return m, y
+
+
+@pytest.mark.parametrize("T,B,D,H,lens", [(20, 4, 32, 48, [20, 17, 9, 1]), (37, 32, 128, 256, None), (12, 40, 64, 32, None),
+                                          (9, 1, 16, 16, [9])])
+def test_bilstm_layer(dev, T, B, D, H, lens):
+    from vistaocr_amd import ops
+    if lens is None:
+        lens = sorted([max(1, T - (i * T) // (B + 3)) for i in range(B)], reverse=True)
+        lens[0] = T
+    x = _rand((T, B, D), 1)
+    for b in range(B):
+        x[lens[b]:, b] = 0.37                         # junk in the padding must not leak
+    params = [_rand(s, 10 + i, 0.25) for i, s in enumerate([(4 * H, D), (4 * H, H), (4 * H,), (4 * H,)] * 2)]
+    xr = x.clone().requires_grad_(True)
+    m, yr = _ref_bilstm(xr, lens, params, H)
+    dy = _rand(yr.shape, 30)
+    yr.backward(dy)
+    xg = x.reshape(T * B, D).to(dev).requires_grad_(True)
+    pg = [p.clone().to(dev).requires_grad_(True) for p in params]
+    lens_dev = torch.tensor(lens, dtype=torch.int32, device=dev)
+    y = ops.BiLstmLayerFn.apply(xg, lens_dev, T, B, *pg)
+    _close(y.view(T, B, 2 * H), yr, 1e-4, 2e-5, "lstm fwd")
+    y.backward(dy.reshape(T * B, 2 * H).to(dev))
+    gx_ref = xr.grad.clone()
+    for b in range(B):
+        gx_ref[lens[b]:, b] = 0
+    _close(xg.grad.view(T, B, D), gx_ref, 1e-3, 2e-5 * float(gx_ref.abs().max()) + 1e-6, "lstm dx")
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0", "weight_ih_l0_reverse", "weight_hh_l0_reverse",
+             "bias_ih_l0_reverse", "bias_hh_l0_reverse"]
+    for nm, p in zip(names, pg):
+        r = getattr(m, nm).grad
+        _close(p.grad, r, 1e-3, 5e-5 * float(r.abs().max()) + 1e-6, "lstm d" + nm)
+
+
+@pytest.mark.parametrize("T,B,V,L", [(30, 4, 20, [5, 3, 1, 0]), (147, 8, 96, None), (60, 3, 166, [29, 10, 2])])
+def test_ctc_loss_and_grad(dev, T, B, V, L):
+    from vistaocr_amd import CTCLoss
+    g = torch.Generator().manual_seed(0)
+    logits = _rand((T, B, V), 1, 3.0)
+    if L is None:
+        L = [12] * B
+    act = [T - 3 * i for i in range(B)]
+    tl = torch.tensor(L, dtype=torch.int32)
+    tg = torch.randint(1, V, (int(tl.sum()),), generator=g).to(torch.int32)
+    if tg.numel() >= 4:
+        tg[1] = tg[0]                                                # repeated label needs the blank in between
+        tg[3] = tg[2]
+    lr = logits.clone().requires_grad_(True)
+    ref = F.ctc_loss(F.log_softmax(lr, 2), tg.long(), torch.tensor(act), tl.long(), blank=0, reduction="sum")
+    ref.backward()
+    lg = logits.clone().to(dev).requires_grad_(True)
+    loss = CTCLoss()(lg, tg, torch.tensor(act, dtype=torch.int32), tl)
+    assert tuple(loss.shape) == (1,)
+    assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref)) + 1e-4, (float(loss), float(ref))
+    loss.backward()
+    _close(lg.grad, lr.grad, 1e-3, 2e-5, "ctc dlogits")
+
+
+def test_argmax_and_collapse(dev):
+    from vistaocr_amd import ops, english_alphabet
+    from vistaocr_amd.decoder import greedy_labels_device, greedy_label_sequences
+    x = _rand((50, 7, 96), 0)
+    x[3, 2, 10] = x[3, 2, 50] = 5.0                                 # tie: first index wins
+    x[4, 1, :] = 0.25
+    idx, mx = ops.argmax_rows(x.to(dev))
+    assert torch.equal(idx.cpu().long(), x.argmax(2))
+    assert torch.equal(mx.cpu(), x.max(2)[0])
+    al = english_alphabet()
+    lens = [50, 50, 44, 30, 12, 2, 1]
+    a = greedy_labels_device(x.to(dev), lens, al)
+    _, b = greedy_label_sequences(x.to(dev), lens, al)
+    assert a == b
+
+
+def test_clamp_adam_matches_torch(dev):
+    from vistaocr_amd import ops
+    n = 10007
+    p0 = _rand((n,), 0)
+    for wd in (0.0, 0.01):
+        pr = p0.clone().requires_grad_(True)
+        opt = torch.optim.Adam([pr], lr=1e-3, weight_decay=wd)
+        pg = p0.clone().to(dev)
+        m = torch.zeros(n, device=dev)
+        v = torch.zeros(n, device=dev)
+        for step in range(1, 6):
+            g = _rand((n,), step, 8.0)
+            g[:100] *= 1e-7
+            pr.grad = g.clone().clamp_(-5, 5)
+            opt.step()
+            ops.clamp_adam(pg, g.to(dev), m, v, 1e-3, 0.9, 0.999, 1e-8, wd, 5.0, 1.0, step)
+        _close(pg, pr, 1e-6, 1e-7, "adam wd=%g" % wd)

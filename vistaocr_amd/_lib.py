@@ -1,0 +1,81 @@
+"""ctypes binding of libvocr.so (the C-ABI declared in include/vocr.h).
+
+There is NO fallback: if the shared library is missing or a call fails, a RuntimeError is raised.  The
+product path never computes on the CPU and never imports oracle/."""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_size_t, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libvocr.so")
+
+P, I, F, Z, U64 = c_void_p, c_int, c_float, c_size_t, c_uint64
+
+# name -> (restype, argtypes); mirrors include/vocr.h one to one (tests/test_abi.py checks both directions)
+SIGNATURES = {
+    "vocr_last_error": (c_char_p, []),
+    "vocr_abi_version": (I, []),
+    "vocr_device_count": (I, []),
+    "vocr_conv3x3_pack_weights": (I, [P, P, P, I, I, P]),
+    "vocr_conv3x3_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "vocr_conv3x3_wgrad_workspace_bytes": (Z, [I, I, I, I, I]),
+    "vocr_conv3x3_wgrad": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "vocr_channel_sum": (I, [P, P, I, I, I, P]),
+    "vocr_bn_workspace_bytes": (Z, [I, I, I]),
+    "vocr_bn_train_stats": (I, [P, I, I, I, F, F, P, P, P, P, P, P]),
+    "vocr_bn_eval_stats": (I, [P, P, I, F, P, P, P]),
+    "vocr_bn_relu_apply": (I, [P, P, P, P, P, P, I, I, I, P]),
+    "vocr_bn_relu_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, P, P]),
+    "vocr_fracpool2x2_fwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
+    "vocr_fracpool2x2_bwd": (I, [P, P, P, I, I, I, I, I, I, P]),
+    "vocr_relu_maxpool2_fwd": (I, [P, P, P, I, I, I, I, P]),
+    "vocr_relu_maxpool2_bwd": (I, [P, P, P, P, I, I, I, I, P]),
+    "vocr_gemm": (I, [I, I, I, I, I, P, I, P, I, P, I, P, I, I, P]),
+    "vocr_colsum": (I, [P, P, I, I, P]),
+    "vocr_relu_bwd": (I, [P, P, P, Z, P]),
+    "vocr_bchw_to_wbch": (I, [P, P, I, I, I, I, P]),
+    "vocr_wbch_to_bchw": (I, [P, P, I, I, I, I, P]),
+    "vocr_mul": (I, [P, P, P, Z, P]),
+    "vocr_add": (I, [P, P, P, Z, P]),
+    "vocr_scale_dev": (I, [P, P, P, Z, P]),
+    "vocr_dropout_fwd": (I, [P, P, P, Z, F, U64, P]),
+    "vocr_lstm_workspace_bytes": (Z, [I, I, I]),
+    "vocr_lstm_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, P]),
+    "vocr_lstm_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, P]),
+    "vocr_ctc_workspace_bytes": (Z, [I, I, I, I]),
+    "vocr_ctc_loss_grad": (I, [P, P, P, P, P, P, P, P, I, I, I, I, P]),
+    "vocr_argmax_rows": (I, [P, P, P, I, I, P]),
+    "vocr_greedy_collapse": (I, [P, P, P, P, P, P, I, I, F, P]),
+    "vocr_clamp_adam": (I, [P, P, P, P, Z, F, F, F, F, F, F, F, I, P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libvocr.so (building is __graft_entry__.build()'s / vistaocr_amd.build's job)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libvocr.so not found at %s — run `python -m vistaocr_amd.build` (needs hipcc). "
+                           "vistaocr_amd has no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().vocr_last_error()
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def call(name, *args):
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        check(rc, name)

@@ -1,0 +1,341 @@
+// BatchNorm2d(+ReLU) training/eval statistics, apply and backward; FractionalMaxPool2d 2x2; ReLU+MaxPool2d(2,2).
+// All HBM-bound streaming kernels over NCHW planes (reference src/models/cnnlstm.py:119-120,127,130,265-266).
+// Reductions accumulate in double and combine in a fixed order (bitwise reproducible).
+#include "vocr_common.h"
+
+namespace {
+
+constexpr int BN_CHUNK_ELEMS = 16384;   // elements of one channel handled by one workgroup of the stats pass
+
+__host__ __device__ inline int bn_nchunk(long per_channel) {
+    long n = (per_channel + BN_CHUNK_ELEMS - 1) / BN_CHUNK_ELEMS;
+    return (int)(n < 1 ? 1 : (n > 512 ? 512 : n));
+}
+
+// element e of channel c in [0, N*HW): plane n = e / HW, offset e % HW
+__device__ __forceinline__ long chan_addr(long e, int c, int C, long HW) {
+    const long n = e / HW, r = e - n * HW;
+    return (n * C + c) * HW + r;
+}
+
+__device__ __forceinline__ void block_reduce2(double& a, double& b, double* red) {
+    a = wave_sum_d(a);
+    b = wave_sum_d(b);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[wave * 2] = a; red[wave * 2 + 1] = b; }
+    __syncthreads();
+    a = (red[0] + red[2]) + (red[4] + red[6]);
+    b = (red[1] + red[3]) + (red[5] + red[7]);
+}
+
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ y, double* __restrict__ part,
+                                                               int N, int C, long HW, int nchunk) {
+    __shared__ double red[8];
+    const int c = blockIdx.x, j = blockIdx.y;
+    const long total = (long)N * HW;
+    const long per = (total + nchunk - 1) / nchunk;
+    const long beg = j * per, end = min(total, beg + per);
+    double s = 0.0, q = 0.0;
+    for (long e = beg + threadIdx.x; e < end; e += 256) {
+        const double v = (double)y[chan_addr(e, c, C, HW)];
+        s += v;
+        q += v * v;
+    }
+    block_reduce2(s, q, red);
+    if (threadIdx.x == 0) {
+        part[((long)c * nchunk + j) * 2] = s;
+        part[((long)c * nchunk + j) * 2 + 1] = q;
+    }
+}
+
+__global__ void bn_stats_final_kernel(const double* __restrict__ part, int C, int nchunk, long count, float eps,
+                                      float momentum, float* __restrict__ mean, float* __restrict__ invstd,
+                                      float* __restrict__ rmean, float* __restrict__ rvar) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int j = 0; j < nchunk; ++j) {
+        s += part[((long)c * nchunk + j) * 2];
+        q += part[((long)c * nchunk + j) * 2 + 1];
+    }
+    const double m = s / (double)count;
+    double var = q / (double)count - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
+    if (rvar) {
+        const double unbiased = count > 1 ? var * (double)count / (double)(count - 1) : var;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+    }
+}
+
+__global__ void bn_eval_stats_kernel(const float* __restrict__ rmean, const float* __restrict__ rvar, int C, float eps,
+                                     float* __restrict__ mean, float* __restrict__ invstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    mean[c] = rmean[c];
+    invstd[c] = 1.0f / sqrtf(rvar[c] + eps);
+}
+
+// grid: (chunks over HW, N*C planes)
+__global__ __launch_bounds__(256) void bn_relu_apply_kernel(const float* __restrict__ y, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ out,
+                                                            int C, long HW) {
+    const long plane = blockIdx.y;
+    const int c = (int)(plane % C);
+    const float mu = mean[c], is = invstd[c], g = gamma[c], b = beta[c];
+    const float* yp = y + plane * HW;
+    float* op = out + plane * HW;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < HW; i += (long)gridDim.x * 256) {
+        const float v = (yp[i] - mu) * is * g + b;
+        op[i] = v > 0.f ? v : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ da, const float* __restrict__ y,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, double* __restrict__ part,
+                                                             int N, int C, long HW, int nchunk) {
+    __shared__ double red[8];
+    const int c = blockIdx.x, j = blockIdx.y;
+    const float mu = mean[c], is = invstd[c], g = gamma[c], b = beta[c];
+    const long total = (long)N * HW;
+    const long per = (total + nchunk - 1) / nchunk;
+    const long beg = j * per, end = min(total, beg + per);
+    double s1 = 0.0, s2 = 0.0;
+    for (long e = beg + threadIdx.x; e < end; e += 256) {
+        const long a = chan_addr(e, c, C, HW);
+        const float xh = (y[a] - mu) * is;
+        const float o = xh * g + b;
+        const float dz = o > 0.f ? da[a] : 0.f;
+        s1 += (double)dz;
+        s2 += (double)dz * (double)xh;
+    }
+    block_reduce2(s1, s2, red);
+    if (threadIdx.x == 0) {
+        part[((long)c * nchunk + j) * 2] = s1;
+        part[((long)c * nchunk + j) * 2 + 1] = s2;
+    }
+}
+
+__global__ void bn_bwd_final_kernel(const double* __restrict__ part, int C, int nchunk, float* __restrict__ dgamma,
+                                    float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int j = 0; j < nchunk; ++j) {
+        s1 += part[((long)c * nchunk + j) * 2];
+        s2 += part[((long)c * nchunk + j) * 2 + 1];
+    }
+    dbeta[c] = (float)s1;
+    dgamma[c] = (float)s2;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ da, const float* __restrict__ y,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
+                                                           const float* __restrict__ dgamma,
+                                                           const float* __restrict__ dbeta, float* __restrict__ dy,
+                                                           int C, long HW, float inv_count) {
+    const long plane = blockIdx.y;
+    const int c = (int)(plane % C);
+    const float mu = mean[c], is = invstd[c], g = gamma[c], b = beta[c];
+    const float k1 = dbeta[c] * inv_count, k2 = dgamma[c] * inv_count, gs = g * is;
+    const float* yp = y + plane * HW;
+    const float* dp = da + plane * HW;
+    float* op = dy + plane * HW;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < HW; i += (long)gridDim.x * 256) {
+        const float xh = (yp[i] - mu) * is;
+        const float o = xh * g + b;
+        const float dz = o > 0.f ? dp[i] : 0.f;
+        op[i] = gs * (dz - k1 - xh * k2);
+    }
+}
+
+// ------------------------------------------------------------------ fractional max pool
+// ATen rule in float32 (aten/src/ATen/native/FractionalMaxPool2d.cpp, restated in oracle/vista_oracle.py
+// fracpool_intervals): start(i) = int((i + u) * alpha) - int(u * alpha), last = in - 2.  No FMA contraction.
+__device__ __forceinline__ int frac_start(int i, float u, float alpha, int in, int out) {
+    if (i == out - 1) return in - 2;
+    const float a = __fmul_rn(__fadd_rn((float)i, u), alpha);
+    const float b = __fmul_rn(u, alpha);
+    return (int)a - (int)b;
+}
+
+__global__ __launch_bounds__(256) void fracpool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ samples,
+                                                           float* __restrict__ out, int32_t* __restrict__ idx, int H,
+                                                           int W, int OH, int OW, float alpha_h, float alpha_w) {
+    const long plane = blockIdx.y;
+    const float uw = samples[plane * 2], uh = samples[plane * 2 + 1];
+    const float* xp = x + plane * (long)H * W;
+    const int total = OH * OW;
+    for (int o = blockIdx.x * 256 + threadIdx.x; o < total; o += gridDim.x * 256) {
+        const int oh = o / OW, ow = o % OW;
+        const int hs = frac_start(oh, uh, alpha_h, H, OH);
+        const int ws = frac_start(ow, uw, alpha_w, W, OW);
+        int best = hs * W + ws;
+        float mv = -INFINITY;
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int dw = 0; dw < 2; ++dw) {
+                const int p = (hs + dh) * W + ws + dw;
+                const float v = xp[p];
+                if (v > mv || v != v) { mv = v; best = p; }
+            }
+        out[plane * total + o] = mv;
+        idx[plane * total + o] = best;
+    }
+}
+
+__global__ __launch_bounds__(256) void pool_bwd_scatter_kernel(const float* __restrict__ dout,
+                                                               const int32_t* __restrict__ idx, float* __restrict__ dx,
+                                                               long in_plane, int out_plane) {
+    const long plane = blockIdx.y;
+    for (int o = blockIdx.x * 256 + threadIdx.x; o < out_plane; o += gridDim.x * 256) {
+        const long oi = plane * out_plane + o;
+        atomicAdd(dx + plane * in_plane + idx[oi], dout[oi]);   // <= 2 contributions per input: order-independent
+    }
+}
+
+__global__ __launch_bounds__(256) void relu_maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                                int32_t* __restrict__ idx, int H, int W, int OH, int OW) {
+    const long plane = blockIdx.y;
+    const float* xp = x + plane * (long)H * W;
+    const int total = OH * OW;
+    for (int o = blockIdx.x * 256 + threadIdx.x; o < total; o += gridDim.x * 256) {
+        const int oh = o / OW, ow = o % OW;
+        int best = (2 * oh) * W + 2 * ow;
+        float mv = -INFINITY;
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int dw = 0; dw < 2; ++dw) {
+                const int p = (2 * oh + dh) * W + 2 * ow + dw;
+                const float v = fmaxf(xp[p], 0.f);
+                if (v > mv) { mv = v; best = p; }
+            }
+        out[plane * total + o] = mv;
+        idx[plane * total + o] = best;
+    }
+}
+
+// windows do not overlap: plain stores into a zero-filled dx; gradient passes only where relu was active
+__global__ __launch_bounds__(256) void relu_maxpool2_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                                const int32_t* __restrict__ idx, float* __restrict__ dx,
+                                                                long in_plane, int out_plane) {
+    const long plane = blockIdx.y;
+    for (int o = blockIdx.x * 256 + threadIdx.x; o < out_plane; o += gridDim.x * 256) {
+        const long oi = plane * out_plane + o;
+        dx[plane * in_plane + idx[oi]] = out[oi] > 0.f ? dout[oi] : 0.f;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t vocr_bn_workspace_bytes(int n, int c, int hw) {
+    if (n <= 0 || c <= 0 || hw <= 0) return 0;
+    return (size_t)c * bn_nchunk((long)n * hw) * 2 * sizeof(double);
+}
+
+extern "C" int vocr_bn_train_stats(const float* y, int n, int c, int hw, float eps, float momentum, float* mean,
+                                   float* invstd, float* running_mean, float* running_var, void* workspace, void* stream) {
+    VOCR_CHECK_ARG(y && mean && invstd && workspace && n > 0 && c > 0 && hw > 0, "vocr_bn_train_stats: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int nchunk = bn_nchunk((long)n * hw);
+    bn_stats_partial_kernel<<<dim3(c, nchunk), 256, 0, s>>>(y, (double*)workspace, n, c, hw, nchunk);
+    VOCR_CHECK_LAUNCH("vocr_bn_train_stats(partial)");
+    bn_stats_final_kernel<<<vocr_cdiv(c, 64), 64, 0, s>>>((const double*)workspace, c, nchunk, (long)n * hw, eps, momentum,
+                                                          mean, invstd, running_mean, running_var);
+    VOCR_CHECK_LAUNCH("vocr_bn_train_stats(final)");
+    return VOCR_OK;
+}
+
+extern "C" int vocr_bn_eval_stats(const float* running_mean, const float* running_var, int c, float eps, float* mean,
+                                  float* invstd, void* stream) {
+    VOCR_CHECK_ARG(running_mean && running_var && mean && invstd && c > 0, "vocr_bn_eval_stats: bad argument");
+    bn_eval_stats_kernel<<<vocr_cdiv(c, 64), 64, 0, (hipStream_t)stream>>>(running_mean, running_var, c, eps, mean, invstd);
+    VOCR_CHECK_LAUNCH("vocr_bn_eval_stats");
+    return VOCR_OK;
+}
+
+static inline dim3 plane_grid(long planes, long per_plane) {
+    long gx = (per_plane + 1023) / 1024;
+    if (gx < 1) gx = 1;
+    if (gx > 64) gx = 64;
+    return dim3((unsigned)gx, (unsigned)planes);
+}
+
+extern "C" int vocr_bn_relu_apply(const float* y, const float* mean, const float* invstd, const float* gamma,
+                                  const float* beta, float* out, int n, int c, int hw, void* stream) {
+    VOCR_CHECK_ARG(y && mean && invstd && gamma && beta && out && n > 0 && c > 0 && hw > 0, "vocr_bn_relu_apply: bad argument");
+    VOCR_CHECK_ARG((long)n * c <= 65535, "vocr_bn_relu_apply: n*c > 65535 planes");
+    bn_relu_apply_kernel<<<plane_grid((long)n * c, hw), 256, 0, (hipStream_t)stream>>>(y, mean, invstd, gamma, beta, out, c, hw);
+    VOCR_CHECK_LAUNCH("vocr_bn_relu_apply");
+    return VOCR_OK;
+}
+
+extern "C" int vocr_bn_relu_bwd(const float* da, const float* y, const float* mean, const float* invstd,
+                                const float* gamma, const float* beta, float* dy, float* dgamma, float* dbeta, int n,
+                                int c, int hw, void* workspace, void* stream) {
+    VOCR_CHECK_ARG(da && y && mean && invstd && gamma && beta && dy && dgamma && dbeta && workspace, "vocr_bn_relu_bwd: null pointer");
+    VOCR_CHECK_ARG(n > 0 && c > 0 && hw > 0 && (long)n * c <= 65535, "vocr_bn_relu_bwd: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    const int nchunk = bn_nchunk((long)n * hw);
+    bn_bwd_partial_kernel<<<dim3(c, nchunk), 256, 0, s>>>(da, y, mean, invstd, gamma, beta, (double*)workspace, n, c, hw, nchunk);
+    VOCR_CHECK_LAUNCH("vocr_bn_relu_bwd(partial)");
+    bn_bwd_final_kernel<<<vocr_cdiv(c, 64), 64, 0, s>>>((const double*)workspace, c, nchunk, dgamma, dbeta);
+    VOCR_CHECK_LAUNCH("vocr_bn_relu_bwd(final)");
+    bn_bwd_apply_kernel<<<plane_grid((long)n * c, hw), 256, 0, s>>>(da, y, mean, invstd, gamma, beta, dgamma, dbeta, dy, c, hw,
+                                                                    1.0f / (float)((long)n * hw));
+    VOCR_CHECK_LAUNCH("vocr_bn_relu_bwd(apply)");
+    return VOCR_OK;
+}
+
+extern "C" int vocr_fracpool2x2_fwd(const float* x, const float* samples, float* out, int32_t* idx, int n, int c, int h,
+                                    int w, int oh, int ow, void* stream) {
+    VOCR_CHECK_ARG(x && samples && out && idx, "vocr_fracpool2x2_fwd: null pointer");
+    VOCR_CHECK_ARG(n > 0 && c > 0 && h >= 2 && w >= 2 && oh >= 1 && ow >= 1 && oh <= h - 1 && ow <= w - 1 && (long)n * c <= 65535,
+                   "vocr_fracpool2x2_fwd: bad shape h=%d w=%d oh=%d ow=%d", h, w, oh, ow);
+    // alpha in float32 exactly as ATen: float(in - pool) / float(out - 1)
+    const float alpha_h = oh > 1 ? (float)(h - 2) / (float)(oh - 1) : 0.f;
+    const float alpha_w = ow > 1 ? (float)(w - 2) / (float)(ow - 1) : 0.f;
+    fracpool_fwd_kernel<<<plane_grid((long)n * c, (long)oh * ow), 256, 0, (hipStream_t)stream>>>(x, samples, out, idx, h, w, oh,
+                                                                                             ow, alpha_h, alpha_w);
+    VOCR_CHECK_LAUNCH("vocr_fracpool2x2_fwd");
+    return VOCR_OK;
+}
+
+extern "C" int vocr_fracpool2x2_bwd(const float* dout, const int32_t* idx, float* dx, int n, int c, int h, int w, int oh,
+                                    int ow, void* stream) {
+    VOCR_CHECK_ARG(dout && idx && dx && n > 0 && c > 0 && (long)n * c <= 65535, "vocr_fracpool2x2_bwd: bad argument");
+    pool_bwd_scatter_kernel<<<plane_grid((long)n * c, (long)oh * ow), 256, 0, (hipStream_t)stream>>>(dout, idx, dx, (long)h * w,
+                                                                                                 oh * ow);
+    VOCR_CHECK_LAUNCH("vocr_fracpool2x2_bwd");
+    return VOCR_OK;
+}
+
+extern "C" int vocr_relu_maxpool2_fwd(const float* x, float* out, int32_t* idx, int n, int c, int h, int w, void* stream) {
+    VOCR_CHECK_ARG(x && out && idx && n > 0 && c > 0 && h >= 2 && w >= 2 && (long)n * c <= 65535, "vocr_relu_maxpool2_fwd: bad argument");
+    const int oh = h / 2, ow = w / 2;
+    relu_maxpool2_fwd_kernel<<<plane_grid((long)n * c, (long)oh * ow), 256, 0, (hipStream_t)stream>>>(x, out, idx, h, w, oh, ow);
+    VOCR_CHECK_LAUNCH("vocr_relu_maxpool2_fwd");
+    return VOCR_OK;
+}
+
+extern "C" int vocr_relu_maxpool2_bwd(const float* dout, const float* out, const int32_t* idx, float* dx, int n, int c,
+                                      int h, int w, void* stream) {
+    VOCR_CHECK_ARG(dout && out && idx && dx && n > 0 && c > 0 && (long)n * c <= 65535, "vocr_relu_maxpool2_bwd: bad argument");
+    const int oh = h / 2, ow = w / 2;
+    relu_maxpool2_bwd_kernel<<<plane_grid((long)n * c, (long)oh * ow), 256, 0, (hipStream_t)stream>>>(dout, out, idx, dx,
+                                                                                                  (long)h * w, oh * ow);
+    VOCR_CHECK_LAUNCH("vocr_relu_maxpool2_bwd");
+    return VOCR_OK;
+}

@@ -1,0 +1,339 @@
+// fp32 MFMA GEMM for the dense layers of the path (bridge Linear, LSTM input projections, prob Linear and
+// their backward).  C[M,N] = op(A)[M,K] * op(B)[K,N] (+bias)(relu)(+=).
+//
+// gfx950 mapping: v_mfma_f32_32x32x2_f32 (exact f32, 64 FLOP/clk/SIMD = the chip's 157 TF f32 peak).
+// One workgroup = 4 waves (one per SIMD); LDS holds K-major tiles As[k][m], Bs[k][n] so a fragment read
+// is 32 consecutive dwords per lane-half (conflict-free ds_read_b32); global->LDS goes through registers
+// and is issued one K-tile ahead of the MFMAs that consume it.
+#include "vocr_common.h"
+
+namespace {
+
+constexpr int BK = 16;
+
+template <int BM, int BN, int WM, int WN, bool A_KCONTIG, bool B_NCONTIG>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(
+    int M, int N, int K, const float* __restrict__ A, long sam, long sak, const float* __restrict__ B, long sbk,
+    long sbn, float* __restrict__ C, int ldc, const float* __restrict__ bias, int relu, int accumulate,
+    int k_per_split) {
+    constexpr int PA = BM + 2;   // pitch ≡ 2 (mod 32): transposing stores from k-contiguous rows stay conflict-free
+    constexpr int PB = BN + 2;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int WAVES_N = BN / WN;
+    constexpr int EA = BM * BK / 256, EB = BN * BK / 256;
+    __shared__ float lds[2 * BK * (PA + PB)];
+    float* const As0 = lds;                    // As[buf] = As0 + buf*BK*PA ; Bs[buf] = Bs0 + buf*BK*PB
+    float* const Bs0 = lds + 2 * BK * PA;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * k_per_split;
+    const int kend = min(K, kbeg + k_per_split);
+    const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float ra[EA], rb[EB];
+
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < EA; ++e) {
+            int m, k;
+            if (A_KCONTIG) { k = tid & 15; m = (tid >> 4) + 16 * e; }
+            else           { m = tid % BM; k = tid / BM + (256 / BM) * e; }
+            const int gm = m0 + m, gk = k0 + k;
+            ra[e] = (gm < M && gk < kend) ? A[gm * sam + gk * sak] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            int n, k;
+            if (B_NCONTIG) { n = tid % BN; k = tid / BN + (256 / BN) * e; }
+            else           { k = tid & 15; n = (tid >> 4) + 16 * e; }
+            const int gn = n0 + n, gk = k0 + k;
+            rb[e] = (gn < N && gk < kend) ? B[gk * sbk + gn * sbn] : 0.f;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < EA; ++e) {
+            int m, k;
+            if (A_KCONTIG) { k = tid & 15; m = (tid >> 4) + 16 * e; }
+            else           { m = tid % BM; k = tid / BM + (256 / BM) * e; }
+            As0[buf * BK * PA + k * PA + m] = ra[e];
+        }
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            int n, k;
+            if (B_NCONTIG) { n = tid % BN; k = tid / BN + (256 / BN) * e; }
+            else           { k = tid & 15; n = (tid >> 4) + 16 * e; }
+            Bs0[buf * BK * PB + k * PB + n] = rb[e];
+        }
+    };
+
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    if (nk > 0) {
+        load_tiles(kbeg);
+        store_tiles(0);
+    }
+    __syncthreads();
+    const int li = lane & 31, lk = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tiles(kbeg + (kt + 1) * BK);
+        const float* as = As0 + cur * BK * PA + wm0 + li;
+        const float* bs = Bs0 + cur * BK * PB + wn0 + li;
+#pragma unroll
+        for (int ks = 0; ks < BK / 2; ++ks) {
+            float af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = as[(ks * 2 + lk) * PA + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = bs[(ks * 2 + lk) * PB + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const bool atomic = gridDim.z > 1;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int gn = n0 + wn0 + j * 32 + li;
+            if (gn >= N) continue;
+            const float bv = bias ? bias[gn] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gm = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (gm >= M) continue;
+                float v = acc[i][j][r] + bv;
+                float* cp = C + (long)gm * ldc + gn;
+                if (atomic) {
+                    atomicAdd(cp, v);
+                } else {
+                    if (accumulate) v += *cp;
+                    if (relu) v = fmaxf(v, 0.f);
+                    *cp = v;
+                }
+            }
+        }
+}
+
+template <int BM, int BN, int WM, int WN>
+void launch_cfg(int ta, int tb, dim3 grid, hipStream_t s, int M, int N, int K, const float* A, long sam, long sak,
+                const float* B, long sbk, long sbn, float* C, int ldc, const float* bias, int relu, int acc, int kps) {
+    if (!ta && !tb)
+        gemm_f32_kernel<BM, BN, WM, WN, true, true><<<grid, 256, 0, s>>>(M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, relu, acc, kps);
+    else if (!ta && tb)
+        gemm_f32_kernel<BM, BN, WM, WN, true, false><<<grid, 256, 0, s>>>(M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, relu, acc, kps);
+    else if (ta && !tb)
+        gemm_f32_kernel<BM, BN, WM, WN, false, true><<<grid, 256, 0, s>>>(M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, relu, acc, kps);
+    else
+        gemm_f32_kernel<BM, BN, WM, WN, false, false><<<grid, 256, 0, s>>>(M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, relu, acc, kps);
+}
+
+__global__ void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int M, int N) {
+    // one workgroup per 64 columns; 4 waves stride the rows; deterministic order
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (n < N)
+        for (int m = wave; m < M; m += 4) s += x[(long)m * N + n];
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && n < N) out[n] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+__global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ out, float* __restrict__ dz, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dz[i] = out[i] > 0.f ? dy[i] : 0.f;
+}
+
+__global__ void mul_kernel(const float* __restrict__ x, const float* __restrict__ m, float* __restrict__ o, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) o[i] = x[i] * m[i];
+}
+
+__global__ void add_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ o, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) o[i] = x[i] + y[i];
+}
+
+__global__ void scale_dev_kernel(const float* __restrict__ x, const float* __restrict__ sc, float* __restrict__ o, size_t n) {
+    const float a = sc[0];
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) o[i] = x[i] * a;
+}
+
+__device__ __forceinline__ uint32_t mix32(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;   // splitmix64 finaliser: counter-based, one draw per element
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    z = z ^ (z >> 31);
+    return (uint32_t)(z >> 32);
+}
+
+__global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ o, float* __restrict__ mask, size_t n,
+                               float p, float scale, uint64_t seed) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const float u = (float)(mix32(seed * 0x9e3779b97f4a7c15ull + i) >> 8) * (1.0f / 16777216.0f);
+        const float mk = (u >= p) ? scale : 0.f;
+        mask[i] = mk;
+        o[i] = x[i] * mk;
+    }
+}
+
+// bchw -> [w][b][c*h]: one workgroup transposes a 64(w) x 64(ch) tile of one image through LDS so both the
+// read (along w) and the write (along c*h) are coalesced.
+__global__ void bchw_to_wbch_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int CH, int W, int fwd) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.z, ch0 = blockIdx.y * 64, w0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 256 threads: 64 x 4
+    if (fwd) {
+        for (int r = ty; r < 64; r += 4) {
+            const int ch = ch0 + r, w = w0 + tx;
+            tile[r][tx] = (ch < CH && w < W) ? x[((long)b * CH + ch) * W + w] : 0.f;
+        }
+        __syncthreads();
+        for (int r = ty; r < 64; r += 4) {
+            const int w = w0 + r, ch = ch0 + tx;
+            if (w < W && ch < CH) out[((long)w * B + b) * CH + ch] = tile[tx][r];
+        }
+    } else {
+        for (int r = ty; r < 64; r += 4) {
+            const int w = w0 + r, ch = ch0 + tx;
+            tile[r][tx] = (w < W && ch < CH) ? x[((long)w * B + b) * CH + ch] : 0.f;
+        }
+        __syncthreads();
+        for (int r = ty; r < 64; r += 4) {
+            const int ch = ch0 + r, w = w0 + tx;
+            if (ch < CH && w < W) out[((long)b * CH + ch) * W + w] = tile[tx][r];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int vocr_gemm(int transa, int transb, int m, int n, int k, const float* a, int lda, const float* b, int ldb,
+                         float* c, int ldc, const float* bias, int relu, int accumulate, void* stream) {
+    VOCR_CHECK_ARG(m > 0 && n > 0 && k > 0, "vocr_gemm: bad shape m=%d n=%d k=%d", m, n, k);
+    VOCR_CHECK_ARG(a && b && c, "vocr_gemm: null pointer");
+    VOCR_CHECK_ARG(lda >= (transa ? m : k) && ldb >= (transb ? k : n) && ldc >= n, "vocr_gemm: bad leading dimension");
+    hipStream_t s = (hipStream_t)stream;
+    const long sam = transa ? 1 : lda, sak = transa ? lda : 1;
+    const long sbk = transb ? 1 : ldb, sbn = transb ? ldb : 1;
+    const long tiles128 = (long)vocr_cdiv(m, 128) * vocr_cdiv(n, 128);
+    const bool big = tiles128 >= 192;
+    const int bm = big ? 128 : 64;
+    const long tiles = (long)vocr_cdiv(m, bm) * vocr_cdiv(n, bm);
+    int splits = 1;
+    if (!bias && !relu && tiles < 256 && k >= 1024) {
+        splits = (int)((512 + tiles - 1) / tiles);
+        const int maxs = k / 256;
+        if (splits > maxs) splits = maxs;
+        if (splits < 1) splits = 1;
+    }
+    int kps = vocr_cdiv(vocr_cdiv(k, splits), BK) * BK;
+    splits = vocr_cdiv(k, kps);
+    if (splits > 1 && !accumulate) {
+        if (hipMemset2DAsync(c, (size_t)ldc * sizeof(float), 0, (size_t)n * sizeof(float), (size_t)m, s) != hipSuccess) {
+            vocr_set_error("vocr_gemm: memset failed");
+            return VOCR_ELAUNCH;
+        }
+    }
+    dim3 grid(vocr_cdiv(n, bm), vocr_cdiv(m, bm), splits);
+    if (big)
+        launch_cfg<128, 128, 64, 64>(transa, transb, grid, s, m, n, k, a, sam, sak, b, sbk, sbn, c, ldc, bias, relu, accumulate, kps);
+    else
+        launch_cfg<64, 64, 32, 32>(transa, transb, grid, s, m, n, k, a, sam, sak, b, sbk, sbn, c, ldc, bias, relu, accumulate, kps);
+    VOCR_CHECK_LAUNCH("vocr_gemm");
+    return VOCR_OK;
+}
+
+extern "C" int vocr_colsum(const float* x, float* out, int m, int n, void* stream) {
+    VOCR_CHECK_ARG(x && out && m > 0 && n > 0, "vocr_colsum: bad argument");
+    colsum_kernel<<<vocr_cdiv(n, 64), 256, 0, (hipStream_t)stream>>>(x, out, m, n);
+    VOCR_CHECK_LAUNCH("vocr_colsum");
+    return VOCR_OK;
+}
+
+static inline int ew_grid(size_t count) {
+    size_t g = (count + 255) / 256;
+    return (int)(g > 2048 ? 2048 : (g ? g : 1));
+}
+
+extern "C" int vocr_relu_bwd(const float* dy, const float* out, float* dz, size_t count, void* stream) {
+    VOCR_CHECK_ARG(dy && out && dz, "vocr_relu_bwd: null pointer");
+    if (count == 0) return VOCR_OK;
+    relu_bwd_kernel<<<ew_grid(count), 256, 0, (hipStream_t)stream>>>(dy, out, dz, count);
+    VOCR_CHECK_LAUNCH("vocr_relu_bwd");
+    return VOCR_OK;
+}
+
+extern "C" int vocr_mul(const float* x, const float* mask, float* out, size_t count, void* stream) {
+    VOCR_CHECK_ARG(x && mask && out, "vocr_mul: null pointer");
+    if (count == 0) return VOCR_OK;
+    mul_kernel<<<ew_grid(count), 256, 0, (hipStream_t)stream>>>(x, mask, out, count);
+    VOCR_CHECK_LAUNCH("vocr_mul");
+    return VOCR_OK;
+}
+
+extern "C" int vocr_add(const float* x, const float* y, float* out, size_t count, void* stream) {
+    VOCR_CHECK_ARG(x && y && out, "vocr_add: null pointer");
+    if (count == 0) return VOCR_OK;
+    add_kernel<<<ew_grid(count), 256, 0, (hipStream_t)stream>>>(x, y, out, count);
+    VOCR_CHECK_LAUNCH("vocr_add");
+    return VOCR_OK;
+}
+
+extern "C" int vocr_scale_dev(const float* x, const float* scalar, float* out, size_t count, void* stream) {
+    VOCR_CHECK_ARG(x && scalar && out, "vocr_scale_dev: null pointer");
+    if (count == 0) return VOCR_OK;
+    scale_dev_kernel<<<ew_grid(count), 256, 0, (hipStream_t)stream>>>(x, scalar, out, count);
+    VOCR_CHECK_LAUNCH("vocr_scale_dev");
+    return VOCR_OK;
+}
+
+extern "C" int vocr_dropout_fwd(const float* x, float* out, float* mask, size_t count, float p, uint64_t seed, void* stream) {
+    VOCR_CHECK_ARG(x && mask && out, "vocr_dropout_fwd: null pointer");
+    VOCR_CHECK_ARG(p >= 0.f && p < 1.f, "vocr_dropout_fwd: p must be in [0,1)");
+    if (count == 0) return VOCR_OK;
+    dropout_kernel<<<ew_grid(count), 256, 0, (hipStream_t)stream>>>(x, out, mask, count, p, 1.0f / (1.0f - p), seed);
+    VOCR_CHECK_LAUNCH("vocr_dropout_fwd");
+    return VOCR_OK;
+}
+
+extern "C" int vocr_bchw_to_wbch(const float* x, float* out, int b, int c, int h, int w, void* stream) {
+    VOCR_CHECK_ARG(x && out && b > 0 && c > 0 && h > 0 && w > 0, "vocr_bchw_to_wbch: bad argument");
+    dim3 grid(vocr_cdiv(w, 64), vocr_cdiv(c * h, 64), b);
+    bchw_to_wbch_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, out, b, c * h, w, 1);
+    VOCR_CHECK_LAUNCH("vocr_bchw_to_wbch");
+    return VOCR_OK;
+}
+
+extern "C" int vocr_wbch_to_bchw(const float* x, float* out, int b, int c, int h, int w, void* stream) {
+    VOCR_CHECK_ARG(x && out && b > 0 && c > 0 && h > 0 && w > 0, "vocr_wbch_to_bchw: bad argument");
+    dim3 grid(vocr_cdiv(w, 64), vocr_cdiv(c * h, 64), b);
+    bchw_to_wbch_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, out, b, c * h, w, 0);
+    VOCR_CHECK_LAUNCH("vocr_wbch_to_bchw");
+    return VOCR_OK;
+}

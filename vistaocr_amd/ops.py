@@ -1,0 +1,411 @@
+"""Host-side operators of the CnnOcrModel path: torch.autograd.Function wrappers that own buffers (torch is
+the allocator / stream provider) and call the hand-written HIP kernels through the C-ABI (include/vocr.h).
+
+Every op raises if its tensors are not on a HIP device: there is no CPU fallback (oracle/ is test-only)."""
+import math
+
+import torch
+
+from . import _lib
+from ._lib import call
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("vistaocr_amd: tensors must live on the MI355X (got a %s tensor); there is no CPU "
+                               "fallback for the HIP path" % t.device)
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _ws(nbytes, device):
+    return torch.empty((max(int(nbytes), 16) + 3) // 4, dtype=torch.float32, device=device)
+
+
+# ------------------------------------------------------------------------------------------------ conv + BN + ReLU
+def conv3x3_pack(weight):
+    cout, cin = weight.shape[0], weight.shape[1]
+    pf = torch.empty(cin * 9, cout, dtype=torch.float32, device=weight.device)
+    pd = torch.empty(cout * 9, cin, dtype=torch.float32, device=weight.device)
+    call("vocr_conv3x3_pack_weights", _p(weight), _p(pf), _p(pd), cout, cin, _stream())
+    return pf, pd
+
+
+def conv3x3_forward(x, wpack, bias, cout):
+    n, cin, h, w = x.shape
+    y = torch.empty(n, cout, h, w, dtype=torch.float32, device=x.device)
+    call("vocr_conv3x3_fwd", _p(x), _p(wpack), _p(bias), _p(y), n, cin, h, w, cout, _stream())
+    return y
+
+
+def conv3x3_wgrad(x, dy):
+    n, cin, h, w = x.shape
+    cout = dy.shape[1]
+    lib = _lib.load()
+    ws = _ws(lib.vocr_conv3x3_wgrad_workspace_bytes(n, cin, h, w, cout), x.device)
+    dw = torch.empty(cout, cin, 3, 3, dtype=torch.float32, device=x.device)
+    call("vocr_conv3x3_wgrad", _p(x), _p(dy), _p(dw), _p(ws), n, cin, h, w, cout, _stream())
+    return dw
+
+
+def channel_sum(x):
+    n, c, h, w = x.shape
+    out = torch.empty(c, dtype=torch.float32, device=x.device)
+    call("vocr_channel_sum", _p(x), _p(out), n, c, h * w, _stream())
+    return out
+
+
+class ConvBnReluFn(torch.autograd.Function):
+    """Conv2d(k3,p1) -> BatchNorm2d -> ReLU (reference ConvBNReLU, src/models/cnnlstm.py:263-266)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, training, eps, momentum):
+        _need_gpu(x, weight, bias, gamma, beta, running_mean, running_var)
+        x = _f32c(x)
+        n, cin, h, w = x.shape
+        cout = weight.shape[0]
+        lib = _lib.load()
+        pf, pd = conv3x3_pack(weight)
+        y = conv3x3_forward(x, pf, bias, cout)
+        mean = torch.empty(cout, dtype=torch.float32, device=x.device)
+        invstd = torch.empty(cout, dtype=torch.float32, device=x.device)
+        if training:
+            ws = _ws(lib.vocr_bn_workspace_bytes(n, cout, h * w), x.device)
+            call("vocr_bn_train_stats", _p(y), n, cout, h * w, eps, momentum, _p(mean), _p(invstd), _p(running_mean),
+                 _p(running_var), _p(ws), _stream())
+        else:
+            call("vocr_bn_eval_stats", _p(running_mean), _p(running_var), cout, eps, _p(mean), _p(invstd), _stream())
+        out = torch.empty_like(y)
+        call("vocr_bn_relu_apply", _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(out), n, cout, h * w, _stream())
+        ctx.training = training
+        ctx.save_for_backward(x, y, mean, invstd, gamma, beta, pd)
+        return out
+
+    @staticmethod
+    def backward(ctx, da):
+        if not ctx.training:
+            raise RuntimeError("vistaocr_amd: backward through eval-mode BatchNorm is not part of the reference path")
+        x, y, mean, invstd, gamma, beta, pd = ctx.saved_tensors
+        da = _f32c(da)
+        n, cin, h, w = x.shape
+        cout = y.shape[1]
+        lib = _lib.load()
+        dy = torch.empty_like(y)
+        dgamma = torch.empty_like(gamma)
+        dbeta = torch.empty_like(beta)
+        ws = _ws(lib.vocr_bn_workspace_bytes(n, cout, h * w), x.device)
+        call("vocr_bn_relu_bwd", _p(da), _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(dy), _p(dgamma), _p(dbeta),
+             n, cout, h * w, _p(ws), _stream())
+        dbias = channel_sum(dy)
+        dw = conv3x3_wgrad(x, dy)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = conv3x3_forward(dy, pd, None, cin)
+        return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None
+
+
+class ConvReluPoolFn(torch.autograd.Function):
+    """rapid_ds stage: Conv2d(k3,p1) -> ReLU -> MaxPool2d(2,2) (src/models/cnnlstm.py:114-121)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _need_gpu(x, weight, bias)
+        x = _f32c(x)
+        n, cin, h, w = x.shape
+        cout = weight.shape[0]
+        pf, pd = conv3x3_pack(weight)
+        y = conv3x3_forward(x, pf, bias, cout)
+        oh, ow = h // 2, w // 2
+        out = torch.empty(n, cout, oh, ow, dtype=torch.float32, device=x.device)
+        idx = torch.empty(n, cout, oh, ow, dtype=torch.int32, device=x.device)
+        call("vocr_relu_maxpool2_fwd", _p(y), _p(out), _p(idx), n, cout, h, w, _stream())
+        ctx.save_for_backward(x, out, idx, pd)
+        ctx.hw = (h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, out, idx, pd = ctx.saved_tensors
+        dout = _f32c(dout)
+        n, cin, _, _ = x.shape
+        cout = out.shape[1]
+        h, w = ctx.hw
+        dy = torch.zeros(n, cout, h, w, dtype=torch.float32, device=x.device)
+        call("vocr_relu_maxpool2_bwd", _p(dout), _p(out), _p(idx), _p(dy), n, cout, h, w, _stream())
+        dbias = channel_sum(dy)
+        dw = conv3x3_wgrad(x, dy)
+        dx = conv3x3_forward(dy, pd, None, cin) if ctx.needs_input_grad[0] else None
+        return dx, dw, dbias
+
+
+class FracPoolFn(torch.autograd.Function):
+    """nn.FractionalMaxPool2d(2, output_ratio=(0.5, 0.7)) with explicit samples (src/models/cnnlstm.py:127,130)."""
+
+    @staticmethod
+    def forward(ctx, x, samples, oh, ow):
+        _need_gpu(x, samples)
+        x = _f32c(x)
+        samples = _f32c(samples)
+        n, c, h, w = x.shape
+        if tuple(samples.shape) != (n, c, 2):
+            raise RuntimeError("fractional pool samples must have shape (N, C, 2)")
+        out = torch.empty(n, c, oh, ow, dtype=torch.float32, device=x.device)
+        idx = torch.empty(n, c, oh, ow, dtype=torch.int32, device=x.device)
+        call("vocr_fracpool2x2_fwd", _p(x), _p(samples), _p(out), _p(idx), n, c, h, w, oh, ow, _stream())
+        ctx.save_for_backward(idx)
+        ctx.shape = (n, c, h, w, oh, ow)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        n, c, h, w, oh, ow = ctx.shape
+        dout = _f32c(dout)
+        dx = torch.zeros(n, c, h, w, dtype=torch.float32, device=dout.device)
+        call("vocr_fracpool2x2_bwd", _p(dout), _p(idx), _p(dx), n, c, h, w, oh, ow, _stream())
+        return dx, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------ dense layers
+def gemm(ta, tb, m, n, k, a, lda, b, ldb, c, ldc, bias=None, relu=False, accumulate=False):
+    call("vocr_gemm", int(ta), int(tb), m, n, k, _p(a), lda, _p(b), ldb, _p(c), ldc, _p(bias), int(relu), int(accumulate),
+         _stream())
+
+
+def colsum(x2d):
+    m, n = x2d.shape
+    out = torch.empty(n, dtype=torch.float32, device=x2d.device)
+    call("vocr_colsum", _p(x2d), _p(out), m, n, _stream())
+    return out
+
+
+class PermuteBchwToWbchFn(torch.autograd.Function):
+    """cnn_output.permute(3, 0, 1, 2).contiguous().view(-1, c*h) (src/models/cnnlstm.py:275-278)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _need_gpu(x)
+        x = _f32c(x)
+        b, c, h, w = x.shape
+        out = torch.empty(w * b, c * h, dtype=torch.float32, device=x.device)
+        call("vocr_bchw_to_wbch", _p(x), _p(out), b, c, h, w, _stream())
+        ctx.shape = (b, c, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        b, c, h, w = ctx.shape
+        dout = _f32c(dout)
+        dx = torch.empty(b, c, h, w, dtype=torch.float32, device=dout.device)
+        call("vocr_wbch_to_bchw", _p(dout), _p(dx), b, c, h, w, _stream())
+        return dx
+
+
+class LinearFn(torch.autograd.Function):
+    """nn.Linear (+ optional ReLU): bridge_layer and prob_layer (src/models/cnnlstm.py:143-154)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        _need_gpu(x, weight, bias)
+        x = _f32c(x)
+        m, k = x.shape
+        n = weight.shape[0]
+        out = torch.empty(m, n, dtype=torch.float32, device=x.device)
+        gemm(0, 1, m, n, k, x, k, weight, k, out, n, bias=bias, relu=relu)
+        ctx.relu = relu
+        ctx.save_for_backward(x, weight, out if relu else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, weight, out = ctx.saved_tensors
+        dout = _f32c(dout)
+        m, k = x.shape
+        n = weight.shape[0]
+        if ctx.relu:
+            dz = torch.empty_like(dout)
+            call("vocr_relu_bwd", _p(dout), _p(out), _p(dz), dout.numel(), _stream())
+        else:
+            dz = dout
+        dw = torch.empty_like(weight)
+        gemm(1, 0, n, k, m, dz, n, x, k, dw, k)                     # dW[n,k] = dz^T[n,m] x[m,k]
+        db = colsum(dz)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            gemm(0, 0, m, k, n, dz, n, weight, k, dx, k)            # dx[m,k] = dz[m,n] W[n,k]
+        return dx, dw, db, None
+
+
+class MulMaskFn(torch.autograd.Function):
+    """inter-layer LSTM dropout with an explicit pre-scaled mask (parity path)."""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        _need_gpu(x, mask)
+        x, mask = _f32c(x), _f32c(mask)
+        out = torch.empty_like(x)
+        call("vocr_mul", _p(x), _p(mask), _p(out), x.numel(), _stream())
+        ctx.save_for_backward(mask)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (mask,) = ctx.saved_tensors
+        dout = _f32c(dout)
+        dx = torch.empty_like(dout)
+        call("vocr_mul", _p(dout), _p(mask), _p(dx), dout.numel(), _stream())
+        return dx, None
+
+
+class DropoutFn(torch.autograd.Function):
+    """nn.LSTM(dropout=p) between layers in training: counter-based mask drawn on device."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        _need_gpu(x)
+        x = _f32c(x)
+        out = torch.empty_like(x)
+        mask = torch.empty_like(x)
+        call("vocr_dropout_fwd", _p(x), _p(out), _p(mask), x.numel(), float(p), int(seed), _stream())
+        ctx.save_for_backward(mask)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (mask,) = ctx.saved_tensors
+        dout = _f32c(dout)
+        dx = torch.empty_like(dout)
+        call("vocr_mul", _p(dout), _p(mask), _p(dx), dout.numel(), _stream())
+        return dx, None, None
+
+
+# ------------------------------------------------------------------------------------------------ LSTM layer
+class BiLstmLayerFn(torch.autograd.Function):
+    """One bidirectional nn.LSTM layer on a packed batch (src/models/cnnlstm.py:148-149,288-290).
+    x: [T*B, Din] time-major; returns y: [T*B, 2H] with zeros past each sequence's length."""
+
+    @staticmethod
+    def forward(ctx, x, lens_dev, T, B, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
+        _need_gpu(x, lens_dev, w_ih_f, w_hh_f, w_ih_r, w_hh_r)
+        x = _f32c(x)
+        lib = _lib.load()
+        din = x.shape[1]
+        H = w_hh_f.shape[1]
+        dev = x.device
+        xproj = torch.empty(2, T * B, 4 * H, dtype=torch.float32, device=dev)
+        bsum = torch.empty(2, 4 * H, dtype=torch.float32, device=dev)
+        call("vocr_add", _p(b_ih_f), _p(b_hh_f), _p(bsum[0]), 4 * H, _stream())
+        call("vocr_add", _p(b_ih_r), _p(b_hh_r), _p(bsum[1]), 4 * H, _stream())
+        gemm(0, 1, T * B, 4 * H, din, x, din, w_ih_f, din, xproj[0], 4 * H, bias=bsum[0])
+        gemm(0, 1, T * B, 4 * H, din, x, din, w_ih_r, din, xproj[1], 4 * H, bias=bsum[1])
+        y = torch.empty(T * B, 2 * H, dtype=torch.float32, device=dev)
+        gates = torch.empty(2, T * B, 4 * H, dtype=torch.float32, device=dev)
+        cell = torch.empty(2, T * B, H, dtype=torch.float32, device=dev)
+        ws = _ws(lib.vocr_lstm_workspace_bytes(T, B, H), dev)
+        call("vocr_lstm_fwd", _p(xproj), _p(w_hh_f), _p(w_hh_r), _p(lens_dev), _p(y), _p(gates), _p(cell), _p(ws), T, B, H,
+             _stream())
+        ctx.dims = (T, B, H, din)
+        ctx.save_for_backward(x, lens_dev, y, gates, cell, w_ih_f, w_hh_f, w_ih_r, w_hh_r)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, lens_dev, y, gates, cell, w_ih_f, w_hh_f, w_ih_r, w_hh_r = ctx.saved_tensors
+        T, B, H, din = ctx.dims
+        dy = _f32c(dy)
+        lib = _lib.load()
+        dev = x.device
+        dg = torch.empty(2, T * B, 4 * H, dtype=torch.float32, device=dev)
+        ws = _ws(lib.vocr_lstm_workspace_bytes(T, B, H), dev)
+        call("vocr_lstm_bwd", _p(dy), _p(w_hh_f), _p(w_hh_r), _p(lens_dev), _p(gates), _p(cell), _p(dg), _p(ws), T, B, H,
+             _stream())
+        G = 4 * H
+        dw_ih_f = torch.empty_like(w_ih_f)
+        dw_ih_r = torch.empty_like(w_ih_r)
+        gemm(1, 0, G, din, T * B, dg[0], G, x, din, dw_ih_f, din)
+        gemm(1, 0, G, din, T * B, dg[1], G, x, din, dw_ih_r, din)
+        db_f = colsum(dg[0])
+        db_r = colsum(dg[1])
+        dw_hh_f = torch.zeros_like(w_hh_f)
+        dw_hh_r = torch.zeros_like(w_hh_r)
+        if T > 1:
+            # forward dir: h_{t-1} = y[t-1, :, :H];   reverse dir: h_{t+1} = y[t+1, :, H:]  (zero past the length)
+            m = (T - 1) * B
+            gemm(1, 0, G, H, m, dg[0][B:], G, y, 2 * H, dw_hh_f, H)
+            gemm(1, 0, G, H, m, dg[1], G, y[B:, H:], 2 * H, dw_hh_r, H)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            gemm(0, 0, T * B, din, G, dg[0], G, w_ih_f, din, dx, din)
+            gemm(0, 0, T * B, din, G, dg[1], G, w_ih_r, din, dx, din, accumulate=True)
+        return dx, None, None, None, dw_ih_f, dw_hh_f, db_f, db_f.clone(), dw_ih_r, dw_hh_r, db_r, db_r.clone()
+
+
+# ------------------------------------------------------------------------------------------------ CTC
+class CtcFn(torch.autograd.Function):
+    """Batch-summed CTC negative log-likelihood on pre-softmax activations, blank = 0."""
+
+    @staticmethod
+    def forward(ctx, logits, labels_dev, offsets_dev, label_lens_dev, act_lens_dev, max_label_len):
+        _need_gpu(logits, labels_dev, offsets_dev, label_lens_dev, act_lens_dev)
+        logits = _f32c(logits)
+        T, B, V = logits.shape
+        lib = _lib.load()
+        dev = logits.device
+        ws = _ws(lib.vocr_ctc_workspace_bytes(T, B, V, max_label_len), dev)
+        nll = torch.empty(B, 1, dtype=torch.float32, device=dev)
+        dlogits = torch.empty_like(logits)
+        call("vocr_ctc_loss_grad", _p(logits), _p(labels_dev), _p(offsets_dev), _p(label_lens_dev), _p(act_lens_dev),
+             _p(nll), _p(dlogits), _p(ws), T, B, V, int(max_label_len), _stream())
+        loss = colsum(nll)                                   # shape (1,): sum over the batch, fixed order
+        ctx.save_for_backward(dlogits)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dlogits,) = ctx.saved_tensors
+        dloss = _f32c(dloss)
+        out = torch.empty_like(dlogits)
+        call("vocr_scale_dev", _p(dlogits), _p(dloss), _p(out), dlogits.numel(), _stream())
+        return out, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------ decode / optimiser
+def argmax_rows(logits):
+    """(idx int32 [T,B], max float32 [T,B]) of logits [T,B,V]; first maximum wins."""
+    _need_gpu(logits)
+    logits = _f32c(logits)
+    T, B, V = logits.shape
+    idx = torch.empty(T, B, dtype=torch.int32, device=logits.device)
+    mx = torch.empty(T, B, dtype=torch.float32, device=logits.device)
+    call("vocr_argmax_rows", _p(logits), _p(idx), _p(mx), T * B, V, _stream())
+    return idx, mx
+
+
+def greedy_collapse(idx, mx, lens_dev, canon_dev, thresh):
+    T, B = idx.shape
+    labels = torch.zeros(B, T, dtype=torch.int32, device=idx.device)
+    counts = torch.empty(B, dtype=torch.int32, device=idx.device)
+    call("vocr_greedy_collapse", _p(idx), _p(mx), _p(lens_dev), _p(canon_dev), _p(labels), _p(counts), T, B, float(thresh),
+         _stream())
+    return labels, counts
+
+
+def clamp_adam(p, g, m, v, lr, beta1, beta2, eps, weight_decay, clamp, grad_scale, step):
+    _need_gpu(p, g, m, v)
+    call("vocr_clamp_adam", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
+         float(weight_decay), float(clamp), float(grad_scale), int(step), _stream())

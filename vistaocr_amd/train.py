@@ -1,0 +1,96 @@
+"""train() step of the reference (src/train_cnn_lstm.py:131-150) with the optimiser side fused for MI355X:
+all parameters live in ONE flat fp32 buffer (params / grads / Adam moments), so zero_grad is one memset, the
+data-parallel exchange is one RCCL all-reduce over xGMI on the flat gradient, and clamp(+-5) + Adam is one
+HBM-streaming kernel (vocr_clamp_adam) instead of ~150 small launches.
+
+Data parallelism: one process per GPU, full replica, per-rank batch; gradients are SUMMED
+across ranks before the clamp (the reference's loss is a batch SUM, so this equals one big batch of B*N)."""
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+class FlatClampAdam(object):
+    """torch.optim.Adam(lr, betas, eps, weight_decay) semantics + the reference's elementwise grad clamp, on a
+    flat parameter buffer.  API subset of torch.optim.Optimizer used by the reference loop: zero_grad(), step(),
+    param_groups[0]['lr'], state_dict()/load_state_dict()."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clamp=5.0):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no parameters")
+        dev = self.params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("FlatClampAdam needs parameters on the MI355X (no CPU fallback)")
+        n = sum(p.numel() for p in self.params)
+        self.flat_p = torch.empty(n, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        with torch.no_grad():
+            for p in self.params:
+                k = p.numel()
+                self.flat_p[off:off + k].copy_(p.data.reshape(-1))
+                p.data = self.flat_p[off:off + k].view_as(p)          # parameter storage now aliases the flat buffer
+                p.grad = self.flat_g[off:off + k].view_as(p)          # autograd accumulates in place into the flat grads
+                off += k
+        self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, clamp=clamp)]
+        self.step_count = 0
+
+    def zero_grad(self, set_to_none=False):
+        self.flat_g.zero_()
+        off = 0
+        for p in self.params:                                         # re-attach if someone set .grad = None
+            k = p.numel()
+            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + off * 4:
+                p.grad = self.flat_g[off:off + k].view_as(p)
+            off += k
+
+    def all_reduce_grads(self, group=None):
+        """Sum gradients over data-parallel ranks (RCCL over xGMI when the backend is 'nccl')."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=group)
+
+    def step(self, grad_scale=1.0):
+        g = self.param_groups[0]
+        self.step_count += 1
+        ops.clamp_adam(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, g["lr"], g["betas"][0], g["betas"][1],
+                       g["eps"], g["weight_decay"], g["clamp"], grad_scale, self.step_count)
+
+    def state_dict(self):
+        return dict(step=self.step_count, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, param_groups=self.param_groups)
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.param_groups[0].update({k: v for k, v in sd["param_groups"][0].items()})
+
+
+def train(batch, model, criterion, optimizer):
+    """One optimisation step — src/train_cnn_lstm.py:131-150.  `optimizer` is a FlatClampAdam (it performs the
+    reference's clamp(-5, 5) inside its fused step); returns the batch-summed loss as a Python float."""
+    input_tensor, target, input_widths, target_widths, metadata = batch
+    input_tensor = input_tensor.cuda(non_blocking=True)
+    optimizer.zero_grad()
+    model_output, model_output_actual_lengths = model(input_tensor, input_widths)
+    loss = criterion(model_output, target, model_output_actual_lengths, target_widths)
+    loss.backward()
+    optimizer.all_reduce_grads()
+    optimizer.step()
+    return loss.data[0].item()
+
+
+def train_async(batch, model, criterion, optimizer):
+    """Same step without the device->host sync of the returned float (returns the loss tensor)."""
+    input_tensor, target, input_widths, target_widths, metadata = batch
+    input_tensor = input_tensor.cuda(non_blocking=True)
+    optimizer.zero_grad()
+    model_output, model_output_actual_lengths = model(input_tensor, input_widths)
+    loss = criterion(model_output, target, model_output_actual_lengths, target_widths)
+    loss.backward()
+    optimizer.all_reduce_grads()
+    optimizer.step()
+    return loss.detach()
