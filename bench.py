@@ -1,0 +1,182 @@
+#!/usr/bin/env python
+"""bench.py — training line-images/sec of the CnnOcrModel hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (modelled on the reference's src/speed_test.py): per GPU a batch of 32
+synthetic 1x30x600 grey lines x~U[0,1), 20 labels/line, English alphabet (V=96), 3x BiLSTM-512, lstm_input_dim 128,
+dropout 0.5, fp32.  One step = forward + CTC + backward + (RCCL all-reduce of the flat gradient) + clamp(+-5) +
+Adam, exactly src/train_cnn_lstm.py:131-150.  The image batch is resident in HBM when the timed region starts
+(targets/lengths stay on the host, as in the reference's contract).  Prints ONE JSON line on rank 0."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+F32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 matrix peak (= vector peak)
+HBM_PEAK_GBS = 8000.0
+
+HP = dict(num_in_channels=1, input_line_height=30, rds_line_height=30, lstm_input_dim=128, num_lstm_layers=3,
+          num_lstm_hidden_units=512, p_lstm_dropout=0.5)
+B, HIMG, WIMG, LABELS = 32, 30, 600, 20
+
+
+def make_batch(rank, vocab):
+    g = torch.Generator().manual_seed(1234 + rank)
+    x = torch.rand(B, 1, HIMG, WIMG, generator=g)
+    widths = torch.full((B,), WIMG, dtype=torch.int32)
+    tgt = torch.randint(1, vocab, (B * LABELS,), generator=g).to(torch.int32)
+    tl = torch.full((B,), LABELS, dtype=torch.int32)
+    return x, tgt, widths, tl
+
+
+def conv_flops(args):
+    n, cin, h, w, cout = args[4:9]
+    return 2.0 * n * h * w * cin * cout * 9
+
+
+CPU_BASELINE_THREADS = 32     # oneDNN/ATen stop scaling (and collapse on the per-time-step LSTM ops) far below 256 threads
+
+
+def cpu_baseline_worker(vocab):
+    """The oracle (CPU restatement of the same step on PyTorch-CPU) on ONE batch-32 step of the same workload."""
+    from oracle import vista_oracle as vo
+    torch.manual_seed(0)
+    n_thr = min(os.cpu_count() or 1, CPU_BASELINE_THREADS)
+    torch.set_num_threads(n_thr)
+    sd = vo.init_uniform_state(HP, vocab, seed=0)
+    opt = torch.optim.Adam([p for _, p in vo.trainable(sd)], lr=1e-3)
+    x, tgt, widths, tl = make_batch(0, vocab)
+    u = (torch.rand(B, 64, 2), torch.rand(B, 128, 2))
+    # tiny warm-up (thread pools, oneDNN primitive caches) on 2 short lines, not timed
+    vo.train_step(sd, HP, opt, x[:2, :, :, :120].contiguous(), [120, 120], tgt[:2 * LABELS][:8], torch.tensor([4, 4], dtype=torch.int32),
+                  (u[0][:2], u[1][:2]))
+    t0 = time.time()
+    vo.train_step(sd, HP, opt, x, widths.tolist(), tgt, tl, u)
+    dt = time.time() - t0
+    return dict(value=round(B / dt, 3), unit="line-images/sec", cores=n_thr, kind="port",
+                sample="1 timed train step (fwd+CTC+bwd+clamp+Adam) of the same batch-32 30x600 workload on the oracle "
+                       "(PyTorch-CPU restatement), %.1f s" % dt)
+
+
+def cpu_baseline(vocab, limit_s=240):
+    """Run the CPU leg in a child process with a hard time limit so a slow host can never stall the bench."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker"], capture_output=True, text=True,
+                           timeout=limit_s, env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+        for line in reversed(r.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return dict(value=None, unit="line-images/sec", cores=0, kind="port", sample="worker failed: " + r.stderr[-200:])
+    except subprocess.TimeoutExpired:
+        return dict(value=round(B / limit_s, 3), unit="line-images/sec", cores=min(os.cpu_count() or 1, CPU_BASELINE_THREADS), kind="port",
+                    sample="upper bound: one batch-32 step did not finish within %d s" % limit_s)
+
+
+def main():
+    if "--cpu-baseline-worker" in sys.argv:
+        import vistaocr_amd as va
+        print(json.dumps(cpu_baseline_worker(len(va.english_alphabet()))))
+        return
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--hidden", type=int, default=512)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import vistaocr_amd as va
+    from vistaocr_amd import _lib
+    hp = dict(HP, num_lstm_hidden_units=args.hidden)
+    al = va.english_alphabet()
+    torch.manual_seed(0)                                  # same init on every rank (replicas)
+    model = va.CnnOcrModel(alphabet=al, verbose=False, **hp)
+    model.train()
+    opt = va.FlatClampAdam(model.parameters(), lr=1e-3)
+    crit = va.CTCLoss()
+    x, tgt, widths, tl = make_batch(rank, len(al))
+    x = x.cuda()
+    batch = (x, tgt, widths, tl, {})
+
+    def step():
+        return va.train_async(batch, model, crit, opt)
+
+    for _ in range(args.warmup):
+        step()
+    timed = ["vocr_conv3x3_fwd", "vocr_conv3x3_wgrad", "vocr_lstm_fwd", "vocr_lstm_bwd", "vocr_gemm"]
+    _lib.enable_timing(timed)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    recs = _lib.timing_records()
+    _lib.enable_timing(None)
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    final_loss = float(loss)
+
+    if rank == 0:
+        ms = 1000.0 * dt / args.steps
+        value = B * world * args.steps / dt
+        # roofline of the dominant kernel: conv3x3 implicit-GEMM (forward + dgrad launches), f32 MFMA-bound
+        cf_flops = sum(conv_flops(a) for a, _, _ in recs.get("vocr_conv3x3_fwd", []))
+        cf_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in recs.get("vocr_conv3x3_fwd", []))
+        n_launch = max(1, len(recs.get("vocr_conv3x3_fwd", [])))
+        achieved = cf_flops / (cf_ms * 1e-3) / 1e12 if cf_ms > 0 else 0.0
+        breakdown = {}
+        for name, lst in recs.items():
+            breakdown[name] = round(sum(e0.elapsed_time(e1) for _, e0, e1 in lst) / args.steps, 3)
+        out = {
+            "metric": "line-images/sec (train, batch 32, 30x600 grey)", "value": round(value, 2), "unit": "line-images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: 32 synthetic 1x30x600 grey lines per GPU, 20 labels/line, V=96, "
+                                   "3xBiLSTM-%d, fwd+CTC+bwd+allreduce+clamp+Adam" % args.hidden,
+                       "global_batch": B * world, "parallelism": "dp%d" % world, "final_loss": round(final_loss, 3)},
+            "roofline": {"bound": "mfma", "kernel": "conv3x3_kernel (implicit-GEMM fwd+dgrad, f32 MFMA 32x32x2)",
+                         "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "avg_launch_ms": round(cf_ms / n_launch, 4), "launches_per_step": n_launch // max(1, args.steps)},
+            "ms_per_step_by_entry_point": breakdown,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(len(al))
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

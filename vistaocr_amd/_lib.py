@@ -75,7 +75,30 @@ def check(rc, what):
         raise RuntimeError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
 
 
+# optional per-entry-point HIP-event timing (bench.py's roofline leg): name -> list of (args, start, end)
+_TIMED = None
+
+
+def enable_timing(names):
+    """Record a HIP event pair on the current torch stream around every call of the named entry points."""
+    global _TIMED
+    _TIMED = {n: [] for n in names} if names else None
+
+
+def timing_records():
+    return _TIMED or {}
+
+
 def call(name, *args):
-    rc = getattr(load(), name)(*args)
+    if _TIMED is not None and name in _TIMED:
+        import torch
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(load(), name)(*args)
+        e1.record()
+        _TIMED[name].append((args, e0, e1))
+    else:
+        rc = getattr(load(), name)(*args)
     if rc != 0:
         check(rc, name)
