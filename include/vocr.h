@@ -59,10 +59,11 @@ int vocr_bn_eval_stats(const float* running_mean, const float* running_var, int 
 /* out = relu((y-mean)*invstd*gamma + beta) */
 int vocr_bn_relu_apply(const float* y, const float* mean, const float* invstd, const float* gamma,
                        const float* beta, float* out, int n, int c, int hw, void* stream);
-/* given da = dL/d(out): dgamma, dbeta and dy = dL/d(y) (training-mode batch-stat backward through ReLU) */
+/* given da = dL/d(out): dgamma, dbeta and dy = dL/d(y) (training-mode batch-stat backward through ReLU);
+ * dconv_bias (may be NULL) receives sum_{n,h,w} dy per channel = the gradient of the conv bias in front. */
 int vocr_bn_relu_bwd(const float* da, const float* y, const float* mean, const float* invstd,
                      const float* gamma, const float* beta, float* dy, float* dgamma, float* dbeta,
-                     int n, int c, int hw, void* workspace, void* stream);
+                     float* dconv_bias, int n, int c, int hw, void* workspace, void* stream);
 
 /* ---- FractionalMaxPool2d(2, output_ratio=(0.5,0.7)) — src/models/cnnlstm.py:127,130 --------------------- */
 /* samples[n][c][2] (u_w, u_h) as ATen's _random_samples; idx = flat h*W+w of the winner (int32) */
@@ -107,8 +108,9 @@ int vocr_dropout_fwd(const float* x, float* out, float* mask, size_t count, floa
 size_t vocr_lstm_workspace_bytes(int t, int b, int h);
 int vocr_lstm_fwd(const float* xproj, const float* whh_fwd, const float* whh_rev, const int32_t* lens, float* y,
                   float* gates, float* cell, void* workspace, int t, int b, int h, void* stream);
-/* dy[T][B][2H] -> dgates[dir][T][B][4H] (gradient w.r.t. pre-activation gates = w.r.t. xproj). */
-int vocr_lstm_bwd(const float* dy, const float* whh_fwd, const float* whh_rev, const int32_t* lens, const float* gates,
+/* dy[T][B][2H] -> dgates[dir][T][B][4H] (gradient w.r.t. pre-activation gates = w.r.t. xproj).
+ * whht_* are the TRANSPOSED recurrent weights [H][4H] (vocr_bchw_to_wbch with b=1 transposes a matrix). */
+int vocr_lstm_bwd(const float* dy, const float* whht_fwd, const float* whht_rev, const int32_t* lens, const float* gates,
                   const float* cell, float* dgates, void* workspace, int t, int b, int h, void* stream);
 
 /* ---- CTC: warpctc_pytorch.CTCLoss — src/train_cnn_lstm.py:358,138 ------------------------------------------ */

@@ -143,7 +143,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ beta,
                                                            const float* __restrict__ dgamma,
                                                            const float* __restrict__ dbeta, float* __restrict__ dy,
-                                                           int C, long HW, float inv_count) {
+                                                           float* __restrict__ dconv_bias, int C, long HW,
+                                                           float inv_count) {
+    __shared__ float redf[4];
     const long plane = blockIdx.y;
     const int c = (int)(plane % C);
     const float mu = mean[c], is = invstd[c], g = gamma[c], b = beta[c];
@@ -151,11 +153,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const float* yp = y + plane * HW;
     const float* dp = da + plane * HW;
     float* op = dy + plane * HW;
+    float acc = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < HW; i += (long)gridDim.x * 256) {
         const float xh = (yp[i] - mu) * is;
         const float o = xh * g + b;
         const float dz = o > 0.f ? dp[i] : 0.f;
-        op[i] = gs * (dz - k1 - xh * k2);
+        const float v = gs * (dz - k1 - xh * k2);
+        op[i] = v;
+        acc += v;
+    }
+    if (dconv_bias) {     // gradient of the conv bias in front of the BN = sum of dy (zero up to rounding); fused here
+        acc = wave_sum(acc);
+        if ((threadIdx.x & 63) == 0) redf[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(dconv_bias + c, (redf[0] + redf[1]) + (redf[2] + redf[3]));
     }
 }
 
@@ -283,8 +294,8 @@ extern "C" int vocr_bn_relu_apply(const float* y, const float* mean, const float
 }
 
 extern "C" int vocr_bn_relu_bwd(const float* da, const float* y, const float* mean, const float* invstd,
-                                const float* gamma, const float* beta, float* dy, float* dgamma, float* dbeta, int n,
-                                int c, int hw, void* workspace, void* stream) {
+                                const float* gamma, const float* beta, float* dy, float* dgamma, float* dbeta,
+                                float* dconv_bias, int n, int c, int hw, void* workspace, void* stream) {
     VOCR_CHECK_ARG(da && y && mean && invstd && gamma && beta && dy && dgamma && dbeta && workspace, "vocr_bn_relu_bwd: null pointer");
     VOCR_CHECK_ARG(n > 0 && c > 0 && hw > 0 && (long)n * c <= 65535, "vocr_bn_relu_bwd: bad shape");
     hipStream_t s = (hipStream_t)stream;
@@ -293,8 +304,12 @@ extern "C" int vocr_bn_relu_bwd(const float* da, const float* y, const float* me
     VOCR_CHECK_LAUNCH("vocr_bn_relu_bwd(partial)");
     bn_bwd_final_kernel<<<vocr_cdiv(c, 64), 64, 0, s>>>((const double*)workspace, c, nchunk, dgamma, dbeta);
     VOCR_CHECK_LAUNCH("vocr_bn_relu_bwd(final)");
-    bn_bwd_apply_kernel<<<plane_grid((long)n * c, hw), 256, 0, s>>>(da, y, mean, invstd, gamma, beta, dgamma, dbeta, dy, c, hw,
-                                                                    1.0f / (float)((long)n * hw));
+    if (dconv_bias && hipMemsetAsync(dconv_bias, 0, (size_t)c * sizeof(float), s) != hipSuccess) {
+        vocr_set_error("vocr_bn_relu_bwd: memset failed");
+        return VOCR_ELAUNCH;
+    }
+    bn_bwd_apply_kernel<<<plane_grid((long)n * c, hw), 256, 0, s>>>(da, y, mean, invstd, gamma, beta, dgamma, dbeta, dy,
+                                                                    dconv_bias, c, hw, 1.0f / (float)((long)n * hw));
     VOCR_CHECK_LAUNCH("vocr_bn_relu_bwd(apply)");
     return VOCR_OK;
 }

@@ -271,19 +271,26 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
     dw[r * 9 + t] = s;
 }
 
-// per-channel sum over (n, h*w): deterministic two-level reduction, double accumulation
-__global__ void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int N, int C, long HW) {
+// per-channel sum over (n, h*w): grid (C, chunks); double accumulation inside a workgroup, float atomics across
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int N, int C,
+                                                          long HW, int nchunk) {
     __shared__ double red[4];
-    const int c = blockIdx.x;
+    const int c = blockIdx.x, j = blockIdx.y;
+    const long total = (long)N * HW;
+    const long per = (total + nchunk - 1) / nchunk;
+    const long beg = j * per, end = min(total, beg + per);
     double s = 0.0;
-    for (int n = 0; n < N; ++n) {
-        const float* p = x + ((long)n * C + c) * HW;
-        for (long i = threadIdx.x; i < HW; i += blockDim.x) s += (double)p[i];
+    for (long e = beg + threadIdx.x; e < end; e += 256) {
+        const long n = e / HW, r = e - n * HW;
+        s += (double)x[(n * C + c) * HW + r];
     }
     s = wave_sum_d(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) out[c] = (float)((red[0] + red[1]) + (red[2] + red[3]));
+    if (threadIdx.x == 0) {
+        const float v = (float)((red[0] + red[1]) + (red[2] + red[3]));
+        if (nchunk > 1) atomicAdd(out + c, v); else out[c] = v;
+    }
 }
 
 int wgrad_splits(int n, int cin, int h, int w, int cout, int* segs_per_split) {
@@ -354,7 +361,15 @@ extern "C" int vocr_conv3x3_wgrad(const float* x, const float* dy, float* dw, vo
 
 extern "C" int vocr_channel_sum(const float* x, float* out, int n, int c, int hw, void* stream) {
     VOCR_CHECK_ARG(x && out && n > 0 && c > 0 && hw > 0, "vocr_channel_sum: bad argument");
-    channel_sum_kernel<<<c, 256, 0, (hipStream_t)stream>>>(x, out, n, c, hw);
+    hipStream_t s = (hipStream_t)stream;
+    long nchunk = ((long)n * hw + 16383) / 16384;
+    if (nchunk > 64) nchunk = 64;
+    if (nchunk < 1) nchunk = 1;
+    if (nchunk > 1 && hipMemsetAsync(out, 0, (size_t)c * sizeof(float), s) != hipSuccess) {
+        vocr_set_error("vocr_channel_sum: memset failed");
+        return VOCR_ELAUNCH;
+    }
+    channel_sum_kernel<<<dim3(c, (unsigned)nchunk), 256, 0, s>>>(x, out, n, c, hw, (int)nchunk);
     VOCR_CHECK_LAUNCH("vocr_channel_sum");
     return VOCR_OK;
 }

@@ -145,17 +145,25 @@ void launch_cfg(int ta, int tb, dim3 grid, hipStream_t s, int M, int N, int K, c
         gemm_f32_kernel<BM, BN, WM, WN, false, false><<<grid, 256, 0, s>>>(M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, relu, acc, kps);
 }
 
-__global__ void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int M, int N) {
-    // one workgroup per 64 columns; 4 waves stride the rows; deterministic order
+// out[n] += sum of rows [r0, r1) of x[:, n]; grid (N/64 column tiles, row splits); float atomics combine splits
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int M, int N,
+                                                     int rows_per_split) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + lane;
-    float s = 0.f;
-    if (n < N)
-        for (int m = wave; m < M; m += 4) s += x[(long)m * N + n];
-    red[wave][lane] = s;
+    const int r0 = blockIdx.y * rows_per_split, r1 = min(M, r0 + rows_per_split);
+    float s0 = 0.f, s1 = 0.f;
+    if (n < N) {
+        int m = r0 + wave;
+        for (; m + 4 < r1; m += 8) { s0 += x[(long)m * N + n]; s1 += x[(long)(m + 4) * N + n]; }
+        if (m < r1) s0 += x[(long)m * N + n];
+    }
+    red[wave][lane] = s0 + s1;
     __syncthreads();
-    if (wave == 0 && n < N) out[n] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (wave == 0 && n < N) {
+        const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        if (gridDim.y > 1) atomicAdd(out + n, v); else out[n] = v;
+    }
 }
 
 __global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ out, float* __restrict__ dz, size_t n) {
@@ -242,13 +250,15 @@ extern "C" int vocr_gemm(int transa, int transb, int m, int n, int k, const floa
     const long sam = transa ? 1 : lda, sak = transa ? lda : 1;
     const long sbk = transb ? 1 : ldb, sbn = transb ? ldb : 1;
     const long tiles128 = (long)vocr_cdiv(m, 128) * vocr_cdiv(n, 128);
-    const bool big = tiles128 >= 192;
+    const bool can_split = !bias && !relu && k >= 1024;
+    // 128x128 tiles (32 FLOP per LDS-staged byte) whenever they can fill the chip, possibly with split-K
+    const bool big = m >= 96 && n >= 96 && (tiles128 >= 192 || (can_split && tiles128 * (k / 512) >= 128));
     const int bm = big ? 128 : 64;
     const long tiles = (long)vocr_cdiv(m, bm) * vocr_cdiv(n, bm);
     int splits = 1;
-    if (!bias && !relu && tiles < 256 && k >= 1024) {
+    if (can_split && tiles < 384) {
         splits = (int)((512 + tiles - 1) / tiles);
-        const int maxs = k / 256;
+        const int maxs = k / 512;
         if (splits > maxs) splits = maxs;
         if (splits < 1) splits = 1;
     }
@@ -271,7 +281,18 @@ extern "C" int vocr_gemm(int transa, int transb, int m, int n, int k, const floa
 
 extern "C" int vocr_colsum(const float* x, float* out, int m, int n, void* stream) {
     VOCR_CHECK_ARG(x && out && m > 0 && n > 0, "vocr_colsum: bad argument");
-    colsum_kernel<<<vocr_cdiv(n, 64), 256, 0, (hipStream_t)stream>>>(x, out, m, n);
+    hipStream_t s = (hipStream_t)stream;
+    const int ctiles = vocr_cdiv(n, 64);
+    int splits = vocr_cdiv(1024, ctiles);
+    if (splits > vocr_cdiv(m, 32)) splits = vocr_cdiv(m, 32);
+    if (splits < 1) splits = 1;
+    const int rps = vocr_cdiv(m, splits);
+    splits = vocr_cdiv(m, rps);
+    if (splits > 1 && hipMemsetAsync(out, 0, (size_t)n * sizeof(float), s) != hipSuccess) {
+        vocr_set_error("vocr_colsum: memset failed");
+        return VOCR_ELAUNCH;
+    }
+    colsum_kernel<<<dim3(ctiles, splits), 256, 0, s>>>(x, out, m, n, rps);
     VOCR_CHECK_LAUNCH("vocr_colsum");
     return VOCR_OK;
 }

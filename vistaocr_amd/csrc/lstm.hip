@@ -132,8 +132,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(const float* __restr
 
     if (step > 0) {
         const float* dgp = dgates + (((long)dir * T + tv) * B) * 4 * H + nbase;
-        const float* whh = dir ? whh_r : whh_f;
-        const float* wp = whh + (long)nbase * H + unit0 + lr;
+        const float* whht = dir ? whh_r : whh_f;          // transposed weights: whhT[unit][n], n over 4H
+        const float* wp = whht + (long)(unit0 + lr) * 4 * H + nbase;
         const float* ga[4];
         bool gv[4];
 #pragma unroll
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(const float* __restr
         }
 #pragma unroll 4
         for (int s = 0; s < KQ; ++s) {
-            const float bw = wp[(long)s * H];
+            const float bw = wp[s];
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt) {
                 if (rt < RT) {
@@ -191,6 +191,222 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(const float* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------ fast paths
+// Same algorithms, shaped for the hardware: every operand a lane needs is a run of consecutive floats, so
+// all global reads are 16-byte loads issued up front (one latency exposure per step instead of one per k).
+
+// H = 64*KQ4, B <= 16*RT.  grid.x = 2 * (H/4).
+template <int KQ4, int RT>
+__global__ __launch_bounds__(256) void lstm_fwd_step_fast(const float* __restrict__ xproj, const float* __restrict__ whh_f,
+                                                          const float* __restrict__ whh_r, const int32_t* __restrict__ lens,
+                                                          float* __restrict__ y, float* __restrict__ gates,
+                                                          float* __restrict__ cell, const float* __restrict__ h_prev,
+                                                          float* __restrict__ h_next, float* __restrict__ cbuf, int T, int B,
+                                                          int step) {
+    constexpr int H = 64 * KQ4;
+    __shared__ float red[4][RT * 16][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int ublocks = H >> 2;
+    const int dir = blockIdx.x / ublocks, unit0 = (blockIdx.x % ublocks) * 4;
+    const int t = dir == 0 ? step : T - 1 - step;
+    const int lr = lane & 15, q = lane >> 4;
+    const int kbase = wave * (H >> 2) + q * (H >> 4);
+    const float* hp = h_prev + (long)dir * B * H;
+    const float* whh = dir ? whh_r : whh_f;
+
+    // cell-update operands are fetched before the MFMA phase so their latency hides under it
+    const bool cellthr = tid < B * 4;
+    const int cb_ = tid >> 2, cu = tid & 3, unit = unit0 + cu;
+    const long gbase = (((long)dir * T + t) * B + (cellthr ? cb_ : 0)) * 4 * H + unit;
+    float xp[4] = {0.f, 0.f, 0.f, 0.f};
+    float cprev = 0.f, hprev = 0.f;
+    int len_b = 0;
+    if (cellthr) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xp[g] = xproj[gbase + (long)g * H];
+        len_b = lens[cb_];
+        if (step > 0) {
+            cprev = cbuf[((long)dir * B + cb_) * H + unit];
+            hprev = hp[(long)cb_ * H + unit];
+        }
+    }
+
+    f32x4 acc[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (step > 0) {
+        const f32x4* wp = (const f32x4*)(whh + ((long)(lr >> 2) * H + unit0 + (lr & 3)) * H + kbase);
+        f32x4 wv[KQ4], hv[RT][KQ4];
+#pragma unroll
+        for (int i = 0; i < KQ4; ++i) wv[i] = wp[i];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int b = rt * 16 + lr;
+            const f32x4* hq = (const f32x4*)(hp + (long)(b < B ? b : 0) * H + kbase);
+#pragma unroll
+            for (int i = 0; i < KQ4; ++i) {
+                f32x4 v = hq[i];
+                if (b >= B) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                hv[rt][i] = v;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);     // keep every load above the MFMA phase: one latency exposure per step
+#pragma unroll
+        for (int i = 0; i < KQ4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[rt][i][e], wv[i][e], acc[rt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][rt * 16 + q * 4 + r][lr] = acc[rt][r];
+    __syncthreads();
+
+    if (cellthr) {
+        const int b = cb_, u = cu;
+        const bool active = t < len_b;
+        const long cidx = ((long)dir * B + b) * H + unit;
+        const long sidx = (((long)dir * T + t) * B + b) * H + unit;
+        float pre[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            pre[g] = ((red[0][b][g * 4 + u] + red[1][b][g * 4 + u]) + (red[2][b][g * 4 + u] + red[3][b][g * 4 + u])) + xp[g];
+        float* hn = h_next + (long)dir * B * H + (long)b * H + unit;
+        float* yo = y + ((long)t * B + b) * 2 * H + dir * H + unit;
+        if (active) {
+            const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
+            const float c = fg * cprev + ig * gg;
+            const float h = og * tanhf(c);
+            gates[gbase] = ig;
+            gates[gbase + H] = fg;
+            gates[gbase + 2l * H] = gg;
+            gates[gbase + 3l * H] = og;
+            cell[sidx] = c;
+            cbuf[cidx] = c;
+            *hn = h;
+            *yo = h;
+        } else {
+            gates[gbase] = 0.f;
+            gates[gbase + H] = 0.f;
+            gates[gbase + 2l * H] = 0.f;
+            gates[gbase + 3l * H] = 0.f;
+            cell[sidx] = 0.f;
+            if (step == 0) cbuf[cidx] = 0.f;
+            *hn = hprev;
+            *yo = 0.f;
+        }
+    }
+}
+
+// H = 128*NCH.  grid.x = 2 * (H/16) * RT : one workgroup per (direction, 16 units, 16 batch rows).
+// whhT = transposed recurrent weights [H][4H] so the B operand (W_hh[n][unit], n running) is contiguous.
+template <int NCH>
+__global__ __launch_bounds__(256) void lstm_bwd_step_fast(const float* __restrict__ dy, const float* __restrict__ whht_f,
+                                                          const float* __restrict__ whht_r, const int32_t* __restrict__ lens,
+                                                          const float* __restrict__ gates, const float* __restrict__ cell,
+                                                          float* __restrict__ dgates, float* __restrict__ dcbuf, int T, int B,
+                                                          int step, int RT) {
+    constexpr int H = 128 * NCH;
+    __shared__ float red[4][16][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int ublocks = H >> 4;
+    int bid = blockIdx.x;
+    const int bt = bid % RT;
+    bid /= RT;
+    const int dir = bid / ublocks, unit0 = (bid % ublocks) * 16;
+    const int t = dir == 0 ? T - 1 - step : step;
+    const int tv = dir == 0 ? t + 1 : t - 1;
+    const int lr = lane & 15, q = lane >> 4;
+    const int nbase = wave * H + q * (H >> 2);
+
+    // epilogue operands first (latency hides under the MFMA phase): one cell per thread
+    const int eb = bt * 16 + (tid >> 4), ej = tid & 15, eunit = unit0 + ej;
+    const bool ev = eb < B;
+    const int ebs = ev ? eb : 0;
+    const int len = lens[ebs];
+    const long gbase = (((long)dir * T + t) * B + ebs) * 4 * H + eunit;
+    const long cb = ((long)dir * B + ebs) * H + eunit;
+    const bool act = ev && t < len;
+    float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, c = 0.f, cprev = 0.f, dyv = 0.f, dcar = 0.f;
+    if (act) {
+        ig = gates[gbase];
+        fg = gates[gbase + H];
+        gg = gates[gbase + 2l * H];
+        og = gates[gbase + 3l * H];
+        c = cell[(((long)dir * T + t) * B + ebs) * H + eunit];
+        const int tp = dir == 0 ? t - 1 : t + 1;
+        cprev = (tp >= 0 && tp < len) ? cell[(((long)dir * T + tp) * B + ebs) * H + eunit] : 0.f;
+        dyv = dy[((long)t * B + ebs) * 2 * H + dir * H + eunit];
+        dcar = step > 0 ? dcbuf[cb] : 0.f;
+    }
+
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (step > 0) {
+        const int b = bt * 16 + lr;
+        const bool bv = b < B;
+        const f32x4* ap = (const f32x4*)(dgates + (((long)dir * T + tv) * B + (bv ? b : 0)) * 4 * H + nbase);
+        const float* whht = dir ? whht_r : whht_f;
+        const f32x4* bp = (const f32x4*)(whht + (long)(unit0 + lr) * 4 * H + nbase);
+        f32x4 av[2][8], bw[2][8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { av[0][i] = ap[i]; bw[0][i] = bp[i]; }
+#pragma unroll
+        for (int cidx = 0; cidx < NCH; ++cidx) {
+            const int cur = cidx & 1, nxt = cur ^ 1;
+            if (cidx + 1 < NCH) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { av[nxt][i] = ap[(cidx + 1) * 8 + i]; bw[nxt][i] = bp[(cidx + 1) * 8 + i]; }
+            }
+            __builtin_amdgcn_sched_barrier(0);   // next chunk's loads stay above this chunk's MFMAs
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bv ? av[cur][i][e] : 0.f, bw[cur][i][e], acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][q * 4 + r][lr] = acc[r];
+    __syncthreads();
+
+    if (ev) {
+        if (!act) {
+            dgates[gbase] = 0.f;
+            dgates[gbase + H] = 0.f;
+            dgates[gbase + 2l * H] = 0.f;
+            dgates[gbase + 3l * H] = 0.f;
+            dcbuf[cb] = 0.f;
+        } else {
+            const int bl = tid >> 4;
+            const float dh = dyv + ((red[0][bl][ej] + red[1][bl][ej]) + (red[2][bl][ej] + red[3][bl][ej]));
+            const float tc = tanhf(c);
+            const float dc = dcar + dh * og * (1.f - tc * tc);
+            dgates[gbase] = dc * gg * ig * (1.f - ig);
+            dgates[gbase + H] = dc * cprev * fg * (1.f - fg);
+            dgates[gbase + 2l * H] = dc * ig * (1.f - gg * gg);
+            dgates[gbase + 3l * H] = dh * tc * og * (1.f - og);
+            dcbuf[cb] = dc * fg;
+        }
+    }
+}
+
+template <int KQ4>
+bool launch_fwd_fast(int rt, dim3 grid, hipStream_t s, const float* xproj, const float* wf, const float* wr, const int32_t* lens,
+                     float* y, float* gates, float* cell, const float* hp, float* hn, float* cb, int T, int B, int step) {
+    switch (rt) {
+        case 1: lstm_fwd_step_fast<KQ4, 1><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, hp, hn, cb, T, B, step); return true;
+        case 2: lstm_fwd_step_fast<KQ4, 2><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, hp, hn, cb, T, B, step); return true;
+        case 3: lstm_fwd_step_fast<KQ4, 3><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, hp, hn, cb, T, B, step); return true;
+        case 4: lstm_fwd_step_fast<KQ4, 4><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, hp, hn, cb, T, B, step); return true;
+    }
+    return false;
+}
+
+inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
 }  // namespace
 
 extern "C" size_t vocr_lstm_workspace_bytes(int t, int b, int h) {
@@ -207,23 +423,47 @@ extern "C" int vocr_lstm_fwd(const float* xproj, const float* whh_fwd, const flo
     const size_t st = (size_t)2 * b * h;
     float* hb[2] = {ws, ws + st};
     float* cb = ws + 2 * st;
+    const int rt = (b + 15) / 16;
+    const bool fast = (h == 64 || h == 128 || h == 256 || h == 512) && aligned16(whh_fwd) && aligned16(whh_rev) && aligned16(ws);
+    const dim3 grid(2 * (h / 4));
     for (int step = 0; step < t; ++step) {
-        lstm_fwd_step_kernel<<<2 * (h / 4), 256, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, hb[step & 1], hb[(step + 1) & 1], cb,
-                                                         t, b, h, step);
+        const float* hp = hb[step & 1];
+        float* hn = hb[(step + 1) & 1];
+        if (fast) {
+            switch (h) {
+                case 64: launch_fwd_fast<1>(rt, grid, s, xproj, whh_fwd, whh_rev, lens, y, gates, cell, hp, hn, cb, t, b, step); break;
+                case 128: launch_fwd_fast<2>(rt, grid, s, xproj, whh_fwd, whh_rev, lens, y, gates, cell, hp, hn, cb, t, b, step); break;
+                case 256: launch_fwd_fast<4>(rt, grid, s, xproj, whh_fwd, whh_rev, lens, y, gates, cell, hp, hn, cb, t, b, step); break;
+                default: launch_fwd_fast<8>(rt, grid, s, xproj, whh_fwd, whh_rev, lens, y, gates, cell, hp, hn, cb, t, b, step); break;
+            }
+        } else {
+            lstm_fwd_step_kernel<<<grid, 256, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, hp, hn, cb, t, b, h, step);
+        }
     }
     VOCR_CHECK_LAUNCH("vocr_lstm_fwd");
     return VOCR_OK;
 }
 
-extern "C" int vocr_lstm_bwd(const float* dy, const float* whh_fwd, const float* whh_rev, const int32_t* lens,
+extern "C" int vocr_lstm_bwd(const float* dy, const float* whht_fwd, const float* whht_rev, const int32_t* lens,
                              const float* gates, const float* cell, float* dgates, void* workspace, int t, int b, int h,
                              void* stream) {
+    const float* whh_fwd = whht_fwd;
+    const float* whh_rev = whht_rev;
     VOCR_CHECK_ARG(dy && whh_fwd && whh_rev && lens && gates && cell && dgates && workspace, "vocr_lstm_bwd: null pointer");
     VOCR_CHECK_ARG(t > 0 && b > 0 && b <= 64 && h > 0 && h % 16 == 0, "vocr_lstm_bwd: need 1<=B<=64 and H%%16==0 (B=%d H=%d)", b, h);
     hipStream_t s = (hipStream_t)stream;
     float* dcb = (float*)workspace;
+    const int rt = (b + 15) / 16;
+    const bool fast = (h == 128 || h == 256 || h == 512) && aligned16(whh_fwd) && aligned16(whh_rev) && aligned16(dgates);
     for (int step = 0; step < t; ++step) {
-        lstm_bwd_step_kernel<<<2 * (h / 16), 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, dcb, t, b, h, step);
+        if (fast) {
+            const dim3 grid(2 * (h / 16) * rt);
+            if (h == 128) lstm_bwd_step_fast<1><<<grid, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, dcb, t, b, step, rt);
+            else if (h == 256) lstm_bwd_step_fast<2><<<grid, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, dcb, t, b, step, rt);
+            else lstm_bwd_step_fast<4><<<grid, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, dcb, t, b, step, rt);
+        } else {
+            lstm_bwd_step_kernel<<<2 * (h / 16), 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, dcb, t, b, h, step);
+        }
     }
     VOCR_CHECK_LAUNCH("vocr_lstm_bwd");
     return VOCR_OK;

@@ -107,9 +107,9 @@ class ConvBnReluFn(torch.autograd.Function):
         dgamma = torch.empty_like(gamma)
         dbeta = torch.empty_like(beta)
         ws = _ws(lib.vocr_bn_workspace_bytes(n, cout, h * w), x.device)
+        dbias = torch.empty(cout, dtype=torch.float32, device=x.device)
         call("vocr_bn_relu_bwd", _p(da), _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(dy), _p(dgamma), _p(dbeta),
-             n, cout, h * w, _p(ws), _stream())
-        dbias = channel_sum(dy)
+             _p(dbias), n, cout, h * w, _p(ws), _stream())
         dw = conv3x3_wgrad(x, dy)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -189,6 +189,14 @@ def colsum(x2d):
     m, n = x2d.shape
     out = torch.empty(n, dtype=torch.float32, device=x2d.device)
     call("vocr_colsum", _p(x2d), _p(out), m, n, _stream())
+    return out
+
+
+def transpose2d(x):
+    """[R][C] -> [C][R] (the bchw->wbch kernel with b=1 is a tiled matrix transpose)."""
+    r, c = x.shape
+    out = torch.empty(c, r, dtype=torch.float32, device=x.device)
+    call("vocr_bchw_to_wbch", _p(x), _p(out), 1, r, 1, c, _stream())
     return out
 
 
@@ -331,7 +339,8 @@ class BiLstmLayerFn(torch.autograd.Function):
         dev = x.device
         dg = torch.empty(2, T * B, 4 * H, dtype=torch.float32, device=dev)
         ws = _ws(lib.vocr_lstm_workspace_bytes(T, B, H), dev)
-        call("vocr_lstm_bwd", _p(dy), _p(w_hh_f), _p(w_hh_r), _p(lens_dev), _p(gates), _p(cell), _p(dg), _p(ws), T, B, H,
+        wt_f, wt_r = transpose2d(w_hh_f), transpose2d(w_hh_r)            # [H][4H]: contiguous B operand for the sweep
+        call("vocr_lstm_bwd", _p(dy), _p(wt_f), _p(wt_r), _p(lens_dev), _p(gates), _p(cell), _p(dg), _p(ws), T, B, H,
              _stream())
         G = 4 * H
         dw_ih_f = torch.empty_like(w_ih_f)
