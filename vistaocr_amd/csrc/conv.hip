@@ -35,16 +35,29 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
 
 struct SegInfo { long base; int h; int w0; int valid; };
 
-template <int CO_T>
+// Out-of-range operands are read from this zero page instead of being selected after the load: the ADDRESS is
+// selected, the load itself stays unconditional, so hipcc keeps all of a chunk's loads in flight together
+// (a select on the loaded value gets turned into one exec-masked branch + s_waitcnt vmcnt(0) per load).
+__device__ __attribute__((aligned(16))) float g_zero_page[64];
+
+// Loader layout (index arithmetic is wave-uniform or hoisted, so the chunk loop issues almost no VALU):
+//   patch : wave w stages the halo rows of its own segment(s): row = (ci, kh), lanes 0..33 = the 34 columns
+//   weights: 16-byte loads, a thread keeps one float4 column and walks rows with a constant stride
+//   K order inside a chunk: MFMA step ks multiplies k = ks (lanes 0-31) and k = ks + 36 (lanes 32-63), i.e.
+//   channels ci and ci+4 of the chunk, so both A and B fragment addresses are lane-constant base + immediate.
+template <int CO_T, bool VECW>
 __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ in, const float* __restrict__ wpack,
-                                                      const float* __restrict__ bias, float* __restrict__ out, int N,
-                                                      int Cin, int H, int W, int Cout, int SW, int nseg_total) {
+                                                      const float* __restrict__ bias, float* __restrict__ out,
+                                                      const float* __restrict__ zero_page, int N, int Cin, int H, int W,
+                                                      int Cout, int SW, int nseg_total) {
     constexpr int WAVES_CO = CO_T / 64;
     constexpr int WAVES_PX = 4 / WAVES_CO;
     constexpr int NSEG = WAVES_PX * 2;
-    constexpr int EA = KC * CO_T / 256;                    // 36 or 18
-    constexpr int EP = (NSEG * PSEG + 255) / 256;          // 13 or 26
-    __shared__ float Wt[KC * CO_T];
+    constexpr int SPW = NSEG / 4;                          // segments staged per wave: 1 or 2
+    constexpr int C4 = CO_T / 4;                           // float4 columns of the weight tile
+    constexpr int RPP = 256 / C4;                          // weight rows per pass: 8 or 16
+    constexpr int EA = (KC + RPP - 1) / RPP;               // 9 or 5 passes
+    __shared__ __attribute__((aligned(16))) float Wt[KC * CO_T];
     __shared__ float P[NSEG * PSEG];
     __shared__ SegInfo segs[NSEG];
 
@@ -77,40 +90,75 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float ra[EA], rp[EP];
+    // ---- hoisted loader state
+    const int wc4 = tid % C4, wr0 = tid / C4;
+    const int wcol = co0 + wc4 * 4;
+    const int wcol_c = VECW ? min(wcol, Cout - 4) : 0;      // clamped: loads are unconditional, results are selected
     const int Ktot = Cin * 9;
+    f32x4 ra[EA];
+    float rp[SPW * 24];
+    int p_h[SPW], p_valid[SPW], p_loff[SPW];
+    const float* p_base[SPW];
+    bool p_colok[SPW];
+#pragma unroll
+    for (int q = 0; q < SPW; ++q) {
+        const SegInfo sg = segs[wave * SPW + q];
+        const int ww = sg.w0 - 1 + lane;
+        p_h[q] = sg.h;
+        p_valid[q] = sg.valid;
+        p_colok[q] = sg.valid && lane < PROW && ww >= 0 && ww < W;
+        p_loff[q] = p_colok[q] ? ww : 0;
+        p_base[q] = in + sg.base;
+    }
 
+    // branch-free: every load is issued from a clamped (always valid) address, invalid lanes are zeroed by a select
     auto load_chunk = [&](int ci0) {
 #pragma unroll
         for (int e = 0; e < EA; ++e) {
-            const int idx = tid + 256 * e;
-            const int kk = idx / CO_T, co = idx % CO_T;
-            const int gk = ci0 * 9 + kk, gco = co0 + co;
-            ra[e] = (gk < Ktot && gco < Cout) ? wpack[(long)gk * Cout + gco] : 0.f;
+            const int r = wr0 + e * RPP;
+            const int gk = ci0 * 9 + r;
+            const bool rok = r < KC && gk < Ktot;
+            const int gkc = min(gk, Ktot - 1);
+            f32x4 v;
+            if (VECW) {
+                const f32x4* src = (const f32x4*)(wpack + (long)gkc * Cout + wcol_c);
+                v = *((rok && wcol < Cout) ? src : (const f32x4*)zero_page);
+            } else {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    const float* src = wpack + (long)gkc * Cout + min(wcol + x, Cout - 1);
+                    v[x] = *((rok && wcol + x < Cout) ? src : zero_page);
+                }
+            }
+            ra[e] = v;
         }
 #pragma unroll
-        for (int e = 0; e < EP; ++e) {
-            const int idx = tid + 256 * e;
-            float v = 0.f;
-            if (idx < NSEG * PSEG) {
-                const int sg = idx / PSEG, r1 = idx % PSEG;
-                const int ci = r1 / PCI, r2 = r1 % PCI;
-                const int kh = r2 / PROW, col = r2 % PROW;
-                const SegInfo s = segs[sg];
-                const int hh = s.h + kh - 1, ww = s.w0 + col - 1, gci = ci0 + ci;
-                if (s.valid && gci < Cin && hh >= 0 && hh < H && ww >= 0 && ww < W)
-                    v = in[s.base + (long)gci * HW + (long)hh * W + ww];
-            }
-            rp[e] = v;
-        }
+        for (int q = 0; q < SPW; ++q)
+#pragma unroll
+            for (int ci = 0; ci < CI_C; ++ci)
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const int hh = p_h[q] + kh - 1;
+                    const bool rowok = (ci0 + ci) < Cin && hh >= 0 && hh < H;                 // wave-uniform
+                    const int cic = min(ci0 + ci, Cin - 1), hhc = min(max(hh, 0), H - 1);
+                    const float* src = p_base[q] + ((long)cic * HW + (long)hhc * W + p_loff[q]);
+                    rp[q * 24 + ci * 3 + kh] = *((rowok && p_colok[q]) ? src : zero_page + lane);
+                }
     };
     auto store_chunk = [&]() {
 #pragma unroll
-        for (int e = 0; e < EA; ++e) Wt[tid + 256 * e] = ra[e];
+        for (int e = 0; e < EA; ++e) {
+            const int r = wr0 + e * RPP;
+            if (r < KC) *(f32x4*)(Wt + r * CO_T + wc4 * 4) = ra[e];
+        }
+        if (lane < PROW) {
 #pragma unroll
-        for (int e = 0; e < EP; ++e) {
-            const int idx = tid + 256 * e;
-            if (idx < NSEG * PSEG) P[idx] = rp[e];
+            for (int q = 0; q < SPW; ++q)
+#pragma unroll
+                for (int ci = 0; ci < CI_C; ++ci)
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh)
+                        P[(wave * SPW + q) * PSEG + ci * PCI + kh * PROW + lane] = rp[q * 24 + ci * 3 + kh];
         }
     };
 
@@ -118,19 +166,15 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
     load_chunk(0);
     store_chunk();
     __syncthreads();
+    const float* wa = Wt + wco + li + lk * (KC / 2) * CO_T;
+    const float* pb0 = P + (wsg + 0) * PSEG + li + lk * (CI_C / 2) * PCI;
+    const float* pb1 = P + (wsg + 1) * PSEG + li + lk * (CI_C / 2) * PCI;
     for (int c = 0; c < nchunks; ++c) {
         if (c + 1 < nchunks) load_chunk((c + 1) * CI_C);
-        const float* wa = Wt + wco + li;
-        const float* pb0 = P + (wsg + 0) * PSEG + li;
-        const float* pb1 = P + (wsg + 1) * PSEG + li;
 #pragma unroll
         for (int ks = 0; ks < KC / 2; ++ks) {
-            const int k0 = 2 * ks, k1 = 2 * ks + 1;
-            const int o0 = (k0 / 9) * PCI + ((k0 % 9) / 3) * PROW + (k0 % 3);
-            const int o1 = (k1 / 9) * PCI + ((k1 % 9) / 3) * PROW + (k1 % 3);
-            const int off = lk ? o1 : o0;
-            const int kr = lk ? k1 : k0;
-            const float a0 = wa[kr * CO_T], a1 = wa[kr * CO_T + 32];
+            const int off = (ks / 9) * PCI + ((ks % 9) / 3) * PROW + (ks % 3);     // compile-time after unrolling
+            const float a0 = wa[ks * CO_T], a1 = wa[ks * CO_T + 32];
             const float b0 = pb0[off], b1 = pb1[off];
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
@@ -165,8 +209,9 @@ constexpr int WG_DYP = SEGW + 1;    // 33: odd pitch -> conflict-free reads acro
 constexpr int WG_XCI = 3 * PROW + 1;  // 103
 
 __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                            float* __restrict__ slab, int N, int Cin, int H, int W,
-                                                            int Cout, int SW, int nseg_total, int segs_per_split) {
+                                                            float* __restrict__ slab,
+                                                            const float* __restrict__ zero_page, int N, int Cin, int H,
+                                                            int W, int Cout, int SW, int nseg_total, int segs_per_split) {
     __shared__ float dyT[64 * WG_DYP];
     __shared__ float xp[64 * WG_XCI];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -182,45 +227,47 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restr
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     constexpr int EDY = 64 * SEGW / 256;               // 8
-    constexpr int EX = (64 * 3 * PROW + 255) / 256;    // 26
-    float rdy[EDY], rx[EX];
+    float rdy[EDY], rx[48];
 
     const int sbeg = split * segs_per_split;
     const int send = min(nseg_total, sbeg + segs_per_split);
+    const int dpx = tid & 31, dco = tid >> 5;           // dy loader: 32 pixels x 8 channels per pass
 
+    // x halo rows: wave w stages channels [16w, 16w+16) x 3 rows, lanes 0..33 = columns (wave-uniform row math)
     auto load_seg = [&](int g) {
         const int n = g / (H * SW), rem = g % (H * SW);
         const int h = rem / SW, w0 = (rem % SW) * SEGW;
+        const float* dyb = dy + (long)n * Cout * HW + (long)h * W;
+        const bool pxok = w0 + dpx < W;
+        const int pxc = min(w0 + dpx, W - 1);
 #pragma unroll
         for (int e = 0; e < EDY; ++e) {
-            const int idx = tid + 256 * e;
-            const int co = idx / SEGW, px = idx % SEGW;
-            const int gco = co0 + co, ww = w0 + px;
-            rdy[e] = (gco < Cout && ww < W) ? dy[((long)n * Cout + gco) * HW + (long)h * W + ww] : 0.f;
+            const int co = co0 + dco + 8 * e;
+            const float* src = dyb + ((long)min(co, Cout - 1) * HW + pxc);   // address select, unconditional load
+            rdy[e] = *((pxok && co < Cout) ? src : zero_page + lane);
         }
+        const int ww = w0 - 1 + lane;
+        const bool colok = lane < PROW && ww >= 0 && ww < W;
+        const int loff = colok ? ww : 0;
+        const float* xb = x + (long)n * Cin * HW;
 #pragma unroll
-        for (int e = 0; e < EX; ++e) {
-            const int idx = tid + 256 * e;
-            float v = 0.f;
-            if (idx < 64 * 3 * PROW) {
-                const int ci = idx / (3 * PROW), r2 = idx % (3 * PROW);
-                const int kh = r2 / PROW, col = r2 % PROW;
-                const int gci = ci0 + ci, hh = h + kh - 1, ww = w0 + col - 1;
-                if (gci < Cin && hh >= 0 && hh < H && ww >= 0 && ww < W) v = x[((long)n * Cin + gci) * HW + (long)hh * W + ww];
+        for (int ci = 0; ci < 16; ++ci)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int hh = h + kh - 1, gci = ci0 + wave * 16 + ci;
+                const bool rowok = gci < Cin && hh >= 0 && hh < H;             // wave-uniform
+                const float* src = xb + ((long)min(gci, Cin - 1) * HW + (long)min(max(hh, 0), H - 1) * W + loff);
+                rx[ci * 3 + kh] = *((rowok && colok) ? src : zero_page + lane);
             }
-            rx[e] = v;
-        }
     };
     auto store_seg = [&]() {
 #pragma unroll
-        for (int e = 0; e < EDY; ++e) {
-            const int idx = tid + 256 * e;
-            dyT[(idx / SEGW) * WG_DYP + (idx % SEGW)] = rdy[e];
-        }
+        for (int e = 0; e < EDY; ++e) dyT[(dco + 8 * e) * WG_DYP + dpx] = rdy[e];
+        if (lane < PROW) {
 #pragma unroll
-        for (int e = 0; e < EX; ++e) {
-            const int idx = tid + 256 * e;
-            if (idx < 64 * 3 * PROW) xp[(idx / (3 * PROW)) * WG_XCI + (idx % (3 * PROW))] = rx[e];
+            for (int ci = 0; ci < 16; ++ci)
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) xp[(wave * 16 + ci) * WG_XCI + kh * PROW + lane] = rx[ci * 3 + kh];
         }
     };
 
@@ -293,6 +340,18 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
     }
 }
 
+const float* zero_page_ptr() {
+    static const float* zp[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!zp[dev]) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_zero_page)) != hipSuccess) return nullptr;
+        zp[dev] = (const float*)p;
+    }
+    return zp[dev];
+}
+
 int wgrad_splits(int n, int cin, int h, int w, int cout, int* segs_per_split) {
     const int SW = vocr_cdiv(w, SEGW);
     const long nseg = (long)n * h * SW;
@@ -323,12 +382,17 @@ extern "C" int vocr_conv3x3_fwd(const float* x, const float* wpack, const float*
     const long nseg = (long)n * h * SW;
     VOCR_CHECK_ARG(nseg < (1l << 30), "vocr_conv3x3_fwd: too many segments");
     hipStream_t s = (hipStream_t)stream;
+    const bool vec = (cout % 4 == 0) && ((((uintptr_t)wpack) & 15) == 0);
+    const float* zp = zero_page_ptr();
+    VOCR_CHECK_ARG(zp != nullptr, "vocr_conv3x3_fwd: no device zero page");
     if (cout > 64) {
         dim3 grid(vocr_cdiv(nseg, 4), vocr_cdiv(cout, 128));
-        conv3x3_kernel<128><<<grid, 256, 0, s>>>(x, wpack, bias, y, n, cin, h, w, cout, SW, (int)nseg);
+        if (vec) conv3x3_kernel<128, true><<<grid, 256, 0, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, SW, (int)nseg);
+        else conv3x3_kernel<128, false><<<grid, 256, 0, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, SW, (int)nseg);
     } else {
         dim3 grid(vocr_cdiv(nseg, 8), 1);
-        conv3x3_kernel<64><<<grid, 256, 0, s>>>(x, wpack, bias, y, n, cin, h, w, cout, SW, (int)nseg);
+        if (vec) conv3x3_kernel<64, true><<<grid, 256, 0, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, SW, (int)nseg);
+        else conv3x3_kernel<64, false><<<grid, 256, 0, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, SW, (int)nseg);
     }
     VOCR_CHECK_LAUNCH("vocr_conv3x3_fwd");
     return VOCR_OK;
@@ -351,7 +415,9 @@ extern "C" int vocr_conv3x3_wgrad(const float* x, const float* dy, float* dw, vo
     const int splits = wgrad_splits(n, cin, h, w, cout, &sps);
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(vocr_cdiv(cin, 64), vocr_cdiv(cout, 64), splits);
-    conv3x3_wgrad_kernel<<<grid, 256, 0, s>>>(x, dy, (float*)workspace, n, cin, h, w, cout, SW, (int)nseg, sps);
+    const float* zp = zero_page_ptr();
+    VOCR_CHECK_ARG(zp != nullptr, "vocr_conv3x3_wgrad: no device zero page");
+    conv3x3_wgrad_kernel<<<grid, 256, 0, s>>>(x, dy, (float*)workspace, zp, n, cin, h, w, cout, SW, (int)nseg, sps);
     VOCR_CHECK_LAUNCH("vocr_conv3x3_wgrad");
     const long total = 9l * cout * cin;
     wgrad_reduce_kernel<<<vocr_cdiv(total, 256), 256, 0, s>>>((const float*)workspace, dw, cout, cin, splits);
