@@ -1,0 +1,65 @@
+"""CPU, world_size 2 (gloo): the data-parallel exchange of the train step — one all-reduce (SUM) over the flat
+gradient buffer that aliases every parameter's .grad — is correct by construction.  (On the GPUs the same call
+runs over RCCL/xGMI; the fused clamp+Adam kernel itself is GPU-only and tested in test_ops_gpu.py.)"""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import vistaocr_amd as va
+    torch.manual_seed(0)                     # replicas: identical init on every rank
+    m = va.CnnOcrModel(alphabet=va.english_alphabet(), gpu=False, verbose=False, input_line_height=30, rds_line_height=30,
+                       lstm_input_dim=16, num_lstm_layers=1, num_lstm_hidden_units=16, p_lstm_dropout=0.0)
+    opt = va.FlatClampAdam(m.parameters(), lr=1e-3)
+    n = opt.flat_g.numel()
+    assert n == sum(p.numel() for p in m.parameters())
+    # parameters and grads alias the flat buffers
+    off = 0
+    for p in m.parameters():
+        assert p.data.data_ptr() == opt.flat_p.data_ptr() + 4 * off
+        assert p.grad.data_ptr() == opt.flat_g.data_ptr() + 4 * off
+        off += p.numel()
+    opt.zero_grad()
+    # autograd accumulates IN PLACE into the flat gradient
+    loss = sum((p * (rank + 1)).sum() for p in m.parameters())
+    loss.backward()
+    assert torch.all(opt.flat_g == float(rank + 1))
+    opt.all_reduce_grads()
+    want = float(sum(r + 1 for r in range(world)))
+    ok = bool(torch.all(opt.flat_g == want))
+    # same replica weights everywhere
+    w = opt.flat_p.clone()
+    dist.all_reduce(w, op=dist.ReduceOp.MAX)
+    ok = ok and bool(torch.equal(w, opt.flat_p))
+    opt.zero_grad()
+    ok = ok and float(opt.flat_g.abs().sum()) == 0.0
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_allreduce_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == [(0, True), (1, True)]

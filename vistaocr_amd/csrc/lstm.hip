@@ -11,6 +11,7 @@
 //                  the gate-gradient computation of the 16 owned units.
 // h / dh ping-pong between two small global buffers (the only cross-workgroup traffic, L2 resident).
 #include "vocr_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_fast(const float* __restric
                                                           float* __restrict__ y, float* __restrict__ gates,
                                                           float* __restrict__ cell, const float* __restrict__ h_prev,
                                                           float* __restrict__ h_next, float* __restrict__ cbuf, int T, int B,
-                                                          int step) {
+                                                          int step, int dbg) {
     constexpr int H = 64 * KQ4;
     __shared__ float red[4][RT * 16][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_fast(const float* __restric
     f32x4 acc[RT];
 #pragma unroll
     for (int i = 0; i < RT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (step > 0) {
+    if (step > 0 && !(dbg & 2)) {
         const f32x4* wp = (const f32x4*)(whh + ((long)(lr >> 2) * H + unit0 + (lr & 3)) * H + kbase);
         f32x4 wv[KQ4], hv[RT][KQ4];
 #pragma unroll
@@ -251,6 +252,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_fast(const float* __restric
             }
         }
         __builtin_amdgcn_sched_barrier(0);     // keep every load above the MFMA phase: one latency exposure per step
+        if (!(dbg & 1)) {
 #pragma unroll
         for (int i = 0; i < KQ4; ++i)
 #pragma unroll
@@ -258,6 +260,12 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_fast(const float* __restric
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
                     acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[rt][i][e], wv[i][e], acc[rt], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < KQ4; ++i)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt] += hv[rt][i] * wv[i];
+        }
     }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -265,7 +273,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_fast(const float* __restric
         for (int r = 0; r < 4; ++r) red[wave][rt * 16 + q * 4 + r][lr] = acc[rt][r];
     __syncthreads();
 
-    if (cellthr) {
+    if (cellthr && !(dbg & 4)) {
         const int b = cb_, u = cu;
         const bool active = t < len_b;
         const long cidx = ((long)dir * B + b) * H + unit;
@@ -396,11 +404,12 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_fast(const float* __restric
 template <int KQ4>
 bool launch_fwd_fast(int rt, dim3 grid, hipStream_t s, const float* xproj, const float* wf, const float* wr, const int32_t* lens,
                      float* y, float* gates, float* cell, const float* hp, float* hn, float* cb, int T, int B, int step) {
+    static const int dbg = getenv("VOCR_LSTM_DEBUG") ? atoi(getenv("VOCR_LSTM_DEBUG")) : 0;   // timing experiments only
     switch (rt) {
-        case 1: lstm_fwd_step_fast<KQ4, 1><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, hp, hn, cb, T, B, step); return true;
-        case 2: lstm_fwd_step_fast<KQ4, 2><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, hp, hn, cb, T, B, step); return true;
-        case 3: lstm_fwd_step_fast<KQ4, 3><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, hp, hn, cb, T, B, step); return true;
-        case 4: lstm_fwd_step_fast<KQ4, 4><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, hp, hn, cb, T, B, step); return true;
+        case 1: lstm_fwd_step_fast<KQ4, 1><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, hp, hn, cb, T, B, step, dbg); return true;
+        case 2: lstm_fwd_step_fast<KQ4, 2><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, hp, hn, cb, T, B, step, dbg); return true;
+        case 3: lstm_fwd_step_fast<KQ4, 3><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, hp, hn, cb, T, B, step, dbg); return true;
+        case 4: lstm_fwd_step_fast<KQ4, 4><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, hp, hn, cb, T, B, step, dbg); return true;
     }
     return false;
 }
