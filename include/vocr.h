@@ -103,7 +103,8 @@ int vocr_dropout_fwd(const float* x, float* out, float* mask, size_t count, floa
 /* ---- nn.LSTM recurrence on a packed, length-sorted batch — src/models/cnnlstm.py:148-149,288-290 ---------- */
 /* One direction pair of one layer.  xproj[dir][T][B][4H] = x W_ih^T + b_ih + b_hh (gate order i,f,g,o),
  * whh_fwd / whh_rev [4H][H] (the two directions' weight_hh), lens[B] int32 (device, descending).  Outputs y[T][B][2H] (zeros past lens),
- * gates[dir][T][B][4H] (post-activation i,f,g,o) and cell[dir][T][B][H] for backward.
+ * gates[dir][T][B][H][4] (post-activation i,f,g,o interleaved per unit, 16-byte aligned) and cell[dir][T][B][H]
+ * for backward.  h_{t-1}/c_{t-1} are read back from y/cell, so the sweep keeps no separate state.
  * workspace: vocr_lstm_workspace_bytes.  Supports B <= 64, H % 16 == 0. */
 size_t vocr_lstm_workspace_bytes(int t, int b, int h);
 int vocr_lstm_fwd(const float* xproj, const float* whh_fwd, const float* whh_rev, const int32_t* lens, float* y,

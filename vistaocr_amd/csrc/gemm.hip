@@ -9,20 +9,28 @@
 
 namespace {
 
-constexpr int BK = 16;
+constexpr int BK = 32;
 
-template <int BM, int BN, int WM, int WN, bool A_KCONTIG, bool B_NCONTIG>
+// Out-of-range operands are read from a zero page by ADDRESS select (the load stays unconditional, so the whole
+// K-tile's loads are in flight together; a select on the loaded value turns into a branch + vmcnt(0) per load).
+__device__ __attribute__((aligned(16))) float g_gemm_zero_page[64];
+
+// VEC: operands are fetched with 16-byte loads along their contiguous dimension (needs 16-B aligned bases,
+// leading dimensions and M/N/K multiples of 4); otherwise 4-byte loads.
+template <int BM, int BN, int WM, int WN, bool A_KCONTIG, bool B_NCONTIG, bool VEC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(
     int M, int N, int K, const float* __restrict__ A, long sam, long sak, const float* __restrict__ B, long sbk,
     long sbn, float* __restrict__ C, int ldc, const float* __restrict__ bias, int relu, int accumulate,
-    int k_per_split) {
-    constexpr int PA = BM + 2;   // pitch ≡ 2 (mod 32): transposing stores from k-contiguous rows stay conflict-free
-    constexpr int PB = BN + 2;
+    int k_per_split, const float* __restrict__ zp) {
+    // LDS tiles are K-major: As[k][m], Bs[k][n].  Pitch ≡ 2 (mod 32) keeps the transposing scalar stores of a
+    // k-contiguous operand at most 2-way conflicted; a multiple of 4 keeps 16-byte stores of an m-contiguous one aligned.
+    constexpr int PA = BM + ((VEC && !A_KCONTIG) ? 4 : 2);
+    constexpr int PB = BN + ((VEC && B_NCONTIG) ? 4 : 2);
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
-    constexpr int EA = BM * BK / 256, EB = BN * BK / 256;
-    __shared__ float lds[2 * BK * (PA + PB)];
-    float* const As0 = lds;                    // As[buf] = As0 + buf*BK*PA ; Bs[buf] = Bs0 + buf*BK*PB
+    constexpr int EA = BM * BK / 256, EB = BN * BK / 256;      // floats per thread per tile
+    __shared__ __attribute__((aligned(16))) float lds[2 * BK * (PA + PB)];
+    float* const As0 = lds;
     float* const Bs0 = lds + 2 * BK * PA;
 
     const int tid = threadIdx.x;
@@ -42,38 +50,89 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
 
     float ra[EA], rb[EB];
 
+    // element maps: (row r along M or N, k) per thread and pass
     auto load_tiles = [&](int k0) {
+        if (VEC) {
 #pragma unroll
-        for (int e = 0; e < EA; ++e) {
-            int m, k;
-            if (A_KCONTIG) { k = tid & 15; m = (tid >> 4) + 16 * e; }
-            else           { m = tid % BM; k = tid / BM + (256 / BM) * e; }
-            const int gm = m0 + m, gk = k0 + k;
-            ra[e] = (gm < M && gk < kend) ? A[gm * sam + gk * sak] : 0.f;
-        }
+            for (int e = 0; e < EA / 4; ++e) {
+                const float* src;
+                bool ok;
+                if (A_KCONTIG) { const int m = (tid >> 3) + 32 * e, k = (tid & 7) * 4; ok = m0 + m < M && k0 + k < kend; src = A + (long)(m0 + m) * sam + (k0 + k); }
+                else           { const int m = (tid % (BM / 4)) * 4, k = tid / (BM / 4) + (1024 / BM) * e; ok = m0 + m < M && k0 + k < kend; src = A + (long)(k0 + k) * sak + (m0 + m); }
+                const f32x4 v = *(const f32x4*)(ok ? src : zp);
+                ra[4 * e] = v[0]; ra[4 * e + 1] = v[1]; ra[4 * e + 2] = v[2]; ra[4 * e + 3] = v[3];
+            }
 #pragma unroll
-        for (int e = 0; e < EB; ++e) {
-            int n, k;
-            if (B_NCONTIG) { n = tid % BN; k = tid / BN + (256 / BN) * e; }
-            else           { k = tid & 15; n = (tid >> 4) + 16 * e; }
-            const int gn = n0 + n, gk = k0 + k;
-            rb[e] = (gn < N && gk < kend) ? B[gk * sbk + gn * sbn] : 0.f;
+            for (int e = 0; e < EB / 4; ++e) {
+                const float* src;
+                bool ok;
+                if (!B_NCONTIG) { const int n = (tid >> 3) + 32 * e, k = (tid & 7) * 4; ok = n0 + n < N && k0 + k < kend; src = B + (long)(n0 + n) * sbn + (k0 + k); }
+                else            { const int n = (tid % (BN / 4)) * 4, k = tid / (BN / 4) + (1024 / BN) * e; ok = n0 + n < N && k0 + k < kend; src = B + (long)(k0 + k) * sbk + (n0 + n); }
+                const f32x4 v = *(const f32x4*)(ok ? src : zp);
+                rb[4 * e] = v[0]; rb[4 * e + 1] = v[1]; rb[4 * e + 2] = v[2]; rb[4 * e + 3] = v[3];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < EA; ++e) {
+                int m, k;
+                if (A_KCONTIG) { k = tid & 31; m = (tid >> 5) + 8 * e; }
+                else           { m = tid % BM; k = tid / BM + (256 / BM) * e; }
+                const bool ok = m0 + m < M && k0 + k < kend;
+                const float* src = A + (long)(m0 + m) * sam + (long)(k0 + k) * sak;
+                ra[e] = *(ok ? src : zp);
+            }
+#pragma unroll
+            for (int e = 0; e < EB; ++e) {
+                int n, k;
+                if (B_NCONTIG) { n = tid % BN; k = tid / BN + (256 / BN) * e; }
+                else           { k = tid & 31; n = (tid >> 5) + 8 * e; }
+                const bool ok = n0 + n < N && k0 + k < kend;
+                const float* src = B + (long)(k0 + k) * sbk + (long)(n0 + n) * sbn;
+                rb[e] = *(ok ? src : zp);
+            }
         }
     };
     auto store_tiles = [&](int buf) {
+        float* as = As0 + buf * BK * PA;
+        float* bs = Bs0 + buf * BK * PB;
+        if (VEC) {
 #pragma unroll
-        for (int e = 0; e < EA; ++e) {
-            int m, k;
-            if (A_KCONTIG) { k = tid & 15; m = (tid >> 4) + 16 * e; }
-            else           { m = tid % BM; k = tid / BM + (256 / BM) * e; }
-            As0[buf * BK * PA + k * PA + m] = ra[e];
-        }
+            for (int e = 0; e < EA / 4; ++e) {
+                if (A_KCONTIG) {
+                    const int m = (tid >> 3) + 32 * e, k = (tid & 7) * 4;
 #pragma unroll
-        for (int e = 0; e < EB; ++e) {
-            int n, k;
-            if (B_NCONTIG) { n = tid % BN; k = tid / BN + (256 / BN) * e; }
-            else           { k = tid & 15; n = (tid >> 4) + 16 * e; }
-            Bs0[buf * BK * PB + k * PB + n] = rb[e];
+                    for (int x = 0; x < 4; ++x) as[(k + x) * PA + m] = ra[4 * e + x];
+                } else {
+                    const int m = (tid % (BM / 4)) * 4, k = tid / (BM / 4) + (1024 / BM) * e;
+                    *(f32x4*)(as + k * PA + m) = (f32x4){ra[4 * e], ra[4 * e + 1], ra[4 * e + 2], ra[4 * e + 3]};
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < EB / 4; ++e) {
+                if (!B_NCONTIG) {
+                    const int n = (tid >> 3) + 32 * e, k = (tid & 7) * 4;
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) bs[(k + x) * PB + n] = rb[4 * e + x];
+                } else {
+                    const int n = (tid % (BN / 4)) * 4, k = tid / (BN / 4) + (1024 / BN) * e;
+                    *(f32x4*)(bs + k * PB + n) = (f32x4){rb[4 * e], rb[4 * e + 1], rb[4 * e + 2], rb[4 * e + 3]};
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < EA; ++e) {
+                int m, k;
+                if (A_KCONTIG) { k = tid & 31; m = (tid >> 5) + 8 * e; }
+                else           { m = tid % BM; k = tid / BM + (256 / BM) * e; }
+                as[k * PA + m] = ra[e];
+            }
+#pragma unroll
+            for (int e = 0; e < EB; ++e) {
+                int n, k;
+                if (B_NCONTIG) { n = tid % BN; k = tid / BN + (256 / BN) * e; }
+                else           { k = tid & 31; n = (tid >> 5) + 8 * e; }
+                bs[k * PB + n] = rb[e];
+            }
         }
     };
 
@@ -87,15 +146,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) load_tiles(kbeg + (kt + 1) * BK);
-        const float* as = As0 + cur * BK * PA + wm0 + li;
-        const float* bs = Bs0 + cur * BK * PB + wn0 + li;
+        const float* as = As0 + cur * BK * PA + wm0 + li + lk * PA;
+        const float* bs = Bs0 + cur * BK * PB + wn0 + li + lk * PB;
 #pragma unroll
         for (int ks = 0; ks < BK / 2; ++ks) {
             float af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = as[(ks * 2 + lk) * PA + i * 32];
+            for (int i = 0; i < TM; ++i) af[i] = as[ks * 2 * PA + i * 32];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = bs[(ks * 2 + lk) * PB + j * 32];
+            for (int j = 0; j < TN; ++j) bf[j] = bs[ks * 2 * PB + j * 32];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -132,17 +191,30 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
         }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool VEC>
 void launch_cfg(int ta, int tb, dim3 grid, hipStream_t s, int M, int N, int K, const float* A, long sam, long sak,
-                const float* B, long sbk, long sbn, float* C, int ldc, const float* bias, int relu, int acc, int kps) {
+                const float* B, long sbk, long sbn, float* C, int ldc, const float* bias, int relu, int acc, int kps,
+                const float* zp) {
     if (!ta && !tb)
-        gemm_f32_kernel<BM, BN, WM, WN, true, true><<<grid, 256, 0, s>>>(M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, relu, acc, kps);
+        gemm_f32_kernel<BM, BN, WM, WN, true, true, VEC><<<grid, 256, 0, s>>>(M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, relu, acc, kps, zp);
     else if (!ta && tb)
-        gemm_f32_kernel<BM, BN, WM, WN, true, false><<<grid, 256, 0, s>>>(M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, relu, acc, kps);
+        gemm_f32_kernel<BM, BN, WM, WN, true, false, VEC><<<grid, 256, 0, s>>>(M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, relu, acc, kps, zp);
     else if (ta && !tb)
-        gemm_f32_kernel<BM, BN, WM, WN, false, true><<<grid, 256, 0, s>>>(M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, relu, acc, kps);
+        gemm_f32_kernel<BM, BN, WM, WN, false, true, VEC><<<grid, 256, 0, s>>>(M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, relu, acc, kps, zp);
     else
-        gemm_f32_kernel<BM, BN, WM, WN, false, false><<<grid, 256, 0, s>>>(M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, relu, acc, kps);
+        gemm_f32_kernel<BM, BN, WM, WN, false, false, VEC><<<grid, 256, 0, s>>>(M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, relu, acc, kps, zp);
+}
+
+const float* gemm_zero_page() {
+    static const float* zp[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!zp[dev]) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_gemm_zero_page)) != hipSuccess) return nullptr;
+        zp[dev] = (const float*)p;
+    }
+    return zp[dev];
 }
 
 // out[n] += sum of rows [r0, r1) of x[:, n]; grid (N/64 column tiles, row splits); float atomics combine splits
@@ -271,10 +343,17 @@ extern "C" int vocr_gemm(int transa, int transb, int m, int n, int k, const floa
         }
     }
     dim3 grid(vocr_cdiv(n, bm), vocr_cdiv(m, bm), splits);
-    if (big)
-        launch_cfg<128, 128, 64, 64>(transa, transb, grid, s, m, n, k, a, sam, sak, b, sbk, sbn, c, ldc, bias, relu, accumulate, kps);
-    else
-        launch_cfg<64, 64, 32, 32>(transa, transb, grid, s, m, n, k, a, sam, sak, b, sbk, sbn, c, ldc, bias, relu, accumulate, kps);
+    const float* zp = gemm_zero_page();
+    VOCR_CHECK_ARG(zp != nullptr, "vocr_gemm: no device zero page");
+    const bool vec = ((((uintptr_t)a) | ((uintptr_t)b)) & 15) == 0 && lda % 4 == 0 && ldb % 4 == 0 && m % 4 == 0 && n % 4 == 0 &&
+                     k % 4 == 0;
+    if (big) {
+        if (vec) launch_cfg<128, 128, 64, 64, true>(transa, transb, grid, s, m, n, k, a, sam, sak, b, sbk, sbn, c, ldc, bias, relu, accumulate, kps, zp);
+        else launch_cfg<128, 128, 64, 64, false>(transa, transb, grid, s, m, n, k, a, sam, sak, b, sbk, sbn, c, ldc, bias, relu, accumulate, kps, zp);
+    } else {
+        if (vec) launch_cfg<64, 64, 32, 32, true>(transa, transb, grid, s, m, n, k, a, sam, sak, b, sbk, sbn, c, ldc, bias, relu, accumulate, kps, zp);
+        else launch_cfg<64, 64, 32, 32, false>(transa, transb, grid, s, m, n, k, a, sam, sak, b, sbk, sbn, c, ldc, bias, relu, accumulate, kps, zp);
+    }
     VOCR_CHECK_LAUNCH("vocr_gemm");
     return VOCR_OK;
 }

@@ -22,8 +22,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(const float* __restr
                                                             const float* __restrict__ whh_r,
                                                             const int32_t* __restrict__ lens, float* __restrict__ y,
                                                             float* __restrict__ gates, float* __restrict__ cell,
-                                                            const float* __restrict__ h_prev, float* __restrict__ h_next,
-                                                            float* __restrict__ cbuf, int T, int B, int H, int step) {
+                                                            int T, int B, int H, int step) {
     __shared__ float red[4][64][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ublocks = H >> 2;
@@ -34,7 +33,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(const float* __restr
     const int KQ = H >> 4;                       // k values per lane: wave covers H/4, lane-quarter covers H/16
     const int kbase = wave * (H >> 2) + q * KQ;
 
-    const float* hp = h_prev + (long)dir * B * H;
+    // h_{t-1} is read back from y (zeros outside a sequence), c_{t-1} from cell: no separate state buffers
+    const int tprev = dir == 0 ? t - 1 : t + 1;
+    const float* hp = y + (long)(step > 0 ? tprev : 0) * B * 2 * H + dir * H;       // row stride 2H
     const float* whh = dir ? whh_r : whh_f;
     const float* wrow = whh + ((long)(lr >> 2) * H + unit0 + (lr & 3)) * H + kbase;
 
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(const float* __restr
     for (int rt = 0; rt < 4; ++rt) {
         const int b = rt * 16 + lr;
         hv[rt] = rt < RT && b < B;
-        ha[rt] = hp + (long)(hv[rt] ? b : 0) * H + kbase;
+        ha[rt] = hp + (long)(hv[rt] ? b : 0) * 2 * H + kbase;
     }
     if (step > 0) {   // h_{-1} = 0: the first step has no recurrent term
 #pragma unroll 4
@@ -73,37 +74,25 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(const float* __restr
         const int b = tid >> 2, u = tid & 3, unit = unit0 + u;
         const bool active = t < lens[b];
         const long gbase = (((long)dir * T + t) * B + b) * 4 * H + unit;
-        const long cidx = ((long)dir * B + b) * H + unit;
         const long sidx = (((long)dir * T + t) * B + b) * H + unit;
         float pre[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             pre[g] = ((red[0][b][g * 4 + u] + red[1][b][g * 4 + u]) + (red[2][b][g * 4 + u] + red[3][b][g * 4 + u])) +
                      xproj[gbase + (long)g * H];
-        const float hprev = step > 0 ? hp[(long)b * H + unit] : 0.f;
-        float* hn = h_next + (long)dir * B * H + (long)b * H + unit;
         float* yo = y + ((long)t * B + b) * 2 * H + dir * H + unit;
+        f32x4* go = (f32x4*)(gates + sidx * 4);           // gates[dir][t][b][unit][i,f,g,o]
         if (active) {
             const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
-            const float cprev = step > 0 ? cbuf[cidx] : 0.f;
+            const float cprev = step > 0 ? cell[(((long)dir * T + tprev) * B + b) * H + unit] : 0.f;
             const float c = fg * cprev + ig * gg;
             const float h = og * tanhf(c);
-            gates[gbase] = ig;
-            gates[gbase + H] = fg;
-            gates[gbase + 2l * H] = gg;
-            gates[gbase + 3l * H] = og;
+            *go = (f32x4){ig, fg, gg, og};
             cell[sidx] = c;
-            cbuf[cidx] = c;
-            *hn = h;
             *yo = h;
         } else {
-            gates[gbase] = 0.f;
-            gates[gbase + H] = 0.f;
-            gates[gbase + 2l * H] = 0.f;
-            gates[gbase + 3l * H] = 0.f;
+            *go = (f32x4){0.f, 0.f, 0.f, 0.f};
             cell[sidx] = 0.f;
-            if (step == 0) cbuf[cidx] = 0.f;
-            *hn = hprev;
             *yo = 0.f;
         }
     }
@@ -176,8 +165,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(const float* __restr
         }
         const float dh = dy[((long)t * B + b) * 2 * H + dir * H + unit] +
                          ((red[0][b][j] + red[1][b][j]) + (red[2][b][j] + red[3][b][j]));
-        const float ig = gates[gbase], fg = gates[gbase + H], gg = gates[gbase + 2l * H], og = gates[gbase + 3l * H];
         const long sidx = (((long)dir * T + t) * B + b) * H + unit;
+        const f32x4 gv = *(const f32x4*)(gates + sidx * 4);
+        const float ig = gv[0], fg = gv[1], gg = gv[2], og = gv[3];
         const float c = cell[sidx];
         const int tp = dir == 0 ? t - 1 : t + 1;   // previous step of the recurrence
         const float cprev = (tp >= 0 && tp < len) ? cell[(((long)dir * T + tp) * B + b) * H + unit] : 0.f;
@@ -201,9 +191,7 @@ template <int KQ4, int RT>
 __global__ __launch_bounds__(256) void lstm_fwd_step_fast(const float* __restrict__ xproj, const float* __restrict__ whh_f,
                                                           const float* __restrict__ whh_r, const int32_t* __restrict__ lens,
                                                           float* __restrict__ y, float* __restrict__ gates,
-                                                          float* __restrict__ cell, const float* __restrict__ h_prev,
-                                                          float* __restrict__ h_next, float* __restrict__ cbuf, int T, int B,
-                                                          int step, int dbg) {
+                                                          float* __restrict__ cell, int T, int B, int step, int dbg) {
     constexpr int H = 64 * KQ4;
     __shared__ float red[4][RT * 16][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -212,7 +200,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_fast(const float* __restric
     const int t = dir == 0 ? step : T - 1 - step;
     const int lr = lane & 15, q = lane >> 4;
     const int kbase = wave * (H >> 2) + q * (H >> 4);
-    const float* hp = h_prev + (long)dir * B * H;
+    // h_{t-1} is read back from y (zeros outside a sequence) and c_{t-1} from cell: no state buffers, 3 stores/cell
+    const int tprev = dir == 0 ? t - 1 : t + 1;
+    const float* hp = y + (long)(step > 0 ? tprev : 0) * B * 2 * H + dir * H;       // row stride 2H
     const float* whh = dir ? whh_r : whh_f;
 
     // cell-update operands are fetched before the MFMA phase so their latency hides under it
@@ -220,16 +210,13 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_fast(const float* __restric
     const int cb_ = tid >> 2, cu = tid & 3, unit = unit0 + cu;
     const long gbase = (((long)dir * T + t) * B + (cellthr ? cb_ : 0)) * 4 * H + unit;
     float xp[4] = {0.f, 0.f, 0.f, 0.f};
-    float cprev = 0.f, hprev = 0.f;
+    float cprev = 0.f;
     int len_b = 0;
     if (cellthr) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) xp[g] = xproj[gbase + (long)g * H];
         len_b = lens[cb_];
-        if (step > 0) {
-            cprev = cbuf[((long)dir * B + cb_) * H + unit];
-            hprev = hp[(long)cb_ * H + unit];
-        }
+        if (step > 0) cprev = cell[(((long)dir * T + tprev) * B + cb_) * H + unit];
     }
 
     f32x4 acc[RT];
@@ -243,7 +230,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_fast(const float* __restric
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             const int b = rt * 16 + lr;
-            const f32x4* hq = (const f32x4*)(hp + (long)(b < B ? b : 0) * H + kbase);
+            const f32x4* hq = (const f32x4*)(hp + (long)(b < B ? b : 0) * 2 * H + kbase);
 #pragma unroll
             for (int i = 0; i < KQ4; ++i) {
                 f32x4 v = hq[i];
@@ -276,34 +263,23 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_fast(const float* __restric
     if (cellthr && !(dbg & 4)) {
         const int b = cb_, u = cu;
         const bool active = t < len_b;
-        const long cidx = ((long)dir * B + b) * H + unit;
         const long sidx = (((long)dir * T + t) * B + b) * H + unit;
         float pre[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             pre[g] = ((red[0][b][g * 4 + u] + red[1][b][g * 4 + u]) + (red[2][b][g * 4 + u] + red[3][b][g * 4 + u])) + xp[g];
-        float* hn = h_next + (long)dir * B * H + (long)b * H + unit;
         float* yo = y + ((long)t * B + b) * 2 * H + dir * H + unit;
+        f32x4* go = (f32x4*)(gates + sidx * 4);           // gates[dir][t][b][unit][i,f,g,o]: one 16-B store
         if (active) {
             const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
             const float c = fg * cprev + ig * gg;
             const float h = og * tanhf(c);
-            gates[gbase] = ig;
-            gates[gbase + H] = fg;
-            gates[gbase + 2l * H] = gg;
-            gates[gbase + 3l * H] = og;
+            *go = (f32x4){ig, fg, gg, og};
             cell[sidx] = c;
-            cbuf[cidx] = c;
-            *hn = h;
             *yo = h;
         } else {
-            gates[gbase] = 0.f;
-            gates[gbase + H] = 0.f;
-            gates[gbase + 2l * H] = 0.f;
-            gates[gbase + 3l * H] = 0.f;
+            *go = (f32x4){0.f, 0.f, 0.f, 0.f};
             cell[sidx] = 0.f;
-            if (step == 0) cbuf[cidx] = 0.f;
-            *hn = hprev;
             *yo = 0.f;
         }
     }
@@ -340,11 +316,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_fast(const float* __restric
     const bool act = ev && t < len;
     float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, c = 0.f, cprev = 0.f, dyv = 0.f, dcar = 0.f;
     if (act) {
-        ig = gates[gbase];
-        fg = gates[gbase + H];
-        gg = gates[gbase + 2l * H];
-        og = gates[gbase + 3l * H];
-        c = cell[(((long)dir * T + t) * B + ebs) * H + eunit];
+        const long sidx = (((long)dir * T + t) * B + ebs) * H + eunit;
+        const f32x4 gv = *(const f32x4*)(gates + sidx * 4);
+        ig = gv[0];
+        fg = gv[1];
+        gg = gv[2];
+        og = gv[3];
+        c = cell[sidx];
         const int tp = dir == 0 ? t - 1 : t + 1;
         cprev = (tp >= 0 && tp < len) ? cell[(((long)dir * T + tp) * B + ebs) * H + eunit] : 0.f;
         dyv = dy[((long)t * B + ebs) * 2 * H + dir * H + eunit];
@@ -403,13 +381,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_fast(const float* __restric
 
 template <int KQ4>
 bool launch_fwd_fast(int rt, dim3 grid, hipStream_t s, const float* xproj, const float* wf, const float* wr, const int32_t* lens,
-                     float* y, float* gates, float* cell, const float* hp, float* hn, float* cb, int T, int B, int step) {
+                     float* y, float* gates, float* cell, int T, int B, int step) {
     static const int dbg = getenv("VOCR_LSTM_DEBUG") ? atoi(getenv("VOCR_LSTM_DEBUG")) : 0;   // timing experiments only
     switch (rt) {
-        case 1: lstm_fwd_step_fast<KQ4, 1><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, hp, hn, cb, T, B, step, dbg); return true;
-        case 2: lstm_fwd_step_fast<KQ4, 2><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, hp, hn, cb, T, B, step, dbg); return true;
-        case 3: lstm_fwd_step_fast<KQ4, 3><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, hp, hn, cb, T, B, step, dbg); return true;
-        case 4: lstm_fwd_step_fast<KQ4, 4><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, hp, hn, cb, T, B, step, dbg); return true;
+        case 1: lstm_fwd_step_fast<KQ4, 1><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, T, B, step, dbg); return true;
+        case 2: lstm_fwd_step_fast<KQ4, 2><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, T, B, step, dbg); return true;
+        case 3: lstm_fwd_step_fast<KQ4, 3><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, T, B, step, dbg); return true;
+        case 4: lstm_fwd_step_fast<KQ4, 4><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, T, B, step, dbg); return true;
     }
     return false;
 }
@@ -428,25 +406,21 @@ extern "C" int vocr_lstm_fwd(const float* xproj, const float* whh_fwd, const flo
     VOCR_CHECK_ARG(xproj && whh_fwd && whh_rev && lens && y && gates && cell && workspace, "vocr_lstm_fwd: null pointer");
     VOCR_CHECK_ARG(t > 0 && b > 0 && b <= 64 && h > 0 && h % 16 == 0, "vocr_lstm_fwd: need 1<=B<=64 and H%%16==0 (B=%d H=%d)", b, h);
     hipStream_t s = (hipStream_t)stream;
-    float* ws = (float*)workspace;
-    const size_t st = (size_t)2 * b * h;
-    float* hb[2] = {ws, ws + st};
-    float* cb = ws + 2 * st;
     const int rt = (b + 15) / 16;
-    const bool fast = (h == 64 || h == 128 || h == 256 || h == 512) && aligned16(whh_fwd) && aligned16(whh_rev) && aligned16(ws);
+    const bool fast = (h == 64 || h == 128 || h == 256 || h == 512) && aligned16(whh_fwd) && aligned16(whh_rev) && aligned16(y) &&
+                      aligned16(gates);
+    VOCR_CHECK_ARG(aligned16(gates), "vocr_lstm_fwd: gates must be 16-byte aligned");
     const dim3 grid(2 * (h / 4));
     for (int step = 0; step < t; ++step) {
-        const float* hp = hb[step & 1];
-        float* hn = hb[(step + 1) & 1];
         if (fast) {
             switch (h) {
-                case 64: launch_fwd_fast<1>(rt, grid, s, xproj, whh_fwd, whh_rev, lens, y, gates, cell, hp, hn, cb, t, b, step); break;
-                case 128: launch_fwd_fast<2>(rt, grid, s, xproj, whh_fwd, whh_rev, lens, y, gates, cell, hp, hn, cb, t, b, step); break;
-                case 256: launch_fwd_fast<4>(rt, grid, s, xproj, whh_fwd, whh_rev, lens, y, gates, cell, hp, hn, cb, t, b, step); break;
-                default: launch_fwd_fast<8>(rt, grid, s, xproj, whh_fwd, whh_rev, lens, y, gates, cell, hp, hn, cb, t, b, step); break;
+                case 64: launch_fwd_fast<1>(rt, grid, s, xproj, whh_fwd, whh_rev, lens, y, gates, cell, t, b, step); break;
+                case 128: launch_fwd_fast<2>(rt, grid, s, xproj, whh_fwd, whh_rev, lens, y, gates, cell, t, b, step); break;
+                case 256: launch_fwd_fast<4>(rt, grid, s, xproj, whh_fwd, whh_rev, lens, y, gates, cell, t, b, step); break;
+                default: launch_fwd_fast<8>(rt, grid, s, xproj, whh_fwd, whh_rev, lens, y, gates, cell, t, b, step); break;
             }
         } else {
-            lstm_fwd_step_kernel<<<grid, 256, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, hp, hn, cb, t, b, h, step);
+            lstm_fwd_step_kernel<<<grid, 256, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, t, b, h, step);
         }
     }
     VOCR_CHECK_LAUNCH("vocr_lstm_fwd");
