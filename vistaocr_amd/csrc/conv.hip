@@ -307,6 +307,90 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restr
         }
 }
 
+// Weight gradient for Cin <= 3 (the first layer: grey or RGB lines).  The generic kernel would spend a 32-wide
+// MFMA N-tile on 1-3 input channels; here N = (ci, tap) <= 27 columns, so all nine taps of all channels share ONE
+// accumulator per wave and the kernel is bound by streaming dy once.  2 waves = 64 output channels.
+__global__ __launch_bounds__(128) void conv3x3_wgrad_smallcin_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                     float* __restrict__ slab, const float* __restrict__ zero_page,
+                                                                     int N, int Cin, int H, int W, int Cout, int SW,
+                                                                     int nseg_total, int segs_per_split) {
+    __shared__ float dyT[64 * WG_DYP];
+    __shared__ float xp[3 * 3 * PROW + 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lk = lane >> 5;
+    const int co0 = blockIdx.y * 64, split = blockIdx.z;
+    const long HW = (long)H * W;
+    const int jci = li / 9, jtap = li % 9;
+    const bool jok = li < Cin * 9;
+    const int joff = jok ? jci * 3 * PROW + (jtap / 3) * PROW + (jtap % 3) : 0;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float rdy[16], rx[3];
+    const int sbeg = split * segs_per_split;
+    const int send = min(nseg_total, sbeg + segs_per_split);
+    const int dpx = tid & 31, dco = tid >> 5;           // 32 pixels x 4 channels per pass, 16 passes
+
+    auto load_seg = [&](int g) {
+        const int n = g / (H * SW), rem = g % (H * SW);
+        const int h = rem / SW, w0 = (rem % SW) * SEGW;
+        const float* dyb = dy + (long)n * Cout * HW + (long)h * W;
+        const bool pxok = w0 + dpx < W;
+        const int pxc = min(w0 + dpx, W - 1);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = co0 + dco + 4 * e;
+            const float* src = dyb + ((long)min(co, Cout - 1) * HW + pxc);
+            rdy[e] = *((pxok && co < Cout) ? src : zero_page + lane);
+        }
+        // halo rows: 3*Cin*3 <= 27 rows of 34 columns; thread t < 102 loads column t%34 of row kh = t/34 for each channel
+        const int kh = tid / PROW, col = tid % PROW;
+        const int hh = h + kh - 1, ww = w0 - 1 + col;
+        const bool ok = tid < 3 * PROW && hh >= 0 && hh < H && ww >= 0 && ww < W;
+        const float* xb = x + (long)n * Cin * HW + (long)min(max(hh, 0), H - 1) * W + min(max(ww, 0), W - 1);
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci) rx[ci] = *((ok && ci < Cin) ? xb + (long)min(ci, Cin - 1) * HW : zero_page + lane);
+    };
+    auto store_seg = [&]() {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dyT[(dco + 4 * e) * WG_DYP + dpx] = rdy[e];
+        if (tid < 3 * PROW) {
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) xp[ci * 3 * PROW + tid] = rx[ci];
+        }
+    };
+    if (sbeg < send) {
+        load_seg(sbeg);
+        store_seg();
+    }
+    __syncthreads();
+    for (int g = sbeg; g < send; ++g) {
+        if (g + 1 < send) load_seg(g + 1);
+        const float* ap = dyT + (wave * 32 + li) * WG_DYP + lk;
+        const float* bp = xp + joff + lk;
+#pragma unroll
+        for (int ks = 0; ks < SEGW / 2; ++ks) {
+            const float b = jok ? bp[2 * ks] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks], b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+        if (g + 1 < send) {
+            store_seg();
+            __syncthreads();
+        }
+    }
+    // slab[split][tap][co][ci]
+    const long plane = (long)Cout * Cin;
+    if (jok) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (co < Cout) slab[((long)split * 9 + jtap) * plane + (long)co * Cin + jci] = acc[r];
+        }
+    }
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cout, int Cin, int splits) {
     const long plane = (long)Cout * Cin;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // index over [tap][co][ci]
@@ -355,8 +439,10 @@ const float* zero_page_ptr() {
 int wgrad_splits(int n, int cin, int h, int w, int cout, int* segs_per_split) {
     const int SW = vocr_cdiv(w, SEGW);
     const long nseg = (long)n * h * SW;
-    const int tiles = vocr_cdiv(cin, 64) * vocr_cdiv(cout, 64);
-    long s = (768 + tiles - 1) / tiles;
+    const int tiles = (cin <= 3 ? 1 : vocr_cdiv(cin, 64)) * vocr_cdiv(cout, 64);
+    // the generic kernel holds one workgroup per CU (9 accumulators per wave): 256 slabs = one full round and a
+    // 3x smaller slab than 768; the small-Cin kernel is light and streams, give it more
+    long s = ((cin <= 3 ? 1024 : 256) + tiles - 1) / tiles;
     if (s > nseg) s = nseg;
     if (s < 1) s = 1;
     const int sps = (int)((nseg + s - 1) / s);
@@ -414,10 +500,15 @@ extern "C" int vocr_conv3x3_wgrad(const float* x, const float* dy, float* dw, vo
     int sps;
     const int splits = wgrad_splits(n, cin, h, w, cout, &sps);
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid(vocr_cdiv(cin, 64), vocr_cdiv(cout, 64), splits);
     const float* zp = zero_page_ptr();
     VOCR_CHECK_ARG(zp != nullptr, "vocr_conv3x3_wgrad: no device zero page");
-    conv3x3_wgrad_kernel<<<grid, 256, 0, s>>>(x, dy, (float*)workspace, zp, n, cin, h, w, cout, SW, (int)nseg, sps);
+    if (cin <= 3) {
+        dim3 grid(1, vocr_cdiv(cout, 64), splits);
+        conv3x3_wgrad_smallcin_kernel<<<grid, 128, 0, s>>>(x, dy, (float*)workspace, zp, n, cin, h, w, cout, SW, (int)nseg, sps);
+    } else {
+        dim3 grid(vocr_cdiv(cin, 64), vocr_cdiv(cout, 64), splits);
+        conv3x3_wgrad_kernel<<<grid, 256, 0, s>>>(x, dy, (float*)workspace, zp, n, cin, h, w, cout, SW, (int)nseg, sps);
+    }
     VOCR_CHECK_LAUNCH("vocr_conv3x3_wgrad");
     const long total = 9l * cout * cin;
     wgrad_reduce_kernel<<<vocr_cdiv(total, 256), 256, 0, s>>>((const float*)workspace, dw, cout, cin, splits);

@@ -199,7 +199,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_fast(const float* __restric
     const int dir = blockIdx.x / ublocks, unit0 = (blockIdx.x % ublocks) * 4;
     const int t = dir == 0 ? step : T - 1 - step;
     const int lr = lane & 15, q = lane >> 4;
-    const int kbase = wave * (H >> 2) + q * (H >> 4);
+    // k owned by (wave, load i, lane-quarter q, element e) = wave*H/4 + 16*i + 4*q + e: the four quarters of a
+    // row read one contiguous 64 B, so a wave-instruction touches 16 cache lines instead of 64
+    const int kbase = wave * (H >> 2) + q * 4;
     // h_{t-1} is read back from y (zeros outside a sequence) and c_{t-1} from cell: no state buffers, 3 stores/cell
     const int tprev = dir == 0 ? t - 1 : t + 1;
     const float* hp = y + (long)(step > 0 ? tprev : 0) * B * 2 * H + dir * H;       // row stride 2H
@@ -226,14 +228,14 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_fast(const float* __restric
         const f32x4* wp = (const f32x4*)(whh + ((long)(lr >> 2) * H + unit0 + (lr & 3)) * H + kbase);
         f32x4 wv[KQ4], hv[RT][KQ4];
 #pragma unroll
-        for (int i = 0; i < KQ4; ++i) wv[i] = wp[i];
+        for (int i = 0; i < KQ4; ++i) wv[i] = wp[i * 4];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             const int b = rt * 16 + lr;
             const f32x4* hq = (const f32x4*)(hp + (long)(b < B ? b : 0) * 2 * H + kbase);
 #pragma unroll
             for (int i = 0; i < KQ4; ++i) {
-                f32x4 v = hq[i];
+                f32x4 v = hq[i * 4];
                 if (b >= B) v = (f32x4){0.f, 0.f, 0.f, 0.f};
                 hv[rt][i] = v;
             }
@@ -287,28 +289,34 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_fast(const float* __restric
 
 // H = 128*NCH.  grid.x = 2 * (H/16) * RT : one workgroup per (direction, 16 units, 16 batch rows).
 // whhT = transposed recurrent weights [H][4H] so the B operand (W_hh[n][unit], n running) is contiguous.
-template <int NCH>
-__global__ __launch_bounds__(256) void lstm_bwd_step_fast(const float* __restrict__ dy, const float* __restrict__ whht_f,
+// UT = units owned by a workgroup (16, or 8 when 16 would leave half the chip idle: the MFMA N-tile is then half
+// used, but each CU pulls half the recurrent weights — the per-CU fetch rate from the Infinity Cache is the limiter).
+template <int NCH, int NW, int UT>
+__global__ __launch_bounds__(64 * NW) void lstm_bwd_step_fast(const float* __restrict__ dy, const float* __restrict__ whht_f,
                                                           const float* __restrict__ whht_r, const int32_t* __restrict__ lens,
                                                           const float* __restrict__ gates, const float* __restrict__ cell,
                                                           float* __restrict__ dgates, float* __restrict__ dcbuf, int T, int B,
-                                                          int step, int RT) {
+                                                          int step, int RT, int dbg) {
     constexpr int H = 128 * NCH;
-    __shared__ float red[4][16][17];
+    constexpr int WPG = NW / 4;                 // waves per gate block
+    constexpr int CH = NCH / WPG;               // 32-wide chunks per lane-quarter
+    static_assert(NCH % WPG == 0, "bad wave split");
+    __shared__ float red[NW][16][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int ublocks = H >> 4;
+    constexpr int ublocks = H / UT;
     int bid = blockIdx.x;
     const int bt = bid % RT;
     bid /= RT;
-    const int dir = bid / ublocks, unit0 = (bid % ublocks) * 16;
+    const int dir = bid / ublocks, unit0 = (bid % ublocks) * UT;
     const int t = dir == 0 ? T - 1 - step : step;
     const int tv = dir == 0 ? t + 1 : t - 1;
     const int lr = lane & 15, q = lane >> 4;
-    const int nbase = wave * H + q * (H >> 2);
+    // n owned by (wave, chunk c, load i, quarter q, element e) = wave range + 128*c + 16*i + 4*q + e (64-B runs per row)
+    const int nbase = (wave / WPG) * H + (wave % WPG) * (H / WPG) + q * 4;
 
     // epilogue operands first (latency hides under the MFMA phase): one cell per thread
-    const int eb = bt * 16 + (tid >> 4), ej = tid & 15, eunit = unit0 + ej;
-    const bool ev = eb < B;
+    const int eb = bt * 16 + ((tid & 255) >> 4), ej = tid & 15, eunit = unit0 + (ej & (UT - 1));
+    const bool ev = eb < B && tid < 256 && ej < UT;
     const int ebs = ev ? eb : 0;
     const int len = lens[ebs];
     const long gbase = (((long)dir * T + t) * B + ebs) * 4 * H + eunit;
@@ -329,33 +337,36 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_fast(const float* __restric
         dcar = step > 0 ? dcbuf[cb] : 0.f;
     }
 
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (step > 0) {
+    // two accumulator chains: a dependent v_mfma_f32_16x16x4_f32 has 40 cycles of latency but issues every 32
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (step > 0 && !(dbg & 2)) {
         const int b = bt * 16 + lr;
         const bool bv = b < B;
         const f32x4* ap = (const f32x4*)(dgates + (((long)dir * T + tv) * B + (bv ? b : 0)) * 4 * H + nbase);
         const float* whht = dir ? whht_r : whht_f;
-        const f32x4* bp = (const f32x4*)(whht + (long)(unit0 + lr) * 4 * H + nbase);
+        const f32x4* bp = (const f32x4*)(whht + (long)(unit0 + (lr & (UT - 1))) * 4 * H + nbase);   // lanes past UT mirror
         f32x4 av[2][8], bw[2][8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { av[0][i] = ap[i]; bw[0][i] = bp[i]; }
+        for (int i = 0; i < 8; ++i) { av[0][i] = ap[i * 4]; bw[0][i] = bp[i * 4]; }
 #pragma unroll
-        for (int cidx = 0; cidx < NCH; ++cidx) {
+        for (int cidx = 0; cidx < CH; ++cidx) {
             const int cur = cidx & 1, nxt = cur ^ 1;
-            if (cidx + 1 < NCH) {
+            if (cidx + 1 < CH) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { av[nxt][i] = ap[(cidx + 1) * 8 + i]; bw[nxt][i] = bp[(cidx + 1) * 8 + i]; }
+                for (int i = 0; i < 8; ++i) { av[nxt][i] = ap[(cidx + 1) * 32 + i * 4]; bw[nxt][i] = bp[(cidx + 1) * 32 + i * 4]; }
             }
             __builtin_amdgcn_sched_barrier(0);   // next chunk's loads stay above this chunk's MFMAs
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < 4; e += 2) {
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bv ? av[cur][i][e] : 0.f, bw[cur][i][e], acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(bv ? av[cur][i][e + 1] : 0.f, bw[cur][i][e + 1], acc2, 0, 0, 0);
+                }
         }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave][q * 4 + r][lr] = acc[r];
+    for (int r = 0; r < 4; ++r) red[wave][q * 4 + r][lr] = acc[r] + acc2[r];
     __syncthreads();
 
     if (ev) {
@@ -367,7 +378,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_fast(const float* __restric
             dcbuf[cb] = 0.f;
         } else {
             const int bl = tid >> 4;
-            const float dh = dyv + ((red[0][bl][ej] + red[1][bl][ej]) + (red[2][bl][ej] + red[3][bl][ej]));
+            float rs = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) rs += red[w][bl][ej];
+            const float dh = dyv + rs;
             const float tc = tanhf(c);
             const float dc = dcar + dh * og * (1.f - tc * tc);
             dgates[gbase] = dc * gg * ig * (1.f - ig);
@@ -440,10 +454,14 @@ extern "C" int vocr_lstm_bwd(const float* dy, const float* whht_fwd, const float
     const bool fast = (h == 128 || h == 256 || h == 512) && aligned16(whh_fwd) && aligned16(whh_rev) && aligned16(dgates);
     for (int step = 0; step < t; ++step) {
         if (fast) {
-            const dim3 grid(2 * (h / 16) * rt);
-            if (h == 128) lstm_bwd_step_fast<1><<<grid, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, dcb, t, b, step, rt);
-            else if (h == 256) lstm_bwd_step_fast<2><<<grid, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, dcb, t, b, step, rt);
-            else lstm_bwd_step_fast<4><<<grid, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, dcb, t, b, step, rt);
+            static const int dbg = getenv("VOCR_LSTM_DEBUG") ? atoi(getenv("VOCR_LSTM_DEBUG")) : 0;   // timing experiments only
+            const bool half = (dbg & 8) != 0;          // 8 units per workgroup (256 WGs at B=32): measured no faster than 16
+            const dim3 g(2 * (h / (half ? 8 : 16)) * rt);
+#define VOCR_BWD(NCH, UT) lstm_bwd_step_fast<NCH, 4, UT><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, dcb, t, b, step, rt, dbg)
+            if (h == 128) { if (half) VOCR_BWD(1, 8); else VOCR_BWD(1, 16); }
+            else if (h == 256) { if (half) VOCR_BWD(2, 8); else VOCR_BWD(2, 16); }
+            else { if (half) VOCR_BWD(4, 8); else VOCR_BWD(4, 16); }
+#undef VOCR_BWD
         } else {
             lstm_bwd_step_kernel<<<2 * (h / 16), 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, dcb, t, b, h, step);
         }

@@ -31,6 +31,26 @@ def _f32c(t):
     return t.contiguous()
 
 
+# ---- side stream: weight-gradient GEMMs of an LSTM layer run concurrently with the next (latency-bound) sweep
+import os as _os
+_SIDE = {"stream": None, "pending": False, "enabled": _os.environ.get("VOCR_SIDE_STREAM", "0") == "1"}   # measured: no net gain (the sweep slows as much), off by default
+
+
+def side_stream():
+    if _SIDE["stream"] is None:
+        import os
+        lo, hi = torch.cuda.Stream.priority_range()        # (lowest priority value, highest priority value)
+        _SIDE["stream"] = torch.cuda.Stream(priority=lo) if os.environ.get("VOCR_SIDE_LOWPRIO", "1") == "1" else torch.cuda.Stream()
+    return _SIDE["stream"]
+
+
+def join_side_stream():
+    """Make the current stream wait for every weight-gradient GEMM issued on the side stream."""
+    if _SIDE["pending"]:
+        torch.cuda.current_stream().wait_stream(_SIDE["stream"])
+        _SIDE["pending"] = False
+
+
 def _ws(nbytes, device):
     return torch.empty((max(int(nbytes), 16) + 3) // 4, dtype=torch.float32, device=device)
 
@@ -107,6 +127,8 @@ class ConvBnReluFn(torch.autograd.Function):
         dgamma = torch.empty_like(gamma)
         dbeta = torch.empty_like(beta)
         ws = _ws(lib.vocr_bn_workspace_bytes(n, cout, h * w), x.device)
+        if not ctx.needs_input_grad[0]:
+            join_side_stream()          # first layer = last backward op: everything issued on the side stream is done after this
         dbias = torch.empty(cout, dtype=torch.float32, device=x.device)
         call("vocr_bn_relu_bwd", _p(da), _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(dy), _p(dgamma), _p(dbeta),
              _p(dbias), n, cout, h * w, _p(ws), _stream())
@@ -143,6 +165,8 @@ class ConvReluPoolFn(torch.autograd.Function):
         n, cin, _, _ = x.shape
         cout = out.shape[1]
         h, w = ctx.hw
+        if not ctx.needs_input_grad[0]:
+            join_side_stream()
         dy = torch.zeros(n, cout, h, w, dtype=torch.float32, device=x.device)
         call("vocr_relu_maxpool2_bwd", _p(dout), _p(out), _p(idx), _p(dy), n, cout, h, w, _stream())
         dbias = channel_sum(dy)
@@ -327,6 +351,7 @@ class BiLstmLayerFn(torch.autograd.Function):
         call("vocr_lstm_fwd", _p(xproj), _p(w_hh_f), _p(w_hh_r), _p(lens_dev), _p(y), _p(gates), _p(cell), _p(ws), T, B, H,
              _stream())
         ctx.dims = (T, B, H, din)
+        ctx.b_refs = (b_ih_f, b_hh_f, b_ih_r, b_hh_r)
         ctx.save_for_backward(x, lens_dev, y, gates, cell, w_ih_f, w_hh_f, w_ih_r, w_hh_r)
         return y
 
@@ -343,25 +368,48 @@ class BiLstmLayerFn(torch.autograd.Function):
         call("vocr_lstm_bwd", _p(dy), _p(wt_f), _p(wt_r), _p(lens_dev), _p(gates), _p(cell), _p(dg), _p(ws), T, B, H,
              _stream())
         G = 4 * H
-        dw_ih_f = torch.empty_like(w_ih_f)
-        dw_ih_r = torch.empty_like(w_ih_r)
-        gemm(1, 0, G, din, T * B, dg[0], G, x, din, dw_ih_f, din)
-        gemm(1, 0, G, din, T * B, dg[1], G, x, din, dw_ih_r, din)
-        db_f = colsum(dg[0])
-        db_r = colsum(dg[1])
-        dw_hh_f = torch.zeros_like(w_hh_f)
-        dw_hh_r = torch.zeros_like(w_hh_r)
-        if T > 1:
-            # forward dir: h_{t-1} = y[t-1, :, :H];   reverse dir: h_{t+1} = y[t+1, :, H:]  (zero past the length)
-            m = (T - 1) * B
-            gemm(1, 0, G, H, m, dg[0][B:], G, y, 2 * H, dw_hh_f, H)
-            gemm(1, 0, G, H, m, dg[1], G, y[B:, H:], 2 * H, dw_hh_r, H)
+        # critical path first: dx feeds the layer below
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             gemm(0, 0, T * B, din, G, dg[0], G, w_ih_f, din, dx, din)
             gemm(0, 0, T * B, din, G, dg[1], G, w_ih_r, din, dx, din, accumulate=True)
-        return dx, None, None, None, dw_ih_f, dw_hh_f, db_f, db_f.clone(), dw_ih_r, dw_hh_r, db_r, db_r.clone()
+
+        # weight gradients: if every parameter already owns a gradient buffer (FlatClampAdam aliases them into one
+        # flat buffer), write them there from the side stream so they overlap the next layer's sweep; otherwise
+        # return them to autograd on the current stream.
+        params = (w_ih_f, w_hh_f, ctx.b_refs[0], ctx.b_refs[1], w_ih_r, w_hh_r, ctx.b_refs[2], ctx.b_refs[3])
+        direct = _SIDE["enabled"] and all(p.grad is not None and p.grad.is_contiguous() for p in params)
+
+        def weight_grads(outs):
+            dwi_f, dwh_f, dbi_f, dbh_f, dwi_r, dwh_r, dbi_r, dbh_r = outs
+            gemm(1, 0, G, din, T * B, dg[0], G, x, din, dwi_f, din)
+            gemm(1, 0, G, din, T * B, dg[1], G, x, din, dwi_r, din)
+            if T > 1:
+                # forward dir: h_{t-1} = y[t-1, :, :H];   reverse dir: h_{t+1} = y[t+1, :, H:]  (zero past the length)
+                m = (T - 1) * B
+                gemm(1, 0, G, H, m, dg[0][B:], G, y, 2 * H, dwh_f, H)
+                gemm(1, 0, G, H, m, dg[1], G, y[B:, H:], 2 * H, dwh_r, H)
+            else:
+                dwh_f.zero_()
+                dwh_r.zero_()
+            call("vocr_colsum", _p(dg[0]), _p(dbi_f), T * B, G, _stream())
+            call("vocr_colsum", _p(dg[1]), _p(dbi_r), T * B, G, _stream())
+            dbh_f.copy_(dbi_f)
+            dbh_r.copy_(dbi_r)
+
+        if direct:
+            side = side_stream()
+            side.wait_stream(torch.cuda.current_stream())
+            for t_ in (dg, x, y):
+                t_.record_stream(side)
+            with torch.cuda.stream(side):
+                weight_grads([p.grad for p in params])
+            _SIDE["pending"] = True
+            return (dx, None, None, None) + (None,) * 8
+        outs = [torch.empty_like(p) for p in params]
+        weight_grads(outs)
+        return (dx, None, None, None) + tuple(outs)
 
 
 # ------------------------------------------------------------------------------------------------ CTC

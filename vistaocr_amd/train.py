@@ -48,11 +48,14 @@ class FlatClampAdam(object):
 
     def all_reduce_grads(self, group=None):
         """Sum gradients over data-parallel ranks (RCCL over xGMI when the backend is 'nccl')."""
+        if self.flat_g.is_cuda:
+            ops.join_side_stream()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=group)
 
     def step(self, grad_scale=1.0):
         g = self.param_groups[0]
+        ops.join_side_stream()
         self.step_count += 1
         ops.clamp_adam(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, g["lr"], g["betas"][0], g["betas"][1],
                        g["eps"], g["weight_decay"], g["clamp"], grad_scale, self.step_count)
