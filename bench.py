@@ -103,7 +103,8 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("VOCR_FORCE_DIST") == "1"      # FORCE: exercise RCCL init/all-reduce on one GPU
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
@@ -114,7 +115,7 @@ def main():
     torch.manual_seed(0)                                  # same init on every rank (replicas)
     model = va.CnnOcrModel(alphabet=al, verbose=False, **hp)
     model.train()
-    opt = va.FlatClampAdam(model.parameters(), lr=1e-3)
+    opt = va.make_optimizer(model, lr=1e-3)          # flat Adam; all-reduce in two buckets, the big one under the CNN backward
     crit = va.CTCLoss()
     x, tgt, widths, tl = make_batch(rank, len(al))
     x = x.cuda()
@@ -128,20 +129,20 @@ def main():
     timed = ["vocr_conv3x3_fwd", "vocr_conv3x3_wgrad", "vocr_lstm_fwd", "vocr_lstm_bwd", "vocr_gemm"]
     _lib.enable_timing(timed)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     recs = _lib.timing_records()
     _lib.enable_timing(None)
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -174,7 +175,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(len(al))
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

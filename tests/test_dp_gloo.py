@@ -63,3 +63,42 @@ def test_flat_gradient_allreduce_world2():
     for p in procs:
         p.join(60)
     assert res == [(0, True), (1, True)]
+
+
+def _worker_buckets(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import vistaocr_amd as va
+    from vistaocr_amd import ops
+    torch.manual_seed(0)
+    m = va.CnnOcrModel(alphabet=va.english_alphabet(), gpu=False, verbose=False, input_line_height=30, rds_line_height=30,
+                       lstm_input_dim=16, num_lstm_layers=1, num_lstm_hidden_units=16, p_lstm_dropout=0.0)
+    opt = va.make_optimizer(m)
+    n_cnn = sum(p.numel() for p in m.cnn.parameters())
+    ok = opt._split == n_cnn and 0 < n_cnn < opt.flat_g.numel()
+    opt.zero_grad()
+    opt.flat_g[opt._split:] = float(rank + 1)          # sequence-side gradients are final ...
+    for fn in ops.BACKWARD_HOOKS["sequence_grads_ready"]:
+        fn()                                            # ... the backward fires the hook: tail all-reduce starts
+    ok = ok and opt._tail_work is not None
+    opt.flat_g[:opt._split] = float(10 * (rank + 1))   # CNN gradients arrive later
+    opt.all_reduce_grads()
+    want_tail = float(sum(r + 1 for r in range(world)))
+    ok = ok and bool(torch.all(opt.flat_g[opt._split:] == want_tail)) and bool(torch.all(opt.flat_g[:opt._split] == 10 * want_tail))
+    ok = ok and opt._tail_work is None
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_two_bucket_allreduce_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_buckets, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == [(0, True), (1, True)]

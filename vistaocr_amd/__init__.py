@@ -5,7 +5,7 @@ from .alphabet import Alphabet, arabic_alphabet, english_alphabet, french_alphab
 from .ctc import CTCLoss                                                                # noqa: F401
 from .decoder import ArgmaxDecoder                                                      # noqa: F401
 from .model import CnnOcrModel                                                          # noqa: F401
-from .train import FlatClampAdam, train, train_async                                    # noqa: F401
+from .train import FlatClampAdam, make_optimizer, train, train_async                                    # noqa: F401
 
 __all__ = ["Alphabet", "english_alphabet", "arabic_alphabet", "french_alphabet", "CTCLoss", "ArgmaxDecoder",
-           "CnnOcrModel", "FlatClampAdam", "train", "train_async"]
+           "CnnOcrModel", "FlatClampAdam", "make_optimizer", "train", "train_async"]

@@ -51,6 +51,16 @@ def join_side_stream():
         _SIDE["pending"] = False
 
 
+# ---- backward milestones: callbacks fired from inside the backward pass (used to start the data-parallel
+# all-reduce of the sequence-side gradients while the CNN backward is still running)
+BACKWARD_HOOKS = {"sequence_grads_ready": []}
+
+
+def _fire(name):
+    for fn in BACKWARD_HOOKS.get(name, ()):
+        fn()
+
+
 def _ws(nbytes, device):
     return torch.empty((max(int(nbytes), 16) + 3) // 4, dtype=torch.float32, device=device)
 
@@ -241,6 +251,8 @@ class PermuteBchwToWbchFn(torch.autograd.Function):
     def backward(ctx, dout):
         b, c, h, w = ctx.shape
         dout = _f32c(dout)
+        # everything above the CNN (bridge, LSTM, prob) has produced its gradients by now
+        _fire("sequence_grads_ready")
         dx = torch.empty(b, c, h, w, dtype=torch.float32, device=dout.device)
         call("vocr_wbch_to_bchw", _p(dout), _p(dx), b, c, h, w, _stream())
         return dx

@@ -16,7 +16,7 @@ class FlatClampAdam(object):
     flat parameter buffer.  API subset of torch.optim.Optimizer used by the reference loop: zero_grad(), step(),
     param_groups[0]['lr'], state_dict()/load_state_dict()."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clamp=5.0):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clamp=5.0, named_split=None):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no parameters")
@@ -36,6 +36,15 @@ class FlatClampAdam(object):
                 off += k
         self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, clamp=clamp)]
         self.step_count = 0
+        # Two all-reduce buckets: [0, split) = parameters whose gradients appear last (rapid_ds + cnn), [split, n) =
+        # bridge + LSTM + prob (88 % of the bytes at H=512), final as soon as the backward reaches the CNN, so their
+        # exchange over xGMI is launched there and hides under the CNN backward.
+        self._split = 0
+        self._tail_work = None
+        if named_split is not None:
+            self._split = int(named_split)
+        if self._split > 0:
+            ops.BACKWARD_HOOKS["sequence_grads_ready"] = [self._start_tail_allreduce]
 
     def zero_grad(self, set_to_none=False):
         self.flat_g.zero_()
@@ -46,11 +55,30 @@ class FlatClampAdam(object):
                 p.grad = self.flat_g[off:off + k].view_as(p)
             off += k
 
+    @staticmethod
+    def _dp_active(group=None):
+        import os
+        return dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or
+                                                                  os.environ.get("VOCR_FORCE_DIST") == "1")
+
+    def _start_tail_allreduce(self):
+        """Backward hook: bridge/LSTM/prob gradients are final -> start their all-reduce asynchronously."""
+        if self._split > 0 and self._tail_work is None and self._dp_active():
+            if self.flat_g.is_cuda:
+                ops.join_side_stream()
+            self._tail_work = dist.all_reduce(self.flat_g[self._split:], op=dist.ReduceOp.SUM, async_op=True)
+
     def all_reduce_grads(self, group=None):
         """Sum gradients over data-parallel ranks (RCCL over xGMI when the backend is 'nccl')."""
         if self.flat_g.is_cuda:
             ops.join_side_stream()
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if not self._dp_active(group):
+            return
+        if self._tail_work is not None:                 # tail bucket already in flight since mid-backward
+            dist.all_reduce(self.flat_g[:self._split], op=dist.ReduceOp.SUM, group=group)
+            self._tail_work.wait()
+            self._tail_work = None
+        else:
             dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=group)
 
     def step(self, grad_scale=1.0):
@@ -68,6 +96,12 @@ class FlatClampAdam(object):
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.param_groups[0].update({k: v for k, v in sd["param_groups"][0].items()})
+
+
+def make_optimizer(model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clamp=5.0):
+    """FlatClampAdam over model.parameters() with the bucket boundary placed after the CNN parameters."""
+    n_cnn = sum(p.numel() for p in list(model.rapid_ds.parameters()) + list(model.cnn.parameters()) if p.requires_grad)
+    return FlatClampAdam(model.parameters(), lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, clamp=clamp, named_split=n_cnn)
 
 
 def train(batch, model, criterion, optimizer):
