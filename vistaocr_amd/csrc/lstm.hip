@@ -194,6 +194,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_fast(const float* __restric
                                                           float* __restrict__ cell, int T, int B, int step, int dbg) {
     constexpr int H = 64 * KQ4;
     __shared__ float red[4][RT * 16][17];
+    __builtin_amdgcn_s_setprio(3);      // latency-critical: win issue arbitration against co-resident throughput kernels
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int ublocks = H >> 2;
     const int dir = blockIdx.x / ublocks, unit0 = (blockIdx.x % ublocks) * 4;
@@ -302,6 +303,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_bwd_step_fast(const float* __res
     constexpr int CH = NCH / WPG;               // 32-wide chunks per lane-quarter
     static_assert(NCH % WPG == 0, "bad wave split");
     __shared__ float red[NW][16][17];
+    __builtin_amdgcn_s_setprio(3);      // latency-critical: win issue arbitration against co-resident throughput kernels
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int ublocks = H / UT;
     int bid = blockIdx.x;
