@@ -258,6 +258,41 @@ def run_decode_edges(CnnOcrModel, ArgmaxDecoder, alphabet):
     print("decode_edges", a)
 
 
+def run_host_logic():
+    """Host-side control logic of the reference that the build mirrors: the plateau scheduler
+    (src/lr_scheduler.py) driven by metric sequences, and SortByWidthCollater (src/datautils.py) on a small batch."""
+    from lr_scheduler import ReduceLROnPlateau
+    from datautils import SortByWidthCollater
+    out = {}
+    metrics = [5.0, 4.0, 4.0, 4.00005, 3.9, 3.95, 3.95, 3.95, 3.95, 3.0, 3.1, 3.1, 3.1, 3.1, 3.1, 3.1, 3.1, 3.1, 3.1, 3.1]
+    for name, kw in [("a", dict(patience=2, min_lr=1e-5)), ("b", dict(patience=0, min_lr=1e-4, cooldown=2)), ("c", dict(patience=1, min_lr=0))]:
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.Adam([p], lr=1e-3)
+        sch = ReduceLROnPlateau(opt, mode="min", **kw)
+        trace = []
+        for m in metrics:
+            r = sch.step(m)
+            trace.append((float(bool(r)), float(opt.param_groups[0]["lr"]), float(bool(sch.finished)), float(sch.wait)))
+        out["sched_" + name] = np.array(trace, dtype=np.float64)
+    out["sched_metrics"] = np.array(metrics, dtype=np.float64)
+    r = np.random.RandomState(0)
+    batch, spec = [], []
+    for i, (w, L) in enumerate([(40, 3), (97, 7), (15, 1), (97, 2), (60, 5)]):
+        img = r.uniform(0, 1, size=(1, 30, w + (3 if i == 0 else 0))).astype(np.float32)     # item 0 arrives pre-padded
+        tr = [int(v) for v in r.randint(1, 96, size=L)]
+        batch.append((torch.from_numpy(img), tr, {"width": w, "utt-id": "utt%d" % i, "writer-id": 10 + i}))
+        spec.append((w, L))
+    x, tgt, widths, tls, meta = SortByWidthCollater(list(batch))
+    out["coll_x"] = x.numpy()
+    out["coll_targets"] = tgt.numpy()
+    out["coll_widths"] = widths.numpy()
+    out["coll_target_lens"] = tls.numpy()
+    out["coll_ids"] = np.array(meta["utt-ids"], dtype=object)
+    out["coll_writers"] = meta["writer-ids"].numpy()
+    np.savez_compressed(os.path.join(OUT, "host_logic.npz"), **out)
+    print("host_logic  scheduler traces + collater batch saved")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -301,6 +336,7 @@ def main():
     run_case("h256", CnnOcrModel, eng, h256, 8, [300] * 8, [12] * 8, "train", save_logits=False)
     run_train2(CnnOcrModel, eng, small, 4, [200, 200, 160, 120], [8, 8, 6, 4])
     run_decode_edges(CnnOcrModel, ArgmaxDecoder, eng)
+    run_host_logic()
     # no bytecode may be left in the read-only reference tree
     for d in (REF, os.path.join(REF, "models")):
         assert not os.path.exists(os.path.join(d, "__pycache__")), d

@@ -95,3 +95,30 @@ def test_batch_64_speed_test_shape():
               p_lstm_dropout=0.0, num_in_channels=1)
     from tests import golden_util as gu
     _run_pair(hp, gu.alphabet_chars("english"), 40, [100] * 30 + [64] * 10, [3] * 40, seed=5)
+
+
+def test_validation_pass_and_snapshot_roundtrip(tmp_path):
+    """test_on_val (src/train_cnn_lstm.py:32-100) on the HIP path + checkpoint written/read with the reference schema."""
+    import os
+    import vistaocr_amd as va
+    from vistaocr_amd.loop import SortByWidthCollater, save_snapshot, test_on_val
+    al = va.english_alphabet()
+    hp = dict(input_line_height=30, rds_line_height=30, lstm_input_dim=32, num_lstm_layers=1, num_lstm_hidden_units=32,
+              p_lstm_dropout=0.0, num_in_channels=1)
+    torch.manual_seed(1)
+    model = va.CnnOcrModel(alphabet=al, verbose=False, **hp)
+    r = np.random.RandomState(0)
+    items = []
+    for i, w in enumerate([120, 90, 150, 64, 200, 33]):
+        items.append((torch.from_numpy(r.uniform(0, 1, size=(1, 30, w)).astype(np.float32)), [int(v) for v in r.randint(1, 96, size=4)],
+                      {"width": w, "utt-id": "u%d" % i}))
+    loader = [SortByWidthCollater(items[:3]), SortByWidthCollater(items[3:])]
+    torch.manual_seed(7)
+    loss, cer, wer = test_on_val(loader, model, va.CTCLoss())
+    assert np.isfinite(loss) and 0.0 <= cer and 0.0 <= wer and model.training
+    opt = va.make_optimizer(model)
+    path = os.path.join(tmp_path, "snap.pth")
+    save_snapshot(path, 3, model, opt, False, 1e-3, loss, cer, wer, 30)
+    m2 = va.CnnOcrModel.FromSavedWeights(path, verbose=False)
+    for k, v in model.state_dict().items():
+        assert torch.equal(v.cpu(), m2.state_dict()[k].cpu()), k

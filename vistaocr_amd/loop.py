@@ -1,0 +1,220 @@
+"""Host-side shell around the hot path: the pieces of src/train_cnn_lstm.py,
+src/lr_scheduler.py and src/datautils.py that drive train()/test_on_val() — restated so a user of the reference finds
+the same control flow: width-grouped sampling, sort-by-width collation, plateau LR schedule with "reload best on LR
+drop", validation with CER/WER, and the reference's checkpoint dictionary.  Pure host logic; the arithmetic stays in
+the HIP path (model / criterion / decoder)."""
+import logging
+import shutil
+import warnings
+
+import numpy as np
+import torch
+
+from .textutils import compute_cer_wer, form_target_transcription
+
+logger = logging.getLogger("root")
+
+
+class ReduceLROnPlateau(object):
+    """src/lr_scheduler.py:10-98.  step(metric) returns True when the LR was lowered (or could not be lowered any
+    further, which sets .finished).  Works with any optimiser exposing .param_groups (FlatClampAdam, torch.optim.*)."""
+
+    def __init__(self, optimizer, mode="min", factor=0.1, patience=10, epsilon=1e-4, cooldown=0, min_lr=0):
+        if not hasattr(optimizer, "param_groups"):
+            raise AssertionError("optimizer has no param_groups")
+        if factor >= 1.0:
+            raise ValueError("ReduceLROnPlateau does not support a factor>=1.0")
+        self.finished = False
+        self.factor, self.min_lr, self.epsilon, self.patience, self.cooldown = factor, min_lr, epsilon, patience, cooldown
+        self.cooldown_counter = 0
+        self.wait = 0
+        self.best = 0
+        self.mode = mode
+        self.optimizer = optimizer
+        self._reset()
+
+    def _reset(self):
+        if self.mode not in ["min", "max"]:
+            raise RuntimeError("ReduceLROnPlateau mode:%s not valid." % self.mode)
+        if self.mode == "min":
+            self.monitor_op = lambda a, b: np.less(a, b - self.epsilon)
+            self.best = np.inf
+        else:
+            self.monitor_op = lambda a, b: np.less(a, b + self.epsilon)      # (sic) the reference's max mode
+            self.best = -np.inf
+        self.cooldown_counter = 0
+        self.wait = 0
+        self.lr_epsilon = self.min_lr * 1e-4
+
+    def reset(self):
+        self._reset()
+
+    def in_cooldown(self):
+        return self.cooldown_counter > 0
+
+    def step(self, metrics):
+        current = metrics
+        if current is None:
+            warnings.warn("Learning Rate Plateau Reducing requires metrics.", RuntimeWarning)
+            return False
+        if self.in_cooldown():
+            self.cooldown_counter -= 1
+            self.wait = 0
+        if self.monitor_op(current, self.best):
+            self.best = current
+            self.wait = 0
+        elif not self.in_cooldown():
+            if self.wait >= self.patience:
+                for group in self.optimizer.param_groups:
+                    old_lr = float(group["lr"])
+                    if old_lr > self.min_lr + self.lr_epsilon:
+                        group["lr"] = max(old_lr * self.factor, self.min_lr)
+                        self.cooldown_counter = self.cooldown
+                        self.wait = 0
+                    else:
+                        self.finished = True
+                return True
+            self.wait += 1
+        return False
+
+
+class GroupedSampler(torch.utils.data.Sampler):
+    """src/datautils.py:4-51 — visit width groups in order, random within a group.  (The reference's generator
+    raises StopIteration inside a generator, a RuntimeError since PEP 479; this one simply returns.)"""
+
+    def __init__(self, data_source, rand=True, max_items=-1, fixed_rand=False):
+        self.size_group_keys = data_source.size_group_keys
+        self.size_groups = data_source.size_groups
+        self.num_samples = len(data_source)
+        self.rand, self.fixed_rand, self.max_items = rand, fixed_rand, max_items
+        self.rand_perm = dict()
+
+    def __iter__(self):
+        n_items = 0
+        for g in self.size_group_keys:
+            if len(self.size_groups[g]) == 0:
+                continue
+            if self.fixed_rand:
+                if g not in self.rand_perm:
+                    self.rand_perm[g] = torch.randperm(len(self.size_groups[g])).long()
+                order = self.rand_perm[g]
+            elif self.rand:
+                order = torch.randperm(len(self.size_groups[g])).long()
+            else:
+                order = range(len(self.size_groups[g]))
+            for g_idx in order:
+                n_items += 1
+                if self.max_items > 0 and n_items > self.max_items:
+                    return
+                yield self.size_groups[g][int(g_idx)]
+
+    def __len__(self):
+        return self.num_samples
+
+
+def SortByWidthCollater(batch):
+    """src/datautils.py:54-176 (non-seq2seq, non-bylang path): sort by metadata['width'] descending, zero-pad the
+    images to the widest, unpadded widths as IntTensor, flat IntTensor targets, target lengths, metadata lists."""
+    batch = sorted(batch, key=lambda d: d[-1]["width"], reverse=True)
+    biggest = batch[0][0].size()
+    x = torch.zeros(len(batch), biggest[0], biggest[1], biggest[2])
+    widths = torch.IntTensor(len(batch))
+    target_lens = torch.IntTensor(len(batch))
+    writer_ids = torch.LongTensor(len(batch))
+    ids, have_writers = [], False
+    for i, (tensor, transcript, md) in enumerate(batch):
+        x[i, :, :, :tensor.size(2)] = tensor
+        widths[i] = md["width"]
+        target_lens[i] = len(transcript)
+        if "writer-id" in md:
+            writer_ids[i] = md["writer-id"]
+            have_writers = True
+        if "utt-id" in md:
+            ids.append(md["utt-id"])
+    targets = torch.IntTensor(int(target_lens.sum().item()))
+    o = 0
+    for _, transcript, _ in batch:
+        for ch in transcript:
+            targets[o] = ch
+            o += 1
+    meta = {}
+    if have_writers:
+        meta["writer-ids"] = writer_ids
+    if ids:
+        meta["utt-ids"] = ids
+    return x, targets, widths, target_lens, meta
+
+
+def test_on_val(val_dataloader, model, criterion):
+    """src/train_cnn_lstm.py:32-100 — running means of loss/batch, CER and WER over the validation loader."""
+    cer_avg = wer_avg = loss_avg = 0.0
+    n = 0
+    model.eval()
+    with torch.no_grad():
+        for x, target, widths, target_lens, _ in val_dataloader:
+            out, lens = model(x.cuda(non_blocking=True), widths)
+            loss = criterion(out, target, lens, target_lens)
+            hyps = model.decode_without_lm(out, lens, uxxxx=True)
+            bsz = x.size(0)
+            n += 1
+            loss_avg += (float(loss) / bsz - loss_avg) / n
+            o = 0
+            bc = bw = 0.0
+            tnp = target.numpy()
+            for i, hyp in enumerate(hyps):
+                L = int(target_lens[i])
+                ref = form_target_transcription(tnp[o:o + L], model.alphabet)
+                o += L
+                c, w = compute_cer_wer(hyp, ref)
+                bc += c
+                bw += w
+            cer_avg += (bc / bsz - cer_avg) / n
+            wer_avg += (bw / bsz - wer_avg) / n
+    model.train()
+    return loss_avg, cer_avg, wer_avg
+
+
+def save_snapshot(path, iteration, model, optimizer, rtl, cur_lr, val_loss, val_cer, val_wer, line_height):
+    """The checkpoint dictionary of src/train_cnn_lstm.py:427-438 (FromSavedWeights reads it back)."""
+    torch.save({"iteration": iteration, "state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
+                "optimizer": optimizer.state_dict(), "model_hyper_params": model.get_hyper_params(), "rtl": rtl,
+                "cur_lr": cur_lr, "val_loss": val_loss, "val_cer": val_cer, "val_wer": val_wer, "line_height": line_height}, path)
+
+
+def fit(model, criterion, optimizer, train_dataloader, validation_dataloader, train_fn, snapshot_prefix, batch_size,
+        n_epochs=1, snapshot_every_n_iterations=1000, patience=10, min_lr=1e-7, rtl=False, line_height=30,
+        validate_fn=test_on_val):
+    """The loop of src/train_cnn_lstm.py:375-470: train, validate every N iterations, plateau schedule on val WER,
+    snapshot, copy to best, reload best after an LR drop, stop when the schedule is exhausted.  Returns a history dict."""
+    snapshot_path = snapshot_prefix + "-cur_snapshot.pth"
+    best_model_path = snapshot_prefix + "-best_model.pth"
+    scheduler = ReduceLROnPlateau(optimizer, mode="min", patience=patience, min_lr=min_lr)
+    lr_alpha = float(optimizer.param_groups[0]["lr"])
+    hist = dict(loss=[], val=[], lr_drops=[], stopped_early=False)
+    iteration = 0
+    best_val_wer = float("inf")
+    for _epoch in range(1, n_epochs + 1):
+        for batch in train_dataloader:
+            iteration += 1
+            hist["loss"].append(train_fn(batch, model, criterion, optimizer) / batch_size)
+            if iteration % snapshot_every_n_iterations != 0:
+                continue
+            val_loss, val_cer, val_wer = validate_fn(validation_dataloader, model, criterion)
+            early_exit = lowered = False
+            if scheduler.step(val_wer):
+                lowered = True
+                hist["lr_drops"].append(iteration)
+                early_exit = scheduler.finished
+                lr_alpha = max(lr_alpha * scheduler.factor, scheduler.min_lr)
+            hist["val"].append((iteration, val_loss, val_cer, val_wer))
+            save_snapshot(snapshot_path, iteration, model, optimizer, rtl, lr_alpha, val_loss, val_cer, val_wer, line_height)
+            if val_wer < best_val_wer:
+                best_val_wer = val_wer
+                shutil.copyfile(snapshot_path, best_model_path)
+            if early_exit:
+                hist["stopped_early"] = True
+                return hist
+            if lowered:
+                weights = torch.load(best_model_path, map_location="cpu", weights_only=False)
+                model.load_state_dict(weights["state_dict"])
+    return hist
