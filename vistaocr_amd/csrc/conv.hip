@@ -45,15 +45,21 @@ __device__ __attribute__((aligned(16))) float g_zero_page[64];
 //   weights: 16-byte loads, a thread keeps one float4 column and walks rows with a constant stride
 //   K order inside a chunk: MFMA step ks multiplies k = ks (lanes 0-31) and k = ks + 36 (lanes 32-63), i.e.
 //   channels ci and ci+4 of the chunk, so both A and B fragment addresses are lane-constant base + immediate.
-template <int CO_T, bool VECW>
+// SPWV = 32-pixel segments per wave (2: wave tile 64co x 64px, 1: 64co x 32px).  The smaller tile halves the work of
+// a workgroup: at batch 32 the layers have only 4-7 full-size workgroups per CU and the last partial round costs 20 %
+// (measured 88 TF at 4.4 WG/CU vs 111 TF at 16 WG/CU); twice as many half-size workgroups let the hardware
+// dispatcher balance the tail.
+template <int CO_T, int SPWV, bool VECW>
 __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ in, const float* __restrict__ wpack,
                                                       const float* __restrict__ bias, float* __restrict__ out,
                                                       const float* __restrict__ zero_page, int N, int Cin, int H, int W,
                                                       int Cout, int SW, int nseg_total) {
     constexpr int WAVES_CO = CO_T / 64;
     constexpr int WAVES_PX = 4 / WAVES_CO;
-    constexpr int NSEG = WAVES_PX * 2;
-    constexpr int SPW = NSEG / 4;                          // segments staged per wave: 1 or 2
+    constexpr int NSEG = WAVES_PX * SPWV;
+    constexpr int RPW = NSEG * 6;                          // halo rows staged per wave (NSEG*24 rows / 4 waves): 12, 24 or 48
+    constexpr int SST = RPW >= 24 ? RPW / 24 : 1;          // segments a wave stages rows for
+    constexpr int ROWS = RPW >= 24 ? 24 : RPW;             // rows per staged segment
     constexpr int C4 = CO_T / 4;                           // float4 columns of the weight tile
     constexpr int RPP = 256 / C4;                          // weight rows per pass: 8 or 16
     constexpr int EA = (KC + RPP - 1) / RPP;               // 9 or 5 passes
@@ -80,13 +86,13 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
     __syncthreads();
 
     const int wco = (wave / WAVES_PX) * 64;
-    const int wsg = (wave % WAVES_PX) * 2;
+    const int wsg = (wave % WAVES_PX) * SPWV;
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][SPWV];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < SPWV; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -96,22 +102,24 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
     const int wcol_c = VECW ? min(wcol, Cout - 4) : 0;      // clamped: loads are unconditional, results are selected
     const int Ktot = Cin * 9;
     f32x4 ra[EA];
-    float rp[SPW * 24];
-    int p_h[SPW], p_valid[SPW], p_loff[SPW];
-    const float* p_base[SPW];
-    bool p_colok[SPW];
+    float rp[SST * ROWS];
+    // this wave stages rows [wave*RPW, (wave+1)*RPW) of the NSEG*24 (segment, ci, kh) halo rows
+    const int st_seg0 = (wave * RPW) / 24;
+    const int st_ci0 = ((wave * RPW) % 24) / 3;
+    int p_h[SST], p_loff[SST];
+    const float* p_base[SST];
+    bool p_colok[SST];
 #pragma unroll
-    for (int q = 0; q < SPW; ++q) {
-        const SegInfo sg = segs[wave * SPW + q];
+    for (int q = 0; q < SST; ++q) {
+        const SegInfo sg = segs[st_seg0 + q];
         const int ww = sg.w0 - 1 + lane;
         p_h[q] = sg.h;
-        p_valid[q] = sg.valid;
         p_colok[q] = sg.valid && lane < PROW && ww >= 0 && ww < W;
         p_loff[q] = p_colok[q] ? ww : 0;
         p_base[q] = in + sg.base;
     }
 
-    // branch-free: every load is issued from a clamped (always valid) address, invalid lanes are zeroed by a select
+    // branch-free: every load is issued from a clamped (always valid) address, invalid lanes read the zero page
     auto load_chunk = [&](int ci0) {
 #pragma unroll
         for (int e = 0; e < EA; ++e) {
@@ -133,17 +141,16 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
             ra[e] = v;
         }
 #pragma unroll
-        for (int q = 0; q < SPW; ++q)
+        for (int q = 0; q < SST; ++q)
 #pragma unroll
-            for (int ci = 0; ci < CI_C; ++ci)
-#pragma unroll
-                for (int kh = 0; kh < 3; ++kh) {
-                    const int hh = p_h[q] + kh - 1;
-                    const bool rowok = (ci0 + ci) < Cin && hh >= 0 && hh < H;                 // wave-uniform
-                    const int cic = min(ci0 + ci, Cin - 1), hhc = min(max(hh, 0), H - 1);
-                    const float* src = p_base[q] + ((long)cic * HW + (long)hhc * W + p_loff[q]);
-                    rp[q * 24 + ci * 3 + kh] = *((rowok && p_colok[q]) ? src : zero_page + lane);
-                }
+            for (int j = 0; j < ROWS; ++j) {
+                const int ci = st_ci0 + j / 3, kh = j % 3;
+                const int hh = p_h[q] + kh - 1;
+                const bool rowok = (ci0 + ci) < Cin && hh >= 0 && hh < H;                 // wave-uniform
+                const int cic = min(ci0 + ci, Cin - 1), hhc = min(max(hh, 0), H - 1);
+                const float* src = p_base[q] + ((long)cic * HW + (long)hhc * W + p_loff[q]);
+                rp[q * ROWS + j] = *((rowok && p_colok[q]) ? src : zero_page + lane);
+            }
     };
     auto store_chunk = [&]() {
 #pragma unroll
@@ -153,12 +160,10 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
         }
         if (lane < PROW) {
 #pragma unroll
-            for (int q = 0; q < SPW; ++q)
+            for (int q = 0; q < SST; ++q)
 #pragma unroll
-                for (int ci = 0; ci < CI_C; ++ci)
-#pragma unroll
-                    for (int kh = 0; kh < 3; ++kh)
-                        P[(wave * SPW + q) * PSEG + ci * PCI + kh * PROW + lane] = rp[q * 24 + ci * 3 + kh];
+                for (int j = 0; j < ROWS; ++j)
+                    P[(st_seg0 + q) * PSEG + (st_ci0 + j / 3) * PCI + (j % 3) * PROW + lane] = rp[q * ROWS + j];
         }
     };
 
@@ -167,19 +172,37 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
     store_chunk();
     __syncthreads();
     const float* wa = Wt + wco + li + lk * (KC / 2) * CO_T;
-    const float* pb0 = P + (wsg + 0) * PSEG + li + lk * (CI_C / 2) * PCI;
-    const float* pb1 = P + (wsg + 1) * PSEG + li + lk * (CI_C / 2) * PCI;
+    const float* pb = P + wsg * PSEG + li + lk * (CI_C / 2) * PCI;
     for (int c = 0; c < nchunks; ++c) {
         if (c + 1 < nchunks) load_chunk((c + 1) * CI_C);
+        // fragment reads run one k-step ahead of the MFMAs that consume them (hipcc otherwise emits
+        // read -> lgkmcnt(0) -> MFMAs per step and exposes the LDS latency)
+        float a0 = wa[0], a1 = wa[32], b[SPWV];
+#pragma unroll
+        for (int j = 0; j < SPWV; ++j) b[j] = pb[j * PSEG];
 #pragma unroll
         for (int ks = 0; ks < KC / 2; ++ks) {
-            const int off = (ks / 9) * PCI + ((ks % 9) / 3) * PROW + (ks % 3);     // compile-time after unrolling
-            const float a0 = wa[ks * CO_T], a1 = wa[ks * CO_T + 32];
-            const float b0 = pb0[off], b1 = pb1[off];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            float a0n = 0.f, a1n = 0.f, bn[SPWV];
+#pragma unroll
+            for (int j = 0; j < SPWV; ++j) bn[j] = 0.f;
+            if (ks + 1 < KC / 2) {
+                const int kn = ks + 1;
+                const int offn = (kn / 9) * PCI + ((kn % 9) / 3) * PROW + (kn % 3);     // compile-time after unrolling
+                a0n = wa[kn * CO_T];
+                a1n = wa[kn * CO_T + 32];
+#pragma unroll
+                for (int j = 0; j < SPWV; ++j) bn[j] = pb[j * PSEG + offn];
+            }
+            __builtin_amdgcn_sched_barrier(0);      // next step's ds_reads are issued BEFORE this step's MFMAs
+#pragma unroll
+            for (int j = 0; j < SPWV; ++j) {
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[j], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[j], acc[1][j], 0, 0, 0);
+            }
+            a0 = a0n;
+            a1 = a1n;
+#pragma unroll
+            for (int j = 0; j < SPWV; ++j) b[j] = bn[j];
         }
         __syncthreads();
         if (c + 1 < nchunks) {
@@ -189,7 +212,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
     }
 
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < SPWV; ++j) {
         const SegInfo s = segs[wsg + j];
         const int ww = s.w0 + li;
         if (!s.valid || ww >= W) continue;
@@ -471,15 +494,22 @@ extern "C" int vocr_conv3x3_fwd(const float* x, const float* wpack, const float*
     const bool vec = (cout % 4 == 0) && ((((uintptr_t)wpack) & 15) == 0);
     const float* zp = zero_page_ptr();
     VOCR_CHECK_ARG(zp != nullptr, "vocr_conv3x3_fwd: no device zero page");
+    // full-size workgroups (128co x 4 segments or 64co x 8 segments); fewer than 6 of them per CU -> half-size (measured)
+    const int co_tiles = cout > 64 ? vocr_cdiv(cout, 128) : 1;
+    const long full_wgs = (long)vocr_cdiv(nseg, cout > 64 ? 4 : 8) * co_tiles;
+    const bool small = full_wgs < 6l * 256;
+#define VOCR_CONV(CO_T, SPWV, NSEG)                                                                                          \
+    do {                                                                                                                    \
+        dim3 grid(vocr_cdiv(nseg, NSEG), co_tiles);                                                                         \
+        if (vec) conv3x3_kernel<CO_T, SPWV, true><<<grid, 256, 0, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, SW, (int)nseg);  \
+        else conv3x3_kernel<CO_T, SPWV, false><<<grid, 256, 0, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, SW, (int)nseg);     \
+    } while (0)
     if (cout > 64) {
-        dim3 grid(vocr_cdiv(nseg, 4), vocr_cdiv(cout, 128));
-        if (vec) conv3x3_kernel<128, true><<<grid, 256, 0, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, SW, (int)nseg);
-        else conv3x3_kernel<128, false><<<grid, 256, 0, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, SW, (int)nseg);
+        if (small) VOCR_CONV(128, 1, 2); else VOCR_CONV(128, 2, 4);
     } else {
-        dim3 grid(vocr_cdiv(nseg, 8), 1);
-        if (vec) conv3x3_kernel<64, true><<<grid, 256, 0, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, SW, (int)nseg);
-        else conv3x3_kernel<64, false><<<grid, 256, 0, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, SW, (int)nseg);
+        if (small) VOCR_CONV(64, 1, 4); else VOCR_CONV(64, 2, 8);
     }
+#undef VOCR_CONV
     VOCR_CHECK_LAUNCH("vocr_conv3x3_fwd");
     return VOCR_OK;
 }
