@@ -288,6 +288,155 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_fast(const float* __restric
     }
 }
 
+// ------------------------------------------------------------------------------------------------ persistent sweep
+// One launch for all T steps.  A workgroup keeps its slice of W_hh in registers for the whole sweep (the per-step
+// kernels re-fetch 8 MB of weights per step because the XCD L2s are dropped at every kernel boundary: PMC FETCH_SIZE
+// 7-10 MB per step launch) and the cell state c in a register.  The only cross-workgroup traffic is h_t itself:
+//   producer: y[t] is stored write-through (sc1) -> every storing wave drains vmcnt -> workgroup barrier -> ONE lane
+//             adds 1 to the direction's arrival counter (agent scope)
+//   consumer: ONE lane polls the counter (relaxed agent-scope load + s_sleep) until all workgroups of its direction
+//             have published step-1 -> workgroup barrier -> EVERY load of h_{t-1} is an sc1 load (bypasses this CU's
+//             L1); the rows of y[t-1] were never read before they were written, so no L2 can hold a stale copy.
+// This is the counter form of the release/acquire-free hand-off of cdna_hip_programming.md Guideline 16 (R1 + sc1
+// loads, table row 1).  Results are independent of dispatch order and XCD placement; every spin is bounded and sets
+// `status[0]` on timeout instead of hanging.  All 2*H/4 workgroups must be co-resident (checked by the host).
+__device__ __forceinline__ f32x4 load_sc1_f32x4(const float* p) {
+    const unsigned long long* q = (const unsigned long long*)p;
+    const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    f32x4 v;
+    v[0] = __uint_as_float((unsigned)a);
+    v[1] = __uint_as_float((unsigned)(a >> 32));
+    v[2] = __uint_as_float((unsigned)b);
+    v[3] = __uint_as_float((unsigned)(b >> 32));
+    return v;
+}
+
+template <int KQ4, int RT>
+__global__ __launch_bounds__(256) void lstm_fwd_persistent(const float* __restrict__ xproj, const float* __restrict__ whh_f,
+                                                           const float* __restrict__ whh_r, const int32_t* __restrict__ lens,
+                                                           float* y, float* __restrict__ gates, float* __restrict__ cell,
+                                                           unsigned* counters, unsigned* status, int T, int B) {
+    constexpr int H = 64 * KQ4;
+    constexpr int ublocks = H >> 2;
+    __shared__ float red[4][RT * 16][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int dir = blockIdx.x / ublocks, unit0 = (blockIdx.x % ublocks) * 4;
+    const int lr = lane & 15, q = lane >> 4;
+    const int kbase = wave * (H >> 2) + q * 4;
+    const float* whh = dir ? whh_r : whh_f;
+    unsigned* counter = counters + dir * 32;                 // one 128-B line per direction
+
+    // resident operands: this lane's W_hh fragment (gate row lr>>2, unit lr&3, k = kbase + 16 i + e)
+    f32x4 wv[KQ4];
+    {
+        const f32x4* wp = (const f32x4*)(whh + ((long)(lr >> 2) * H + unit0 + (lr & 3)) * H + kbase);
+#pragma unroll
+        for (int i = 0; i < KQ4; ++i) wv[i] = wp[i * 4];
+    }
+    const bool cellthr = tid < B * 4;
+    const int cb_ = tid >> 2, cu = tid & 3, unit = unit0 + cu;
+    const int len_b = cellthr ? lens[cb_] : 0;
+    float cstate = 0.f;
+    bool timed_out = false;
+
+    for (int step = 0; step < T; ++step) {
+        const int t = dir == 0 ? step : T - 1 - step;
+        const int tprev = dir == 0 ? t - 1 : t + 1;
+        const long gbase = (((long)dir * T + t) * B + (cellthr ? cb_ : 0)) * 4 * H + unit;
+        float xp[4] = {0.f, 0.f, 0.f, 0.f};
+        if (cellthr) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) xp[g] = xproj[gbase + (long)g * H];      // written by an earlier kernel: plain loads
+        }
+        f32x4 acc[RT];
+#pragma unroll
+        for (int i = 0; i < RT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (step > 0) {
+            if (tid == 0 && !timed_out) {
+                const unsigned target = (unsigned)ublocks * (unsigned)step;
+                unsigned spins = 0;
+                while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 24)) {                                    // ~seconds: give up, flag it, keep going
+                        __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        timed_out = true;
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            const float* hp = y + (long)tprev * B * 2 * H + dir * H;
+            f32x4 hv[RT][KQ4];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const int b = rt * 16 + lr;
+                const float* hq = hp + (long)(b < B ? b : 0) * 2 * H + kbase;
+#pragma unroll
+                for (int i = 0; i < KQ4; ++i) {
+                    f32x4 v = load_sc1_f32x4(hq + i * 16);
+                    if (b >= B) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    hv[rt][i] = v;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < KQ4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+                        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[rt][i][e], wv[i][e], acc[rt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][rt * 16 + q * 4 + r][lr] = acc[rt][r];
+        __syncthreads();
+
+        if (cellthr) {
+            const int b = cb_, u = cu;
+            const bool active = t < len_b;
+            const long sidx = (((long)dir * T + t) * B + b) * H + unit;
+            float pre[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                pre[g] = ((red[0][b][g * 4 + u] + red[1][b][g * 4 + u]) + (red[2][b][g * 4 + u] + red[3][b][g * 4 + u])) + xp[g];
+            float* yo = y + ((long)t * B + b) * 2 * H + dir * H + unit;
+            f32x4* go = (f32x4*)(gates + sidx * 4);
+            float h = 0.f;
+            if (active) {
+                const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
+                const float c = fg * cstate + ig * gg;
+                h = og * tanhf(c);
+                *go = (f32x4){ig, fg, gg, og};
+                cell[sidx] = c;
+                cstate = c;
+            } else {
+                *go = (f32x4){0.f, 0.f, 0.f, 0.f};
+                cell[sidx] = 0.f;
+                cstate = 0.f;
+            }
+            __hip_atomic_store(yo, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // write-through (sc1) payload
+        }
+        // publish: every storing wave drains its stores, then one lane signals
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <int KQ4>
+void launch_fwd_persistent(int rt, dim3 grid, hipStream_t s, const float* xproj, const float* wf, const float* wr, const int32_t* lens,
+                           float* y, float* gates, float* cell, unsigned* counters, unsigned* status, int T, int B) {
+    switch (rt) {
+        case 1: lstm_fwd_persistent<KQ4, 1><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, counters, status, T, B); break;
+        case 2: lstm_fwd_persistent<KQ4, 2><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, counters, status, T, B); break;
+        case 3: lstm_fwd_persistent<KQ4, 3><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, counters, status, T, B); break;
+        default: lstm_fwd_persistent<KQ4, 4><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, counters, status, T, B); break;
+    }
+}
+
 // H = 128*NCH.  grid.x = 2 * (H/16) * RT : one workgroup per (direction, 16 units, 16 batch rows).
 // whhT = transposed recurrent weights [H][4H] so the B operand (W_hh[n][unit], n running) is contiguous.
 // UT = units owned by a workgroup (16, or 8 when 16 would leave half the chip idle: the MFMA N-tile is then half
@@ -410,11 +559,25 @@ bool launch_fwd_fast(int rt, dim3 grid, hipStream_t s, const float* xproj, const
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+// workgroups of 256 threads that are certainly co-resident: one per CU (a persistent sweep deadlocks if a
+// workgroup it waits for is not running; the kernels need < 1/4 of a CU's registers and LDS, so one per CU is safe)
+int resident_workgroup_capacity() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (!cus[dev]) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        cus[dev] = prop.multiProcessorCount;
+    }
+    return cus[dev];
+}
+
 }  // namespace
 
 extern "C" size_t vocr_lstm_workspace_bytes(int t, int b, int h) {
     if (t <= 0 || b <= 0 || h <= 0) return 0;
-    return (size_t)6 * 2 * b * h * sizeof(float);   // h ping-pong (2 x [2][B][H]) + c ([2][B][H]) + spare
+    return (size_t)6 * 2 * b * h * sizeof(float) + 1024;   // dc carry [2][B][H] (+ spare); 1 KiB of arrival counters / status
 }
 
 extern "C" int vocr_lstm_fwd(const float* xproj, const float* whh_fwd, const float* whh_rev, const int32_t* lens, float* y,
@@ -427,6 +590,27 @@ extern "C" int vocr_lstm_fwd(const float* xproj, const float* whh_fwd, const flo
                       aligned16(gates);
     VOCR_CHECK_ARG(aligned16(gates), "vocr_lstm_fwd: gates must be 16-byte aligned");
     const dim3 grid(2 * (h / 4));
+    // measured on MI355X (scripts/lstm_bench.py, T=294 B=32 H=512): persistent 7.8 us/step vs 7.3 us/step for one launch
+    // per step: the in-kernel all-to-all (128 arrivals on a counter + sc1 payload) costs more than a kernel boundary,
+    // so the persistent sweep stays opt-in (VOCR_LSTM_PERSISTENT=1).
+    static const int persistent_mode = getenv("VOCR_LSTM_PERSISTENT") ? atoi(getenv("VOCR_LSTM_PERSISTENT")) : 0;
+    if (fast && persistent_mode && (int)grid.x <= resident_workgroup_capacity() && h >= 64) {
+        // counters: [0] fwd arrivals, [32] rev arrivals (separate 128-B lines), status word at [64]
+        unsigned* counters = (unsigned*)workspace;
+        unsigned* status = counters + 64;
+        if (hipMemsetAsync(counters, 0, 65 * sizeof(unsigned), s) != hipSuccess) {
+            vocr_set_error("vocr_lstm_fwd: memset failed");
+            return VOCR_ELAUNCH;
+        }
+        switch (h) {
+            case 64: launch_fwd_persistent<1>(rt, grid, s, xproj, whh_fwd, whh_rev, lens, y, gates, cell, counters, status, t, b); break;
+            case 128: launch_fwd_persistent<2>(rt, grid, s, xproj, whh_fwd, whh_rev, lens, y, gates, cell, counters, status, t, b); break;
+            case 256: launch_fwd_persistent<4>(rt, grid, s, xproj, whh_fwd, whh_rev, lens, y, gates, cell, counters, status, t, b); break;
+            default: launch_fwd_persistent<8>(rt, grid, s, xproj, whh_fwd, whh_rev, lens, y, gates, cell, counters, status, t, b); break;
+        }
+        VOCR_CHECK_LAUNCH("vocr_lstm_fwd(persistent)");
+        return VOCR_OK;
+    }
     for (int step = 0; step < t; ++step) {
         if (fast) {
             switch (h) {
