@@ -51,6 +51,26 @@ def join_side_stream():
         _SIDE["pending"] = False
 
 
+# ---- direct gradient sinks: when an optimiser has pre-attached a gradient buffer to every parameter (FlatClampAdam's
+# flat buffer, zeroed once per step), the backward kernels write weight gradients straight into it instead of
+# returning fresh tensors for autograd to add (saves ~56 small add kernels and allocations per step).  Valid because
+# every parameter of the model is used exactly once per forward.
+DIRECT_GRADS = {"enabled": False}
+
+
+def _sinks(params):
+    """The .grad buffers of `params` if direct mode is on and every one is attached and contiguous, else None."""
+    if not DIRECT_GRADS["enabled"]:
+        return None
+    out = []
+    for p in params:
+        g = p.grad
+        if g is None or not g.is_contiguous() or g.dtype != torch.float32:
+            return None
+        out.append(g)
+    return out
+
+
 # ---- backward milestones: callbacks fired from inside the backward pass (used to start the data-parallel
 # all-reduce of the sequence-side gradients while the CNN backward is still running)
 BACKWARD_HOOKS = {"sequence_grads_ready": []}
@@ -81,19 +101,19 @@ def conv3x3_forward(x, wpack, bias, cout):
     return y
 
 
-def conv3x3_wgrad(x, dy):
+def conv3x3_wgrad(x, dy, out=None):
     n, cin, h, w = x.shape
     cout = dy.shape[1]
     lib = _lib.load()
     ws = _ws(lib.vocr_conv3x3_wgrad_workspace_bytes(n, cin, h, w, cout), x.device)
-    dw = torch.empty(cout, cin, 3, 3, dtype=torch.float32, device=x.device)
+    dw = out if out is not None else torch.empty(cout, cin, 3, 3, dtype=torch.float32, device=x.device)
     call("vocr_conv3x3_wgrad", _p(x), _p(dy), _p(dw), _p(ws), n, cin, h, w, cout, _stream())
     return dw
 
 
-def channel_sum(x):
+def channel_sum(x, out=None):
     n, c, h, w = x.shape
-    out = torch.empty(c, dtype=torch.float32, device=x.device)
+    out = out if out is not None else torch.empty(c, dtype=torch.float32, device=x.device)
     call("vocr_channel_sum", _p(x), _p(out), n, c, h * w, _stream())
     return out
 
@@ -121,6 +141,7 @@ class ConvBnReluFn(torch.autograd.Function):
         out = torch.empty_like(y)
         call("vocr_bn_relu_apply", _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(out), n, cout, h * w, _stream())
         ctx.training = training
+        ctx.prefs = (weight, bias, gamma, beta)
         ctx.save_for_backward(x, y, mean, invstd, gamma, beta, pd)
         return out
 
@@ -134,18 +155,25 @@ class ConvBnReluFn(torch.autograd.Function):
         cout = y.shape[1]
         lib = _lib.load()
         dy = torch.empty_like(y)
-        dgamma = torch.empty_like(gamma)
-        dbeta = torch.empty_like(beta)
+        sinks = _sinks(ctx.prefs)
+        if sinks is not None:
+            dw, dbias, dgamma, dbeta = sinks
+        else:
+            dw = None
+            dgamma = torch.empty_like(gamma)
+            dbeta = torch.empty_like(beta)
+            dbias = torch.empty(cout, dtype=torch.float32, device=x.device)
         ws = _ws(lib.vocr_bn_workspace_bytes(n, cout, h * w), x.device)
         if not ctx.needs_input_grad[0]:
             join_side_stream()          # first layer = last backward op: everything issued on the side stream is done after this
-        dbias = torch.empty(cout, dtype=torch.float32, device=x.device)
         call("vocr_bn_relu_bwd", _p(da), _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(dy), _p(dgamma), _p(dbeta),
              _p(dbias), n, cout, h * w, _p(ws), _stream())
-        dw = conv3x3_wgrad(x, dy)
+        dw = conv3x3_wgrad(x, dy, out=dw)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = conv3x3_forward(dy, pd, None, cin)
+        if sinks is not None:
+            return dx, None, None, None, None, None, None, None, None, None
         return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None
 
 
@@ -165,6 +193,7 @@ class ConvReluPoolFn(torch.autograd.Function):
         idx = torch.empty(n, cout, oh, ow, dtype=torch.int32, device=x.device)
         call("vocr_relu_maxpool2_fwd", _p(y), _p(out), _p(idx), n, cout, h, w, _stream())
         ctx.save_for_backward(x, out, idx, pd)
+        ctx.prefs = (weight, bias)
         ctx.hw = (h, w)
         return out
 
@@ -179,9 +208,12 @@ class ConvReluPoolFn(torch.autograd.Function):
             join_side_stream()
         dy = torch.zeros(n, cout, h, w, dtype=torch.float32, device=x.device)
         call("vocr_relu_maxpool2_bwd", _p(dout), _p(out), _p(idx), _p(dy), n, cout, h, w, _stream())
-        dbias = channel_sum(dy)
-        dw = conv3x3_wgrad(x, dy)
+        sinks = _sinks(ctx.prefs)
+        dbias = channel_sum(dy, out=sinks[1] if sinks else None)
+        dw = conv3x3_wgrad(x, dy, out=sinks[0] if sinks else None)
         dx = conv3x3_forward(dy, pd, None, cin) if ctx.needs_input_grad[0] else None
+        if sinks is not None:
+            return dx, None, None
         return dx, dw, dbias
 
 
@@ -219,9 +251,9 @@ def gemm(ta, tb, m, n, k, a, lda, b, ldb, c, ldc, bias=None, relu=False, accumul
          _stream())
 
 
-def colsum(x2d):
+def colsum(x2d, out=None):
     m, n = x2d.shape
-    out = torch.empty(n, dtype=torch.float32, device=x2d.device)
+    out = out if out is not None else torch.empty(n, dtype=torch.float32, device=x2d.device)
     call("vocr_colsum", _p(x2d), _p(out), m, n, _stream())
     return out
 
@@ -270,6 +302,7 @@ class LinearFn(torch.autograd.Function):
         out = torch.empty(m, n, dtype=torch.float32, device=x.device)
         gemm(0, 1, m, n, k, x, k, weight, k, out, n, bias=bias, relu=relu)
         ctx.relu = relu
+        ctx.prefs = (weight, bias)
         ctx.save_for_backward(x, weight, out if relu else None)
         return out
 
@@ -284,13 +317,16 @@ class LinearFn(torch.autograd.Function):
             call("vocr_relu_bwd", _p(dout), _p(out), _p(dz), dout.numel(), _stream())
         else:
             dz = dout
-        dw = torch.empty_like(weight)
+        sinks = _sinks(ctx.prefs)
+        dw = sinks[0] if sinks else torch.empty_like(weight)
         gemm(1, 0, n, k, m, dz, n, x, k, dw, k)                     # dW[n,k] = dz^T[n,m] x[m,k]
-        db = colsum(dz)
+        db = colsum(dz, out=sinks[1] if sinks else None)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             gemm(0, 0, m, k, n, dz, n, weight, k, dx, k)            # dx[m,k] = dz[m,n] W[n,k]
+        if sinks is not None:
+            return dx, None, None, None
         return dx, dw, db, None
 
 
@@ -391,7 +427,8 @@ class BiLstmLayerFn(torch.autograd.Function):
         # flat buffer), write them there from the side stream so they overlap the next layer's sweep; otherwise
         # return them to autograd on the current stream.
         params = (w_ih_f, w_hh_f, ctx.b_refs[0], ctx.b_refs[1], w_ih_r, w_hh_r, ctx.b_refs[2], ctx.b_refs[3])
-        direct = _SIDE["enabled"] and all(p.grad is not None and p.grad.is_contiguous() for p in params)
+        sinks = _sinks(params)
+        direct = sinks is not None
 
         def weight_grads(outs):
             dwi_f, dwh_f, dbi_f, dbh_f, dwi_r, dwh_r, dbi_r, dbh_r = outs
@@ -410,14 +447,17 @@ class BiLstmLayerFn(torch.autograd.Function):
             dbh_f.copy_(dbi_f)
             dbh_r.copy_(dbi_r)
 
-        if direct:
+        if direct and _SIDE["enabled"]:
             side = side_stream()
             side.wait_stream(torch.cuda.current_stream())
             for t_ in (dg, x, y):
                 t_.record_stream(side)
             with torch.cuda.stream(side):
-                weight_grads([p.grad for p in params])
+                weight_grads(sinks)
             _SIDE["pending"] = True
+            return (dx, None, None, None) + (None,) * 8
+        if direct:
+            weight_grads(sinks)
             return (dx, None, None, None) + (None,) * 8
         outs = [torch.empty_like(p) for p in params]
         weight_grads(outs)

@@ -36,6 +36,9 @@ class FlatClampAdam(object):
                 off += k
         self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, clamp=clamp)]
         self.step_count = 0
+        # every parameter now owns a persistent gradient buffer that zero_grad() clears once per step: let the backward
+        # kernels write weight gradients straight into it (each parameter is used once per forward)
+        ops.DIRECT_GRADS["enabled"] = dev.type == "cuda"
         # Two all-reduce buckets: [0, split) = parameters whose gradients appear last (rapid_ds + cnn), [split, n) =
         # bridge + LSTM + prob (88 % of the bytes at H=512), final as soon as the backward reaches the CNN, so their
         # exchange over xGMI is launched there and hides under the CNN backward.
