@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hidden", type=int, default=512)
+    ap.add_argument("--conv-dtype", default="fp32", choices=["fp32", "fp16"],
+                    help="fp16 = BASELINE config 5's fp16-operand conv MFMA (fp32 accumulate); the headline metric is fp32")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -111,6 +113,8 @@ def main():
     import vistaocr_amd as va
     from vistaocr_amd import _lib
     hp = dict(HP, num_lstm_hidden_units=args.hidden)
+    if args.conv_dtype != "fp32":
+        hp["conv_dtype"] = args.conv_dtype
     al = va.english_alphabet()
     torch.manual_seed(0)                                  # same init on every rank (replicas)
     model = va.CnnOcrModel(alphabet=al, verbose=False, **hp)
@@ -162,7 +166,8 @@ def main():
         out = {
             "metric": "line-images/sec (train, batch 32, 30x600 grey)", "value": round(value, 2), "unit": "line-images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.conv_dtype == "fp32" else "f32 with fp16 conv operands (fp32 accumulate)", "data": "synthetic",
             "config": {"workload": "configs[1]: 32 synthetic 1x30x600 grey lines per GPU, 20 labels/line, V=96, "
                                    "3xBiLSTM-%d, fwd+CTC+bwd+allreduce+clamp+Adam" % args.hidden,
                        "global_batch": B * world, "parallelism": "dp%d" % world, "final_loss": round(final_loss, 3)},

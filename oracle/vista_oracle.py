@@ -130,6 +130,30 @@ def trainable(sd):
     return [(k, v) for k, v in sd.items() if v.requires_grad]
 
 
+# ----------------------------------------------------------------------------- conv operand rounding (config 5)
+class _ConvF16Operands(torch.autograd.Function):
+    """Semantics of the build's fp16-operand conv (BASELINE config 5): forward and data-gradient multiply
+    fp16-ROUNDED operands and accumulate in fp32; the weight gradient is computed from the unrounded fp32 tensors."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return F.conv2d(x.half().float(), w.half().float(), b, padding=1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx = torch.nn.grad.conv2d_input(x.shape, w.half().float(), dy.half().float(), padding=1)
+        dw = torch.nn.grad.conv2d_weight(x, w.shape, dy, padding=1)
+        return dx, dw, dy.sum((0, 2, 3))
+
+
+def _conv(x, w, b, conv_dtype):
+    if conv_dtype == "fp16":
+        return _ConvF16Operands.apply(x, w, b)
+    return F.conv2d(x, w, b, padding=1)
+
+
 # ----------------------------------------------------------------------------- forward
 def _lstm_module(sd, hp):
     D, H, L = hp["lstm_input_dim"], hp["num_lstm_hidden_units"], hp["num_lstm_layers"]
@@ -186,7 +210,7 @@ def forward(sd, hp, x, widths, pool_samples, training, lstm_training=None, dropo
         lstm_training = training
     a = x
     for i in range(num_rds_layers(hp)):                              # cnnlstm.py:114-121
-        a = F.conv2d(a, sd["rapid_ds.%02d-conv.weight" % i], sd["rapid_ds.%02d-conv.bias" % i], padding=1)
+        a = _conv(a, sd["rapid_ds.%02d-conv.weight" % i], sd["rapid_ds.%02d-conv.bias" % i], hp.get("conv_dtype", "fp32"))
         a = F.max_pool2d(F.relu(a), 2, stride=2)
     pool_i = 0
     for step in CONV_PLAN:                                           # cnnlstm.py:124-134
@@ -197,7 +221,7 @@ def forward(sd, hp, x, widths, pool_samples, training, lstm_training=None, dropo
                 taps["pool%d" % pool_i] = a
             pool_i += 1
             continue
-        a = F.conv2d(a, sd["cnn.%d.weight" % step], sd["cnn.%d.bias" % step], padding=1)
+        a = _conv(a, sd["cnn.%d.weight" % step], sd["cnn.%d.bias" % step], hp.get("conv_dtype", "fp32"))
         bn = "cnn.%d." % (step + 1)
         a = F.batch_norm(a, sd[bn + "running_mean"], sd[bn + "running_var"], sd[bn + "weight"], sd[bn + "bias"],
                          training=training, momentum=0.1, eps=1e-5)

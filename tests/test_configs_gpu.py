@@ -12,10 +12,11 @@ from oracle import vista_oracle as vo
 pytestmark = pytest.mark.gpu
 
 
-def _run_pair(hp, chars, B, widths, labels_per_line, seed, ltr=True):
+def _run_pair(hp, chars, B, widths, labels_per_line, seed, ltr=True, loss_rtol=1e-3, logit_rtol=5e-4, grad_rtol=1e-2,
+              min_label_agreement=1.0, state_kw=None):
     import vistaocr_amd as va
     V = len(chars)
-    sd_np = cf.closed_form_state(hp, V)
+    sd_np = cf.closed_form_state(hp, V, **(state_kw or {}))
     x, w, tgt, tl = cf.closed_form_batch(B, hp.get("num_in_channels", 1), hp["input_line_height"], widths, V, labels_per_line, seed=seed)
     r = np.random.RandomState(seed + 100)
     s1 = r.uniform(0, 0.999, size=(B, 64, 2)).astype(np.float32)
@@ -37,25 +38,26 @@ def _run_pair(hp, chars, B, widths, labels_per_line, seed, ltr=True):
     lo_loss = vo.ctc_criterion(lo, torch.from_numpy(tgt), ln, torch.from_numpy(tl))
     lo_loss.backward()
     assert lens.tolist() == ln.tolist()
-    assert abs(float(loss) - float(lo_loss)) <= 1e-3 * abs(float(lo_loss)), (float(loss), float(lo_loss))
+    assert abs(float(loss) - float(lo_loss)) <= loss_rtol * abs(float(lo_loss)), (float(loss), float(lo_loss))
     lg = logits.detach().cpu()
     T = lg.shape[0]
     valid = torch.arange(T).unsqueeze(1) < ln.unsqueeze(0)
     # fp32 logits with a different summation order: tolerance relative to the logit scale (the 512-hidden, 3-layer
     # closed-form model saturates its gates and reaches |logit| ~ 20, measured error 3e-3 there, 2e-5 at H=48)
     scale = max(1.0, float(lo.detach().abs()[valid].max()))
-    assert float((lg - lo.detach()).abs()[valid].max()) < 5e-4 * scale, (float((lg - lo.detach()).abs()[valid].max()), scale)
+    assert float((lg - lo.detach()).abs()[valid].max()) < logit_rtol * scale, (float((lg - lo.detach()).abs()[valid].max()), scale)
     top2 = torch.sort(lo.detach(), dim=2, descending=True)[0]
     margin = top2[:, :, 0] - top2[:, :, 1]
     safe = valid & (margin > 1e-3)
-    assert torch.equal(lg.argmax(2)[safe], lo.detach().argmax(2)[safe]), "per-frame argmax differs on well-separated frames"
-    if float(margin[valid].min()) > 1e-3:
+    agree = float((lg.argmax(2)[safe] == lo.detach().argmax(2)[safe]).float().mean())
+    assert agree >= min_label_agreement, "per-frame argmax agreement %.4f on well-separated frames" % agree
+    if min_label_agreement >= 1.0 and float(margin[valid].min()) > 1e-3:
         assert model.decode_labels(logits, lens) == vo.greedy_decode(lo.detach(), ln, al.idx_to_char, uxxxx=True)[1]
     for k, p in model.named_parameters():
         if k.startswith("cnn.") and k.endswith(".bias") and int(k.split(".")[1]) in (0, 3, 7, 10, 14, 17, 20):
             continue
         rn = float(osd[k].grad.double().norm())
-        assert abs(float(p.grad.double().norm()) - rn) <= 1e-2 * rn + 1e-5, k
+        assert abs(float(p.grad.double().norm()) - rn) <= grad_rtol * rn + 1e-5, k
     return model, logits, lens
 
 
@@ -77,6 +79,23 @@ def test_config5_rds_60px_hidden512():
               p_lstm_dropout=0.5, num_in_channels=1)
     model, logits, lens = _run_pair(hp, chars, 3, [400, 322, 128], [12, 9, 3], seed=11)
     assert lens.tolist() == [98, 78, 30]
+
+
+def test_config5_fp16_conv_mfma():
+    """Config 5 as BASELINE.json words it: 60-px lines, rapid_ds, 512-hidden BiLSTM, fp16 conv MFMA with fp32 accumulate
+    (CTC in fp32).  The oracle applies the same operand rounding (oracle/vista_oracle.py _ConvF16Operands)."""
+    from tests import golden_util as gu
+    chars = gu.alphabet_chars("english")
+    hp = dict(input_line_height=60, rds_line_height=30, lstm_input_dim=128, num_lstm_layers=3, num_lstm_hidden_units=512,
+              p_lstm_dropout=0.5, num_in_channels=1, conv_dtype="fp16")
+    # fp16 operand rounding is a discontinuity: a 1e-7 difference in an activation (summation order) can flip its
+    # rounding at the next layer, which acts as 2^-11-sized noise that the saturated 512-hidden closed-form LSTM
+    # amplifies.  Per SURVEY.md §7, fp16 results get a looser loss tolerance and a label-agreement rate; the
+    # 1e-3 / bit-exact contract applies to the fp32 path only.
+    # (recurrent weights drawn from the reference's own init range +-0.08 so the 512-hidden LSTM is not saturated)
+    model, logits, lens = _run_pair(hp, chars, 3, [400, 322, 128], [12, 9, 3], seed=11, loss_rtol=1e-2, logit_rtol=2e-2,
+                                    grad_rtol=0.1, min_label_agreement=0.97, state_kw=dict(lstm_scale=0.08, prob_scale=0.5))
+    assert lens.tolist() == [98, 78, 30] and model.conv_dtype == "fp16"
 
 
 def test_rgb_input_three_channels():

@@ -59,6 +59,29 @@ def test_conv3x3_fwd_dgrad_wgrad(dev, n, cin, h, w, cout):
     _close(db, dy.sum((0, 2, 3)), 1e-5, 1e-4, "channel_sum")
 
 
+@pytest.mark.parametrize("n,cin,h,w,cout", [(2, 1, 30, 70, 64), (2, 64, 15, 45, 128), (1, 128, 7, 33, 256), (1, 16, 9, 40, 64), (1, 24, 12, 31, 16)])
+def test_conv3x3_f16_operands(dev, n, cin, h, w, cout):
+    """fp16-operand MFMA conv (config 5): products of fp16-rounded operands, fp32 accumulation — compared with the same
+    rounding done on the CPU, so the only difference left is the summation order."""
+    from vistaocr_amd import ops
+    x = _rand((n, cin, h, w), 1)
+    wt = _rand((cout, cin, 3, 3), 2, 0.2)
+    bias = _rand((cout,), 3)
+    dy = _rand((n, cout, h, w), 4)
+    xh, wh, dyh = x.half().float(), wt.half().float(), dy.half().float()
+    yr = F.conv2d(xh, wh, bias, padding=1)
+    dxr = torch.nn.grad.conv2d_input(x.shape, wh, dyh, padding=1)
+    pf, pd = ops.conv3x3_pack_f16(wt.to(dev))
+    y = ops.conv3x3_forward_f16(x.to(dev), pf, bias.to(dev), cout)
+    _close(y, yr, 1e-5, 2e-5 * (cin * 9) ** 0.5, "conv f16 fwd")
+    dx = ops.conv3x3_forward_f16(dy.to(dev), pd, None, cin)
+    _close(dx, dxr, 1e-5, 2e-5 * (cout * 9) ** 0.5, "conv f16 dgrad")
+    # and it really is fp16 rounding: it differs from the fp32 conv by about 2^-11 relative, not more
+    y32 = F.conv2d(x, wt, bias, padding=1)
+    rel = float((y.cpu() - y32).abs().max() / y32.abs().max())
+    assert rel < 5e-3
+
+
 @pytest.mark.parametrize("n,c,h,w", [(4, 64, 30, 50), (3, 128, 7, 33)])
 def test_conv_bn_relu_fn(dev, n, c, h, w):
     from vistaocr_amd import ops

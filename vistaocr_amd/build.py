@@ -7,7 +7,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-SOURCES = ["gemm.hip", "conv.hip", "bn_pool.hip", "lstm.hip", "ctc.hip", "misc.cpp"]
+SOURCES = ["gemm.hip", "conv.hip", "conv_f16.hip", "bn_pool.hip", "lstm.hip", "ctc.hip", "misc.cpp"]
 LIB = os.path.join(CSRC, "libvocr.so")
 ARCH = "gfx950"
 

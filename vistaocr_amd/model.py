@@ -120,6 +120,10 @@ class CnnOcrModel(nn.Module):
         self.gpu = kwargs.get("gpu", True)
         self.multigpu = kwargs.get("multigpu", True)     # accepted for compatibility; DP is process-level (train.py)
         self.verbose = kwargs.get("verbose", True)
+        # extension (BASELINE config 5): 'fp16' rounds conv operands to fp16 for the matrix cores, fp32 accumulate
+        self.conv_dtype = kwargs.get("conv_dtype", "fp32")
+        if self.conv_dtype not in ("fp32", "fp16"):
+            raise Exception("conv_dtype must be 'fp32' or 'fp16'")
         self.lattice_decoder = None
 
         if self.rds_line_height > self.input_line_height:
@@ -212,7 +216,7 @@ class CnnOcrModel(nn.Module):
         a = x
         for i in range(self.num_rds_layers):
             conv = getattr(self.rapid_ds, "%02d-conv" % i)
-            a = ops.ConvReluPoolFn.apply(a, conv.weight, conv.bias)
+            a = ops.ConvReluPoolFn.apply(a, conv.weight, conv.bias, self.conv_dtype == "fp16")
         pool_i = 0
         for step in self._plan:
             if step == "pool":
@@ -227,7 +231,7 @@ class CnnOcrModel(nn.Module):
                 continue
             conv, bn = step
             a = ops.ConvBnReluFn.apply(a, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                       self.training, bn.eps, bn.momentum)
+                                       self.training, bn.eps, bn.momentum, self.conv_dtype == "fp16")
             if self.training:
                 bn.num_batches_tracked += 1
         b, c, h, w = a.shape

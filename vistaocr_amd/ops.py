@@ -94,6 +94,23 @@ def conv3x3_pack(weight):
     return pf, pd
 
 
+def conv3x3_pack_f16(weight):
+    """fp16 weight packs (forward, data-gradient) for the fp16-operand MFMA conv."""
+    cout, cin = weight.shape[0], weight.shape[1]
+    lib = _lib.load()
+    pf = torch.empty(lib.vocr_conv3x3_f16_pack_bytes(cout, cin, 0) // 2, dtype=torch.float16, device=weight.device)
+    pd = torch.empty(lib.vocr_conv3x3_f16_pack_bytes(cout, cin, 1) // 2, dtype=torch.float16, device=weight.device)
+    call("vocr_conv3x3_f16_pack_weights", _p(weight), _p(pf), _p(pd), cout, cin, _stream())
+    return pf, pd
+
+
+def conv3x3_forward_f16(x, wpack16, bias, cout):
+    n, cin, h, w = x.shape
+    y = torch.empty(n, cout, h, w, dtype=torch.float32, device=x.device)
+    call("vocr_conv3x3_f16_fwd", _p(x), _p(wpack16), _p(bias), _p(y), n, cin, h, w, cout, _stream())
+    return y
+
+
 def conv3x3_forward(x, wpack, bias, cout):
     n, cin, h, w = x.shape
     y = torch.empty(n, cout, h, w, dtype=torch.float32, device=x.device)
@@ -122,14 +139,19 @@ class ConvBnReluFn(torch.autograd.Function):
     """Conv2d(k3,p1) -> BatchNorm2d -> ReLU (reference ConvBNReLU, src/models/cnnlstm.py:263-266)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, training, eps, momentum):
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, training, eps, momentum, f16=False):
         _need_gpu(x, weight, bias, gamma, beta, running_mean, running_var)
         x = _f32c(x)
         n, cin, h, w = x.shape
         cout = weight.shape[0]
         lib = _lib.load()
-        pf, pd = conv3x3_pack(weight)
-        y = conv3x3_forward(x, pf, bias, cout)
+        ctx.f16 = bool(f16)
+        if ctx.f16:
+            pf, pd = conv3x3_pack_f16(weight)
+            y = conv3x3_forward_f16(x, pf, bias, cout)
+        else:
+            pf, pd = conv3x3_pack(weight)
+            y = conv3x3_forward(x, pf, bias, cout)
         mean = torch.empty(cout, dtype=torch.float32, device=x.device)
         invstd = torch.empty(cout, dtype=torch.float32, device=x.device)
         if training:
@@ -171,23 +193,28 @@ class ConvBnReluFn(torch.autograd.Function):
         dw = conv3x3_wgrad(x, dy, out=dw)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = conv3x3_forward(dy, pd, None, cin)
+            dx = conv3x3_forward_f16(dy, pd, None, cin) if ctx.f16 else conv3x3_forward(dy, pd, None, cin)
         if sinks is not None:
-            return dx, None, None, None, None, None, None, None, None, None
-        return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None
+            return dx, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None
 
 
 class ConvReluPoolFn(torch.autograd.Function):
     """rapid_ds stage: Conv2d(k3,p1) -> ReLU -> MaxPool2d(2,2) (src/models/cnnlstm.py:114-121)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, f16=False):
         _need_gpu(x, weight, bias)
         x = _f32c(x)
         n, cin, h, w = x.shape
         cout = weight.shape[0]
-        pf, pd = conv3x3_pack(weight)
-        y = conv3x3_forward(x, pf, bias, cout)
+        ctx.f16 = bool(f16)
+        if ctx.f16:
+            pf, pd = conv3x3_pack_f16(weight)
+            y = conv3x3_forward_f16(x, pf, bias, cout)
+        else:
+            pf, pd = conv3x3_pack(weight)
+            y = conv3x3_forward(x, pf, bias, cout)
         oh, ow = h // 2, w // 2
         out = torch.empty(n, cout, oh, ow, dtype=torch.float32, device=x.device)
         idx = torch.empty(n, cout, oh, ow, dtype=torch.int32, device=x.device)
@@ -211,10 +238,12 @@ class ConvReluPoolFn(torch.autograd.Function):
         sinks = _sinks(ctx.prefs)
         dbias = channel_sum(dy, out=sinks[1] if sinks else None)
         dw = conv3x3_wgrad(x, dy, out=sinks[0] if sinks else None)
-        dx = conv3x3_forward(dy, pd, None, cin) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = conv3x3_forward_f16(dy, pd, None, cin) if ctx.f16 else conv3x3_forward(dy, pd, None, cin)
         if sinks is not None:
-            return dx, None, None
-        return dx, dw, dbias
+            return dx, None, None, None
+        return dx, dw, dbias, None
 
 
 class FracPoolFn(torch.autograd.Function):
