@@ -106,53 +106,65 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
     // this wave stages rows [wave*RPW, (wave+1)*RPW) of the NSEG*24 (segment, ci, kh) halo rows
     const int st_seg0 = (wave * RPW) / 24;
     const int st_ci0 = ((wave * RPW) % 24) / 3;
-    int p_h[SST], p_loff[SST];
+    // halo loads: channel base = wave-uniform pointer (scalar), position = one 32-bit lane offset per staged row;
+    // out-of-range rows / columns / channels read a clamped in-range element and are zeroed by a 0/1 factor at the LDS
+    // store, so a load is a single instruction and the loop carries almost no address arithmetic.
+    int p_off[SST][3];
+    float p_m[SST][3];
     const float* p_base[SST];
-    bool p_colok[SST];
 #pragma unroll
     for (int q = 0; q < SST; ++q) {
         const SegInfo sg = segs[st_seg0 + q];
         const int ww = sg.w0 - 1 + lane;
-        p_h[q] = sg.h;
-        p_colok[q] = sg.valid && lane < PROW && ww >= 0 && ww < W;
-        p_loff[q] = p_colok[q] ? ww : 0;
+        const bool colok = sg.valid && lane < PROW && ww >= 0 && ww < W;
+        const int loff = min(max(ww, 0), W - 1);
         p_base[q] = in + sg.base;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int hh = sg.h + kh - 1;
+            p_m[q][kh] = (colok && hh >= 0 && hh < H) ? 1.f : 0.f;
+            p_off[q][kh] = min(max(hh, 0), H - 1) * W + loff;
+        }
     }
 
-    // branch-free: every load is issued from a clamped (always valid) address, invalid lanes read the zero page
+    auto load_weights = [&](int ci0, int e) {
+        const int r = wr0 + e * RPP;
+        const int gk = ci0 * 9 + r;
+        const bool rok = r < KC && gk < Ktot;
+        const int gkc = min(gk, Ktot - 1);
+        f32x4 v;
+        if (VECW) {
+            const f32x4* src = (const f32x4*)(wpack + (long)gkc * Cout + wcol_c);
+            v = *((rok && wcol < Cout) ? src : (const f32x4*)zero_page);
+        } else {
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const float* src = wpack + (long)gkc * Cout + min(wcol + x, Cout - 1);
+                v[x] = *((rok && wcol + x < Cout) ? src : zero_page);
+            }
+        }
+        ra[e] = v;
+    };
+    auto load_halo_row = [&](int ci0, int q, int j) {
+        const int ci = st_ci0 + j / 3, kh = j % 3;
+        const float* cb = p_base[q] + (long)min(ci0 + ci, Cin - 1) * HW;      // wave-uniform
+        rp[q * ROWS + j] = cb[p_off[q][kh]];
+    };
+    // the loads of one chunk, cut into KC/2 = 36 slices that are issued between the k-steps of the previous chunk
+    constexpr int NLOAD = SST * ROWS + EA;
+    auto load_slice = [&](int ci0, int ks) {
+#pragma unroll
+        for (int i = 0; i < (NLOAD + KC / 2 - 1) / (KC / 2); ++i) {
+            const int id = ks + i * (KC / 2);
+            if (id < SST * ROWS) load_halo_row(ci0, id / ROWS, id % ROWS);
+            else if (id < NLOAD) load_weights(ci0, id - SST * ROWS);
+        }
+    };
     auto load_chunk = [&](int ci0) {
 #pragma unroll
-        for (int e = 0; e < EA; ++e) {
-            const int r = wr0 + e * RPP;
-            const int gk = ci0 * 9 + r;
-            const bool rok = r < KC && gk < Ktot;
-            const int gkc = min(gk, Ktot - 1);
-            f32x4 v;
-            if (VECW) {
-                const f32x4* src = (const f32x4*)(wpack + (long)gkc * Cout + wcol_c);
-                v = *((rok && wcol < Cout) ? src : (const f32x4*)zero_page);
-            } else {
-#pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    const float* src = wpack + (long)gkc * Cout + min(wcol + x, Cout - 1);
-                    v[x] = *((rok && wcol + x < Cout) ? src : zero_page);
-                }
-            }
-            ra[e] = v;
-        }
-#pragma unroll
-        for (int q = 0; q < SST; ++q)
-#pragma unroll
-            for (int j = 0; j < ROWS; ++j) {
-                const int ci = st_ci0 + j / 3, kh = j % 3;
-                const int hh = p_h[q] + kh - 1;
-                const bool rowok = (ci0 + ci) < Cin && hh >= 0 && hh < H;                 // wave-uniform
-                const int cic = min(ci0 + ci, Cin - 1), hhc = min(max(hh, 0), H - 1);
-                const float* src = p_base[q] + ((long)cic * HW + (long)hhc * W + p_loff[q]);
-                rp[q * ROWS + j] = *((rowok && p_colok[q]) ? src : zero_page + lane);
-            }
+        for (int ks = 0; ks < KC / 2; ++ks) load_slice(ci0, ks);
     };
-    auto store_chunk = [&]() {
+    auto store_chunk = [&](int ci0) {
 #pragma unroll
         for (int e = 0; e < EA; ++e) {
             const int r = wr0 + e * RPP;
@@ -162,19 +174,22 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
 #pragma unroll
             for (int q = 0; q < SST; ++q)
 #pragma unroll
-                for (int j = 0; j < ROWS; ++j)
-                    P[(st_seg0 + q) * PSEG + (st_ci0 + j / 3) * PCI + (j % 3) * PROW + lane] = rp[q * ROWS + j];
+                for (int j = 0; j < ROWS; ++j) {
+                    const int ci = st_ci0 + j / 3, kh = j % 3;
+                    const float cm = (ci0 + ci) < Cin ? 1.f : 0.f;                     // wave-uniform
+                    P[(st_seg0 + q) * PSEG + ci * PCI + kh * PROW + lane] = rp[q * ROWS + j] * (p_m[q][kh] * cm);
+                }
         }
     };
 
     const int nchunks = (Cin + CI_C - 1) / CI_C;
     load_chunk(0);
-    store_chunk();
+    store_chunk(0);
     __syncthreads();
     const float* wa = Wt + wco + li + lk * (KC / 2) * CO_T;
     const float* pb = P + wsg * PSEG + li + lk * (CI_C / 2) * PCI;
     for (int c = 0; c < nchunks; ++c) {
-        if (c + 1 < nchunks) load_chunk((c + 1) * CI_C);
+        const int cnext = min(c + 1, nchunks - 1) * CI_C;     // branch-free prefetch (the last chunk re-loads itself, unused)
         // fragment reads run one k-step ahead of the MFMAs that consume them (hipcc otherwise emits
         // read -> lgkmcnt(0) -> MFMAs per step and exposes the LDS latency)
         float a0 = wa[0], a1 = wa[32], b[SPWV];
@@ -182,6 +197,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
         for (int j = 0; j < SPWV; ++j) b[j] = pb[j * PSEG];
 #pragma unroll
         for (int ks = 0; ks < KC / 2; ++ks) {
+            load_slice(cnext, ks);                  // next chunk's global loads ride between this chunk's MFMAs
             float a0n = 0.f, a1n = 0.f, bn[SPWV];
 #pragma unroll
             for (int j = 0; j < SPWV; ++j) bn[j] = 0.f;
@@ -206,7 +222,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
         }
         __syncthreads();
         if (c + 1 < nchunks) {
-            store_chunk();
+            store_chunk((c + 1) * CI_C);
             __syncthreads();
         }
     }
@@ -256,67 +272,105 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restr
     const int send = min(nseg_total, sbeg + segs_per_split);
     const int dpx = tid & 31, dco = tid >> 5;           // dy loader: 32 pixels x 8 channels per pass
 
-    // x halo rows: wave w stages channels [16w, 16w+16) x 3 rows, lanes 0..33 = columns (wave-uniform row math)
-    auto load_seg = [&](int g) {
+    // Loader: 32-bit element offsets from the tensor bases (host guarantees < 2^31 elements); everything that does not
+    // depend on the segment is hoisted; the per-segment part is three scalars.  The 56 loads of segment g+1 are issued in
+    // 16 slices BETWEEN the k-steps of segment g (one basic block, no branch), so their address arithmetic shares issue
+    // slots with the MFMAs instead of running ahead of them (it used to cost ~30 % of the loop: 370 VALU + 600 SALU
+    // before the first MFMA).
+    // channel bases are wave-uniform pointers (scalar registers), the per-segment position is one 32-bit lane offset
+    // per row: a load is ONE instruction (saddr + voffset).  Out-of-range rows/columns/channels load a clamped in-range
+    // element and are zeroed by a 0/1 factor when they are written to LDS.
+    const float* dy_cb[EDY];
+    float dy_m[EDY];
+#pragma unroll
+    for (int e = 0; e < EDY; ++e) {
+        const int co = co0 + dco + 8 * e;
+        dy_m[e] = co < Cout ? 1.f : 0.f;
+        dy_cb[e] = dy + (long)min(co, Cout - 1) * HW;
+    }
+    const float* x_cb[16];
+    float x_m[16];
+#pragma unroll
+    for (int ci = 0; ci < 16; ++ci) {
+        const int gci = ci0 + wave * 16 + ci;
+        x_m[ci] = gci < Cin ? 1.f : 0.f;
+        x_cb[ci] = x + (long)min(gci, Cin - 1) * HW;
+    }
+    struct SegPos { int dy_off; int x_off[3]; float dy_ok; float row_ok[3]; };
+    auto seg_pos = [&](int g) {
+        SegPos p;
         const int n = g / (H * SW), rem = g % (H * SW);
         const int h = rem / SW, w0 = (rem % SW) * SEGW;
-        const float* dyb = dy + (long)n * Cout * HW + (long)h * W;
-        const bool pxok = w0 + dpx < W;
-        const int pxc = min(w0 + dpx, W - 1);
-#pragma unroll
-        for (int e = 0; e < EDY; ++e) {
-            const int co = co0 + dco + 8 * e;
-            const float* src = dyb + ((long)min(co, Cout - 1) * HW + pxc);   // address select, unconditional load
-            rdy[e] = *((pxok && co < Cout) ? src : zero_page + lane);
-        }
+        p.dy_ok = w0 + dpx < W ? 1.f : 0.f;
+        p.dy_off = n * Cout * (int)HW + h * W + min(w0 + dpx, W - 1);
         const int ww = w0 - 1 + lane;
         const bool colok = lane < PROW && ww >= 0 && ww < W;
-        const int loff = colok ? ww : 0;
-        const float* xb = x + (long)n * Cin * HW;
+        const int loff = min(max(ww, 0), W - 1);
 #pragma unroll
-        for (int ci = 0; ci < 16; ++ci)
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                const int hh = h + kh - 1, gci = ci0 + wave * 16 + ci;
-                const bool rowok = gci < Cin && hh >= 0 && hh < H;             // wave-uniform
-                const float* src = xb + ((long)min(gci, Cin - 1) * HW + (long)min(max(hh, 0), H - 1) * W + loff);
-                rx[ci * 3 + kh] = *((rowok && colok) ? src : zero_page + lane);
-            }
+        for (int kh = 0; kh < 3; ++kh) {
+            const int hh = h + kh - 1;
+            p.row_ok[kh] = (colok && hh >= 0 && hh < H) ? 1.f : 0.f;
+            p.x_off[kh] = n * Cin * (int)HW + min(max(hh, 0), H - 1) * W + loff;
+        }
+        return p;
     };
-    auto store_seg = [&]() {
+    // slice q (0..15) of the loads of one segment: dy pass q/2 (even q) and x rows [3q, 3q+3)
+    auto load_slice = [&](const SegPos& p, int q) {
+        if ((q & 1) == 0) rdy[q >> 1] = dy_cb[q >> 1][p.dy_off];
 #pragma unroll
-        for (int e = 0; e < EDY; ++e) dyT[(dco + 8 * e) * WG_DYP + dpx] = rdy[e];
+        for (int j = 0; j < 3; ++j) {
+            const int r = 3 * q + j;
+            rx[r] = x_cb[r / 3][p.x_off[r % 3]];
+        }
+    };
+    auto store_seg = [&](const SegPos& p) {
+#pragma unroll
+        for (int e = 0; e < EDY; ++e) dyT[(dco + 8 * e) * WG_DYP + dpx] = rdy[e] * (dy_m[e] * p.dy_ok);
         if (lane < PROW) {
 #pragma unroll
             for (int ci = 0; ci < 16; ++ci)
 #pragma unroll
-                for (int kh = 0; kh < 3; ++kh) xp[(wave * 16 + ci) * WG_XCI + kh * PROW + lane] = rx[ci * 3 + kh];
+                for (int kh = 0; kh < 3; ++kh)
+                    xp[(wave * 16 + ci) * WG_XCI + kh * PROW + lane] = rx[ci * 3 + kh] * (x_m[ci] * p.row_ok[kh]);
         }
     };
 
     if (sbeg < send) {
-        load_seg(sbeg);
-        store_seg();
+        const SegPos p0 = seg_pos(sbeg);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) load_slice(p0, q);
+        store_seg(p0);
     }
     __syncthreads();
     for (int g = sbeg; g < send; ++g) {
-        if (g + 1 < send) load_seg(g + 1);
+        const SegPos pn = seg_pos(min(g + 1, send - 1));      // branch-free: the last iteration re-loads its own segment (unused)
         const float* ap = dyT + (wco + li) * WG_DYP + lk;
         const float* bp = xp + (wci + li) * WG_XCI + lk;
+        // fragment reads run one k-step ahead of their MFMAs (one wave per SIMD: nothing else hides the LDS latency)
+        float a = ap[0], b[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) b[t] = bp[(t / 3) * PROW + (t % 3)];
 #pragma unroll
         for (int ks = 0; ks < SEGW / 2; ++ks) {
-            const float a = ap[2 * ks];
+            load_slice(pn, ks);
+            float an = 0.f, bn[9];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const float b = bp[(t / 3) * PROW + (t % 3) + 2 * ks];
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+            for (int t = 0; t < 9; ++t) bn[t] = 0.f;
+            if (ks + 1 < SEGW / 2) {
+                an = ap[2 * (ks + 1)];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) bn[t] = bp[(t / 3) * PROW + (t % 3) + 2 * (ks + 1)];
             }
+            __builtin_amdgcn_sched_barrier(0);      // loads of the next segment and next step's ds_reads stay above the MFMAs
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[t], acc[t], 0, 0, 0);
+            a = an;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) b[t] = bn[t];
         }
         __syncthreads();
-        if (g + 1 < send) {
-            store_seg();
-            __syncthreads();
-        }
+        store_seg(pn);
+        __syncthreads();
     }
     // slab[split][tap][co][ci]  (ci contiguous -> coalesced stores)
     const long plane = (long)Cout * Cin;
@@ -525,6 +579,7 @@ extern "C" int vocr_conv3x3_wgrad(const float* x, const float* dy, float* dw, vo
                                   int w, int cout, void* stream) {
     VOCR_CHECK_ARG(x && dy && dw && workspace, "vocr_conv3x3_wgrad: null pointer");
     VOCR_CHECK_ARG(n > 0 && cin > 0 && h > 0 && w > 0 && cout > 0, "vocr_conv3x3_wgrad: bad shape");
+    VOCR_CHECK_ARG((long)n * (cin > cout ? cin : cout) * h * w < (1l << 31), "vocr_conv3x3_wgrad: tensor exceeds 2^31 elements");
     const int SW = vocr_cdiv(w, SEGW);
     const long nseg = (long)n * h * SW;
     int sps;
