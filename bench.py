@@ -160,6 +160,12 @@ def main():
         cf_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in recs.get("vocr_conv3x3_fwd", []))
         n_launch = max(1, len(recs.get("vocr_conv3x3_fwd", [])))
         achieved = cf_flops / (cf_ms * 1e-3) / 1e12 if cf_ms > 0 else 0.0
+        traffic = None
+        try:        # HBM-side bytes per launch of the same kernel from the committed PMC passes (cannot be collected live)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "conv_traffic.json")))
+            traffic = int((tj["fetch_KB_per_launch"] + tj["write_KB_per_launch"]) * 1024)
+        except Exception:
+            pass
         breakdown = {}
         for name, lst in recs.items():
             breakdown[name] = round(sum(e0.elapsed_time(e1) for _, e0, e1 in lst) / args.steps, 3)
@@ -173,7 +179,7 @@ def main():
                        "global_batch": B * world, "parallelism": "dp%d" % world, "final_loss": round(final_loss, 3)},
             "roofline": {"bound": "mfma", "kernel": "conv3x3_kernel (implicit-GEMM fwd+dgrad, f32 MFMA 32x32x2)",
                          "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "avg_launch_ms": round(cf_ms / n_launch, 4), "launches_per_step": n_launch // max(1, args.steps)},
             "ms_per_step_by_entry_point": breakdown,
         }
