@@ -28,18 +28,32 @@ __device__ __forceinline__ void block_reduce2(double& a, double& b, double* red)
     b = (red[1] + red[3]) + (red[5] + red[7]);
 }
 
+// V = elements per load (4, 2 or 1): chosen by the host so that HW % V == 0 and the chunk size is a multiple of V, hence a
+// vector never straddles two (n, c) planes and every plane base is V*4-byte aligned.
+template <int V> struct VecT { typedef float type __attribute__((ext_vector_type(V))); };
+template <> struct VecT<1> { typedef float type; };
+template <int V> __device__ __forceinline__ float vget(const typename VecT<V>::type& v, int i) { return v[i]; }
+template <> __device__ __forceinline__ float vget<1>(const float& v, int) { return v; }
+template <int V> __device__ __forceinline__ void vset(typename VecT<V>::type& v, int i, float x) { v[i] = x; }
+template <> __device__ __forceinline__ void vset<1>(float& v, int, float x) { v = x; }
+
+template <int V>
 __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ y, double* __restrict__ part,
-                                                               int N, int C, long HW, int nchunk) {
+                                                               int N, int C, long HW, int nchunk, long per) {
+    typedef typename VecT<V>::type vec;
     __shared__ double red[8];
     const int c = blockIdx.x, j = blockIdx.y;
     const long total = (long)N * HW;
-    const long per = (total + nchunk - 1) / nchunk;
     const long beg = j * per, end = min(total, beg + per);
     double s = 0.0, q = 0.0;
-    for (long e = beg + threadIdx.x; e < end; e += 256) {
-        const double v = (double)y[chan_addr(e, c, C, HW)];
-        s += v;
-        q += v * v;
+    for (long e = beg + (long)threadIdx.x * V; e < end; e += 256 * V) {
+        const vec v = *(const vec*)(y + chan_addr(e, c, C, HW));
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const double x = (double)vget<V>(v, i);
+            s += x;
+            q += x * x;
+        }
     }
     block_reduce2(s, q, red);
     if (threadIdx.x == 0) {
@@ -79,42 +93,57 @@ __global__ void bn_eval_stats_kernel(const float* __restrict__ rmean, const floa
 }
 
 // grid: (chunks over HW, N*C planes)
+template <int V>
 __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const float* __restrict__ y, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ out,
                                                             int C, long HW) {
+    typedef typename VecT<V>::type vec;
     const long plane = blockIdx.y;
     const int c = (int)(plane % C);
     const float mu = mean[c], is = invstd[c], g = gamma[c], b = beta[c];
-    const float* yp = y + plane * HW;
-    float* op = out + plane * HW;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < HW; i += (long)gridDim.x * 256) {
-        const float v = (yp[i] - mu) * is * g + b;
-        op[i] = v > 0.f ? v : 0.f;
+    const vec* yp = (const vec*)(y + plane * HW);
+    vec* op = (vec*)(out + plane * HW);
+    const long nv = HW / V;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+        const vec in = yp[i];
+        vec o;
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float v = (vget<V>(in, k) - mu) * is * g + b;
+            vset<V>(o, k, v > 0.f ? v : 0.f);
+        }
+        op[i] = o;
     }
 }
 
+template <int V>
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ da, const float* __restrict__ y,
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ invstd,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, double* __restrict__ part,
-                                                             int N, int C, long HW, int nchunk) {
+                                                             int N, int C, long HW, int nchunk, long per) {
+    typedef typename VecT<V>::type vec;
     __shared__ double red[8];
     const int c = blockIdx.x, j = blockIdx.y;
     const float mu = mean[c], is = invstd[c], g = gamma[c], b = beta[c];
     const long total = (long)N * HW;
-    const long per = (total + nchunk - 1) / nchunk;
     const long beg = j * per, end = min(total, beg + per);
     double s1 = 0.0, s2 = 0.0;
-    for (long e = beg + threadIdx.x; e < end; e += 256) {
+    for (long e = beg + (long)threadIdx.x * V; e < end; e += 256 * V) {
         const long a = chan_addr(e, c, C, HW);
-        const float xh = (y[a] - mu) * is;
-        const float o = xh * g + b;
-        const float dz = o > 0.f ? da[a] : 0.f;
-        s1 += (double)dz;
-        s2 += (double)dz * (double)xh;
+        const vec yv = *(const vec*)(y + a);
+        const vec dv = *(const vec*)(da + a);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float xh = (vget<V>(yv, k) - mu) * is;
+            const float o = xh * g + b;
+            const float dz = o > 0.f ? vget<V>(dv, k) : 0.f;
+            s1 += (double)dz;
+            s2 += (double)dz * (double)xh;
+        }
     }
     block_reduce2(s1, s2, red);
     if (threadIdx.x == 0) {
@@ -136,6 +165,7 @@ __global__ void bn_bwd_final_kernel(const double* __restrict__ part, int C, int 
     dgamma[c] = (float)s2;
 }
 
+template <int V>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ da, const float* __restrict__ y,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ invstd,
@@ -145,22 +175,30 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ dbeta, float* __restrict__ dy,
                                                            float* __restrict__ dconv_bias, int C, long HW,
                                                            float inv_count) {
+    typedef typename VecT<V>::type vec;
     __shared__ float redf[4];
     const long plane = blockIdx.y;
     const int c = (int)(plane % C);
     const float mu = mean[c], is = invstd[c], g = gamma[c], b = beta[c];
     const float k1 = dbeta[c] * inv_count, k2 = dgamma[c] * inv_count, gs = g * is;
-    const float* yp = y + plane * HW;
-    const float* dp = da + plane * HW;
-    float* op = dy + plane * HW;
+    const vec* yp = (const vec*)(y + plane * HW);
+    const vec* dp = (const vec*)(da + plane * HW);
+    vec* op = (vec*)(dy + plane * HW);
+    const long nv = HW / V;
     float acc = 0.f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < HW; i += (long)gridDim.x * 256) {
-        const float xh = (yp[i] - mu) * is;
-        const float o = xh * g + b;
-        const float dz = o > 0.f ? dp[i] : 0.f;
-        const float v = gs * (dz - k1 - xh * k2);
-        op[i] = v;
-        acc += v;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+        const vec yv = yp[i], dv = dp[i];
+        vec o;
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float xh = (vget<V>(yv, k) - mu) * is;
+            const float ov = xh * g + b;
+            const float dz = ov > 0.f ? vget<V>(dv, k) : 0.f;
+            const float v = gs * (dz - k1 - xh * k2);
+            vset<V>(o, k, v);
+            acc += v;
+        }
+        op[i] = o;
     }
     if (dconv_bias) {     // gradient of the conv bias in front of the BN = sum of dy (zero up to rounding); fused here
         acc = wave_sum(acc);
@@ -251,6 +289,19 @@ __global__ __launch_bounds__(256) void relu_maxpool2_bwd_kernel(const float* __r
 
 }  // namespace
 
+// widest load (in floats) usable on planes of hw elements starting at these bases
+static inline int vec_width(int hw, const void* a, const void* b) {
+    const uintptr_t m = (uintptr_t)a | (uintptr_t)b;
+    if (hw % 4 == 0 && (m & 15) == 0) return 4;
+    if (hw % 2 == 0 && (m & 7) == 0) return 2;
+    return 1;
+}
+// elements of one channel per reduction chunk, rounded up to a multiple of 4 so that vectors never straddle chunks
+static inline long chunk_len(long per_channel, int nchunk) {
+    const long per = (per_channel + nchunk - 1) / nchunk;
+    return (per + 3) / 4 * 4;
+}
+
 extern "C" size_t vocr_bn_workspace_bytes(int n, int c, int hw) {
     if (n <= 0 || c <= 0 || hw <= 0) return 0;
     return (size_t)c * bn_nchunk((long)n * hw) * 2 * sizeof(double);
@@ -261,7 +312,11 @@ extern "C" int vocr_bn_train_stats(const float* y, int n, int c, int hw, float e
     VOCR_CHECK_ARG(y && mean && invstd && workspace && n > 0 && c > 0 && hw > 0, "vocr_bn_train_stats: bad argument");
     hipStream_t s = (hipStream_t)stream;
     const int nchunk = bn_nchunk((long)n * hw);
-    bn_stats_partial_kernel<<<dim3(c, nchunk), 256, 0, s>>>(y, (double*)workspace, n, c, hw, nchunk);
+    const int V = vec_width(hw, y, y);
+    const long per = chunk_len((long)n * hw, nchunk);
+    if (V == 4) bn_stats_partial_kernel<4><<<dim3(c, nchunk), 256, 0, s>>>(y, (double*)workspace, n, c, hw, nchunk, per);
+    else if (V == 2) bn_stats_partial_kernel<2><<<dim3(c, nchunk), 256, 0, s>>>(y, (double*)workspace, n, c, hw, nchunk, per);
+    else bn_stats_partial_kernel<1><<<dim3(c, nchunk), 256, 0, s>>>(y, (double*)workspace, n, c, hw, nchunk, per);
     VOCR_CHECK_LAUNCH("vocr_bn_train_stats(partial)");
     bn_stats_final_kernel<<<vocr_cdiv(c, 64), 64, 0, s>>>((const double*)workspace, c, nchunk, (long)n * hw, eps, momentum,
                                                           mean, invstd, running_mean, running_var);
@@ -288,7 +343,11 @@ extern "C" int vocr_bn_relu_apply(const float* y, const float* mean, const float
                                   const float* beta, float* out, int n, int c, int hw, void* stream) {
     VOCR_CHECK_ARG(y && mean && invstd && gamma && beta && out && n > 0 && c > 0 && hw > 0, "vocr_bn_relu_apply: bad argument");
     VOCR_CHECK_ARG((long)n * c <= 65535, "vocr_bn_relu_apply: n*c > 65535 planes");
-    bn_relu_apply_kernel<<<plane_grid((long)n * c, hw), 256, 0, (hipStream_t)stream>>>(y, mean, invstd, gamma, beta, out, c, hw);
+    const int V = vec_width(hw, y, out);
+    const dim3 grid = plane_grid((long)n * c, hw / V);
+    if (V == 4) bn_relu_apply_kernel<4><<<grid, 256, 0, (hipStream_t)stream>>>(y, mean, invstd, gamma, beta, out, c, hw);
+    else if (V == 2) bn_relu_apply_kernel<2><<<grid, 256, 0, (hipStream_t)stream>>>(y, mean, invstd, gamma, beta, out, c, hw);
+    else bn_relu_apply_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(y, mean, invstd, gamma, beta, out, c, hw);
     VOCR_CHECK_LAUNCH("vocr_bn_relu_apply");
     return VOCR_OK;
 }
@@ -300,7 +359,11 @@ extern "C" int vocr_bn_relu_bwd(const float* da, const float* y, const float* me
     VOCR_CHECK_ARG(n > 0 && c > 0 && hw > 0 && (long)n * c <= 65535, "vocr_bn_relu_bwd: bad shape");
     hipStream_t s = (hipStream_t)stream;
     const int nchunk = bn_nchunk((long)n * hw);
-    bn_bwd_partial_kernel<<<dim3(c, nchunk), 256, 0, s>>>(da, y, mean, invstd, gamma, beta, (double*)workspace, n, c, hw, nchunk);
+    const int V = (vec_width(hw, da, y) < vec_width(hw, dy, dy)) ? vec_width(hw, da, y) : vec_width(hw, dy, dy);
+    const long per = chunk_len((long)n * hw, nchunk);
+    if (V == 4) bn_bwd_partial_kernel<4><<<dim3(c, nchunk), 256, 0, s>>>(da, y, mean, invstd, gamma, beta, (double*)workspace, n, c, hw, nchunk, per);
+    else if (V == 2) bn_bwd_partial_kernel<2><<<dim3(c, nchunk), 256, 0, s>>>(da, y, mean, invstd, gamma, beta, (double*)workspace, n, c, hw, nchunk, per);
+    else bn_bwd_partial_kernel<1><<<dim3(c, nchunk), 256, 0, s>>>(da, y, mean, invstd, gamma, beta, (double*)workspace, n, c, hw, nchunk, per);
     VOCR_CHECK_LAUNCH("vocr_bn_relu_bwd(partial)");
     bn_bwd_final_kernel<<<vocr_cdiv(c, 64), 64, 0, s>>>((const double*)workspace, c, nchunk, dgamma, dbeta);
     VOCR_CHECK_LAUNCH("vocr_bn_relu_bwd(final)");
@@ -308,8 +371,11 @@ extern "C" int vocr_bn_relu_bwd(const float* da, const float* y, const float* me
         vocr_set_error("vocr_bn_relu_bwd: memset failed");
         return VOCR_ELAUNCH;
     }
-    bn_bwd_apply_kernel<<<plane_grid((long)n * c, hw), 256, 0, s>>>(da, y, mean, invstd, gamma, beta, dgamma, dbeta, dy,
-                                                                    dconv_bias, c, hw, 1.0f / (float)((long)n * hw));
+    const dim3 grid = plane_grid((long)n * c, hw / V);
+    const float inv_count = 1.0f / (float)((long)n * hw);
+    if (V == 4) bn_bwd_apply_kernel<4><<<grid, 256, 0, s>>>(da, y, mean, invstd, gamma, beta, dgamma, dbeta, dy, dconv_bias, c, hw, inv_count);
+    else if (V == 2) bn_bwd_apply_kernel<2><<<grid, 256, 0, s>>>(da, y, mean, invstd, gamma, beta, dgamma, dbeta, dy, dconv_bias, c, hw, inv_count);
+    else bn_bwd_apply_kernel<1><<<grid, 256, 0, s>>>(da, y, mean, invstd, gamma, beta, dgamma, dbeta, dy, dconv_bias, c, hw, inv_count);
     VOCR_CHECK_LAUNCH("vocr_bn_relu_bwd(apply)");
     return VOCR_OK;
 }
