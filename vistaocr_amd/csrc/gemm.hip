@@ -238,29 +238,44 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     }
 }
 
-__global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ out, float* __restrict__ dz, size_t n) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+// elementwise glue: 16-byte main loop (count4 = count/4 vectors) + scalar tail, grid-stride
+__global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ out, float* __restrict__ dz, size_t n, int vec) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) dz[i] = out[i] > 0.f ? dy[i] : 0.f;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n4 = vec ? n / 4 : 0;
+    for (size_t v = i; v < n4; v += stride) {
+        const f32x4 d = ((const f32x4*)dy)[v], o = ((const f32x4*)out)[v];
+        f32x4 r;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = o[k] > 0.f ? d[k] : 0.f;
+        ((f32x4*)dz)[v] = r;
+    }
+    for (size_t e = n4 * 4 + i; e < n; e += stride) dz[e] = out[e] > 0.f ? dy[e] : 0.f;
 }
 
-__global__ void mul_kernel(const float* __restrict__ x, const float* __restrict__ m, float* __restrict__ o, size_t n) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void mul_kernel(const float* __restrict__ x, const float* __restrict__ m, float* __restrict__ o, size_t n, int vec) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) o[i] = x[i] * m[i];
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n4 = vec ? n / 4 : 0;
+    for (size_t v = i; v < n4; v += stride) ((f32x4*)o)[v] = ((const f32x4*)x)[v] * ((const f32x4*)m)[v];
+    for (size_t e = n4 * 4 + i; e < n; e += stride) o[e] = x[e] * m[e];
 }
 
-__global__ void add_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ o, size_t n) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void add_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ o, size_t n, int vec) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) o[i] = x[i] + y[i];
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n4 = vec ? n / 4 : 0;
+    for (size_t v = i; v < n4; v += stride) ((f32x4*)o)[v] = ((const f32x4*)x)[v] + ((const f32x4*)y)[v];
+    for (size_t e = n4 * 4 + i; e < n; e += stride) o[e] = x[e] + y[e];
 }
 
-__global__ void scale_dev_kernel(const float* __restrict__ x, const float* __restrict__ sc, float* __restrict__ o, size_t n) {
+__global__ void scale_dev_kernel(const float* __restrict__ x, const float* __restrict__ sc, float* __restrict__ o, size_t n, int vec) {
     const float a = sc[0];
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) o[i] = x[i] * a;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n4 = vec ? n / 4 : 0;
+    for (size_t v = i; v < n4; v += stride) ((f32x4*)o)[v] = ((const f32x4*)x)[v] * a;
+    for (size_t e = n4 * 4 + i; e < n; e += stride) o[e] = x[e] * a;
 }
 
 __device__ __forceinline__ uint32_t mix32(uint64_t z) {
@@ -271,14 +286,26 @@ __device__ __forceinline__ uint32_t mix32(uint64_t z) {
 }
 
 __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ o, float* __restrict__ mask, size_t n,
-                               float p, float scale, uint64_t seed) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+                               float p, float scale, uint64_t seed, int vec) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) {
-        const float u = (float)(mix32(seed * 0x9e3779b97f4a7c15ull + i) >> 8) * (1.0f / 16777216.0f);
-        const float mk = (u >= p) ? scale : 0.f;
-        mask[i] = mk;
-        o[i] = x[i] * mk;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n4 = vec ? n / 4 : 0;
+    auto draw = [&](size_t e) {
+        const float u = (float)(mix32(seed * 0x9e3779b97f4a7c15ull + e) >> 8) * (1.0f / 16777216.0f);
+        return (u >= p) ? scale : 0.f;
+    };
+    for (size_t v = i; v < n4; v += stride) {
+        const f32x4 xv = ((const f32x4*)x)[v];
+        f32x4 mk;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mk[k] = draw(4 * v + k);
+        ((f32x4*)mask)[v] = mk;
+        ((f32x4*)o)[v] = xv * mk;
+    }
+    for (size_t e = n4 * 4 + i; e < n; e += stride) {
+        const float mk = draw(e);
+        mask[e] = mk;
+        o[e] = x[e] * mk;
     }
 }
 
@@ -384,14 +411,17 @@ extern "C" int vocr_colsum(const float* x, float* out, int m, int n, void* strea
 }
 
 static inline int ew_grid(size_t count) {
-    size_t g = (count + 255) / 256;
+    size_t g = (count / 4 + 255) / 256;
     return (int)(g > 2048 ? 2048 : (g ? g : 1));
+}
+static inline int ew_vec(const void* a, const void* b, const void* c) {
+    return ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c)) & 15) == 0;
 }
 
 extern "C" int vocr_relu_bwd(const float* dy, const float* out, float* dz, size_t count, void* stream) {
     VOCR_CHECK_ARG(dy && out && dz, "vocr_relu_bwd: null pointer");
     if (count == 0) return VOCR_OK;
-    relu_bwd_kernel<<<ew_grid(count), 256, 0, (hipStream_t)stream>>>(dy, out, dz, count);
+    relu_bwd_kernel<<<ew_grid(count), 256, 0, (hipStream_t)stream>>>(dy, out, dz, count, ew_vec(dy, out, dz));
     VOCR_CHECK_LAUNCH("vocr_relu_bwd");
     return VOCR_OK;
 }
@@ -399,7 +429,7 @@ extern "C" int vocr_relu_bwd(const float* dy, const float* out, float* dz, size_
 extern "C" int vocr_mul(const float* x, const float* mask, float* out, size_t count, void* stream) {
     VOCR_CHECK_ARG(x && mask && out, "vocr_mul: null pointer");
     if (count == 0) return VOCR_OK;
-    mul_kernel<<<ew_grid(count), 256, 0, (hipStream_t)stream>>>(x, mask, out, count);
+    mul_kernel<<<ew_grid(count), 256, 0, (hipStream_t)stream>>>(x, mask, out, count, ew_vec(x, mask, out));
     VOCR_CHECK_LAUNCH("vocr_mul");
     return VOCR_OK;
 }
@@ -407,7 +437,7 @@ extern "C" int vocr_mul(const float* x, const float* mask, float* out, size_t co
 extern "C" int vocr_add(const float* x, const float* y, float* out, size_t count, void* stream) {
     VOCR_CHECK_ARG(x && y && out, "vocr_add: null pointer");
     if (count == 0) return VOCR_OK;
-    add_kernel<<<ew_grid(count), 256, 0, (hipStream_t)stream>>>(x, y, out, count);
+    add_kernel<<<ew_grid(count), 256, 0, (hipStream_t)stream>>>(x, y, out, count, ew_vec(x, y, out));
     VOCR_CHECK_LAUNCH("vocr_add");
     return VOCR_OK;
 }
@@ -415,7 +445,7 @@ extern "C" int vocr_add(const float* x, const float* y, float* out, size_t count
 extern "C" int vocr_scale_dev(const float* x, const float* scalar, float* out, size_t count, void* stream) {
     VOCR_CHECK_ARG(x && scalar && out, "vocr_scale_dev: null pointer");
     if (count == 0) return VOCR_OK;
-    scale_dev_kernel<<<ew_grid(count), 256, 0, (hipStream_t)stream>>>(x, scalar, out, count);
+    scale_dev_kernel<<<ew_grid(count), 256, 0, (hipStream_t)stream>>>(x, scalar, out, count, ew_vec(x, out, out));
     VOCR_CHECK_LAUNCH("vocr_scale_dev");
     return VOCR_OK;
 }
@@ -424,7 +454,7 @@ extern "C" int vocr_dropout_fwd(const float* x, float* out, float* mask, size_t 
     VOCR_CHECK_ARG(x && mask && out, "vocr_dropout_fwd: null pointer");
     VOCR_CHECK_ARG(p >= 0.f && p < 1.f, "vocr_dropout_fwd: p must be in [0,1)");
     if (count == 0) return VOCR_OK;
-    dropout_kernel<<<ew_grid(count), 256, 0, (hipStream_t)stream>>>(x, out, mask, count, p, 1.0f / (1.0f - p), seed);
+    dropout_kernel<<<ew_grid(count), 256, 0, (hipStream_t)stream>>>(x, out, mask, count, p, 1.0f / (1.0f - p), seed, ew_vec(x, out, mask));
     VOCR_CHECK_LAUNCH("vocr_dropout_fwd");
     return VOCR_OK;
 }
