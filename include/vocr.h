@@ -46,11 +46,14 @@ int vocr_conv3x3_wgrad(const float* x, const float* dy, float* dw, void* workspa
 /* fp16-operand variant (BASELINE config 5: "fp16 conv MFMA", fp32 accumulate): tensors stay fp32 in HBM, operands are
  * rounded to fp16 on the way into the matrix cores (v_mfma_f32_32x32x16_f16).  Weight packs are fp16:
  * fwd  [ceil(cin/16)][9][2][cout][8],  dgrad [ceil(cout/16)][9][2][cin][8] (taps flipped); sizes from *_pack_bytes.
- * dgrad = vocr_conv3x3_f16_fwd(dy, wpack_dgrad, NULL, dx, n, cout, h, w, cin).  The weight gradient stays on the f32 path. */
+ * dgrad = vocr_conv3x3_f16_fwd(dy, wpack_dgrad, NULL, dx, n, cout, h, w, cin).
+ * vocr_conv3x3_wgrad_f16: same contract and workspace as vocr_conv3x3_wgrad, dy and x rounded to fp16 for the MFMA. */
 size_t vocr_conv3x3_f16_pack_bytes(int cout, int cin, int dgrad);
 int vocr_conv3x3_f16_pack_weights(const float* w, void* wpack_fwd, void* wpack_dgrad, int cout, int cin, void* stream);
 int vocr_conv3x3_f16_fwd(const float* x, const void* wpack, const float* bias, float* y,
                          int n, int cin, int h, int w, int cout, void* stream);
+int vocr_conv3x3_wgrad_f16(const float* x, const float* dy, float* dw, void* workspace,
+                           int n, int cin, int h, int w, int cout, void* stream);
 /* per-channel sum over (n,h,w): conv bias gradient.  out[c] */
 int vocr_channel_sum(const float* x, float* out, int n, int c, int hw, void* stream);
 

@@ -132,8 +132,8 @@ def trainable(sd):
 
 # ----------------------------------------------------------------------------- conv operand rounding (config 5)
 class _ConvF16Operands(torch.autograd.Function):
-    """Semantics of the build's fp16-operand conv (BASELINE config 5): forward and data-gradient multiply
-    fp16-ROUNDED operands and accumulate in fp32; the weight gradient is computed from the unrounded fp32 tensors."""
+    """Semantics of the build's fp16-operand conv (BASELINE config 5): forward, data-gradient and weight-gradient all
+    multiply fp16-ROUNDED operands and accumulate in fp32 (first layer, Cin <= 3: weight gradient from fp32 operands)."""
 
     @staticmethod
     def forward(ctx, x, w, b):
@@ -144,7 +144,10 @@ class _ConvF16Operands(torch.autograd.Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dx = torch.nn.grad.conv2d_input(x.shape, w.half().float(), dy.half().float(), padding=1)
-        dw = torch.nn.grad.conv2d_weight(x, w.shape, dy, padding=1)
+        if x.shape[1] <= 3:
+            dw = torch.nn.grad.conv2d_weight(x, w.shape, dy, padding=1)
+        else:
+            dw = torch.nn.grad.conv2d_weight(x.half().float(), w.shape, dy.half().float(), padding=1)
         return dx, dw, dy.sum((0, 2, 3))
 
 

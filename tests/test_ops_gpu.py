@@ -76,6 +76,10 @@ def test_conv3x3_f16_operands(dev, n, cin, h, w, cout):
     _close(y, yr, 1e-5, 2e-5 * (cin * 9) ** 0.5, "conv f16 fwd")
     dx = ops.conv3x3_forward_f16(dy.to(dev), pd, None, cin)
     _close(dx, dxr, 1e-5, 2e-5 * (cout * 9) ** 0.5, "conv f16 dgrad")
+    if cin > 3:
+        dwr = torch.nn.grad.conv2d_weight(xh, wt.shape, dyh, padding=1)
+        dw = ops.conv3x3_wgrad(x.to(dev), dy.to(dev), f16=True)
+        _close(dw, dwr, 1e-4, 2e-4 * math.sqrt(n * h * w), "conv f16 wgrad")
     # and it really is fp16 rounding: it differs from the fp32 conv by about 2^-11 relative, not more
     y32 = F.conv2d(x, wt, bias, padding=1)
     rel = float((y.cpu() - y32).abs().max() / y32.abs().max())

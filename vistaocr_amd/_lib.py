@@ -23,6 +23,7 @@ SIGNATURES = {
     "vocr_conv3x3_f16_pack_bytes": (Z, [I, I, I]),
     "vocr_conv3x3_f16_pack_weights": (I, [P, P, P, I, I, P]),
     "vocr_conv3x3_f16_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "vocr_conv3x3_wgrad_f16": (I, [P, P, P, P, I, I, I, I, I, P]),
     "vocr_channel_sum": (I, [P, P, I, I, I, P]),
     "vocr_bn_workspace_bytes": (Z, [I, I, I]),
     "vocr_bn_train_stats": (I, [P, I, I, I, F, F, P, P, P, P, P, P]),

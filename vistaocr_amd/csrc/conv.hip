@@ -468,6 +468,126 @@ __global__ __launch_bounds__(128) void conv3x3_wgrad_smallcin_kernel(const float
     }
 }
 
+// Weight gradient with fp16 operands on v_mfma_f32_32x32x16_f16 (config 5), fp32 accumulation: M = co, N = ci, K = pixels.
+// One 32-pixel segment = 2 MFMA k-steps per tap; lane-half h owns pixels 8h..8h+7 of a k-step, so both fragments are
+// 16-byte LDS reads: dy rows dyH[co][px] and — because a tap shifts the pixel window by kw — three pre-shifted copies of
+// the halo rows, xH[kw][ci][kh][px] (row pitch 40 halfs = 80 B: conflict-free ds_read_b128).
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+constexpr int WH_P = 40;     // halfs per LDS row (32 pixels + pad)
+
+__global__ __launch_bounds__(256) void conv3x3_wgrad_f16_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                float* __restrict__ slab, int N, int Cin, int H, int W,
+                                                                int Cout, int SW, int nseg_total, int segs_per_split) {
+    __shared__ __attribute__((aligned(16))) _Float16 dyH[64 * WH_P];
+    __shared__ __attribute__((aligned(16))) _Float16 xH[3 * 64 * 3 * WH_P];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lk = lane >> 5;
+    const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64, split = blockIdx.z;
+    const int wco = (wave >> 1) * 32, wci = (wave & 1) * 32;
+    const long HW = (long)H * W;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float rdy[8], rx[48];
+    const int sbeg = split * segs_per_split;
+    const int send = min(nseg_total, sbeg + segs_per_split);
+    const int dpx = tid & 31, dco = tid >> 5;
+
+    const float* dy_cb[8];
+    float dy_m[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int co = co0 + dco + 8 * e;
+        dy_m[e] = co < Cout ? 1.f : 0.f;
+        dy_cb[e] = dy + (long)min(co, Cout - 1) * HW;
+    }
+    const float* x_cb[16];
+    float x_m[16];
+#pragma unroll
+    for (int ci = 0; ci < 16; ++ci) {
+        const int gci = ci0 + wave * 16 + ci;
+        x_m[ci] = gci < Cin ? 1.f : 0.f;
+        x_cb[ci] = x + (long)min(gci, Cin - 1) * HW;
+    }
+    struct SegPos { int dy_off; int x_off[3]; float dy_ok; float row_ok[3]; };
+    auto seg_pos = [&](int g) {
+        SegPos p;
+        const int n = g / (H * SW), rem = g % (H * SW);
+        const int h = rem / SW, w0 = (rem % SW) * SEGW;
+        p.dy_ok = w0 + dpx < W ? 1.f : 0.f;
+        p.dy_off = n * Cout * (int)HW + h * W + min(w0 + dpx, W - 1);
+        const int ww = w0 - 1 + lane;
+        const bool colok = lane < PROW && ww >= 0 && ww < W;
+        const int loff = min(max(ww, 0), W - 1);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int hh = h + kh - 1;
+            p.row_ok[kh] = (colok && hh >= 0 && hh < H) ? 1.f : 0.f;
+            p.x_off[kh] = n * Cin * (int)HW + min(max(hh, 0), H - 1) * W + loff;
+        }
+        return p;
+    };
+    auto load_seg = [&](const SegPos& p) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rdy[e] = dy_cb[e][p.dy_off];
+#pragma unroll
+        for (int r = 0; r < 48; ++r) rx[r] = x_cb[r / 3][p.x_off[r % 3]];
+    };
+    auto store_seg = [&](const SegPos& p) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dyH[(dco + 8 * e) * WH_P + dpx] = (_Float16)(rdy[e] * (dy_m[e] * p.dy_ok));
+        if (lane < PROW) {
+#pragma unroll
+            for (int ci = 0; ci < 16; ++ci)
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const _Float16 v = (_Float16)(rx[ci * 3 + kh] * (x_m[ci] * p.row_ok[kh]));
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const int ppos = lane - kw;          // copy kw holds column (p + kw) at position p
+                        if (ppos >= 0 && ppos < SEGW) xH[((kw * 64 + wave * 16 + ci) * 3 + kh) * WH_P + ppos] = v;
+                    }
+                }
+        }
+    };
+    if (sbeg < send) {
+        const SegPos p0 = seg_pos(sbeg);
+        load_seg(p0);
+        store_seg(p0);
+    }
+    __syncthreads();
+    for (int g = sbeg; g < send; ++g) {
+        const SegPos pn = seg_pos(min(g + 1, send - 1));
+        load_seg(pn);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const half8_t a = *(const half8_t*)(dyH + (wco + li) * WH_P + 16 * ks + 8 * lk);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int kh = t / 3, kw = t % 3;
+                const half8_t b = *(const half8_t*)(xH + ((kw * 64 + wci + li) * 3 + kh) * WH_P + 16 * ks + 8 * lk);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        store_seg(pn);
+        __syncthreads();
+    }
+    const long plane = (long)Cout * Cin;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wco + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            const int ci = ci0 + wci + li;
+            if (co < Cout && ci < Cin) slab[((long)split * 9 + t) * plane + (long)co * Cin + ci] = acc[t][r];
+        }
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cout, int Cin, int splits) {
     const long plane = (long)Cout * Cin;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // index over [tap][co][ci]
@@ -598,6 +718,26 @@ extern "C" int vocr_conv3x3_wgrad(const float* x, const float* dy, float* dw, vo
     const long total = 9l * cout * cin;
     wgrad_reduce_kernel<<<vocr_cdiv(total, 256), 256, 0, s>>>((const float*)workspace, dw, cout, cin, splits);
     VOCR_CHECK_LAUNCH("vocr_conv3x3_wgrad(reduce)");
+    return VOCR_OK;
+}
+
+extern "C" int vocr_conv3x3_wgrad_f16(const float* x, const float* dy, float* dw, void* workspace, int n, int cin, int h,
+                                      int w, int cout, void* stream) {
+    VOCR_CHECK_ARG(x && dy && dw && workspace, "vocr_conv3x3_wgrad_f16: null pointer");
+    VOCR_CHECK_ARG(n > 0 && cin > 0 && h > 0 && w > 0 && cout > 0, "vocr_conv3x3_wgrad_f16: bad shape");
+    VOCR_CHECK_ARG((long)n * (cin > cout ? cin : cout) * h * w < (1l << 31), "vocr_conv3x3_wgrad_f16: tensor exceeds 2^31 elements");
+    if (cin <= 3) return vocr_conv3x3_wgrad(x, dy, dw, workspace, n, cin, h, w, cout, stream);   // first layer: memory-bound f32 path
+    const int SW = vocr_cdiv(w, SEGW);
+    const long nseg = (long)n * h * SW;
+    int sps;
+    const int splits = wgrad_splits(n, cin, h, w, cout, &sps);
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(vocr_cdiv(cin, 64), vocr_cdiv(cout, 64), splits);
+    conv3x3_wgrad_f16_kernel<<<grid, 256, 0, s>>>(x, dy, (float*)workspace, n, cin, h, w, cout, SW, (int)nseg, sps);
+    VOCR_CHECK_LAUNCH("vocr_conv3x3_wgrad_f16");
+    const long total = 9l * cout * cin;
+    wgrad_reduce_kernel<<<vocr_cdiv(total, 256), 256, 0, s>>>((const float*)workspace, dw, cout, cin, splits);
+    VOCR_CHECK_LAUNCH("vocr_conv3x3_wgrad_f16(reduce)");
     return VOCR_OK;
 }
 

@@ -118,13 +118,13 @@ def conv3x3_forward(x, wpack, bias, cout):
     return y
 
 
-def conv3x3_wgrad(x, dy, out=None):
+def conv3x3_wgrad(x, dy, out=None, f16=False):
     n, cin, h, w = x.shape
     cout = dy.shape[1]
     lib = _lib.load()
     ws = _ws(lib.vocr_conv3x3_wgrad_workspace_bytes(n, cin, h, w, cout), x.device)
     dw = out if out is not None else torch.empty(cout, cin, 3, 3, dtype=torch.float32, device=x.device)
-    call("vocr_conv3x3_wgrad", _p(x), _p(dy), _p(dw), _p(ws), n, cin, h, w, cout, _stream())
+    call("vocr_conv3x3_wgrad_f16" if f16 else "vocr_conv3x3_wgrad", _p(x), _p(dy), _p(dw), _p(ws), n, cin, h, w, cout, _stream())
     return dw
 
 
@@ -190,7 +190,7 @@ class ConvBnReluFn(torch.autograd.Function):
             join_side_stream()          # first layer = last backward op: everything issued on the side stream is done after this
         call("vocr_bn_relu_bwd", _p(da), _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(dy), _p(dgamma), _p(dbeta),
              _p(dbias), n, cout, h * w, _p(ws), _stream())
-        dw = conv3x3_wgrad(x, dy, out=dw)
+        dw = conv3x3_wgrad(x, dy, out=dw, f16=ctx.f16)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = conv3x3_forward_f16(dy, pd, None, cin) if ctx.f16 else conv3x3_forward(dy, pd, None, cin)
@@ -237,7 +237,7 @@ class ConvReluPoolFn(torch.autograd.Function):
         call("vocr_relu_maxpool2_bwd", _p(dout), _p(out), _p(idx), _p(dy), n, cout, h, w, _stream())
         sinks = _sinks(ctx.prefs)
         dbias = channel_sum(dy, out=sinks[1] if sinks else None)
-        dw = conv3x3_wgrad(x, dy, out=sinks[0] if sinks else None)
+        dw = conv3x3_wgrad(x, dy, out=sinks[0] if sinks else None, f16=ctx.f16)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = conv3x3_forward_f16(dy, pd, None, cin) if ctx.f16 else conv3x3_forward(dy, pd, None, cin)
