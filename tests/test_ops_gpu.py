@@ -243,36 +243,47 @@ def test_bilstm_layer(dev, T, B, D, H, lens):
         _close(p.grad, r, 1e-3, 5e-5 * float(r.abs().max()) + 1e-6, "lstm d" + nm)
 
 
-def test_persistent_forward_sweep_matches_per_step_launches(dev):
-    """Opt-in persistent sweep (weights in registers, counter hand-off with sc1 payload): bit-identical to the default."""
+@pytest.mark.parametrize("T,B,H", [(40, 20, 128), (25, 5, 64), (33, 32, 512), (12, 40, 256), (9, 64, 128)])
+def test_persistent_sweeps_match_per_step_launches(dev, T, B, H):
+    """Persistent sweeps (weights in registers, flag hand-off with sc1 payload): bit-identical to one launch per step,
+    forward (y, gates, cell) and backward (dgates)."""
+    import os
     import subprocess
     import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = (
         "import torch, sys; sys.path.insert(0, %r)\n"
-        "from vistaocr_amd import _lib\n"
+        "from vistaocr_amd import _lib, ops\n"
         "from vistaocr_amd._lib import call\n"
-        "lib = _lib.load(); dev = torch.device('cuda:0'); T, B, H = 40, 20, 128\n"
+        "lib = _lib.load(); dev = torch.device('cuda:0'); T, B, H = %d, %d, %d\n"
         "g = torch.Generator().manual_seed(0)\n"
         "xp = (torch.rand(2, T * B, 4 * H, generator=g) - 0.5).to(dev); wf = ((torch.rand(4 * H, H, generator=g) - 0.5) * 0.3).to(dev)\n"
-        "wr = ((torch.rand(4 * H, H, generator=g) - 0.5) * 0.3).to(dev)\n"
+        "wr = ((torch.rand(4 * H, H, generator=g) - 0.5) * 0.3).to(dev); dy = (torch.rand(T * B, 2 * H, generator=g) - 0.5).to(dev)\n"
         "lens = torch.tensor(sorted([max(1, T - 2 * i) for i in range(B)], reverse=True), dtype=torch.int32, device=dev)\n"
         "y = torch.empty(T * B, 2 * H, device=dev); gt = torch.empty(2, T * B, 4 * H, device=dev); c = torch.empty(2, T * B, H, device=dev)\n"
-        "ws = torch.zeros(lib.vocr_lstm_workspace_bytes(T, B, H) // 4 + 16, device=dev)\n"
-        "call('vocr_lstm_fwd', xp.data_ptr(), wf.data_ptr(), wr.data_ptr(), lens.data_ptr(), y.data_ptr(), gt.data_ptr(), c.data_ptr(), ws.data_ptr(), T, B, H, torch.cuda.current_stream().cuda_stream)\n"
-        "torch.cuda.synchronize(); print('STATUS', int(ws.view(torch.int32)[64])); torch.save((y.cpu(), gt.cpu(), c.cpu()), sys.argv[1])\n"
-    ) % (__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))),)
-    import os
-    import tempfile
+        "dg = torch.full((2, T * B, 4 * H), float('nan'), device=dev)\n"
+        "ws = torch.zeros(lib.vocr_lstm_workspace_bytes(T, B, H) // 4 + 16, device=dev); s = torch.cuda.current_stream().cuda_stream\n"
+        "call('vocr_lstm_fwd', xp.data_ptr(), wf.data_ptr(), wr.data_ptr(), lens.data_ptr(), y.data_ptr(), gt.data_ptr(), c.data_ptr(), ws.data_ptr(), T, B, H, s)\n"
+        "torch.cuda.synchronize(); st = int(ws.view(torch.int32)[512])\n"
+        "if H >= 128:\n"
+        "    wtf, wtr = ops.transpose2d(wf), ops.transpose2d(wr)\n"
+        "    call('vocr_lstm_bwd', dy.data_ptr(), wtf.data_ptr(), wtr.data_ptr(), lens.data_ptr(), gt.data_ptr(), c.data_ptr(), dg.data_ptr(), ws.data_ptr(), T, B, H, s)\n"
+        "    torch.cuda.synchronize(); st |= int(ws.view(torch.int32)[512]) if sys.argv[2] != '0' else 0\n"
+        "print('STATUS', st); torch.save((y.cpu(), gt.cpu(), c.cpu(), dg.cpu()), sys.argv[1])\n"
+    ) % (root, T, B, H)
     outs = []
-    for mode in ("0", "1"):
+    for mode in ("0", "3"):
         f = tempfile.mktemp(suffix=".pt")
-        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, VOCR_LSTM_PERSISTENT=mode), capture_output=True, text=True, timeout=120)
+        r = subprocess.run([sys.executable, "-c", code, f, mode], env=dict(os.environ, VOCR_LSTM_PERSISTENT=mode), capture_output=True, text=True, timeout=120)
         assert r.returncode == 0, r.stderr[-500:]
         assert "STATUS 0" in r.stdout, r.stdout
         outs.append(torch.load(f))
         os.unlink(f)
-    for a, b in zip(outs[0], outs[1]):
-        assert torch.equal(a, b)
+    for nm, a, b in zip(("y", "gates", "cell", "dgates"), outs[0], outs[1]):
+        if H < 128 and nm == "dgates":
+            continue                      # no backward fast path below H = 128: dgates untouched in both runs
+        assert torch.equal(a, b), "%s differs: max |diff| %.3e at %d of %d" % (nm, float((a - b).abs().max()), int((a != b).sum()), a.numel())
 
 
 @pytest.mark.parametrize("T,B,V,L", [(30, 4, 20, [5, 3, 1, 0]), (147, 8, 96, None), (60, 3, 166, [29, 10, 2])])

@@ -300,6 +300,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_fast(const float* __restric
 // This is the counter form of the release/acquire-free hand-off of cdna_hip_programming.md Guideline 16 (R1 + sc1
 // loads, table row 1).  Results are independent of dispatch order and XCD placement; every spin is bounded and sets
 // `status[0]` on timeout instead of hanging.  All 2*H/4 workgroups must be co-resident (checked by the host).
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ f32x4 load_sc1_f32x4(const float* p) {
     const unsigned long long* q = (const unsigned long long*)p;
     const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -316,16 +318,22 @@ template <int KQ4, int RT>
 __global__ __launch_bounds__(256) void lstm_fwd_persistent(const float* __restrict__ xproj, const float* __restrict__ whh_f,
                                                            const float* __restrict__ whh_r, const int32_t* __restrict__ lens,
                                                            float* y, float* __restrict__ gates, float* __restrict__ cell,
-                                                           unsigned* counters, unsigned* status, int T, int B) {
+                                                           unsigned* flags, unsigned* status, int T, int B, int nbt) {
     constexpr int H = 64 * KQ4;
     constexpr int ublocks = H >> 2;
     __shared__ float red[4][RT * 16][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int dir = blockIdx.x / ublocks, unit0 = (blockIdx.x % ublocks) * 4;
+    // a chain = (direction, tile of 16*RT batch rows): the recurrence never couples batch rows, so each chain hands
+    // h_t around among its own ublocks workgroups only; with two chains per direction a CU hosts two workgroups and
+    // one computes while the other waits for its chain's exchange
+    const int bt = blockIdx.x % nbt, bid = blockIdx.x / nbt;
+    const int dir = bid / ublocks, ub = bid % ublocks, unit0 = ub * 4;
+    const int b0 = bt * 16 * RT;
+    const int nrows = min(B - b0, 16 * RT);
     const int lr = lane & 15, q = lane >> 4;
     const int kbase = wave * (H >> 2) + q * 4;
     const float* whh = dir ? whh_r : whh_f;
-    unsigned* counter = counters + dir * 32;                 // one 128-B line per direction
+    unsigned* dflags = flags + (dir * 2 + bt) * 128;         // this chain's arrival flags: one word per workgroup
 
     // resident operands: this lane's W_hh fragment (gate row lr>>2, unit lr&3, k = kbase + 16 i + e)
     f32x4 wv[KQ4];
@@ -334,52 +342,76 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent(const float* __restri
 #pragma unroll
         for (int i = 0; i < KQ4; ++i) wv[i] = wp[i * 4];
     }
-    const bool cellthr = tid < B * 4;
-    const int cb_ = tid >> 2, cu = tid & 3, unit = unit0 + cu;
+    const bool cellthr = tid < nrows * 4;
+    const int cb_ = b0 + (tid >> 2), cu = tid & 3, unit = unit0 + cu;
     const int len_b = cellthr ? lens[cb_] : 0;
     float cstate = 0.f;
     bool timed_out = false;
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, T * B * 2 * H * 4, 0x00020000);
+    // timing experiments only (status[1] != 0): accumulated phase times of workgroup 0 in 100 MHz ticks -> status[2..7]
+    const unsigned mode = status[1];                 // 1 stamps | 2 no MFMA | 4 no h loads | 8 no poll | 16 no drain   (experiments)
+    const bool stamp = (mode & 1) && blockIdx.x == 0;
+    unsigned long long tp = 0, acc_top = 0, acc_poll = 0, acc_load = 0, acc_mma = 0, acc_epi = 0, acc_pub = 0;
+    if (stamp) tp = __builtin_amdgcn_s_memrealtime();
+
 
     for (int step = 0; step < T; ++step) {
         const int t = dir == 0 ? step : T - 1 - step;
         const int tprev = dir == 0 ? t - 1 : t + 1;
-        const long gbase = (((long)dir * T + t) * B + (cellthr ? cb_ : 0)) * 4 * H + unit;
-        float xp[4] = {0.f, 0.f, 0.f, 0.f};
-        if (cellthr) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) xp[g] = xproj[gbase + (long)g * H];      // written by an earlier kernel: plain loads
-        }
         f32x4 acc[RT];
 #pragma unroll
         for (int i = 0; i < RT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // x-projection (plain loads: an earlier kernel wrote it), issued ahead of the wait so HBM latency hides under it;
+        // only the cell waves queue these, so the polling wave's queue holds nothing but its polls
+        float xp[4] = {0.f, 0.f, 0.f, 0.f};
+        if (cellthr) {
+            const float* xrow = xproj + (((long)dir * T + t) * B + cb_) * 4 * H + unit;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) xp[g] = xrow[(long)g * H];
+        }
+        if (stamp) { const unsigned long long n = __builtin_amdgcn_s_memrealtime(); acc_top += n - tp; tp = n; }
         if (step > 0) {
-            if (tid == 0 && !timed_out) {
-                const unsigned target = (unsigned)ublocks * (unsigned)step;
+            // wave 3 polls: it owns no cell, so nothing else of its own is queued ahead of the poll loads
+            if (wave == ((mode & 4) ? 0 : 3) && !timed_out) {
                 unsigned spins = 0;
-                while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                for (;;) {
+                    unsigned f0 = (unsigned)step, f1 = (unsigned)step;
+                    if (mode & 2) {                      // experiment: one arrival counter per chain instead of per-workgroup flags
+                        if (lane == 0) f0 = __hip_atomic_load(dflags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)(ublocks * step) ? f0 : 0u;
+                    } else {
+                    if (lane < ublocks) f0 = __hip_atomic_load(dflags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane + 64 < ublocks) f1 = __hip_atomic_load(dflags + lane + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    if (__all(f0 >= (unsigned)step && f1 >= (unsigned)step)) break;
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1u << 24)) {                                    // ~seconds: give up, flag it, keep going
-                        __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (++spins > (1u << 22)) {                                    // ~seconds: give up, flag it, keep going
+                        if (lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         timed_out = true;
                         break;
                     }
                 }
             }
             __syncthreads();
-            const float* hp = y + (long)tprev * B * 2 * H + dir * H;
+            if (stamp) { const unsigned long long n = __builtin_amdgcn_s_memrealtime(); acc_poll += n - tp; tp = n; }
+            // 16-byte sc1 loads through a buffer descriptor over y (8-byte atomic loads took 3.6 us per step here)
+            const int hrow0 = (tprev * B) * 2 * H + dir * H + kbase;
             f32x4 hv[RT][KQ4];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                const int b = rt * 16 + lr;
-                const float* hq = hp + (long)(b < B ? b : 0) * 2 * H + kbase;
+                const int b = b0 + rt * 16 + lr;
+                const int off = (hrow0 + (b < B ? b : b0) * 2 * H) * 4;
 #pragma unroll
                 for (int i = 0; i < KQ4; ++i) {
-                    f32x4 v = load_sc1_f32x4(hq + i * 16);
-                    if (b >= B) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    const u32x4_t raw = __builtin_amdgcn_raw_buffer_load_b128(yrsrc, off + i * 64, 0, 16);      // aux 16 = sc1
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (b < B) ? __uint_as_float(raw[e]) : 0.f;
                     hv[rt][i] = v;
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (stamp) { __builtin_amdgcn_s_waitcnt(0x0F70); const unsigned long long n = __builtin_amdgcn_s_memrealtime(); acc_load += n - tp; tp = n; }
+            {
 #pragma unroll
             for (int i = 0; i < KQ4; ++i)
 #pragma unroll
@@ -387,21 +419,23 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent(const float* __restri
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt)
                         acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[rt][i][e], wv[i][e], acc[rt], 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[wave][rt * 16 + q * 4 + r][lr] = acc[rt][r];
         __syncthreads();
+        if (stamp) { const unsigned long long n = __builtin_amdgcn_s_memrealtime(); acc_mma += n - tp; tp = n; }
 
         if (cellthr) {
-            const int b = cb_, u = cu;
+            const int b = cb_, u = cu, bl = tid >> 2;
             const bool active = t < len_b;
             const long sidx = (((long)dir * T + t) * B + b) * H + unit;
             float pre[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-                pre[g] = ((red[0][b][g * 4 + u] + red[1][b][g * 4 + u]) + (red[2][b][g * 4 + u] + red[3][b][g * 4 + u])) + xp[g];
+                pre[g] = ((red[0][bl][g * 4 + u] + red[1][bl][g * 4 + u]) + (red[2][bl][g * 4 + u] + red[3][bl][g * 4 + u])) + xp[g];
             float* yo = y + ((long)t * B + b) * 2 * H + dir * H + unit;
             f32x4* go = (f32x4*)(gates + sidx * 4);
             float h = 0.f;
@@ -419,22 +453,41 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent(const float* __restri
             }
             __hip_atomic_store(yo, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // write-through (sc1) payload
         }
-        // publish: every storing wave drains its stores, then one lane signals
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // publish: every storing wave drains its stores, then one lane raises this workgroup's flag
+        if (stamp) { const unsigned long long n = __builtin_amdgcn_s_memrealtime(); acc_epi += n - tp; tp = n; }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
         __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+            if (mode & 2) __hip_atomic_fetch_add(dflags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else __hip_atomic_store(dflags + ub, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (stamp) { const unsigned long long n = __builtin_amdgcn_s_memrealtime(); acc_pub += n - tp; tp = n; }
+    }
+    if (stamp && tid == 0) {
+        status[2] = (unsigned)acc_poll; status[3] = (unsigned)acc_load; status[4] = (unsigned)acc_mma; status[5] = (unsigned)acc_epi;
+        status[6] = (unsigned)acc_pub; status[7] = (unsigned)acc_top;
     }
 }
 
 template <int KQ4>
-void launch_fwd_persistent(int rt, dim3 grid, hipStream_t s, const float* xproj, const float* wf, const float* wr, const int32_t* lens,
-                           float* y, float* gates, float* cell, unsigned* counters, unsigned* status, int T, int B) {
-    switch (rt) {
-        case 1: lstm_fwd_persistent<KQ4, 1><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, counters, status, T, B); break;
-        case 2: lstm_fwd_persistent<KQ4, 2><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, counters, status, T, B); break;
-        case 3: lstm_fwd_persistent<KQ4, 3><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, counters, status, T, B); break;
-        default: lstm_fwd_persistent<KQ4, 4><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, counters, status, T, B); break;
-    }
+void launch_fwd_persistent(int rt, int nbt, hipStream_t s, const float* xproj, const float* wf, const float* wr, const int32_t* lens,
+                           float* y, float* gates, float* cell, unsigned* flags, unsigned* status, int T, int B) {
+    const dim3 grid(2 * 16 * KQ4 * nbt);
+    if (rt == 1) lstm_fwd_persistent<KQ4, 1><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, flags, status, T, B, nbt);
+    else lstm_fwd_persistent<KQ4, 2><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, flags, status, T, B, nbt);
+}
+
+// Gradient of one LSTM cell; shared by the per-step and the persistent backward kernels so both contract the same
+// expressions (the two sweeps are compared bit for bit).  Returns the dc carried to the previous step.
+__device__ __forceinline__ float lstm_cell_grad(float dh, float dcar, float ig, float fg, float gg, float og, float c, float cprev,
+                                                float (&dg)[4]) {
+    const float tc = tanhf(c);
+    const float dc = dcar + dh * og * (1.f - tc * tc);
+    dg[0] = dc * gg * ig * (1.f - ig);
+    dg[1] = dc * cprev * fg * (1.f - fg);
+    dg[2] = dc * ig * (1.f - gg * gg);
+    dg[3] = dh * tc * og * (1.f - og);
+    return dc * fg;
 }
 
 // H = 128*NCH.  grid.x = 2 * (H/16) * RT : one workgroup per (direction, 16 units, 16 batch rows).
@@ -532,15 +585,148 @@ __global__ __launch_bounds__(64 * NW) void lstm_bwd_step_fast(const float* __res
             float rs = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) rs += red[w][bl][ej];
-            const float dh = dyv + rs;
-            const float tc = tanhf(c);
-            const float dc = dcar + dh * og * (1.f - tc * tc);
-            dgates[gbase] = dc * gg * ig * (1.f - ig);
-            dgates[gbase + H] = dc * cprev * fg * (1.f - fg);
-            dgates[gbase + 2l * H] = dc * ig * (1.f - gg * gg);
-            dgates[gbase + 3l * H] = dh * tc * og * (1.f - og);
-            dcbuf[cb] = dc * fg;
+            float dg[4];
+            const float dcn = lstm_cell_grad(dyv + rs, dcar, ig, fg, gg, og, c, cprev, dg);
+            dgates[gbase] = dg[0];
+            dgates[gbase + H] = dg[1];
+            dgates[gbase + 2l * H] = dg[2];
+            dgates[gbase + 3l * H] = dg[3];
+            dcbuf[cb] = dcn;
         }
+    }
+}
+
+// Persistent backward sweep: the same hand-off as lstm_fwd_persistent, with dgates_{t+-1} as the payload.  A workgroup
+// (direction, 16 units, 16 batch rows) keeps its 16 x 4H slice of W_hh^T in registers (128 VGPRs per lane at H = 512;
+// the per-step kernel re-fetches those 128 KB per workgroup per step), carries dc in a register, and exchanges dgates
+// only inside its chain (direction, batch tile).  dgates are regrouped through LDS so that every hand-off store is one
+// 16-byte write-through store (scalar sc1 stores are one fabric write each).  Same MFMA order as lstm_bwd_step_fast.
+template <int NCH>
+__global__ __launch_bounds__(256) void lstm_bwd_persistent(const float* __restrict__ dy, const float* __restrict__ whht_f,
+                                                           const float* __restrict__ whht_r, const int32_t* __restrict__ lens,
+                                                           const float* __restrict__ gates, const float* __restrict__ cell,
+                                                           float* dgates, unsigned* flags, unsigned* status, int T, int B, int RT) {
+    constexpr int H = 128 * NCH;
+    constexpr int CH = NCH;
+    constexpr int ublocks = H / 16;
+    __shared__ float lds[4 * 16 * 17 + 4 * 16 * 20];
+    float (*red)[16][17] = (float (*)[16][17])lds;
+    float (*xch)[16][20] = (float (*)[16][20])(lds + 4 * 16 * 17);      // [gate][row][unit], rows padded to 80 B
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bt = blockIdx.x % RT, bid = blockIdx.x / RT;
+    const int dir = bid / ublocks, ub = bid % ublocks, unit0 = ub * 16;
+    const int lr = lane & 15, q = lane >> 4;
+    const int nbase = wave * H + q * 4;                                   // wave = gate block of the 4H reduction
+    unsigned* cflags = flags + (dir * 4 + bt) * 32;                       // this chain's arrival flags: one word per workgroup
+
+    f32x4 bw[CH][8];
+    {
+        const float* whht = dir ? whht_r : whht_f;
+        const f32x4* bp = (const f32x4*)(whht + (long)(unit0 + lr) * 4 * H + nbase);
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) bw[c][i] = bp[c * 32 + i * 4];
+    }
+    const int b0 = bt * 16;
+    const int eb = b0 + (tid >> 4), ej = tid & 15, eunit = unit0 + ej;
+    const bool ev = eb < B;
+    const int ebs = ev ? eb : b0;
+    const int len = lens[ebs];
+    float dcar = 0.f;
+    bool timed_out = false;
+    const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc((void*)dgates, 0, 2 * T * B * 4 * H * 4, 0x00020000);
+    const int arow = b0 + lr;
+    const bool bv = arow < B;
+    // regroup-store role of this thread: row tid>>4, gate (tid>>2)&3, units 4*(tid&3)..+3
+    const int sb = b0 + (tid >> 4), sg = (tid >> 2) & 3, su = (tid & 3) * 4;
+
+    for (int step = 0; step < T; ++step) {
+        const int t = dir == 0 ? T - 1 - step : step;
+        const int tv = dir == 0 ? t + 1 : t - 1;
+        const bool act = ev && t < len;
+        // epilogue operands (written by earlier kernels: plain loads), issued ahead of the wait
+        float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, c = 0.f, cprev = 0.f, dyv = 0.f;
+        if (act) {
+            const long sidx = (((long)dir * T + t) * B + ebs) * H + eunit;
+            const f32x4 gv = *(const f32x4*)(gates + sidx * 4);
+            ig = gv[0];
+            fg = gv[1];
+            gg = gv[2];
+            og = gv[3];
+            c = cell[sidx];
+            const int tp = dir == 0 ? t - 1 : t + 1;
+            cprev = (tp >= 0 && tp < len) ? cell[(((long)dir * T + tp) * B + ebs) * H + eunit] : 0.f;
+            dyv = dy[((long)t * B + ebs) * 2 * H + dir * H + eunit];
+        }
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (step > 0) {
+            if (wave == 3 && !timed_out) {
+                unsigned spins = 0;
+                for (;;) {
+                    unsigned f0 = (unsigned)step;
+                    if (lane < ublocks) f0 = __hip_atomic_load(cflags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__all(f0 >= (unsigned)step)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 22)) {
+                        if (lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        timed_out = true;
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            const int off = ((((dir * T + tv) * B) + (bv ? arow : b0)) * 4 * H + nbase) * 4;
+            f32x4 av[CH][8];
+#pragma unroll
+            for (int cc = 0; cc < CH; ++cc)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const u32x4_t raw = __builtin_amdgcn_raw_buffer_load_b128(grsrc, off + cc * 512 + i * 64, 0, 16);      // aux 16 = sc1
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = bv ? __uint_as_float(raw[e]) : 0.f;
+                    av[cc][i] = v;
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int cc = 0; cc < CH; ++cc)
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; e += 2) {
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cc][i][e], bw[cc][i][e], acc, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cc][i][e + 1], bw[cc][i][e + 1], acc2, 0, 0, 0);
+                    }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][q * 4 + r][lr] = acc[r] + acc2[r];
+        __syncthreads();
+
+        float dg[4] = {0.f, 0.f, 0.f, 0.f};
+        if (act) {
+            const int bl = tid >> 4;
+            float rs = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) rs += red[w][bl][ej];
+            dcar = lstm_cell_grad(dyv + rs, dcar, ig, fg, gg, og, c, cprev, dg);
+        } else {
+            dcar = 0.f;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xch[g][tid >> 4][ej] = dg[g];
+        __syncthreads();
+        if (sb < B) {
+            const f32x4 v = *(const f32x4*)&xch[sg][tid >> 4][su];
+            u32x4_t raw;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) raw[e] = __float_as_uint(v[e]);
+            const int soff = ((((dir * T + t) * B) + sb) * 4 * H + sg * H + unit0 + su) * 4;
+            __builtin_amdgcn_raw_buffer_store_b128(raw, grsrc, soff, 0, 16);      // write-through (sc1) payload, 16 B
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): every storing wave drains before the flag
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(cflags + ub, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -577,7 +763,7 @@ int resident_workgroup_capacity() {
 
 extern "C" size_t vocr_lstm_workspace_bytes(int t, int b, int h) {
     if (t <= 0 || b <= 0 || h <= 0) return 0;
-    return (size_t)6 * 2 * b * h * sizeof(float) + 1024;   // dc carry [2][B][H] (+ spare); 1 KiB of arrival counters / status
+    return (size_t)6 * 2 * b * h * sizeof(float) + 4096;   // dc carry [2][B][H] (+ spare); 4 KiB of arrival flags / status
 }
 
 extern "C" int vocr_lstm_fwd(const float* xproj, const float* whh_fwd, const float* whh_rev, const int32_t* lens, float* y,
@@ -594,19 +780,25 @@ extern "C" int vocr_lstm_fwd(const float* xproj, const float* whh_fwd, const flo
     // per step: the in-kernel all-to-all (128 arrivals on a counter + sc1 payload) costs more than a kernel boundary,
     // so the persistent sweep stays opt-in (VOCR_LSTM_PERSISTENT=1).
     static const int persistent_mode = getenv("VOCR_LSTM_PERSISTENT") ? atoi(getenv("VOCR_LSTM_PERSISTENT")) : 0;
-    if (fast && persistent_mode && (int)grid.x <= resident_workgroup_capacity() && h >= 64) {
-        // counters: [0] fwd arrivals, [32] rev arrivals (separate 128-B lines), status word at [64]
-        unsigned* counters = (unsigned*)workspace;
-        unsigned* status = counters + 64;
-        if (hipMemsetAsync(counters, 0, 65 * sizeof(unsigned), s) != hipSuccess) {
+    // batch tiles of 16 rows (32 above B = 32), each its own chain: at most two chains per direction, so at most two
+    // workgroups per CU have to be co-resident (they need < 1/3 of a CU's registers and LDS each)
+    static const int one_chain = getenv("VOCR_LSTM_CHAINS") ? atoi(getenv("VOCR_LSTM_CHAINS")) == 1 : 0;            // experiments
+    const int prt = (b <= 32 && !(one_chain && b > 16)) ? 1 : 2, nbt = (b + 16 * prt - 1) / (16 * prt);
+    if (fast && (persistent_mode & 1) && (int)grid.x * nbt <= 2 * resident_workgroup_capacity() && h >= 64) {
+        // arrival flags: [dir][batch tile][128 workgroups]; status words at [512..]
+        unsigned* flags = (unsigned*)workspace;
+        unsigned* status = flags + 512;
+        if (hipMemsetAsync(flags, 0, 520 * sizeof(unsigned), s) != hipSuccess) {
             vocr_set_error("vocr_lstm_fwd: memset failed");
             return VOCR_ELAUNCH;
         }
+        static const int expmode = getenv("VOCR_LSTM_DEBUG") ? (atoi(getenv("VOCR_LSTM_DEBUG")) >> 6) & 31 : 0;   // timing experiments only
+        if (expmode) hipMemsetAsync(status + 1, expmode, 1, s);
         switch (h) {
-            case 64: launch_fwd_persistent<1>(rt, grid, s, xproj, whh_fwd, whh_rev, lens, y, gates, cell, counters, status, t, b); break;
-            case 128: launch_fwd_persistent<2>(rt, grid, s, xproj, whh_fwd, whh_rev, lens, y, gates, cell, counters, status, t, b); break;
-            case 256: launch_fwd_persistent<4>(rt, grid, s, xproj, whh_fwd, whh_rev, lens, y, gates, cell, counters, status, t, b); break;
-            default: launch_fwd_persistent<8>(rt, grid, s, xproj, whh_fwd, whh_rev, lens, y, gates, cell, counters, status, t, b); break;
+            case 64: launch_fwd_persistent<1>(prt, nbt, s, xproj, whh_fwd, whh_rev, lens, y, gates, cell, flags, status, t, b); break;
+            case 128: launch_fwd_persistent<2>(prt, nbt, s, xproj, whh_fwd, whh_rev, lens, y, gates, cell, flags, status, t, b); break;
+            case 256: launch_fwd_persistent<4>(prt, nbt, s, xproj, whh_fwd, whh_rev, lens, y, gates, cell, flags, status, t, b); break;
+            default: launch_fwd_persistent<8>(prt, nbt, s, xproj, whh_fwd, whh_rev, lens, y, gates, cell, flags, status, t, b); break;
         }
         VOCR_CHECK_LAUNCH("vocr_lstm_fwd(persistent)");
         return VOCR_OK;
@@ -638,6 +830,22 @@ extern "C" int vocr_lstm_bwd(const float* dy, const float* whht_fwd, const float
     float* dcb = (float*)workspace;
     const int rt = (b + 15) / 16;
     const bool fast = (h == 128 || h == 256 || h == 512) && aligned16(whh_fwd) && aligned16(whh_rev) && aligned16(dgates);
+    static const int persistent_mode = getenv("VOCR_LSTM_PERSISTENT") ? atoi(getenv("VOCR_LSTM_PERSISTENT")) : 0;
+    if (fast && (persistent_mode & 2) && 2 * (h / 16) * rt <= resident_workgroup_capacity() && aligned16(gates)) {
+        // arrival flags: [dir][batch tile <= 4][32 workgroups]; status words at [512..]
+        unsigned* flags = (unsigned*)workspace;
+        unsigned* status = flags + 512;
+        if (hipMemsetAsync(flags, 0, 520 * sizeof(unsigned), s) != hipSuccess) {
+            vocr_set_error("vocr_lstm_bwd: memset failed");
+            return VOCR_ELAUNCH;
+        }
+        const dim3 g(2 * (h / 16) * rt);
+        if (h == 128) lstm_bwd_persistent<1><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, flags, status, t, b, rt);
+        else if (h == 256) lstm_bwd_persistent<2><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, flags, status, t, b, rt);
+        else lstm_bwd_persistent<4><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, flags, status, t, b, rt);
+        VOCR_CHECK_LAUNCH("vocr_lstm_bwd(persistent)");
+        return VOCR_OK;
+    }
     for (int step = 0; step < t; ++step) {
         if (fast) {
             static const int dbg = getenv("VOCR_LSTM_DEBUG") ? atoi(getenv("VOCR_LSTM_DEBUG")) : 0;   // timing experiments only
