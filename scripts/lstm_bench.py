@@ -1,4 +1,4 @@
-"""Micro-benchmark (GPU box): per-step time of the LSTM recurrent sweeps at the BASELINE shape."""
+"""Micro-benchmark (GPU box): per-step time of the LSTM recurrent sweeps at the BASELINE shape (VOCR_LSTM_PERSISTENT=0 for one launch per step)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -25,7 +25,3 @@ for name, fn in (("fwd", fwd), ("bwd", bwd)):
     for _ in range(5): fn()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
     print("%s dbg=%s: %.3f ms per sweep, %.2f us per step" % (name, os.environ.get("VOCR_LSTM_DEBUG", "0"), dt * 1e3, dt * 1e6 / T))
-if os.environ.get("VOCR_LSTM_PERSISTENT") in ("1", "3") and os.environ.get("VOCR_LSTM_DEBUG") and int(os.environ["VOCR_LSTM_DEBUG"]) & 64:
-    fwd(); torch.cuda.synchronize()
-    st = ws[512:520].view(torch.int32).cpu().tolist()
-    print("persistent fwd, workgroup 0, per step: poll+barrier %.2f us | h loads %.2f us | MFMA+reduce %.2f us | epilogue %.2f us | drain+publish %.2f us | loop top %.2f us   (status %d)" % tuple([v / 100.0 / T for v in st[2:8]] + [st[0]]))

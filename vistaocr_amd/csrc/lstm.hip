@@ -293,47 +293,38 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_fast(const float* __restric
 // kernels re-fetch 8 MB of weights per step because the XCD L2s are dropped at every kernel boundary: PMC FETCH_SIZE
 // 7-10 MB per step launch) and the cell state c in a register.  The only cross-workgroup traffic is h_t itself:
 //   producer: y[t] is stored write-through (sc1) -> every storing wave drains vmcnt -> workgroup barrier -> ONE lane
-//             adds 1 to the direction's arrival counter (agent scope)
-//   consumer: ONE lane polls the counter (relaxed agent-scope load + s_sleep) until all workgroups of its direction
-//             have published step-1 -> workgroup barrier -> EVERY load of h_{t-1} is an sc1 load (bypasses this CU's
-//             L1); the rows of y[t-1] were never read before they were written, so no L2 can hold a stale copy.
-// This is the counter form of the release/acquire-free hand-off of cdna_hip_programming.md Guideline 16 (R1 + sc1
-// loads, table row 1).  Results are independent of dispatch order and XCD placement; every spin is bounded and sets
-// `status[0]` on timeout instead of hanging.  All 2*H/4 workgroups must be co-resident (checked by the host).
+//             raises this workgroup's arrival flag (an sc1 store of step+1)
+//   consumer: wave 3 (it owns no cell, so its memory queue holds nothing but polls) re-reads the flags of its chain
+//             (relaxed agent-scope loads + s_sleep) until every workgroup has published step-1 -> workgroup barrier ->
+//             EVERY load of h_{t-1} is a 16-byte sc1 buffer load (bypasses this CU's L1); the rows of y[t-1] were never
+//             read before they were written, so no cache can hold a stale copy.
+// This is the flag form of the release/acquire-free hand-off of cdna_hip_programming.md Guideline 16 (R1 + sc1 loads,
+// table row 1).  Results are independent of dispatch order and XCD placement and bit-identical to the per-step
+// kernels (same MFMA and reduction order).  Every spin is bounded; a timeout sets status[0] and the sweep's last step
+// then writes NaN, so a failed hand-off can never pass silently.  All workgroups must be co-resident (host check).
+//
+// Measured (MI355X, T=294 B=32 H=512, scripts/lstm_bench.py): 6.9 us/step vs 7.3 us/step for one launch per step.
+// Tried and not faster: one arrival counter per direction instead of flags (same), polling from wave 0 (same),
+// two batch-tile chains per direction with two workgroups per CU (7.6), 8-byte sc1 loads (7.8), prefetching the next
+// step's x-projection behind the h loads (same), and a flag-free variant that pre-fills y with a NaN pattern and
+// re-reads h until no element is the pattern (7.2: four polling waves per CU saturate the fabric).  Ablation: a
+// workgroup's own loop without any waiting is already 5.0 us (h loads 1.5-2.4, MFMA+reduce 1.5, epilogue+publish 1).
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ f32x4 load_sc1_f32x4(const float* p) {
-    const unsigned long long* q = (const unsigned long long*)p;
-    const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    f32x4 v;
-    v[0] = __uint_as_float((unsigned)a);
-    v[1] = __uint_as_float((unsigned)(a >> 32));
-    v[2] = __uint_as_float((unsigned)b);
-    v[3] = __uint_as_float((unsigned)(b >> 32));
-    return v;
-}
 
 template <int KQ4, int RT>
 __global__ __launch_bounds__(256) void lstm_fwd_persistent(const float* __restrict__ xproj, const float* __restrict__ whh_f,
                                                            const float* __restrict__ whh_r, const int32_t* __restrict__ lens,
                                                            float* y, float* __restrict__ gates, float* __restrict__ cell,
-                                                           unsigned* flags, unsigned* status, int T, int B, int nbt) {
+                                                           unsigned* flags, unsigned* status, int T, int B) {
     constexpr int H = 64 * KQ4;
     constexpr int ublocks = H >> 2;
     __shared__ float red[4][RT * 16][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // a chain = (direction, tile of 16*RT batch rows): the recurrence never couples batch rows, so each chain hands
-    // h_t around among its own ublocks workgroups only; with two chains per direction a CU hosts two workgroups and
-    // one computes while the other waits for its chain's exchange
-    const int bt = blockIdx.x % nbt, bid = blockIdx.x / nbt;
-    const int dir = bid / ublocks, ub = bid % ublocks, unit0 = ub * 4;
-    const int b0 = bt * 16 * RT;
-    const int nrows = min(B - b0, 16 * RT);
+    const int dir = blockIdx.x / ublocks, ub = blockIdx.x % ublocks, unit0 = ub * 4;
     const int lr = lane & 15, q = lane >> 4;
     const int kbase = wave * (H >> 2) + q * 4;
     const float* whh = dir ? whh_r : whh_f;
-    unsigned* dflags = flags + (dir * 2 + bt) * 128;         // this chain's arrival flags: one word per workgroup
+    unsigned* dflags = flags + dir * 128;                    // this direction's arrival flags: one word per workgroup
 
     // resident operands: this lane's W_hh fragment (gate row lr>>2, unit lr&3, k = kbase + 16 i + e)
     f32x4 wv[KQ4];
@@ -342,46 +333,33 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent(const float* __restri
 #pragma unroll
         for (int i = 0; i < KQ4; ++i) wv[i] = wp[i * 4];
     }
-    const bool cellthr = tid < nrows * 4;
-    const int cb_ = b0 + (tid >> 2), cu = tid & 3, unit = unit0 + cu;
+    const bool cellthr = tid < B * 4;
+    const int cb_ = tid >> 2, cu = tid & 3, unit = unit0 + cu;
     const int len_b = cellthr ? lens[cb_] : 0;
     float cstate = 0.f;
     bool timed_out = false;
     const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, T * B * 2 * H * 4, 0x00020000);
-    // timing experiments only (status[1] != 0): accumulated phase times of workgroup 0 in 100 MHz ticks -> status[2..7]
-    const unsigned mode = status[1];                 // 1 stamps | 2 no MFMA | 4 no h loads | 8 no poll | 16 no drain   (experiments)
-    const bool stamp = (mode & 1) && blockIdx.x == 0;
-    unsigned long long tp = 0, acc_top = 0, acc_poll = 0, acc_load = 0, acc_mma = 0, acc_epi = 0, acc_pub = 0;
-    if (stamp) tp = __builtin_amdgcn_s_memrealtime();
-
 
     for (int step = 0; step < T; ++step) {
         const int t = dir == 0 ? step : T - 1 - step;
         const int tprev = dir == 0 ? t - 1 : t + 1;
-        f32x4 acc[RT];
-#pragma unroll
-        for (int i = 0; i < RT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // x-projection (plain loads: an earlier kernel wrote it), issued ahead of the wait so HBM latency hides under it;
-        // only the cell waves queue these, so the polling wave's queue holds nothing but its polls
+        // x-projection (plain loads: an earlier kernel wrote it), issued ahead of the wait so HBM latency hides under it
         float xp[4] = {0.f, 0.f, 0.f, 0.f};
         if (cellthr) {
             const float* xrow = xproj + (((long)dir * T + t) * B + cb_) * 4 * H + unit;
 #pragma unroll
             for (int g = 0; g < 4; ++g) xp[g] = xrow[(long)g * H];
         }
-        if (stamp) { const unsigned long long n = __builtin_amdgcn_s_memrealtime(); acc_top += n - tp; tp = n; }
+        f32x4 acc[RT];
+#pragma unroll
+        for (int i = 0; i < RT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (step > 0) {
-            // wave 3 polls: it owns no cell, so nothing else of its own is queued ahead of the poll loads
-            if (wave == ((mode & 4) ? 0 : 3) && !timed_out) {
+            if (wave == 3 && !timed_out) {
                 unsigned spins = 0;
                 for (;;) {
                     unsigned f0 = (unsigned)step, f1 = (unsigned)step;
-                    if (mode & 2) {                      // experiment: one arrival counter per chain instead of per-workgroup flags
-                        if (lane == 0) f0 = __hip_atomic_load(dflags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)(ublocks * step) ? f0 : 0u;
-                    } else {
                     if (lane < ublocks) f0 = __hip_atomic_load(dflags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (lane + 64 < ublocks) f1 = __hip_atomic_load(dflags + lane + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
                     if (__all(f0 >= (unsigned)step && f1 >= (unsigned)step)) break;
                     __builtin_amdgcn_s_sleep(1);
                     if (++spins > (1u << 22)) {                                    // ~seconds: give up, flag it, keep going
@@ -392,14 +370,12 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent(const float* __restri
                 }
             }
             __syncthreads();
-            if (stamp) { const unsigned long long n = __builtin_amdgcn_s_memrealtime(); acc_poll += n - tp; tp = n; }
-            // 16-byte sc1 loads through a buffer descriptor over y (8-byte atomic loads took 3.6 us per step here)
             const int hrow0 = (tprev * B) * 2 * H + dir * H + kbase;
             f32x4 hv[RT][KQ4];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                const int b = b0 + rt * 16 + lr;
-                const int off = (hrow0 + (b < B ? b : b0) * 2 * H) * 4;
+                const int b = rt * 16 + lr;
+                const int off = (hrow0 + (b < B ? b : 0) * 2 * H) * 4;
 #pragma unroll
                 for (int i = 0; i < KQ4; ++i) {
                     const u32x4_t raw = __builtin_amdgcn_raw_buffer_load_b128(yrsrc, off + i * 64, 0, 16);      // aux 16 = sc1
@@ -410,8 +386,6 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent(const float* __restri
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (stamp) { __builtin_amdgcn_s_waitcnt(0x0F70); const unsigned long long n = __builtin_amdgcn_s_memrealtime(); acc_load += n - tp; tp = n; }
-            {
 #pragma unroll
             for (int i = 0; i < KQ4; ++i)
 #pragma unroll
@@ -419,23 +393,21 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent(const float* __restri
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt)
                         acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[rt][i][e], wv[i][e], acc[rt], 0, 0, 0);
-            }
         }
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[wave][rt * 16 + q * 4 + r][lr] = acc[rt][r];
         __syncthreads();
-        if (stamp) { const unsigned long long n = __builtin_amdgcn_s_memrealtime(); acc_mma += n - tp; tp = n; }
 
         if (cellthr) {
-            const int b = cb_, u = cu, bl = tid >> 2;
+            const int b = cb_, u = cu;
             const bool active = t < len_b;
             const long sidx = (((long)dir * T + t) * B + b) * H + unit;
             float pre[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-                pre[g] = ((red[0][bl][g * 4 + u] + red[1][bl][g * 4 + u]) + (red[2][bl][g * 4 + u] + red[3][bl][g * 4 + u])) + xp[g];
+                pre[g] = ((red[0][b][g * 4 + u] + red[1][b][g * 4 + u]) + (red[2][b][g * 4 + u] + red[3][b][g * 4 + u])) + xp[g];
             float* yo = y + ((long)t * B + b) * 2 * H + dir * H + unit;
             f32x4* go = (f32x4*)(gates + sidx * 4);
             float h = 0.f;
@@ -451,30 +423,27 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent(const float* __restri
                 cell[sidx] = 0.f;
                 cstate = 0.f;
             }
+            if (step == T - 1 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+                h = __uint_as_float(0x7FC00000u);                                        // a hand-off timed out: fail loudly
             __hip_atomic_store(yo, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // write-through (sc1) payload
         }
         // publish: every storing wave drains its stores, then one lane raises this workgroup's flag
-        if (stamp) { const unsigned long long n = __builtin_amdgcn_s_memrealtime(); acc_epi += n - tp; tp = n; }
         __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
         __syncthreads();
-        if (tid == 0) {
-            if (mode & 2) __hip_atomic_fetch_add(dflags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else __hip_atomic_store(dflags + ub, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (stamp) { const unsigned long long n = __builtin_amdgcn_s_memrealtime(); acc_pub += n - tp; tp = n; }
-    }
-    if (stamp && tid == 0) {
-        status[2] = (unsigned)acc_poll; status[3] = (unsigned)acc_load; status[4] = (unsigned)acc_mma; status[5] = (unsigned)acc_epi;
-        status[6] = (unsigned)acc_pub; status[7] = (unsigned)acc_top;
+        if (tid == 0) __hip_atomic_store(dflags + ub, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
 template <int KQ4>
-void launch_fwd_persistent(int rt, int nbt, hipStream_t s, const float* xproj, const float* wf, const float* wr, const int32_t* lens,
+void launch_fwd_persistent(int rt, hipStream_t s, const float* xproj, const float* wf, const float* wr, const int32_t* lens,
                            float* y, float* gates, float* cell, unsigned* flags, unsigned* status, int T, int B) {
-    const dim3 grid(2 * 16 * KQ4 * nbt);
-    if (rt == 1) lstm_fwd_persistent<KQ4, 1><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, flags, status, T, B, nbt);
-    else lstm_fwd_persistent<KQ4, 2><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, flags, status, T, B, nbt);
+    const dim3 grid(2 * 16 * KQ4);
+    switch (rt) {
+        case 1: lstm_fwd_persistent<KQ4, 1><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, flags, status, T, B); break;
+        case 2: lstm_fwd_persistent<KQ4, 2><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, flags, status, T, B); break;
+        case 3: lstm_fwd_persistent<KQ4, 3><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, flags, status, T, B); break;
+        default: lstm_fwd_persistent<KQ4, 4><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, flags, status, T, B); break;
+    }
 }
 
 // Gradient of one LSTM cell; shared by the per-step and the persistent backward kernels so both contract the same
@@ -721,6 +690,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_persistent(const float* __restri
             u32x4_t raw;
 #pragma unroll
             for (int e = 0; e < 4; ++e) raw[e] = __float_as_uint(v[e]);
+            if (step == T - 1 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+                raw = (u32x4_t){0x7FC00000u, 0x7FC00000u, 0x7FC00000u, 0x7FC00000u};        // a hand-off timed out: fail loudly
             const int soff = ((((dir * T + t) * B) + sb) * 4 * H + sg * H + unit0 + su) * 4;
             __builtin_amdgcn_raw_buffer_store_b128(raw, grsrc, soff, 0, 16);      // write-through (sc1) payload, 16 B
         }
@@ -776,29 +747,21 @@ extern "C" int vocr_lstm_fwd(const float* xproj, const float* whh_fwd, const flo
                       aligned16(gates);
     VOCR_CHECK_ARG(aligned16(gates), "vocr_lstm_fwd: gates must be 16-byte aligned");
     const dim3 grid(2 * (h / 4));
-    // measured on MI355X (scripts/lstm_bench.py, T=294 B=32 H=512): persistent 7.8 us/step vs 7.3 us/step for one launch
-    // per step: the in-kernel all-to-all (128 arrivals on a counter + sc1 payload) costs more than a kernel boundary,
-    // so the persistent sweep stays opt-in (VOCR_LSTM_PERSISTENT=1).
-    static const int persistent_mode = getenv("VOCR_LSTM_PERSISTENT") ? atoi(getenv("VOCR_LSTM_PERSISTENT")) : 0;
-    // batch tiles of 16 rows (32 above B = 32), each its own chain: at most two chains per direction, so at most two
-    // workgroups per CU have to be co-resident (they need < 1/3 of a CU's registers and LDS each)
-    static const int one_chain = getenv("VOCR_LSTM_CHAINS") ? atoi(getenv("VOCR_LSTM_CHAINS")) == 1 : 0;            // experiments
-    const int prt = (b <= 32 && !(one_chain && b > 16)) ? 1 : 2, nbt = (b + 16 * prt - 1) / (16 * prt);
-    if (fast && (persistent_mode & 1) && (int)grid.x * nbt <= 2 * resident_workgroup_capacity() && h >= 64) {
-        // arrival flags: [dir][batch tile][128 workgroups]; status words at [512..]
+    // persistent sweep by default (VOCR_LSTM_PERSISTENT: bit 0 forward, bit 1 backward; 0 = one launch per step)
+    static const int persistent_mode = getenv("VOCR_LSTM_PERSISTENT") ? atoi(getenv("VOCR_LSTM_PERSISTENT")) : 3;
+    if (fast && (persistent_mode & 1) && (int)grid.x <= resident_workgroup_capacity() && h >= 64) {
+        // arrival flags: [dir][128 workgroups]; status words at [512..]
         unsigned* flags = (unsigned*)workspace;
         unsigned* status = flags + 512;
         if (hipMemsetAsync(flags, 0, 520 * sizeof(unsigned), s) != hipSuccess) {
             vocr_set_error("vocr_lstm_fwd: memset failed");
             return VOCR_ELAUNCH;
         }
-        static const int expmode = getenv("VOCR_LSTM_DEBUG") ? (atoi(getenv("VOCR_LSTM_DEBUG")) >> 6) & 31 : 0;   // timing experiments only
-        if (expmode) hipMemsetAsync(status + 1, expmode, 1, s);
         switch (h) {
-            case 64: launch_fwd_persistent<1>(prt, nbt, s, xproj, whh_fwd, whh_rev, lens, y, gates, cell, flags, status, t, b); break;
-            case 128: launch_fwd_persistent<2>(prt, nbt, s, xproj, whh_fwd, whh_rev, lens, y, gates, cell, flags, status, t, b); break;
-            case 256: launch_fwd_persistent<4>(prt, nbt, s, xproj, whh_fwd, whh_rev, lens, y, gates, cell, flags, status, t, b); break;
-            default: launch_fwd_persistent<8>(prt, nbt, s, xproj, whh_fwd, whh_rev, lens, y, gates, cell, flags, status, t, b); break;
+            case 64: launch_fwd_persistent<1>(rt, s, xproj, whh_fwd, whh_rev, lens, y, gates, cell, flags, status, t, b); break;
+            case 128: launch_fwd_persistent<2>(rt, s, xproj, whh_fwd, whh_rev, lens, y, gates, cell, flags, status, t, b); break;
+            case 256: launch_fwd_persistent<4>(rt, s, xproj, whh_fwd, whh_rev, lens, y, gates, cell, flags, status, t, b); break;
+            default: launch_fwd_persistent<8>(rt, s, xproj, whh_fwd, whh_rev, lens, y, gates, cell, flags, status, t, b); break;
         }
         VOCR_CHECK_LAUNCH("vocr_lstm_fwd(persistent)");
         return VOCR_OK;
@@ -830,7 +793,7 @@ extern "C" int vocr_lstm_bwd(const float* dy, const float* whht_fwd, const float
     float* dcb = (float*)workspace;
     const int rt = (b + 15) / 16;
     const bool fast = (h == 128 || h == 256 || h == 512) && aligned16(whh_fwd) && aligned16(whh_rev) && aligned16(dgates);
-    static const int persistent_mode = getenv("VOCR_LSTM_PERSISTENT") ? atoi(getenv("VOCR_LSTM_PERSISTENT")) : 0;
+    static const int persistent_mode = getenv("VOCR_LSTM_PERSISTENT") ? atoi(getenv("VOCR_LSTM_PERSISTENT")) : 3;
     if (fast && (persistent_mode & 2) && 2 * (h / 16) * rt <= resident_workgroup_capacity() && aligned16(gates)) {
         // arrival flags: [dir][batch tile <= 4][32 workgroups]; status words at [512..]
         unsigned* flags = (unsigned*)workspace;
