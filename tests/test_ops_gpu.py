@@ -273,7 +273,7 @@ def test_persistent_sweeps_match_per_step_launches(dev, T, B, H):
         "print('STATUS', st); torch.save((y.cpu(), gt.cpu(), c.cpu(), dg.cpu()), sys.argv[1])\n"
     ) % (root, T, B, H)
     outs = []
-    for mode in ("0", "3"):
+    for mode in ("0", "3", "11", "7"):       # per-step | chain sweeps | forward chain forced write-through | all-CU forward sweep
         f = tempfile.mktemp(suffix=".pt")
         r = subprocess.run([sys.executable, "-c", code, f, mode], env=dict(os.environ, VOCR_LSTM_PERSISTENT=mode), capture_output=True, text=True, timeout=120)
         assert r.returncode == 0, r.stderr[-500:]

@@ -446,6 +446,179 @@ void launch_fwd_persistent(int rt, hipStream_t s, const float* xproj, const floa
     }
 }
 
+// ------------------------------------------------------------------------------------------------ chain sweeps
+// The recurrence never couples batch rows, so (direction, tile of 16 batch rows) is an independent chain: <= 8 of them.
+// A chain's H/16 workgroups (<= 32: one XCD's CUs) take blockIdx = member*8 + chain, i.e. equal blockIdx % 8, which the
+// dispatcher has been observed to deal to ONE XCD.  That placement is never assumed: every workgroup publishes its
+// HW_REG_XCC_ID at the start (write-through), every member reads all of them, and only if the whole chain sits on one
+// XCD does the chain switch its payload and flag stores from write-through (sc1) to plain stores.  Plain stores stay
+// in that XCD's L2, which is the coherence point of all its CUs, and the consumer's sc1 loads (L1 bypassed,
+// L2 served) then hit them at L2 latency instead of making a fabric round trip per step.  With any other placement the
+// chain runs the write-through protocol of lstm_fwd_persistent unchanged, so results never depend on placement.
+__device__ __forceinline__ unsigned xcc_id() {
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return x;
+}
+
+// Returns true iff all `members` workgroups of this chain report the same XCC id.  ids: one word per member, zeroed
+// by the host.  Called by every thread of the workgroup; scratch is one LDS word.
+__device__ __forceinline__ bool chain_is_xcd_local(unsigned* ids, int members, int member, unsigned* status, unsigned* scratch) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned mine = xcc_id() + 1u;
+    if (tid == 0) __hip_atomic_store(ids + member, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wave == 3) {
+        unsigned spins = 0;
+        bool same = false;
+        for (;;) {
+            unsigned v = mine;
+            if (lane < members) v = __hip_atomic_load(ids + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all(v != 0u)) { same = __all(v == mine); break; }
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 22)) {
+                if (lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+        if (lane == 0) *scratch = same ? 1u : 0u;
+    }
+    __syncthreads();
+    const bool r = *scratch != 0u;
+    __syncthreads();
+    return r;
+}
+
+// Forward chain sweep.  H = 64*KQ4; grid.x = 8 * (H/16); workgroup = (chain, 16 units): four 16-row gate tiles x 16
+// batch rows x K = H, W_hh slice (64 x H floats, 128 VGPRs per lane at H = 512) resident.  Same MFMA and reduction
+// order per output element as lstm_fwd_step_fast, so results are bit-identical.
+template <int KQ4>
+__global__ __launch_bounds__(256) void lstm_fwd_chain(const float* __restrict__ xproj, const float* __restrict__ whh_f,
+                                                      const float* __restrict__ whh_r, const int32_t* __restrict__ lens,
+                                                      float* y, float* __restrict__ gates, float* __restrict__ cell,
+                                                      unsigned* flags, unsigned* ids, unsigned* status, int T, int B, int nbt, int force_wt) {
+    constexpr int H = 64 * KQ4;
+    constexpr int members = H >> 4;
+    __shared__ float lds[4 * 16 * 65 + 4];
+    float (*red)[16][65] = (float (*)[16][65])lds;
+    const int chain = blockIdx.x & 7, member = blockIdx.x >> 3;
+    if (chain >= 2 * nbt) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int dir = chain / nbt, bt = chain % nbt;
+    const int unit0 = member * 16, b0 = bt * 16;
+    const int nrows = min(B - b0, 16);
+    const int lr = lane & 15, q = lane >> 4;
+    const int kbase = wave * (H >> 2) + q * 4;
+    const float* whh = dir ? whh_r : whh_f;
+    unsigned* cflags = flags + chain * 32;
+    const bool local = chain_is_xcd_local(ids + chain * 32, members, member, status, (unsigned*)(lds + 4 * 16 * 65)) && !force_wt;
+
+    // resident W_hh fragments: tile j holds units unit0+4j..+3; B-operand lane lr = gate (lr>>2), unit 4j + (lr&3)
+    f32x4 wv[4][KQ4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x4* wp = (const f32x4*)(whh + ((long)(lr >> 2) * H + unit0 + 4 * j + (lr & 3)) * H + kbase);
+#pragma unroll
+        for (int i = 0; i < KQ4; ++i) wv[j][i] = wp[i * 4];
+    }
+    const int bl = tid >> 4, cu = tid & 15, cb_ = b0 + bl, unit = unit0 + cu;
+    const bool cellthr = bl < nrows;
+    const int len_b = cellthr ? lens[cb_] : 0;
+    const int ccol = (cu >> 2) * 16 + (cu & 3);
+    float cstate = 0.f;
+    bool timed_out = false;
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, T * B * 2 * H * 4, 0x00020000);
+    const int arow = b0 + lr;
+    const bool av = arow < B;
+
+    for (int step = 0; step < T; ++step) {
+        const int t = dir == 0 ? step : T - 1 - step;
+        const int tprev = dir == 0 ? t - 1 : t + 1;
+        float xp[4] = {0.f, 0.f, 0.f, 0.f};
+        if (cellthr) {
+            const float* xrow = xproj + (((long)dir * T + t) * B + cb_) * 4 * H + unit;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) xp[g] = xrow[(long)g * H];
+        }
+        f32x4 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (step > 0) {
+            if (wave == 3 && !timed_out) {
+                unsigned spins = 0;
+                for (;;) {
+                    unsigned f0 = (unsigned)step;
+                    if (lane < members) f0 = __hip_atomic_load(cflags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__all(f0 >= (unsigned)step)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 22)) {
+                        if (lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        timed_out = true;
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            const int off = ((tprev * B + (av ? arow : b0)) * 2 * H + dir * H + kbase) * 4;
+            f32x4 hv[KQ4];
+#pragma unroll
+            for (int i = 0; i < KQ4; ++i) {
+                const u32x4_t raw = __builtin_amdgcn_raw_buffer_load_b128(yrsrc, off + i * 64, 0, 16);      // aux 16 = sc1: L1 bypassed
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = av ? __uint_as_float(raw[e]) : 0.f;
+                hv[i] = v;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < KQ4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[i][e], wv[j][i][e], acc[j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][q * 4 + r][j * 16 + lr] = acc[j][r];
+        __syncthreads();
+
+        if (cellthr) {
+            const bool active = t < len_b;
+            const long sidx = (((long)dir * T + t) * B + cb_) * H + unit;
+            float pre[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                pre[g] = ((red[0][bl][g * 4 + ccol] + red[1][bl][g * 4 + ccol]) + (red[2][bl][g * 4 + ccol] + red[3][bl][g * 4 + ccol])) + xp[g];
+            float* yo = y + ((long)t * B + cb_) * 2 * H + dir * H + unit;
+            f32x4* go = (f32x4*)(gates + sidx * 4);
+            float h = 0.f;
+            if (active) {
+                const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
+                const float c = fg * cstate + ig * gg;
+                h = og * tanhf(c);
+                *go = (f32x4){ig, fg, gg, og};
+                cell[sidx] = c;
+                cstate = c;
+            } else {
+                *go = (f32x4){0.f, 0.f, 0.f, 0.f};
+                cell[sidx] = 0.f;
+                cstate = 0.f;
+            }
+            if (step == T - 1 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+                h = __uint_as_float(0x7FC00000u);                                        // a hand-off timed out: fail loudly
+            if (local) __hip_atomic_store(yo, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // stays in this XCD's L2
+            else __hip_atomic_store(yo, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                // write-through (sc1)
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): every storing wave drains before the flag
+        __syncthreads();
+        if (tid == 0) {
+            if (local) __hip_atomic_store(cflags + member, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else __hip_atomic_store(cflags + member, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // Gradient of one LSTM cell; shared by the per-step and the persistent backward kernels so both contract the same
 // expressions (the two sweeps are compared bit for bit).  Returns the dc carried to the previous step.
 __device__ __forceinline__ float lstm_cell_grad(float dh, float dcar, float ig, float fg, float gg, float og, float c, float cprev,
@@ -565,11 +738,12 @@ __global__ __launch_bounds__(64 * NW) void lstm_bwd_step_fast(const float* __res
     }
 }
 
-// Persistent backward sweep: the same hand-off as lstm_fwd_persistent, with dgates_{t+-1} as the payload.  A workgroup
-// (direction, 16 units, 16 batch rows) keeps its 16 x 4H slice of W_hh^T in registers (128 VGPRs per lane at H = 512;
-// the per-step kernel re-fetches those 128 KB per workgroup per step), carries dc in a register, and exchanges dgates
-// only inside its chain (direction, batch tile).  dgates are regrouped through LDS so that every hand-off store is one
-// 16-byte write-through store (scalar sc1 stores are one fabric write each).  Same MFMA order as lstm_bwd_step_fast.
+// Backward chain sweep: the write-through hand-off of lstm_fwd_persistent with dgates_{t+-1} as the payload and the
+// chain layout of lstm_fwd_chain (blockIdx = member*8 + chain, so a chain's 32 workgroups share an XCD's L2 for their
+// common reads).  A workgroup (chain, 16 units) keeps its 16 x 4H slice of W_hh^T in registers (128 VGPRs per lane at
+// H = 512; the per-step kernel re-fetches those 128 KB per workgroup per step), carries dc in a register, and regroups
+// dgates through LDS so that every hand-off store is one 16-byte write-through store (scalar sc1 stores are one fabric
+// write each).  Same MFMA order as lstm_bwd_step_fast: bit-identical.  Measured 6.4 us/step vs 10.2 per-step launches.
 template <int NCH>
 __global__ __launch_bounds__(256) void lstm_bwd_persistent(const float* __restrict__ dy, const float* __restrict__ whht_f,
                                                            const float* __restrict__ whht_r, const int32_t* __restrict__ lens,
@@ -581,12 +755,14 @@ __global__ __launch_bounds__(256) void lstm_bwd_persistent(const float* __restri
     __shared__ float lds[4 * 16 * 17 + 4 * 16 * 20];
     float (*red)[16][17] = (float (*)[16][17])lds;
     float (*xch)[16][20] = (float (*)[16][20])(lds + 4 * 16 * 17);      // [gate][row][unit], rows padded to 80 B
+    // chain = (direction, batch tile) = blockIdx % 8, member = 16-unit block = blockIdx / 8 (see "chain sweeps" above)
+    const int chain = blockIdx.x & 7, ub = blockIdx.x >> 3;
+    if (chain >= 2 * RT) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bt = blockIdx.x % RT, bid = blockIdx.x / RT;
-    const int dir = bid / ublocks, ub = bid % ublocks, unit0 = ub * 16;
+    const int dir = chain / RT, bt = chain % RT, unit0 = ub * 16;
     const int lr = lane & 15, q = lane >> 4;
     const int nbase = wave * H + q * 4;                                   // wave = gate block of the 4H reduction
-    unsigned* cflags = flags + (dir * 4 + bt) * 32;                       // this chain's arrival flags: one word per workgroup
+    unsigned* cflags = flags + chain * 32;                                // this chain's arrival flags: one word per workgroup
 
     f32x4 bw[CH][8];
     {
@@ -645,18 +821,14 @@ __global__ __launch_bounds__(256) void lstm_bwd_persistent(const float* __restri
                 }
             }
             __syncthreads();
+            // A rows past B are clamped to a valid row and never masked: row r of A only reaches row r of the product,
+            // which the epilogue ignores (masking the loaded values made hipcc serialise the 32 loads, one round trip each)
             const int off = ((((dir * T + tv) * B) + (bv ? arow : b0)) * 4 * H + nbase) * 4;
-            f32x4 av[CH][8];
+            u32x4_t av[CH][8];
 #pragma unroll
             for (int cc = 0; cc < CH; ++cc)
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const u32x4_t raw = __builtin_amdgcn_raw_buffer_load_b128(grsrc, off + cc * 512 + i * 64, 0, 16);      // aux 16 = sc1
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = bv ? __uint_as_float(raw[e]) : 0.f;
-                    av[cc][i] = v;
-                }
+                for (int i = 0; i < 8; ++i) av[cc][i] = __builtin_amdgcn_raw_buffer_load_b128(grsrc, off + cc * 512 + i * 64, 0, 16);      // aux 16 = sc1
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int cc = 0; cc < CH; ++cc)
@@ -664,8 +836,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_persistent(const float* __restri
                 for (int i = 0; i < 8; ++i)
 #pragma unroll
                     for (int e = 0; e < 4; e += 2) {
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cc][i][e], bw[cc][i][e], acc, 0, 0, 0);
-                        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cc][i][e + 1], bw[cc][i][e + 1], acc2, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av[cc][i][e]), bw[cc][i][e], acc, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av[cc][i][e + 1]), bw[cc][i][e + 1], acc2, 0, 0, 0);
                     }
         }
 #pragma unroll
@@ -693,7 +865,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_persistent(const float* __restri
             if (step == T - 1 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
                 raw = (u32x4_t){0x7FC00000u, 0x7FC00000u, 0x7FC00000u, 0x7FC00000u};        // a hand-off timed out: fail loudly
             const int soff = ((((dir * T + t) * B) + sb) * 4 * H + sg * H + unit0 + su) * 4;
-            __builtin_amdgcn_raw_buffer_store_b128(raw, grsrc, soff, 0, 16);      // write-through (sc1) payload, 16 B
+            // write-through (sc1) payload, 16 B.  (Keeping the lines in the XCD's L2 with sc0/plain/nt stores when the
+            // chain sits on one XCD, as the forward sweep does, measured 6.6 vs 6.4 us per step here: not used.)
+            __builtin_amdgcn_raw_buffer_store_b128(raw, grsrc, soff, 0, 16);
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): every storing wave drains before the flag
         __syncthreads();
@@ -749,6 +923,22 @@ extern "C" int vocr_lstm_fwd(const float* xproj, const float* whh_fwd, const flo
     const dim3 grid(2 * (h / 4));
     // persistent sweep by default (VOCR_LSTM_PERSISTENT: bit 0 forward, bit 1 backward; 0 = one launch per step)
     static const int persistent_mode = getenv("VOCR_LSTM_PERSISTENT") ? atoi(getenv("VOCR_LSTM_PERSISTENT")) : 3;
+    if (fast && (persistent_mode & 1) && !(persistent_mode & 4) && 8 * (h / 16) <= resident_workgroup_capacity()) {
+        // chain sweep.  arrival flags: [chain <= 8][32 workgroups] at [0..255], XCC ids at [256..511]; status words at [512..]
+        unsigned* flags = (unsigned*)workspace;
+        unsigned* status = flags + 512;
+        if (hipMemsetAsync(flags, 0, 520 * sizeof(unsigned), s) != hipSuccess) {
+            vocr_set_error("vocr_lstm_fwd: memset failed");
+            return VOCR_ELAUNCH;
+        }
+        const dim3 cg(8 * (h / 16));
+        const int fwt = (persistent_mode & 8) ? 1 : 0;       // experiments: write-through hand-off even on one XCD
+#define VOCR_CHAIN(KQ4) lstm_fwd_chain<KQ4><<<cg, 256, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, flags, flags + 256, status, t, b, rt, fwt)
+        if (h == 64) VOCR_CHAIN(1); else if (h == 128) VOCR_CHAIN(2); else if (h == 256) VOCR_CHAIN(4); else VOCR_CHAIN(8);
+#undef VOCR_CHAIN
+        VOCR_CHECK_LAUNCH("vocr_lstm_fwd(chain)");
+        return VOCR_OK;
+    }
     if (fast && (persistent_mode & 1) && (int)grid.x <= resident_workgroup_capacity() && h >= 64) {
         // arrival flags: [dir][128 workgroups]; status words at [512..]
         unsigned* flags = (unsigned*)workspace;
@@ -794,15 +984,15 @@ extern "C" int vocr_lstm_bwd(const float* dy, const float* whht_fwd, const float
     const int rt = (b + 15) / 16;
     const bool fast = (h == 128 || h == 256 || h == 512) && aligned16(whh_fwd) && aligned16(whh_rev) && aligned16(dgates);
     static const int persistent_mode = getenv("VOCR_LSTM_PERSISTENT") ? atoi(getenv("VOCR_LSTM_PERSISTENT")) : 3;
-    if (fast && (persistent_mode & 2) && 2 * (h / 16) * rt <= resident_workgroup_capacity() && aligned16(gates)) {
-        // arrival flags: [dir][batch tile <= 4][32 workgroups]; status words at [512..]
+    if (fast && (persistent_mode & 2) && 8 * (h / 16) <= resident_workgroup_capacity() && aligned16(gates)) {
+        // arrival flags: [chain <= 8][32 workgroups] at [0..255]; status words at [512..]
         unsigned* flags = (unsigned*)workspace;
         unsigned* status = flags + 512;
         if (hipMemsetAsync(flags, 0, 520 * sizeof(unsigned), s) != hipSuccess) {
             vocr_set_error("vocr_lstm_bwd: memset failed");
             return VOCR_ELAUNCH;
         }
-        const dim3 g(2 * (h / 16) * rt);
+        const dim3 g(8 * (h / 16));
         if (h == 128) lstm_bwd_persistent<1><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, flags, status, t, b, rt);
         else if (h == 256) lstm_bwd_persistent<2><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, flags, status, t, b, rt);
         else lstm_bwd_persistent<4><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, flags, status, t, b, rt);
