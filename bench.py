@@ -185,9 +185,19 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(len(al))
-        print(json.dumps(out))
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST thing on stdout: flush whatever native libraries (RCCL's version banner) still
+        # hold in C stdio buffers first
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
