@@ -273,18 +273,25 @@ def test_persistent_sweeps_match_per_step_launches(dev, T, B, H):
         "print('STATUS', st); torch.save((y.cpu(), gt.cpu(), c.cpu(), dg.cpu()), sys.argv[1])\n"
     ) % (root, T, B, H)
     outs = []
-    for mode in ("0", "3", "11", "7"):       # per-step | chain sweeps | forward chain forced write-through | all-CU forward sweep
+    # per-step | chain sweeps (backward: K-owner partial sums) | + N-owner backward | forward forced write-through | all-CU forward
+    modes = ("0", "3", "19", "11", "7")
+    for mode in modes:
         f = tempfile.mktemp(suffix=".pt")
         r = subprocess.run([sys.executable, "-c", code, f, mode], env=dict(os.environ, VOCR_LSTM_PERSISTENT=mode), capture_output=True, text=True, timeout=120)
         assert r.returncode == 0, r.stderr[-500:]
         assert "STATUS 0" in r.stdout, r.stdout
         outs.append(torch.load(f))
         os.unlink(f)
-    for other in outs[1:]:
+    for mode, other in zip(modes[1:], outs[1:]):
         for nm, a, b in zip(("y", "gates", "cell", "dgates"), outs[0], other):
             if H < 128 and nm == "dgates":
                 continue                      # no backward fast path below H = 128: dgates untouched in both runs
-            assert torch.equal(a, b), "%s differs: max |diff| %.3e at %d of %d" % (nm, float((a - b).abs().max()), int((a != b).sum()), a.numel())
+            if nm == "dgates" and not int(mode) & 16:
+                # the K-owner backward sums the recurrent term in a different (fixed) order: fp32 rounding differences only
+                tol = 2e-5 * float(a.abs().max())
+                assert float((a - b).abs().max()) <= tol, "%s (mode %s): max |diff| %.3e > %.3e" % (nm, mode, float((a - b).abs().max()), tol)
+                continue
+            assert torch.equal(a, b), "%s (mode %s) differs: max |diff| %.3e at %d of %d" % (nm, mode, float((a - b).abs().max()), int((a != b).sum()), a.numel())
 
 
 @pytest.mark.parametrize("T,B,V,L", [(30, 4, 20, [5, 3, 1, 0]), (147, 8, 96, None), (60, 3, 166, [29, 10, 2])])

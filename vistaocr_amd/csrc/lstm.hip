@@ -893,6 +893,146 @@ __global__ __launch_bounds__(256) void lstm_bwd_persistent(const float* __restri
     }
 }
 
+// Backward chain sweep, second form ("K-owner").  lstm_bwd_persistent spends 4.7 of its 6.3 us per step loading the
+// chain's dgates (128 KB per workgroup, 32 times the same bytes per XCD) before and under its MFMAs.  Here a workgroup
+// multiplies the dgates it has just produced itself (16 rows x 64 gate-units, straight from LDS) with its 64 x H slice of
+// W_hh and hands out PARTIAL sums instead: out[row][n] for all H units, one 1-KB block per consumer.  The exchange is
+// then 32 KB written and 32 KB read per workgroup per step, the reads are 32 fully coalesced dword loads per thread
+// summed in a fixed order (deterministic), and no global load sits in front of the MFMAs.
+//   MFMA roles: A = W_hh^T fragment (m = unit within a 16-unit tile), B = own dgates (n = batch row); k = 4*ks + q is
+//   mapped to (gate q, local unit ks) so that both operands are 16 contiguous floats per lane.
+//   D[m = 4q + r][n = lr] = partial of (unit n0 + 4q + r, row lr): four consecutive units per lane -> one 16-byte
+//   write-through store per tile, no regrouping.
+// Partial buffers are double-buffered by step parity (a producer can only be one step ahead of its slowest consumer).
+template <int NCH>
+__global__ __launch_bounds__(256) void lstm_bwd_kowner(const float* __restrict__ dy, const float* __restrict__ whht_f,
+                                                       const float* __restrict__ whht_r, const int32_t* __restrict__ lens,
+                                                       const float* __restrict__ gates, const float* __restrict__ cell,
+                                                       float* __restrict__ dgates, float* partials, unsigned* flags, unsigned* ids,
+                                                       unsigned* status, int T, int B, int RT, int force_wt) {
+    constexpr int H = 128 * NCH;
+    constexpr int members = H / 16;
+    constexpr int TPW = members / 4;                  // 16-unit output tiles per wave
+    constexpr int DP = 68;                            // LDS row pitch (floats): 16-B reads of 16 rows hit 64 distinct banks
+    __shared__ float dgl[16 * DP + 4];                // own dgates [row][gate][local unit] (+ one scratch word)
+    const int chain = blockIdx.x & 7, member = blockIdx.x >> 3;
+    if (chain >= 2 * RT) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int dir = chain / RT, bt = chain % RT, unit0 = member * 16;
+    const int lr = lane & 15, q = lane >> 4;
+    unsigned* cflags = flags + chain * 32;
+    // chain on one XCD: partials and flags stay in its L2 (sc0 stores); the loads stay sc1 (L1 bypassed) because a
+    // partial block is rewritten every other step, so an L1 copy of it would be stale
+    const bool local = chain_is_xcd_local(ids + chain * 32, members, member, status, (unsigned*)(dgl + 16 * DP)) && !force_wt;
+
+    // resident A fragments: aw[j][i][e] = W_hh[q*H + unit0 + 4i + e][n0 + lr] = whht[n0 + lr][q*H + unit0 + 4i + e]
+    f32x4 aw[TPW][4];
+    {
+        const float* whht = dir ? whht_r : whht_f;
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+            const f32x4* wp = (const f32x4*)(whht + (long)((wave * TPW + j) * 16 + lr) * 4 * H + q * H + unit0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) aw[j][i] = wp[i];
+        }
+    }
+    const int b0 = bt * 16;
+    const int eb = b0 + (tid >> 4), ej = tid & 15, eunit = unit0 + ej;
+    const bool ev = eb < B;
+    const int ebs = ev ? eb : b0;
+    const int len = lens[ebs];
+    float dcar = 0.f;
+    bool timed_out = false;
+    const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc((void*)partials, 0, 2 * 8 * 32 * 32 * 256 * 4, 0x00020000);
+
+    for (int step = 0; step < T; ++step) {
+        const int t = dir == 0 ? T - 1 - step : step;
+        const bool act = ev && t < len;
+        // epilogue operands (written by earlier kernels: plain loads), issued ahead of the wait
+        float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, c = 0.f, cprev = 0.f, dyv = 0.f;
+        if (act) {
+            const long sidx = (((long)dir * T + t) * B + ebs) * H + eunit;
+            const f32x4 gv = *(const f32x4*)(gates + sidx * 4);
+            ig = gv[0];
+            fg = gv[1];
+            gg = gv[2];
+            og = gv[3];
+            c = cell[sidx];
+            const int tp = dir == 0 ? t - 1 : t + 1;
+            cprev = (tp >= 0 && tp < len) ? cell[(((long)dir * T + tp) * B + ebs) * H + eunit] : 0.f;
+            dyv = dy[((long)t * B + ebs) * 2 * H + dir * H + eunit];
+        }
+        float rs = 0.f;
+        if (step > 0) {
+            if (wave == 3 && !timed_out) {
+                unsigned spins = 0;
+                for (;;) {
+                    unsigned f0 = (unsigned)step;
+                    if (lane < members) f0 = __hip_atomic_load(cflags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__all(f0 >= (unsigned)step)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 22)) {
+                        if (lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        timed_out = true;
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            // this workgroup's block of every member's partials of the previous step: [member m][row][unit] -> thread = (row, unit)
+            const int pbase = (((((step - 1) & 1) * 8 + chain) * 32 + member) * 32 * 256 + tid) * 4;
+            float pv[members];
+#pragma unroll
+            for (int m = 0; m < members; ++m) pv[m] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(prsrc, pbase + m * 1024, 0, 16));   // sc1
+#pragma unroll
+            for (int m = 0; m < members; ++m) rs += pv[m];
+        }
+        float dg[4] = {0.f, 0.f, 0.f, 0.f};
+        if (act) dcar = lstm_cell_grad(dyv + rs, dcar, ig, fg, gg, og, c, cprev, dg);
+        else dcar = 0.f;
+        if (step == T - 1 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+            dg[0] = dg[1] = dg[2] = dg[3] = __uint_as_float(0x7FC00000u);        // a hand-off timed out: fail loudly
+        if (ev) {
+            const long gbase = (((long)dir * T + t) * B + eb) * 4 * H + eunit;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dgates[gbase + (long)g * H] = dg[g];     // for the weight/input-gradient GEMMs: plain stores
+        }
+        if (step + 1 < T) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dgl[(tid >> 4) * DP + g * 16 + ej] = dg[g];
+            __syncthreads();
+            f32x4 bv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bv[i] = *(const f32x4*)&dgl[lr * DP + q * 16 + 4 * i];
+            f32x4 acc[TPW];
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int j = 0; j < TPW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[j][i][e], bv[i][e], acc[j], 0, 0, 0);
+            // consumer c = wave*TPW + j gets [producer = member][row = lr][units 4q..4q+3]
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) {
+                u32x4_t raw;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) raw[e] = __float_as_uint(acc[j][e]);
+                const int soff = (((((step & 1) * 8 + chain) * 32 + (wave * TPW + j)) * 32 + member) * 256 + lr * 16 + q * 4) * 4;
+                if (local) __builtin_amdgcn_raw_buffer_store_b128(raw, prsrc, soff, 0, 1);        // sc0: stays in this XCD's L2
+                else __builtin_amdgcn_raw_buffer_store_b128(raw, prsrc, soff, 0, 16);            // write-through (sc1), 16 B
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): every storing wave drains before the flag
+        }
+        __syncthreads();                                     // also: dgl is free for the next step
+        if (tid == 0) {
+            if (local) __hip_atomic_store(cflags + member, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else __hip_atomic_store(cflags + member, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 template <int KQ4>
 bool launch_fwd_fast(int rt, dim3 grid, hipStream_t s, const float* xproj, const float* wf, const float* wr, const int32_t* lens,
                      float* y, float* gates, float* cell, int T, int B, int step) {
@@ -926,7 +1066,9 @@ int resident_workgroup_capacity() {
 
 extern "C" size_t vocr_lstm_workspace_bytes(int t, int b, int h) {
     if (t <= 0 || b <= 0 || h <= 0) return 0;
-    return (size_t)6 * 2 * b * h * sizeof(float) + 4096;   // dc carry [2][B][H] (+ spare); 4 KiB of arrival flags / status
+    // dc carry [2][B][H] (+ spare); 4 KiB of arrival flags / status; 16 MiB of partial-sum blocks for the backward chain
+    // sweep (2 parities x 8 chains x 32 consumers x 32 producers x 1 KiB)
+    return (size_t)6 * 2 * b * h * sizeof(float) + 4096 + ((size_t)16 << 20);
 }
 
 extern "C" int vocr_lstm_fwd(const float* xproj, const float* whh_fwd, const float* whh_rev, const int32_t* lens, float* y,
@@ -1011,6 +1153,16 @@ extern "C" int vocr_lstm_bwd(const float* dy, const float* whht_fwd, const float
             return VOCR_ELAUNCH;
         }
         const dim3 g(8 * (h / 16));
+        if (!(persistent_mode & 16)) {
+            // K-owner form: partial sums [parity][chain][consumer][producer][16 x 16] behind the flags/status words
+            float* partials = (float*)((char*)workspace + 4096);
+            const int fwt = (persistent_mode & 8) ? 1 : 0;       // experiments: write-through hand-off even on one XCD
+            if (h == 128) lstm_bwd_kowner<1><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, t, b, rt, fwt);
+            else if (h == 256) lstm_bwd_kowner<2><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, t, b, rt, fwt);
+            else lstm_bwd_kowner<4><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, t, b, rt, fwt);
+            VOCR_CHECK_LAUNCH("vocr_lstm_bwd(k-owner)");
+            return VOCR_OK;
+        }
         if (h == 128) lstm_bwd_persistent<1><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, flags, status, t, b, rt);
         else if (h == 256) lstm_bwd_persistent<2><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, flags, status, t, b, rt);
         else lstm_bwd_persistent<4><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, flags, status, t, b, rt);
