@@ -120,6 +120,12 @@ int vocr_dropout_fwd(const float* x, float* out, float* mask, size_t count, floa
 size_t vocr_lstm_workspace_bytes(int t, int b, int h);
 int vocr_lstm_fwd(const float* xproj, const float* whh_fwd, const float* whh_rev, const int32_t* lens, float* y,
                   float* gates, float* cell, void* workspace, int t, int b, int h, void* stream);
+/* Steps [step_begin, step_end) of the same sweep (step s is time s for the forward direction, T-1-s for the reverse
+ * one): a later range resumes from the h (in y) and c (in cell) an earlier call left.  Lets the host overlap the
+ * x-projection GEMM of the later time steps with the first half of the sweep.  vocr_lstm_fwd == range [0, t). */
+int vocr_lstm_fwd_range(const float* xproj, const float* whh_fwd, const float* whh_rev, const int32_t* lens, float* y,
+                        float* gates, float* cell, void* workspace, int t, int b, int h, int step_begin, int step_end,
+                        void* stream);
 /* dy[T][B][2H] -> dgates[dir][T][B][4H] (gradient w.r.t. pre-activation gates = w.r.t. xproj).
  * whht_* are the TRANSPOSED recurrent weights [H][4H] (vocr_bchw_to_wbch with b=1 transposes a matrix). */
 int vocr_lstm_bwd(const float* dy, const float* whht_fwd, const float* whht_rev, const int32_t* lens, const float* gates,

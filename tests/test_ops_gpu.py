@@ -294,6 +294,34 @@ def test_persistent_sweeps_match_per_step_launches(dev, T, B, H):
             assert torch.equal(a, b), "%s (mode %s) differs: max |diff| %.3e at %d of %d" % (nm, mode, float((a - b).abs().max()), int((a != b).sum()), a.numel())
 
 
+@pytest.mark.parametrize("T,B,H,cut", [(40, 20, 128, 20), (33, 32, 512, 7), (12, 40, 256, 11), (25, 5, 64, 12)])
+def test_lstm_forward_step_ranges_resume_bit_exactly(dev, T, B, H, cut):
+    """vocr_lstm_fwd_range: steps [0, cut) then [cut, T) leave exactly what one whole sweep leaves (y, gates, cell)."""
+    from vistaocr_amd import _lib
+    from vistaocr_amd._lib import call
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(1)
+    xp = (torch.rand(2, T * B, 4 * H, generator=g) - 0.5).to(dev)
+    wf = ((torch.rand(4 * H, H, generator=g) - 0.5) * 0.3).to(dev)
+    wr = ((torch.rand(4 * H, H, generator=g) - 0.5) * 0.3).to(dev)
+    lens = torch.tensor(sorted([max(1, T - 2 * i) for i in range(B)], reverse=True), dtype=torch.int32, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for ranges in (((0, T),), ((0, cut), (cut, T))):
+        y = torch.full((T * B, 2 * H), float("nan"), device=dev)
+        gt = torch.full((2, T * B, 4 * H), float("nan"), device=dev)
+        c = torch.full((2, T * B, H), float("nan"), device=dev)
+        ws = torch.zeros(lib.vocr_lstm_workspace_bytes(T, B, H) // 4 + 16, device=dev)
+        for a, b in ranges:
+            call("vocr_lstm_fwd_range", xp.data_ptr(), wf.data_ptr(), wr.data_ptr(), lens.data_ptr(), y.data_ptr(), gt.data_ptr(),
+                 c.data_ptr(), ws.data_ptr(), T, B, H, a, b, s)
+        torch.cuda.synchronize()
+        outs.append((y.cpu(), gt.cpu(), c.cpu()))
+    for nm, a, b in zip(("y", "gates", "cell"), outs[0], outs[1]):
+        assert not torch.isnan(a).any()
+        assert torch.equal(a, b), "%s differs after resuming: max |diff| %.3e" % (nm, float((a - b).abs().max()))
+
+
 @pytest.mark.parametrize("T,B,V,L", [(30, 4, 20, [5, 3, 1, 0]), (147, 8, 96, None), (60, 3, 166, [29, 10, 2])])
 def test_ctc_loss_and_grad(dev, T, B, V, L):
     from vistaocr_amd import CTCLoss

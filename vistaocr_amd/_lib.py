@@ -45,6 +45,7 @@ SIGNATURES = {
     "vocr_dropout_fwd": (I, [P, P, P, Z, F, U64, P]),
     "vocr_lstm_workspace_bytes": (Z, [I, I, I]),
     "vocr_lstm_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, P]),
+    "vocr_lstm_fwd_range": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "vocr_lstm_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, P]),
     "vocr_ctc_workspace_bytes": (Z, [I, I, I, I]),
     "vocr_ctc_loss_grad": (I, [P, P, P, P, P, P, P, P, I, I, I, I, P]),

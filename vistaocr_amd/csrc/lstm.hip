@@ -495,13 +495,15 @@ template <int KQ4>
 __global__ __launch_bounds__(256) void lstm_fwd_chain(const float* __restrict__ xproj, const float* __restrict__ whh_f,
                                                       const float* __restrict__ whh_r, const int32_t* __restrict__ lens,
                                                       float* y, float* __restrict__ gates, float* __restrict__ cell,
-                                                      unsigned* flags, unsigned* ids, unsigned* status, int T, int B, int nbt, int force_wt) {
+                                                      unsigned* flags, unsigned* ids, unsigned* status, int T, int B, int nbt, int force_wt,
+                                                      int s0, int s1) {
     constexpr int H = 64 * KQ4;
     constexpr int members = H >> 4;
     __shared__ float lds[4 * 16 * 65 + 4];
     float (*red)[16][65] = (float (*)[16][65])lds;
     const int chain = blockIdx.x & 7, member = blockIdx.x >> 3;
     if (chain >= 2 * nbt) return;
+    __builtin_amdgcn_s_setprio(3);      // latency-critical: win issue arbitration against co-resident GEMM waves
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int dir = chain / nbt, bt = chain % nbt;
     const int unit0 = member * 16, b0 = bt * 16;
@@ -524,7 +526,12 @@ __global__ __launch_bounds__(256) void lstm_fwd_chain(const float* __restrict__ 
     const bool cellthr = bl < nrows;
     const int len_b = cellthr ? lens[cb_] : 0;
     const int ccol = (cu >> 2) * 16 + (cu & 3);
+    // steps [s0, s1) of the sweep: a later range resumes from what the earlier launch left in y (h) and cell (c)
     float cstate = 0.f;
+    if (s0 > 0 && cellthr) {
+        const int tp0 = dir == 0 ? s0 - 1 : T - s0;
+        cstate = cell[(((long)dir * T + tp0) * B + cb_) * H + unit];
+    }
     bool timed_out = false;
     const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, T * B * 2 * H * 4, 0x00020000);
     const int arow = b0 + lr;
@@ -542,20 +549,20 @@ __global__ __launch_bounds__(256) void lstm_fwd_chain(const float* __restrict__ 
         for (int g = 0; g < 4; ++g) xv[g] = xrow[(long)g * H];
     };
     float xn[4];
-    x_loads(0, xn);
+    x_loads(s0, xn);
 
-    for (int step = 0; step < T; ++step) {
+    for (int step = s0; step < s1; ++step) {
         const int t = dir == 0 ? step : T - 1 - step;
         const int tprev = dir == 0 ? t - 1 : t + 1;
         float xp[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) xp[g] = xn[g];
-        if (step == 0) x_loads(T > 1 ? 1 : 0, xn);
+        if (step == 0) x_loads(T > 1 ? 1 : 0, xn);      // (step 0 has no h to load: the prefetch rides alone)
         f32x4 acc[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (step > 0) {
-            if (wave == 3 && !timed_out) {
+            if (wave == 3 && !timed_out && step > s0) {
                 unsigned spins = 0;
                 for (;;) {
                     unsigned f0 = (unsigned)step;
@@ -623,7 +630,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_chain(const float* __restrict__ 
                 cell[sidx] = 0.f;
                 cstate = 0.f;
             }
-            if (step == T - 1 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+            if (step == s1 - 1 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
                 h = __uint_as_float(0x7FC00000u);                                        // a hand-off timed out: fail loudly
             if (local) __hip_atomic_store(yo, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // stays in this XCD's L2
             else __hip_atomic_store(yo, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                // write-through (sc1)
@@ -917,6 +924,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kowner(const float* __restrict__
     __shared__ float dgl[16 * DP + 4];                // own dgates [row][gate][local unit] (+ one scratch word)
     const int chain = blockIdx.x & 7, member = blockIdx.x >> 3;
     if (chain >= 2 * RT) return;
+    __builtin_amdgcn_s_setprio(3);      // latency-critical: win issue arbitration against co-resident GEMM waves
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int dir = chain / RT, bt = chain % RT, unit0 = member * 16;
     const int lr = lane & 15, q = lane >> 4;
@@ -1071,10 +1079,13 @@ extern "C" size_t vocr_lstm_workspace_bytes(int t, int b, int h) {
     return (size_t)6 * 2 * b * h * sizeof(float) + 4096 + ((size_t)16 << 20);
 }
 
-extern "C" int vocr_lstm_fwd(const float* xproj, const float* whh_fwd, const float* whh_rev, const int32_t* lens, float* y,
-                             float* gates, float* cell, void* workspace, int t, int b, int h, void* stream) {
+extern "C" int vocr_lstm_fwd_range(const float* xproj, const float* whh_fwd, const float* whh_rev, const int32_t* lens, float* y,
+                                   float* gates, float* cell, void* workspace, int t, int b, int h, int step_begin, int step_end,
+                                   void* stream) {
     VOCR_CHECK_ARG(xproj && whh_fwd && whh_rev && lens && y && gates && cell && workspace, "vocr_lstm_fwd: null pointer");
     VOCR_CHECK_ARG(t > 0 && b > 0 && b <= 64 && h > 0 && h % 16 == 0, "vocr_lstm_fwd: need 1<=B<=64 and H%%16==0 (B=%d H=%d)", b, h);
+    VOCR_CHECK_ARG(0 <= step_begin && step_begin < step_end && step_end <= t, "vocr_lstm_fwd: bad step range [%d, %d) of %d", step_begin, step_end, t);
+    const bool whole = step_begin == 0 && step_end == t;
     hipStream_t s = (hipStream_t)stream;
     const int rt = (b + 15) / 16;
     const bool fast = (h == 64 || h == 128 || h == 256 || h == 512) && aligned16(whh_fwd) && aligned16(whh_rev) && aligned16(y) &&
@@ -1093,13 +1104,13 @@ extern "C" int vocr_lstm_fwd(const float* xproj, const float* whh_fwd, const flo
         }
         const dim3 cg(8 * (h / 16));
         const int fwt = (persistent_mode & 8) ? 1 : 0;       // experiments: write-through hand-off even on one XCD
-#define VOCR_CHAIN(KQ4) lstm_fwd_chain<KQ4><<<cg, 256, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, flags, flags + 256, status, t, b, rt, fwt)
+#define VOCR_CHAIN(KQ4) lstm_fwd_chain<KQ4><<<cg, 256, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, flags, flags + 256, status, t, b, rt, fwt, step_begin, step_end)
         if (h == 64) VOCR_CHAIN(1); else if (h == 128) VOCR_CHAIN(2); else if (h == 256) VOCR_CHAIN(4); else VOCR_CHAIN(8);
 #undef VOCR_CHAIN
         VOCR_CHECK_LAUNCH("vocr_lstm_fwd(chain)");
         return VOCR_OK;
     }
-    if (fast && (persistent_mode & 1) && (int)grid.x <= resident_workgroup_capacity() && h >= 64) {
+    if (fast && whole && (persistent_mode & 1) && (int)grid.x <= resident_workgroup_capacity() && h >= 64) {
         // arrival flags: [dir][128 workgroups]; status words at [512..]
         unsigned* flags = (unsigned*)workspace;
         unsigned* status = flags + 512;
@@ -1116,7 +1127,7 @@ extern "C" int vocr_lstm_fwd(const float* xproj, const float* whh_fwd, const flo
         VOCR_CHECK_LAUNCH("vocr_lstm_fwd(persistent)");
         return VOCR_OK;
     }
-    for (int step = 0; step < t; ++step) {
+    for (int step = step_begin; step < step_end; ++step) {
         if (fast) {
             switch (h) {
                 case 64: launch_fwd_fast<1>(rt, grid, s, xproj, whh_fwd, whh_rev, lens, y, gates, cell, t, b, step); break;
@@ -1130,6 +1141,11 @@ extern "C" int vocr_lstm_fwd(const float* xproj, const float* whh_fwd, const flo
     }
     VOCR_CHECK_LAUNCH("vocr_lstm_fwd");
     return VOCR_OK;
+}
+
+extern "C" int vocr_lstm_fwd(const float* xproj, const float* whh_fwd, const float* whh_rev, const int32_t* lens, float* y,
+                             float* gates, float* cell, void* workspace, int t, int b, int h, void* stream) {
+    return vocr_lstm_fwd_range(xproj, whh_fwd, whh_rev, lens, y, gates, cell, workspace, t, b, h, 0, t, stream);
 }
 
 extern "C" int vocr_lstm_bwd(const float* dy, const float* whht_fwd, const float* whht_rev, const int32_t* lens,

@@ -422,14 +422,38 @@ class BiLstmLayerFn(torch.autograd.Function):
         bsum = torch.empty(2, 4 * H, dtype=torch.float32, device=dev)
         call("vocr_add", _p(b_ih_f), _p(b_hh_f), _p(bsum[0]), 4 * H, _stream())
         call("vocr_add", _p(b_ih_r), _p(b_hh_r), _p(bsum[1]), 4 * H, _stream())
-        gemm(0, 1, T * B, 4 * H, din, x, din, w_ih_f, din, xproj[0], 4 * H, bias=bsum[0])
-        gemm(0, 1, T * B, 4 * H, din, x, din, w_ih_r, din, xproj[1], 4 * H, bias=bsum[1])
         y = torch.empty(T * B, 2 * H, dtype=torch.float32, device=dev)
         gates = torch.empty(2, T * B, 4 * H, dtype=torch.float32, device=dev)
         cell = torch.empty(2, T * B, H, dtype=torch.float32, device=dev)
         ws = _ws(lib.vocr_lstm_workspace_bytes(T, B, H), dev)
-        call("vocr_lstm_fwd", _p(xproj), _p(w_hh_f), _p(w_hh_r), _p(lens_dev), _p(y), _p(gates), _p(cell), _p(ws), T, B, H,
-             _stream())
+        G = 4 * H
+
+        def xgemm(d, r0, r1):                       # x-projection of time-major rows [r0, r1) for direction d
+            gemm(0, 1, r1 - r0, G, din, x[r0:r1], din, w_ih_r if d else w_ih_f, din, xproj[d][r0:r1], G, bias=bsum[d])
+
+        Th = T // 2
+        if _SIDE["enabled"] and Th >= 16 and Th * B * din >= (1 << 20):
+            # The sweep keeps half the chip idle, so only the x-projection of the rows its first half needs (forward
+            # direction: t < Th; reverse direction: t >= T - Th) runs ahead of it; the other halves run on the side
+            # stream under steps [0, Th) and steps [Th, T) start when they are done (vocr_lstm_fwd_range).
+            side = side_stream()
+            for t_ in (x, xproj, bsum, w_ih_f, w_ih_r):
+                t_.record_stream(side)
+            xgemm(0, 0, Th * B)
+            xgemm(1, (T - Th) * B, T * B)
+            side.wait_stream(torch.cuda.current_stream())      # behind the first halves: they must not share the chip
+            with torch.cuda.stream(side):
+                xgemm(0, Th * B, T * B)
+                xgemm(1, 0, (T - Th) * B)
+            args = (_p(xproj), _p(w_hh_f), _p(w_hh_r), _p(lens_dev), _p(y), _p(gates), _p(cell), _p(ws), T, B, H)
+            call("vocr_lstm_fwd_range", *args, 0, Th, _stream())
+            torch.cuda.current_stream().wait_stream(side)
+            call("vocr_lstm_fwd_range", *args, Th, T, _stream())
+        else:
+            xgemm(0, 0, T * B)
+            xgemm(1, 0, T * B)
+            call("vocr_lstm_fwd", _p(xproj), _p(w_hh_f), _p(w_hh_r), _p(lens_dev), _p(y), _p(gates), _p(cell), _p(ws), T, B, H,
+                 _stream())
         ctx.dims = (T, B, H, din)
         ctx.b_refs = (b_ih_f, b_hh_f, b_ih_r, b_hh_r)
         ctx.save_for_backward(x, lens_dev, y, gates, cell, w_ih_f, w_hh_f, w_ih_r, w_hh_r)
