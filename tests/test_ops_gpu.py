@@ -273,8 +273,9 @@ def test_persistent_sweeps_match_per_step_launches(dev, T, B, H):
         "print('STATUS', st); torch.save((y.cpu(), gt.cpu(), c.cpu(), dg.cpu()), sys.argv[1])\n"
     ) % (root, T, B, H)
     outs = []
-    # per-step | chain sweeps (backward: K-owner partial sums) | + N-owner backward | forward forced write-through | all-CU forward
-    modes = ("0", "3", "19", "11", "7")
+    # per-step | default sweeps (8-row 4x4x1 chains where they apply, else as 35) | 16-row chains, K-owner backward |
+    # 16-row chains, N-owner backward | forced write-through hand-off | all-CU forward sweep
+    modes = ("0", "3", "35", "51", "43", "39")
     for mode in modes:
         f = tempfile.mktemp(suffix=".pt")
         r = subprocess.run([sys.executable, "-c", code, f, mode], env=dict(os.environ, VOCR_LSTM_PERSISTENT=mode), capture_output=True, text=True, timeout=120)
@@ -282,13 +283,15 @@ def test_persistent_sweeps_match_per_step_launches(dev, T, B, H):
         assert "STATUS 0" in r.stdout, r.stdout
         outs.append(torch.load(f))
         os.unlink(f)
+    eight_row = H == 512 and B <= 32                 # mode 3 then runs the 4x4x1 kernels: another (fixed) summation order
     for mode, other in zip(modes[1:], outs[1:]):
         for nm, a, b in zip(("y", "gates", "cell", "dgates"), outs[0], other):
             if H < 128 and nm == "dgates":
                 continue                      # no backward fast path below H = 128: dgates untouched in both runs
-            if nm == "dgates" and not int(mode) & 16:
-                # the K-owner backward sums the recurrent term in a different (fixed) order: fp32 rounding differences only
-                tol = 2e-5 * float(a.abs().max())
+            reordered = (mode == "3" and eight_row) or (nm == "dgates" and not int(mode) & 16)
+            if reordered:
+                # same arithmetic, different fp32 summation order: rounding differences only
+                tol = 3e-5 * float(a.abs().max())
                 assert float((a - b).abs().max()) <= tol, "%s (mode %s): max |diff| %.3e > %.3e" % (nm, mode, float((a - b).abs().max()), tol)
                 continue
             assert torch.equal(a, b), "%s (mode %s) differs: max |diff| %.3e at %d of %d" % (nm, mode, float((a - b).abs().max()), int((a != b).sum()), a.numel())

@@ -644,6 +644,179 @@ __global__ __launch_bounds__(256) void lstm_fwd_chain(const float* __restrict__ 
     }
 }
 
+__device__ __forceinline__ int wave_of(unsigned tid) { return (int)(tid >> 6); }
+
+// Forward chain sweep on 8-row chains (see lstm_bwd_kowner8 for why): 8 chains fill all 8 XCDs at a batch of 32 and
+// v_mfma_f32_4x4x1_16b_f32 keeps the MFMA rate with only 8 batch rows.  One instruction = 2 row-groups x 8 column-groups
+// = 8 rows x 32 gate columns x one k; the workgroup's 64 gate columns take two instructions per k, K = H is split
+// over the 8 waves (64 k each: 16 16-byte loads of h per lane, W_hh slice in 128 VGPRs), the eight partial tiles are
+// reduced through LDS in a fixed order.  Hand-off, placement check, x-projection prefetch and step ranges as in
+// lstm_fwd_chain.  H = 64*KQ4 with KQ4 % 8 == 0.
+template <int KQ4>
+__global__ __launch_bounds__(512) void lstm_fwd_chain8(const float* __restrict__ xproj, const float* __restrict__ whh_f,
+                                                       const float* __restrict__ whh_r, const int32_t* __restrict__ lens,
+                                                       float* y, float* __restrict__ gates, float* __restrict__ cell,
+                                                       unsigned* flags, unsigned* ids, unsigned* status, int T, int B, int NT8, int force_wt,
+                                                       int s0, int s1) {
+    constexpr int H = 64 * KQ4;
+    constexpr int members = H >> 4;
+    constexpr int KW = H / 8;                         // k per wave
+    constexpr int NL = KW / 4;                        // 16-byte loads per lane per step
+    constexpr int HP = KW + 4;                        // staging row pitch: 16-byte reads of 8 rows hit distinct banks
+    __shared__ float lds[8 * 8 * 65 + 4 + 8 * 8 * HP];
+    float (*red)[8][65] = (float (*)[8][65])lds;
+    float* hst = lds + 8 * 8 * 65 + 4 + wave_of(threadIdx.x) * 8 * HP;      // this wave's h_{t-1}[8 rows][its KW k]
+    const int chain = blockIdx.x & 7, member = blockIdx.x >> 3;
+    if (chain >= 2 * NT8) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int dir = chain / NT8, bt = chain % NT8;
+    const int unit0 = member * 16, b0 = bt * 8;
+    const int nrows = min(B - b0, 8);
+    const int blk = lane >> 2, li = lane & 3, cg = blk >> 1, rg = blk & 1;
+    const int kbase = wave * KW;
+    const float* whh = dir ? whh_r : whh_f;
+    unsigned* cflags = flags + chain * 32;
+    const bool local = chain_is_xcd_local(ids + chain * 32, members, member, status, (unsigned*)(lds + 8 * 8 * 65)) && !force_wt;
+
+    // resident B operand: column 32*I + 4*cg + li = (gate, local unit) = (col >> 4, col & 15)
+    f32x4 wv[2][NL];
+#pragma unroll
+    for (int I = 0; I < 2; ++I) {
+        const int col = 32 * I + 4 * cg + li;
+        const f32x4* wp = (const f32x4*)(whh + ((long)(col >> 4) * H + unit0 + (col & 15)) * H + kbase);
+#pragma unroll
+        for (int i = 0; i < NL; ++i) wv[I][i] = wp[i];
+    }
+    const int bl = (tid >> 4) & 7, cu = tid & 15, cb_ = b0 + bl, unit = unit0 + cu;
+    const bool cellthr = tid < 128 && bl < nrows;
+    const int len_b = cellthr ? lens[cb_] : 0;
+    float cstate = 0.f;
+    if (s0 > 0 && cellthr) {
+        const int tp0 = dir == 0 ? s0 - 1 : T - s0;
+        cstate = cell[(((long)dir * T + tp0) * B + cb_) * H + unit];
+    }
+    bool timed_out = false;
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, T * B * 2 * H * 4, 0x00020000);
+    // h_{t-1} is fetched in whole lines (lane = 16-byte piece p of the wave's [8 rows][KW] slice: rows clamped, never
+    // masked - A row r only reaches output row r) and broadcast to the 8 column-group lanes through LDS; having every
+    // lane load its own row's 64 k directly asked L2 for each line 8 times (5.0 vs 3.9 us per step).
+    constexpr int PPR = KW / 4;                       // pieces per row
+    constexpr int NP = 8 * PPR / 64;                  // pieces per lane
+    int poff[NP], pdst[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int p = lane + 64 * j, prow = p / PPR, pc = p % PPR;
+        const int grow = b0 + prow < B ? b0 + prow : b0;
+        poff[j] = (grow * 2 * H + dir * H + kbase + 4 * pc) * 4;
+        pdst[j] = prow * HP + 4 * pc;
+    }
+    const float* hrd = hst + (4 * rg + li) * HP;
+
+    const int xb = cellthr ? cb_ : b0;
+    auto x_loads = [&](int st, float (&xv)[4]) {
+        const int tt = dir == 0 ? st : T - 1 - st;
+        const float* xrow = xproj + (((long)dir * T + tt) * B + xb) * 4 * H + unit;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xv[g] = xrow[(long)g * H];
+    };
+    float xn[4] = {0.f, 0.f, 0.f, 0.f};
+    if (tid < 128) x_loads(s0, xn);
+
+    for (int step = s0; step < s1; ++step) {
+        const int t = dir == 0 ? step : T - 1 - step;
+        const int tprev = dir == 0 ? t - 1 : t + 1;
+        float xp[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xp[g] = xn[g];
+        if (step == 0 && tid < 128) x_loads(T > 1 ? 1 : 0, xn);
+        f32x4 acc[2];
+        acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (step > 0) {
+            if (wave == 7 && !timed_out && step > s0) {
+                unsigned spins = 0;
+                for (;;) {
+                    unsigned f0 = (unsigned)step;
+                    if (lane < members) f0 = __hip_atomic_load(cflags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__all(f0 >= (unsigned)step)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 22)) {
+                        if (lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        timed_out = true;
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            const int toff = tprev * B * 2 * H * 4;
+            u32x4_t pv[NP];
+            if (local) {            // one XCD: plain loads of the L2-resident hand-off (see lstm_fwd_chain)
+#pragma unroll
+                for (int j = 0; j < NP; ++j) pv[j] = __builtin_amdgcn_raw_buffer_load_b128(yrsrc, toff + poff[j], 0, 0);
+            } else {
+#pragma unroll
+                for (int j = 0; j < NP; ++j) pv[j] = __builtin_amdgcn_raw_buffer_load_b128(yrsrc, toff + poff[j], 0, 16);      // aux 16 = sc1
+            }
+            if (tid < 128) x_loads(step + 1 < T ? step + 1 : step, xn);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) *(u32x4_t*)(hst + pdst[j]) = pv[j];
+            // same wave writes and reads its staging rows: the LDS counter orders them, no barrier
+            f32x4 hv[NL];
+#pragma unroll
+            for (int i = 0; i < NL; ++i) hv[i] = *(const f32x4*)(hrd + 4 * i);
+#pragma unroll
+            for (int i = 0; i < NL; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int I = 0; I < 2; ++I)
+                        acc[I] = __builtin_amdgcn_mfma_f32_4x4x1f32(hv[i][e], wv[I][i][e], acc[I], 0, 0, 0);
+        }
+        // acc[I][r] = partial of (row 4*rg + r, column 32*I + 4*cg + li)
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][4 * rg + r][32 * I + 4 * cg + li] = acc[I][r];
+        __syncthreads();
+
+        if (cellthr) {
+            const bool active = t < len_b;
+            const long sidx = (((long)dir * T + t) * B + cb_) * H + unit;
+            float pre[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = g * 16 + cu;
+                pre[g] = (((red[0][bl][col] + red[1][bl][col]) + (red[2][bl][col] + red[3][bl][col])) +
+                          ((red[4][bl][col] + red[5][bl][col]) + (red[6][bl][col] + red[7][bl][col]))) + xp[g];
+            }
+            float* yo = y + ((long)t * B + cb_) * 2 * H + dir * H + unit;
+            f32x4* go = (f32x4*)(gates + sidx * 4);
+            float h = 0.f;
+            if (active) {
+                const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
+                const float c = fg * cstate + ig * gg;
+                h = og * tanhf(c);
+                *go = (f32x4){ig, fg, gg, og};
+                cell[sidx] = c;
+                cstate = c;
+            } else {
+                *go = (f32x4){0.f, 0.f, 0.f, 0.f};
+                cell[sidx] = 0.f;
+                cstate = 0.f;
+            }
+            if (step == s1 - 1 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+                h = __uint_as_float(0x7FC00000u);                                        // a hand-off timed out: fail loudly
+            if (local) __hip_atomic_store(yo, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // stays in this XCD's L2
+            else __hip_atomic_store(yo, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                // write-through (sc1)
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): every storing wave drains before the flag
+        __syncthreads();
+        if (tid == 0) {
+            if (local) __hip_atomic_store(cflags + member, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else __hip_atomic_store(cflags + member, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // Gradient of one LSTM cell; shared by the per-step and the persistent backward kernels so both contract the same
 // expressions (the two sweeps are compared bit for bit).  Returns the dc carried to the previous step.
 __device__ __forceinline__ float lstm_cell_grad(float dh, float dcar, float ig, float fg, float gg, float og, float c, float cprev,
@@ -1041,6 +1214,160 @@ __global__ __launch_bounds__(256) void lstm_bwd_kowner(const float* __restrict__
     }
 }
 
+// K-owner backward sweep on 8-row chains ("kowner8").  With 16-row chains a batch of 32 makes only 4 chains = 4 XCDs,
+// and the 1.7 us MFMA phase (the chain's 32 CUs multiplying 16 rows) is the largest piece of a step.  8-row chains fill
+// all 8 XCDs, but v_mfma_f32_16x16x4_f32 would idle half its rows, so this kernel uses v_mfma_f32_4x4x1_16b_f32: 16
+// independent 4x4 outer products per instruction at the same FLOP rate, laid out as 8 unit-groups x 2 row-groups, i.e.
+// 32 units x 8 rows x one k per instruction (probed layout, scripts/mfma4x4_probe.hip: lane 4b+j, register r holds
+// A[4b+r] * B[4b+j]).  An outer product needs one A and one B value per lane per k, four times the operand registers of
+// the 16x16 form, hence 8 waves: wave w keeps W_hh^T for units [64w, 64w+64) x its 64 (gate, unit) rows in 128 VGPRs.
+// Everything else is lstm_bwd_kowner: own dgates from LDS, 512-byte partial blocks per (consumer, producer), 32
+// coalesced dword loads summed in a fixed order.
+template <int NCH>
+__global__ __launch_bounds__(512) void lstm_bwd_kowner8(const float* __restrict__ dy, const float* __restrict__ whht_f,
+                                                        const float* __restrict__ whht_r, const int32_t* __restrict__ lens,
+                                                        const float* __restrict__ gates, const float* __restrict__ cell,
+                                                        float* __restrict__ dgates, float* partials, unsigned* flags, unsigned* ids,
+                                                        unsigned* status, int T, int B, int NT8, int force_wt) {
+    constexpr int H = 128 * NCH;
+    constexpr int members = H / 16;
+    constexpr int NG = H / 32 / 8;                    // 32-unit output groups per wave (2 at H = 512)
+    constexpr int DP = 68;
+    __shared__ float dgl[8 * DP + 4];                 // own dgates [row][gate][local unit] (+ one scratch word)
+    const int chain = blockIdx.x & 7, member = blockIdx.x >> 3;
+    if (chain >= 2 * NT8) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int dir = chain / NT8, bt = chain % NT8, unit0 = member * 16;
+    const int blk = lane >> 2, li = lane & 3, ug = blk >> 1, rg = blk & 1;
+    unsigned* cflags = flags + chain * 32;
+    const bool local = chain_is_xcd_local(ids + chain * 32, members, member, status, (unsigned*)(dgl + 8 * DP)) && !force_wt;
+
+    // resident A operand: aw[g][gate][i][e] = W_hh[gate*H + unit0 + 4i + e][n] = whht[n][gate*H + unit0 + 4i + e],
+    // n = 32*(wave*NG + g) + 4*ug + li
+    f32x4 aw[NG][4][4];
+    {
+        const float* whht = dir ? whht_r : whht_f;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int n = 32 * (wave * NG + g) + 4 * ug + li;
+#pragma unroll
+            for (int gate = 0; gate < 4; ++gate) {
+                const f32x4* wp = (const f32x4*)(whht + (long)n * 4 * H + gate * H + unit0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) aw[g][gate][i] = wp[i];
+            }
+        }
+    }
+    const int b0 = bt * 8;
+    const bool cellw = tid < 128;                     // waves 0-1: one cell (row, unit) per thread
+    const int eb = b0 + ((tid >> 4) & 7), ej = tid & 15, eunit = unit0 + ej;
+    const bool ev = cellw && eb < B;
+    const int ebs = eb < B ? eb : b0;
+    const int len = lens[ebs];
+    float dcar = 0.f;
+    bool timed_out = false;
+    const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc((void*)partials, 0, 2 * 8 * 32 * 32 * 128 * 4, 0x00020000);
+
+    for (int step = 0; step < T; ++step) {
+        const int t = dir == 0 ? T - 1 - step : step;
+        const bool act = ev && t < len;
+        float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, c = 0.f, cprev = 0.f, dyv = 0.f;
+        if (act) {
+            const long sidx = (((long)dir * T + t) * B + ebs) * H + eunit;
+            const f32x4 gv = *(const f32x4*)(gates + sidx * 4);
+            ig = gv[0];
+            fg = gv[1];
+            gg = gv[2];
+            og = gv[3];
+            c = cell[sidx];
+            const int tp = dir == 0 ? t - 1 : t + 1;
+            cprev = (tp >= 0 && tp < len) ? cell[(((long)dir * T + tp) * B + ebs) * H + eunit] : 0.f;
+            dyv = dy[((long)t * B + ebs) * 2 * H + dir * H + eunit];
+        }
+        float rs = 0.f;
+        if (step > 0) {
+            if (wave == 7 && !timed_out) {
+                unsigned spins = 0;
+                for (;;) {
+                    unsigned f0 = (unsigned)step;
+                    if (lane < members) f0 = __hip_atomic_load(cflags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__all(f0 >= (unsigned)step)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 22)) {
+                        if (lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        timed_out = true;
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            if (cellw) {
+                // this workgroup's block of every member's partials of the previous step: [member m][row][unit]
+                const int pbase = (((((step - 1) & 1) * 8 + chain) * 32 + member) * 32 * 128 + tid) * 4;
+                float pv[members];
+#pragma unroll
+                for (int m = 0; m < members; ++m) pv[m] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(prsrc, pbase + m * 512, 0, 16));   // sc1
+#pragma unroll
+                for (int m = 0; m < members; ++m) rs += pv[m];
+            }
+        }
+        if (cellw) {
+            float dg[4] = {0.f, 0.f, 0.f, 0.f};
+            if (act) dcar = lstm_cell_grad(dyv + rs, dcar, ig, fg, gg, og, c, cprev, dg);
+            else dcar = 0.f;
+            if (step == T - 1 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+                dg[0] = dg[1] = dg[2] = dg[3] = __uint_as_float(0x7FC00000u);        // a hand-off timed out: fail loudly
+            if (ev) {
+                const long gbase = (((long)dir * T + t) * B + eb) * 4 * H + eunit;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) dgates[gbase + (long)g * H] = dg[g];     // for the weight/input-gradient GEMMs: plain stores
+            }
+            if (step + 1 < T) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) dgl[(tid >> 4) * DP + g * 16 + ej] = dg[g];
+            }
+        }
+        if (step + 1 < T) {
+            __syncthreads();
+            // B operand: own dgates of row 4*rg + li, all 64 (gate, unit) values
+            f32x4 bv[4][4];
+#pragma unroll
+            for (int gate = 0; gate < 4; ++gate)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bv[gate][i] = *(const f32x4*)&dgl[(4 * rg + li) * DP + gate * 16 + 4 * i];
+            f32x4 acc[NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int gate = 0; gate < 4; ++gate)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int g = 0; g < NG; ++g)
+                            acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(aw[g][gate][i][e], bv[gate][i][e], acc[g], 0, 0, 0);
+            // acc[g][r] = partial of (unit 32*(wave*NG+g) + 4*ug + r, row 4*rg + li): 4 consecutive units of one row
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                u32x4_t raw;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) raw[e] = __float_as_uint(acc[g][e]);
+                const int cons = 2 * (wave * NG + g) + (ug >> 2);
+                const int soff = ((((((step & 1) * 8 + chain) * 32 + cons) * 32 + member) * 8 + 4 * rg + li) * 16 + 4 * (ug & 3)) * 4;
+                if (local) __builtin_amdgcn_raw_buffer_store_b128(raw, prsrc, soff, 0, 1);        // sc0: stays in this XCD's L2
+                else __builtin_amdgcn_raw_buffer_store_b128(raw, prsrc, soff, 0, 16);            // write-through (sc1), 16 B
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): every storing wave drains before the flag
+        }
+        __syncthreads();                                     // also: dgl is free for the next step
+        if (tid == 0) {
+            if (local) __hip_atomic_store(cflags + member, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else __hip_atomic_store(cflags + member, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 template <int KQ4>
 bool launch_fwd_fast(int rt, dim3 grid, hipStream_t s, const float* xproj, const float* wf, const float* wr, const int32_t* lens,
                      float* y, float* gates, float* cell, int T, int B, int step) {
@@ -1104,6 +1431,13 @@ extern "C" int vocr_lstm_fwd_range(const float* xproj, const float* whh_fwd, con
         }
         const dim3 cg(8 * (h / 16));
         const int fwt = (persistent_mode & 8) ? 1 : 0;       // experiments: write-through hand-off even on one XCD
+        const int nt8 = (b + 7) / 8;
+        if (2 * nt8 <= 8 && !(persistent_mode & 32) && h == 512) {      // 8-row chains on all 8 XCDs, 4x4x1 MFMA
+            lstm_fwd_chain8<8><<<cg, 512, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, flags, flags + 256, status, t, b, nt8, fwt,
+                                                  step_begin, step_end);
+            VOCR_CHECK_LAUNCH("vocr_lstm_fwd(chain, 8-row)");
+            return VOCR_OK;
+        }
 #define VOCR_CHAIN(KQ4) lstm_fwd_chain<KQ4><<<cg, 256, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, flags, flags + 256, status, t, b, rt, fwt, step_begin, step_end)
         if (h == 64) VOCR_CHAIN(1); else if (h == 128) VOCR_CHAIN(2); else if (h == 256) VOCR_CHAIN(4); else VOCR_CHAIN(8);
 #undef VOCR_CHAIN
@@ -1172,6 +1506,13 @@ extern "C" int vocr_lstm_bwd(const float* dy, const float* whht_fwd, const float
         if (!(persistent_mode & 16)) {
             // K-owner form: partial sums [parity][chain][consumer][producer][16 x 16] behind the flags/status words
             float* partials = (float*)((char*)workspace + 4096);
+            const int nt8 = (b + 7) / 8;
+            if (2 * nt8 <= 8 && !(persistent_mode & 32) && h == 512) {      // 8-row chains on all 8 XCDs, 4x4x1 MFMA
+                const int fwt8 = (persistent_mode & 8) ? 1 : 0;
+                lstm_bwd_kowner8<4><<<g, 512, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, t, b, nt8, fwt8);
+                VOCR_CHECK_LAUNCH("vocr_lstm_bwd(k-owner, 8-row chains)");
+                return VOCR_OK;
+            }
             const int fwt = (persistent_mode & 8) ? 1 : 0;       // experiments: write-through hand-off even on one XCD
             if (h == 128) lstm_bwd_kowner<1><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, t, b, rt, fwt);
             else if (h == 256) lstm_bwd_kowner<2><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, t, b, rt, fwt);
