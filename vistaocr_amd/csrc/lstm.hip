@@ -1432,9 +1432,13 @@ extern "C" int vocr_lstm_fwd_range(const float* xproj, const float* whh_fwd, con
         const dim3 cg(8 * (h / 16));
         const int fwt = (persistent_mode & 8) ? 1 : 0;       // experiments: write-through hand-off even on one XCD
         const int nt8 = (b + 7) / 8;
-        if (2 * nt8 <= 8 && !(persistent_mode & 32) && h == 512) {      // 8-row chains on all 8 XCDs, 4x4x1 MFMA
-            lstm_fwd_chain8<8><<<cg, 512, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, flags, flags + 256, status, t, b, nt8, fwt,
-                                                  step_begin, step_end);
+        if (2 * nt8 <= 8 && !(persistent_mode & 32) && (h == 512 || h == 256)) {      // 8-row chains on all 8 XCDs, 4x4x1 MFMA
+            if (h == 512)
+                lstm_fwd_chain8<8><<<cg, 512, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, flags, flags + 256, status, t, b, nt8, fwt,
+                                                      step_begin, step_end);
+            else
+                lstm_fwd_chain8<4><<<cg, 512, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, flags, flags + 256, status, t, b, nt8, fwt,
+                                                      step_begin, step_end);
             VOCR_CHECK_LAUNCH("vocr_lstm_fwd(chain, 8-row)");
             return VOCR_OK;
         }
@@ -1507,9 +1511,12 @@ extern "C" int vocr_lstm_bwd(const float* dy, const float* whht_fwd, const float
             // K-owner form: partial sums [parity][chain][consumer][producer][16 x 16] behind the flags/status words
             float* partials = (float*)((char*)workspace + 4096);
             const int nt8 = (b + 7) / 8;
-            if (2 * nt8 <= 8 && !(persistent_mode & 32) && h == 512) {      // 8-row chains on all 8 XCDs, 4x4x1 MFMA
+            if (2 * nt8 <= 8 && !(persistent_mode & 32) && (h == 512 || h == 256)) {      // 8-row chains on all 8 XCDs, 4x4x1 MFMA
                 const int fwt8 = (persistent_mode & 8) ? 1 : 0;
-                lstm_bwd_kowner8<4><<<g, 512, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, t, b, nt8, fwt8);
+                if (h == 512)
+                    lstm_bwd_kowner8<4><<<g, 512, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, t, b, nt8, fwt8);
+                else
+                    lstm_bwd_kowner8<2><<<g, 512, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, t, b, nt8, fwt8);
                 VOCR_CHECK_LAUNCH("vocr_lstm_bwd(k-owner, 8-row chains)");
                 return VOCR_OK;
             }
