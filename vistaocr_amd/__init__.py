@@ -6,6 +6,7 @@ from .ctc import CTCLoss                                                        
 from .decoder import ArgmaxDecoder                                                      # noqa: F401
 from .model import CnnOcrModel                                                          # noqa: F401
 from .train import FlatClampAdam, make_optimizer, train, train_async                                    # noqa: F401
+from .dataset import OcrDataset                                                         # noqa: F401
 
 __all__ = ["Alphabet", "english_alphabet", "arabic_alphabet", "french_alphabet", "CTCLoss", "ArgmaxDecoder",
-           "CnnOcrModel", "FlatClampAdam", "make_optimizer", "train", "train_async"]
+           "CnnOcrModel", "FlatClampAdam", "make_optimizer", "train", "train_async", "OcrDataset"]

@@ -1,0 +1,218 @@
+"""Line-image dataset reader and host-side image transforms.
+
+Restates the behaviour of the reference's `OcrDataset` (src/ocr_dataset.py:16-209) and of the three transforms the
+reference's drivers compose for this path, `Scale(new_h=...)` -> `InvertBlackWhite()` -> `ToTensor()`
+(src/imagetransforms.py:383-385,423-434,453-492; composed at src/decode_testset.py:48-65 and
+src/train_cnn_lstm.py:215-243).  Host code only: it produces the `(image[C,H,W] float, label indices, metadata)`
+items that `loop.SortByWidthCollater` batches for `CnnOcrModel`.
+
+What is NOT pinned here: the reference decodes the LMDB payload with `cv2.imdecode` and rescales with `cv2.resize`
+(INTER_CUBIC); neither `cv2` nor `lmdb` exists in the build image, so
+  * `LmdbImageStore` imports both lazily and fails loudly without them;
+  * `NpyDirImageStore` (one decoded `<id>.npy` array per line) is the store the tests use;
+  * `Scale` calls `cv2.resize` when OpenCV is importable and otherwise a numpy bicubic with OpenCV's conventions
+    (a = -0.75, half-pixel centres, replicated border) whose rounding has not been compared with OpenCV's:
+    "parity unpinned" for the rescale.  Images already at the model's line height never touch that code.
+"""
+import json
+import os
+
+import numpy as np
+import torch
+
+from .alphabet import Alphabet
+
+SIZE_GROUP_LIMITS = [150, 200, 300, 350, 450, 600, np.inf]      # src/ocr_dataset.py:59
+
+
+# ----------------------------------------------------------------------------------------------- image stores
+class NpyDirImageStore:
+    """`<dir>/<id>.npy`: the decoded pixels of one line (uint8, H x W or H x W x C)."""
+
+    def __init__(self, directory):
+        self.directory = directory
+
+    def get(self, utt_id):
+        return np.load(os.path.join(self.directory, utt_id + ".npy"))
+
+
+class LmdbImageStore:
+    """`line-images.lmdb`: key = utterance id (ASCII) -> encoded image bytes (src/ocr_dataset.py:42-46,156-157)."""
+
+    def __init__(self, path):
+        try:
+            import cv2          # noqa: F401
+            import lmdb
+        except ImportError as e:            # pragma: no cover - neither module exists in the build image
+            raise ImportError("LmdbImageStore needs the `lmdb` and `cv2` modules (%s); use NpyDirImageStore or pass "
+                              "your own object with a get(id) -> ndarray method" % e)
+        self._env = lmdb.Environment(path, map_size=int(1e12), readonly=True, lock=False)
+        self._txn = self._env.begin(buffers=True)
+
+    def get(self, utt_id):                  # pragma: no cover
+        import cv2
+        return cv2.imdecode(np.asarray(self._txn.get(utt_id.encode("ascii")), dtype=np.uint8), -1)
+
+
+# ------------------------------------------------------------------------------------------------- transforms
+class Compose:
+    def __init__(self, transforms):
+        self.transforms = list(transforms)
+
+    def __call__(self, img):
+        for t in self.transforms:
+            img = t(img)
+        return img
+
+
+def _cubic_weights(frac, a=-0.75):
+    """OpenCV's bicubic kernel taps for sample offsets -1, 0, 1, 2 around a source position with fraction `frac`."""
+    x = np.stack([frac + 1.0, frac, 1.0 - frac, 2.0 - frac], axis=-1)
+    w = np.where(x <= 1.0, ((a + 2.0) * x - (a + 3.0)) * x * x + 1.0, ((a * x - 5.0 * a) * x + 8.0 * a) * x - 4.0 * a)
+    return w
+
+
+def _resize_bicubic(img, new_w, new_h):
+    src = img.astype(np.float64)
+    h, w = src.shape[:2]
+
+    def taps(n_out, n_in):
+        pos = (np.arange(n_out) + 0.5) * (n_in / n_out) - 0.5
+        base = np.floor(pos).astype(np.int64)
+        idx = np.clip(base[:, None] + np.arange(-1, 3)[None, :], 0, n_in - 1)
+        return idx, _cubic_weights(pos - base)
+
+    iy, wy = taps(new_h, h)
+    ix, wx = taps(new_w, w)
+    rows = (src[iy] * wy.reshape(wy.shape + (1,) * (src.ndim - 1))).sum(axis=1)            # [new_h, w, ...]
+    cols = np.moveaxis(rows, 1, 0)[ix]                                                      # [new_w, 4, new_h, ...]
+    out = (cols * wx.reshape(wx.shape + (1,) * (cols.ndim - 2))).sum(axis=1)               # [new_w, new_h, ...]
+    out = np.moveaxis(out, 0, 1)
+    if img.dtype == np.uint8:
+        out = np.clip(np.rint(out), 0, 255).astype(np.uint8)
+    return out
+
+
+class Scale:
+    """src/imagetransforms.py:453-492, the `new_h` / `new_w` form: the other side follows the aspect ratio with the
+    reference's truncation `int(w * float(new_h / h))`; a non-positive result falls back to width 1."""
+
+    def __init__(self, new_h=None, new_w=None, preserve_aspect_ratio=True):
+        assert isinstance(new_h, int) or isinstance(new_w, int)
+        self.new_h, self.new_w, self.preserve_aspect_ratio = new_h, new_w, preserve_aspect_ratio
+
+    def target_size(self, h, w):
+        nh, nw = self.new_h or h, self.new_w or w
+        if self.preserve_aspect_ratio and self.new_h is None:
+            nh = int(h * float(self.new_w / w))
+        if self.preserve_aspect_ratio and self.new_w is None:
+            nw = int(w * float(self.new_h / h))
+        if nw <= 0 or nh <= 0:
+            nw = 1
+        return nh, nw
+
+    def __call__(self, img):
+        h, w = img.shape[:2]
+        nh, nw = self.target_size(h, w)
+        if (nh, nw) == (h, w):
+            return img
+        try:
+            import cv2
+            return cv2.resize(img, (nw, nh), cv2.INTER_CUBIC)          # pragma: no cover - cv2 absent in the build image
+        except ImportError:
+            return _resize_bicubic(img, nw, max(nh, 1))
+
+
+class InvertBlackWhite:
+    """src/imagetransforms.py:383-385: `-img + 255`, which is 255 - img also in uint8 wrap-around arithmetic."""
+
+    def __call__(self, img):
+        return -img + 255
+
+
+class ToTensor:
+    """src/imagetransforms.py:423-434: H x W (x C) in [0, 255] -> float tensor C x H x W in [0, 1]."""
+
+    def __call__(self, pic):
+        if pic.ndim == 2:
+            h, w = pic.shape
+            return torch.from_numpy(np.ascontiguousarray(pic)).view(1, h, w).float().div(255)
+        return torch.from_numpy(np.ascontiguousarray(pic.transpose((2, 0, 1)))).float().div(255)
+
+
+def decode_transforms(line_height, num_in_channels=1):
+    """The inference-time pipeline of src/decode_testset.py:48-65 for a model's line height."""
+    del num_in_channels          # the grey/colour conversion steps of the reference need cv2; images are used as stored
+    return Compose([Scale(new_h=line_height), InvertBlackWhite(), ToTensor()])
+
+
+# ---------------------------------------------------------------------------------------------------- dataset
+class OcrDataset(torch.utils.data.Dataset):
+    """`desc.json` {train, validation, test: [{id, trans, width, height?, writer?}]} + an image store.
+
+    Same public attributes as the reference (`alphabet`, `size_group_limits`, `size_group_keys`, `size_groups`,
+    `size_groups_dict`, `writer_id_map`, `nentries`, `max_index`) so `loop.GroupedSampler` and the training shell
+    work on it unchanged; `__getitem__` returns `(image, label indices, metadata)` exactly like the reference."""
+
+    def __init__(self, data_dir, split, transforms, alphabet=None, image_store=None, max_allowed_width=1200):
+        self.max_allowed_width = max_allowed_width
+        self.data_dir, self.split, self.preprocess = data_dir, split, transforms
+        with open(os.path.join(data_dir, "desc.json"), "r") as fh:
+            self.data_desc = json.load(fh)
+        self.alphabet = alphabet if alphabet is not None else self._infer_alphabet()
+        if image_store is None:
+            npy_dir = os.path.join(data_dir, "line-images")
+            image_store = NpyDirImageStore(npy_dir) if os.path.isdir(npy_dir) else LmdbImageStore(
+                os.path.join(data_dir, "line-images.lmdb"))
+        self.images = image_store
+
+        # width groups at a nominal 30-px line height (src/ocr_dataset.py:59-96): an entry joins the first group whose
+        # limit exceeds its normalised width, provided it is under max_allowed_width; wider lines are dropped
+        self.size_group_limits = list(SIZE_GROUP_LIMITS)
+        self.size_group_keys = self.size_group_limits
+        self.size_groups = {k: [] for k in self.size_group_limits}
+        self.size_groups_dict = {k: dict() for k in self.size_group_limits}
+        self.writer_id_map = dict()
+        for idx, entry in enumerate(self.data_desc[self.split]):
+            if "writer" in entry and entry["writer"] not in self.writer_id_map:
+                self.writer_id_map[entry["writer"]] = len(self.writer_id_map)
+            if "height" in entry and "width" in entry:
+                normalized_width = entry["width"] * (30 / entry["height"])
+            elif "width" in entry:
+                normalized_width = entry["width"]
+            else:
+                raise Exception("Json entry must list width & height of image.")
+            for limit in self.size_group_limits:
+                if normalized_width < limit and normalized_width < self.max_allowed_width:
+                    self.size_groups[limit].append(idx)
+                    self.size_groups_dict[limit][idx] = 1
+                    break
+        self.nentries = sum(len(v) for v in self.size_groups.values())
+        self.max_index = max([max(v) for v in self.size_groups.values() if v], default=0)
+
+    def _infer_alphabet(self):
+        """src/ocr_dataset.py:109-120: CTC blank first, then every token of every split's transcriptions, sorted."""
+        unique = set()
+        for split in ("train", "validation", "test"):
+            for entry in self.data_desc.get(split, []):
+                unique.update(entry["trans"].split())
+        return Alphabet(["<ctc-blank>", *sorted(unique)])
+
+    def __getitem__(self, index):
+        entry = self.data_desc[self.split][index]
+        img = self.images.get(entry["id"])
+        if img.ndim == 3 and img.shape[2] == 4:          # RGBA: drop alpha (src/ocr_dataset.py:164-166)
+            img = img[:, :, :3]
+        line_image = self.preprocess(img)
+        if line_image.size(2) < 15:                      # narrower than the CNN can take: pad to 15 px with ONES (:173-176)
+            padded = torch.ones(line_image.size(0), line_image.size(1), 15)
+            padded[:, :, :line_image.size(2)] = line_image
+            line_image = padded
+        metadata = {"utt-id": entry["id"], "width": line_image.size(2)}
+        if "writer" in entry:
+            metadata["writer-id"] = self.writer_id_map[entry["writer"]]
+        transcription = [self.alphabet.char_to_idx[ch] for ch in entry["trans"].split()]
+        return line_image, transcription, metadata
+
+    def __len__(self):
+        return self.nentries
