@@ -272,7 +272,7 @@ class FracPoolFn(torch.autograd.Function):
         (idx,) = ctx.saved_tensors
         n, c, h, w, oh, ow = ctx.shape
         dout = _f32c(dout)
-        dx = torch.zeros(n, c, h, w, dtype=torch.float32, device=dout.device)
+        dx = torch.empty(n, c, h, w, dtype=torch.float32, device=dout.device)       # fully written by the kernel
         call("vocr_fracpool2x2_bwd", _p(dout), _p(idx), _p(dx), n, c, h, w, oh, ow, _stream())
         return dx, None, None, None
 
