@@ -131,6 +131,10 @@ int vocr_lstm_fwd_range(const float* xproj, const float* whh_fwd, const float* w
  * whht_* are the TRANSPOSED recurrent weights [H][4H] (vocr_bchw_to_wbch with b=1 transposes a matrix). */
 int vocr_lstm_bwd(const float* dy, const float* whht_fwd, const float* whht_rev, const int32_t* lens, const float* gates,
                   const float* cell, float* dgates, void* workspace, int t, int b, int h, void* stream);
+/* Same, and dbias[dir][4H] = sum over (t, b) of dgates[dir] (the gradient of b_ih and of b_hh): accumulated inside the
+ * sweep where the kernel supports it, else by column sums afterwards.  dbias may be NULL. */
+int vocr_lstm_bwd_bias(const float* dy, const float* whht_fwd, const float* whht_rev, const int32_t* lens, const float* gates,
+                       const float* cell, float* dgates, float* dbias, void* workspace, int t, int b, int h, void* stream);
 
 /* ---- CTC: warpctc_pytorch.CTCLoss — src/train_cnn_lstm.py:358,138 ------------------------------------------ */
 /* logits[T][B][V] pre-softmax, blank = 0.  labels flat int32 (device), label_offsets[B], label_lens[B],

@@ -297,6 +297,35 @@ def test_persistent_sweeps_match_per_step_launches(dev, T, B, H):
             assert torch.equal(a, b), "%s (mode %s) differs: max |diff| %.3e at %d of %d" % (nm, mode, float((a - b).abs().max()), int((a != b).sum()), a.numel())
 
 
+@pytest.mark.parametrize("T,B,H", [(33, 32, 512), (21, 27, 256), (12, 40, 256), (17, 9, 128)])
+def test_lstm_backward_bias_gradient_is_the_column_sum_of_dgates(dev, T, B, H):
+    """vocr_lstm_bwd_bias: dbias[dir] accumulated inside the sweep (8-row K-owner kernel) or by column sums (other paths)."""
+    from vistaocr_amd import _lib, ops
+    from vistaocr_amd._lib import call
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(2)
+    xp = (torch.rand(2, T * B, 4 * H, generator=g) - 0.5).to(dev)
+    wf = ((torch.rand(4 * H, H, generator=g) - 0.5) * 0.3).to(dev)
+    wr = ((torch.rand(4 * H, H, generator=g) - 0.5) * 0.3).to(dev)
+    dy = (torch.rand(T * B, 2 * H, generator=g) - 0.5).to(dev)
+    lens = torch.tensor(sorted([max(1, T - 2 * i) for i in range(B)], reverse=True), dtype=torch.int32, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    y = torch.empty(T * B, 2 * H, device=dev)
+    gt = torch.empty(2, T * B, 4 * H, device=dev)
+    c = torch.empty(2, T * B, H, device=dev)
+    dg = torch.empty(2, T * B, 4 * H, device=dev)
+    db = torch.full((2, 4 * H), float("nan"), device=dev)
+    ws = torch.zeros(lib.vocr_lstm_workspace_bytes(T, B, H) // 4 + 16, device=dev)
+    call("vocr_lstm_fwd", xp.data_ptr(), wf.data_ptr(), wr.data_ptr(), lens.data_ptr(), y.data_ptr(), gt.data_ptr(), c.data_ptr(),
+         ws.data_ptr(), T, B, H, s)
+    wtf, wtr = ops.transpose2d(wf), ops.transpose2d(wr)
+    call("vocr_lstm_bwd_bias", dy.data_ptr(), wtf.data_ptr(), wtr.data_ptr(), lens.data_ptr(), gt.data_ptr(), c.data_ptr(),
+         dg.data_ptr(), db.data_ptr(), ws.data_ptr(), T, B, H, s)
+    torch.cuda.synchronize()
+    ref = dg.double().sum(dim=1)
+    assert float((db.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-6       # fp32 summation-order tolerance
+
+
 @pytest.mark.parametrize("T,B,H,cut", [(40, 20, 128, 20), (33, 32, 512, 7), (12, 40, 256, 11), (25, 5, 64, 12), (21, 27, 256, 9)])
 def test_lstm_forward_step_ranges_resume_bit_exactly(dev, T, B, H, cut):
     """vocr_lstm_fwd_range: steps [0, cut) then [cut, T) leave exactly what one whole sweep leaves (y, gates, cell)."""

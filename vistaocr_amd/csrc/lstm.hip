@@ -1228,7 +1228,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_kowner8(const float* __restrict_
                                                         const float* __restrict__ whht_r, const int32_t* __restrict__ lens,
                                                         const float* __restrict__ gates, const float* __restrict__ cell,
                                                         float* __restrict__ dgates, float* partials, unsigned* flags, unsigned* ids,
-                                                        unsigned* status, int T, int B, int NT8, int force_wt) {
+                                                        unsigned* status, float* bias_part, int T, int B, int NT8, int force_wt) {
     constexpr int H = 128 * NCH;
     constexpr int members = H / 16;
     constexpr int NG = H / 32 / 8;                    // 32-unit output groups per wave (2 at H = 512)
@@ -1265,6 +1265,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_kowner8(const float* __restrict_
     const int ebs = eb < B ? eb : b0;
     const int len = lens[ebs];
     float dcar = 0.f;
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};               // this cell's share of the bias gradient: sum of its dgates over time
     bool timed_out = false;
     const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc((void*)partials, 0, 2 * 8 * 32 * 32 * 128 * 4, 0x00020000);
 
@@ -1320,7 +1321,10 @@ __global__ __launch_bounds__(512) void lstm_bwd_kowner8(const float* __restrict_
             if (ev) {
                 const long gbase = (((long)dir * T + t) * B + eb) * 4 * H + eunit;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) dgates[gbase + (long)g * H] = dg[g];     // for the weight/input-gradient GEMMs: plain stores
+                for (int g = 0; g < 4; ++g) {
+                    dgates[gbase + (long)g * H] = dg[g];     // for the weight/input-gradient GEMMs: plain stores
+                    bs[g] += dg[g];
+                }
             }
             if (step + 1 < T) {
 #pragma unroll
@@ -1366,6 +1370,30 @@ __global__ __launch_bounds__(512) void lstm_bwd_kowner8(const float* __restrict_
             else __hip_atomic_store(cflags + member, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    // bias gradient of this chain's rows: sum the 8 rows in a fixed order -> bias_part[chain][gate*H + unit]
+    if (bias_part) {
+        if (cellw) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dgl[(tid >> 4) * DP + g * 16 + ej] = bs[g];
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int g = tid >> 4, u = tid & 15;
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v += dgl[r * DP + g * 16 + u];
+            bias_part[(long)chain * 4 * H + g * H + unit0 + u] = v;
+        }
+    }
+}
+
+// dbias[dir][j] = sum over the direction's batch-tile chains, fixed order
+__global__ void lstm_bias_combine_kernel(const float* __restrict__ part, float* __restrict__ dbias, int G, int nt) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, dir = blockIdx.y;
+    if (j >= G) return;
+    float v = 0.f;
+    for (int c = 0; c < nt; ++c) v += part[(long)(dir * nt + c) * G + j];
+    dbias[(long)dir * G + j] = v;
 }
 
 template <int KQ4>
@@ -1403,7 +1431,8 @@ extern "C" size_t vocr_lstm_workspace_bytes(int t, int b, int h) {
     if (t <= 0 || b <= 0 || h <= 0) return 0;
     // dc carry [2][B][H] (+ spare); 4 KiB of arrival flags / status; 16 MiB of partial-sum blocks for the backward chain
     // sweep (2 parities x 8 chains x 32 consumers x 32 producers x 1 KiB)
-    return (size_t)6 * 2 * b * h * sizeof(float) + 4096 + ((size_t)16 << 20);
+    // + per-chain bias-gradient rows [8][4H]
+    return (size_t)6 * 2 * b * h * sizeof(float) + 4096 + ((size_t)16 << 20) + (size_t)8 * 4 * h * sizeof(float);
 }
 
 extern "C" int vocr_lstm_fwd_range(const float* xproj, const float* whh_fwd, const float* whh_rev, const int32_t* lens, float* y,
@@ -1486,9 +1515,27 @@ extern "C" int vocr_lstm_fwd(const float* xproj, const float* whh_fwd, const flo
     return vocr_lstm_fwd_range(xproj, whh_fwd, whh_rev, lens, y, gates, cell, workspace, t, b, h, 0, t, stream);
 }
 
+extern "C" int vocr_colsum(const float* x, float* out, int m, int n, void* stream);
+
 extern "C" int vocr_lstm_bwd(const float* dy, const float* whht_fwd, const float* whht_rev, const int32_t* lens,
                              const float* gates, const float* cell, float* dgates, void* workspace, int t, int b, int h,
                              void* stream) {
+    return vocr_lstm_bwd_bias(dy, whht_fwd, whht_rev, lens, gates, cell, dgates, nullptr, workspace, t, b, h, stream);
+}
+
+// every path but the 8-row K-owner kernel: bias gradient = column sums of the finished dgates
+static int lstm_bias_by_colsum(const float* dgates, float* dbias, int t, int b, int h, void* stream) {
+    if (!dbias) return VOCR_OK;
+    for (int dir = 0; dir < 2; ++dir) {
+        const int rc = vocr_colsum(dgates + (size_t)dir * t * b * 4 * h, dbias + (size_t)dir * 4 * h, t * b, 4 * h, stream);
+        if (rc != VOCR_OK) return rc;
+    }
+    return VOCR_OK;
+}
+
+extern "C" int vocr_lstm_bwd_bias(const float* dy, const float* whht_fwd, const float* whht_rev, const int32_t* lens,
+                                  const float* gates, const float* cell, float* dgates, float* dbias, void* workspace, int t,
+                                  int b, int h, void* stream) {
     const float* whh_fwd = whht_fwd;
     const float* whh_rev = whht_rev;
     VOCR_CHECK_ARG(dy && whh_fwd && whh_rev && lens && gates && cell && dgates && workspace, "vocr_lstm_bwd: null pointer");
@@ -1513,11 +1560,16 @@ extern "C" int vocr_lstm_bwd(const float* dy, const float* whht_fwd, const float
             const int nt8 = (b + 7) / 8;
             if (2 * nt8 <= 8 && !(persistent_mode & 32) && (h == 512 || h == 256)) {      // 8-row chains on all 8 XCDs, 4x4x1 MFMA
                 const int fwt8 = (persistent_mode & 8) ? 1 : 0;
+                float* bpart = dbias ? (float*)((char*)workspace + 4096 + ((size_t)16 << 20)) : nullptr;     // [chain][4H]
                 if (h == 512)
-                    lstm_bwd_kowner8<4><<<g, 512, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, t, b, nt8, fwt8);
+                    lstm_bwd_kowner8<4><<<g, 512, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, bpart, t, b, nt8, fwt8);
                 else
-                    lstm_bwd_kowner8<2><<<g, 512, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, t, b, nt8, fwt8);
+                    lstm_bwd_kowner8<2><<<g, 512, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, bpart, t, b, nt8, fwt8);
                 VOCR_CHECK_LAUNCH("vocr_lstm_bwd(k-owner, 8-row chains)");
+                if (dbias) {
+                    lstm_bias_combine_kernel<<<dim3(vocr_cdiv(4 * h, 256), 2), 256, 0, s>>>(bpart, dbias, 4 * h, nt8);
+                    VOCR_CHECK_LAUNCH("vocr_lstm_bwd(bias combine)");
+                }
                 return VOCR_OK;
             }
             const int fwt = (persistent_mode & 8) ? 1 : 0;       // experiments: write-through hand-off even on one XCD
@@ -1525,13 +1577,13 @@ extern "C" int vocr_lstm_bwd(const float* dy, const float* whht_fwd, const float
             else if (h == 256) lstm_bwd_kowner<2><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, t, b, rt, fwt);
             else lstm_bwd_kowner<4><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, t, b, rt, fwt);
             VOCR_CHECK_LAUNCH("vocr_lstm_bwd(k-owner)");
-            return VOCR_OK;
+            return lstm_bias_by_colsum(dgates, dbias, t, b, h, stream);
         }
         if (h == 128) lstm_bwd_persistent<1><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, flags, status, t, b, rt);
         else if (h == 256) lstm_bwd_persistent<2><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, flags, status, t, b, rt);
         else lstm_bwd_persistent<4><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, flags, status, t, b, rt);
         VOCR_CHECK_LAUNCH("vocr_lstm_bwd(persistent)");
-        return VOCR_OK;
+        return lstm_bias_by_colsum(dgates, dbias, t, b, h, stream);
     }
     for (int step = 0; step < t; ++step) {
         if (fast) {
@@ -1548,5 +1600,5 @@ extern "C" int vocr_lstm_bwd(const float* dy, const float* whht_fwd, const float
         }
     }
     VOCR_CHECK_LAUNCH("vocr_lstm_bwd");
-    return VOCR_OK;
+    return lstm_bias_by_colsum(dgates, dbias, t, b, h, stream);
 }

@@ -469,8 +469,9 @@ class BiLstmLayerFn(torch.autograd.Function):
         dg = torch.empty(2, T * B, 4 * H, dtype=torch.float32, device=dev)
         ws = _ws(lib.vocr_lstm_workspace_bytes(T, B, H), dev)
         wt_f, wt_r = transpose2d(w_hh_f), transpose2d(w_hh_r)            # [H][4H]: contiguous B operand for the sweep
-        call("vocr_lstm_bwd", _p(dy), _p(wt_f), _p(wt_r), _p(lens_dev), _p(gates), _p(cell), _p(dg), _p(ws), T, B, H,
-             _stream())
+        dbias = torch.empty(2, 4 * H, dtype=torch.float32, device=dev)          # gradient of b_ih (= of b_hh), both directions
+        call("vocr_lstm_bwd_bias", _p(dy), _p(wt_f), _p(wt_r), _p(lens_dev), _p(gates), _p(cell), _p(dg), _p(dbias), _p(ws),
+             T, B, H, _stream())
         G = 4 * H
         # critical path first: dx feeds the layer below
         dx = None
@@ -498,15 +499,15 @@ class BiLstmLayerFn(torch.autograd.Function):
             else:
                 dwh_f.zero_()
                 dwh_r.zero_()
-            call("vocr_colsum", _p(dg[0]), _p(dbi_f), T * B, G, _stream())
-            call("vocr_colsum", _p(dg[1]), _p(dbi_r), T * B, G, _stream())
-            dbh_f.copy_(dbi_f)
-            dbh_r.copy_(dbi_r)
+            dbi_f.copy_(dbias[0])
+            dbi_r.copy_(dbias[1])
+            dbh_f.copy_(dbias[0])
+            dbh_r.copy_(dbias[1])
 
         if direct and _SIDE["enabled"]:
             side = side_stream()
             side.wait_stream(torch.cuda.current_stream())
-            for t_ in (dg, x, y):
+            for t_ in (dg, x, y, dbias):
                 t_.record_stream(side)
             with torch.cuda.stream(side):
                 weight_grads(sinks)
