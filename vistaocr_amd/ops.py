@@ -193,7 +193,18 @@ class ConvBnReluFn(torch.autograd.Function):
             join_side_stream()          # first layer = last backward op: everything issued on the side stream is done after this
         call("vocr_bn_relu_bwd", _p(da), _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(dy), _p(dgamma), _p(dbeta),
              _p(dbias), n, cout, h * w, _p(ws), _stream())
-        dw = conv3x3_wgrad(x, dy, out=dw, f16=ctx.f16)
+        if sinks is not None and _SIDE["enabled"] and ctx.needs_input_grad[0] and _os.environ.get("VOCR_CONV_OVERLAP", "1") == "1":
+            # weight gradient (off the critical path, written straight into the optimiser's buffer) on the low-priority side
+            # stream beside the data gradient: each kernel's last partial round of workgroups is filled by the other's
+            side = side_stream()
+            side.wait_stream(torch.cuda.current_stream())
+            for t_ in (x, dy):
+                t_.record_stream(side)
+            with torch.cuda.stream(side):
+                conv3x3_wgrad(x, dy, out=dw, f16=ctx.f16)
+            _SIDE["pending"] = True
+        else:
+            dw = conv3x3_wgrad(x, dy, out=dw, f16=ctx.f16)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = conv3x3_forward_f16(dy, pd, None, cin) if ctx.f16 else conv3x3_forward(dy, pd, None, cin)
