@@ -443,10 +443,12 @@ class BiLstmLayerFn(torch.autograd.Function):
             gemm(0, 1, r1 - r0, G, din, x[r0:r1], din, w_ih_r if d else w_ih_f, din, xproj[d][r0:r1], G, bias=bsum[d])
 
         Th = T // 2
-        if _SIDE["enabled"] and Th >= 16 and Th * B * din >= (1 << 20):
-            # The sweep keeps half the chip idle, so only the x-projection of the rows its first half needs (forward
+        if _SIDE["enabled"] and Th >= 16 and Th * B * din >= (1 << 20) and _os.environ.get("VOCR_XPROJ_SPLIT", "0") == "1":
+            # Opt-in (VOCR_XPROJ_SPLIT=1): only the x-projection of the rows the sweep's first half needs (forward
             # direction: t < Th; reverse direction: t >= T - Th) runs ahead of it; the other halves run on the side
-            # stream under steps [0, Th) and steps [Th, T) start when they are done (vocr_lstm_fwd_range).
+            # stream under steps [0, Th) and steps [Th, T) start when they are done (vocr_lstm_fwd_range).  Worth
+            # +0.6 % while the 16-row sweeps left half the chip idle; with the 8-row sweeps on all 8 XCDs the
+            # co-running GEMM costs the sweep more than it hides (same-box A/B 1370 vs 1422 img/s), so it is off.
             side = side_stream()
             for t_ in (x, xproj, bsum, w_ih_f, w_ih_r):
                 t_.record_stream(side)
@@ -515,7 +517,7 @@ class BiLstmLayerFn(torch.autograd.Function):
             dbh_f.copy_(dbias[0])
             dbh_r.copy_(dbias[1])
 
-        if direct and _SIDE["enabled"]:
+        if direct and _SIDE["enabled"] and _os.environ.get("VOCR_LSTM_DW_OVERLAP", "1") == "1":
             side = side_stream()
             side.wait_stream(torch.cuda.current_stream())
             for t_ in (dg, x, y, dbias):
