@@ -288,163 +288,28 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_fast(const float* __restric
     }
 }
 
-// ------------------------------------------------------------------------------------------------ persistent sweep
-// One launch for all T steps.  A workgroup keeps its slice of W_hh in registers for the whole sweep (the per-step
-// kernels re-fetch 8 MB of weights per step because the XCD L2s are dropped at every kernel boundary: PMC FETCH_SIZE
-// 7-10 MB per step launch) and the cell state c in a register.  The only cross-workgroup traffic is h_t itself:
-//   producer: y[t] is stored write-through (sc1) -> every storing wave drains vmcnt -> workgroup barrier -> ONE lane
+// ------------------------------------------------------------------------------------------------ persistent sweeps
+// One launch for all T steps of a layer.  A workgroup keeps its slice of W_hh in registers for the whole sweep (the
+// per-step kernels re-fetch 8 MB of weights per step because the XCD L2s are dropped at every kernel boundary: PMC
+// FETCH_SIZE 7-10 MB per step launch) and the cell state c in a register.  The only cross-workgroup traffic is the
+// hand-off of h_t (forward) or of partial sums (backward):
+//   producer: payload stored write-through (sc1) -> every storing wave drains vmcnt -> workgroup barrier -> ONE lane
 //             raises this workgroup's arrival flag (an sc1 store of step+1)
-//   consumer: wave 3 (it owns no cell, so its memory queue holds nothing but polls) re-reads the flags of its chain
-//             (relaxed agent-scope loads + s_sleep) until every workgroup has published step-1 -> workgroup barrier ->
-//             EVERY load of h_{t-1} is a 16-byte sc1 buffer load (bypasses this CU's L1); the rows of y[t-1] were never
-//             read before they were written, so no cache can hold a stale copy.
+//   consumer: the last wave (it owns no cell, so its memory queue holds nothing but polls) re-reads the flags of its
+//             chain (relaxed agent-scope loads + s_sleep) until every workgroup has published the previous step ->
+//             workgroup barrier -> EVERY load of the payload is an sc1 load (bypasses this CU's L1).
 // This is the flag form of the release/acquire-free hand-off of cdna_hip_programming.md Guideline 16 (R1 + sc1 loads,
-// table row 1).  Results are independent of dispatch order and XCD placement and bit-identical to the per-step
-// kernels (same MFMA and reduction order).  Every spin is bounded; a timeout sets status[0] and the sweep's last step
-// then writes NaN, so a failed hand-off can never pass silently.  All workgroups must be co-resident (host check).
+// table row 1).  Results are independent of dispatch order and XCD placement.  Every spin is bounded; a timeout sets
+// status[0] and the sweep's last step then writes NaN, so a failed hand-off can never pass silently.  All workgroups
+// must be co-resident (host check).
 //
-// Measured (MI355X, T=294 B=32 H=512, scripts/lstm_bench.py): 6.9 us/step vs 7.3 us/step for one launch per step.
-// Tried and not faster: one arrival counter per direction instead of flags (same), polling from wave 0 (same),
-// two batch-tile chains per direction with two workgroups per CU (7.6), 8-byte sc1 loads (7.8), prefetching the next
-// step's x-projection behind the h loads (same), and a flag-free variant that pre-fills y with a NaN pattern and
-// re-reads h until no element is the pattern (7.2: four polling waves per CU saturate the fabric).  Ablation: a
-// workgroup's own loop without any waiting is already 5.0 us (h loads 1.5-2.4, MFMA+reduce 1.5, epilogue+publish 1).
+// History (MI355X, T=294 B=32 H=512, scripts/lstm_bench.py; one launch per step: 7.3 us fwd / 10.3 us bwd per step).
+// A first persistent forward over all 256 CUs (4 units per workgroup, one chain of 128 workgroups per direction on 8
+// XCDs) only reached 6.9 us: the signalling form (one counter, per-workgroup flags, polling wave 0 or 3), two
+// workgroups per CU on independent chains, 8-byte vs 16-byte sc1 loads, and a flag-free variant that pre-fills y with
+// a NaN pattern and re-reads h until no element is the pattern all stayed within +-0.5 us of it; a workgroup's own
+// loop without any waiting was already 5.0 us.  What changed the picture is below: small chains that live on one XCD.
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-
-template <int KQ4, int RT>
-__global__ __launch_bounds__(256) void lstm_fwd_persistent(const float* __restrict__ xproj, const float* __restrict__ whh_f,
-                                                           const float* __restrict__ whh_r, const int32_t* __restrict__ lens,
-                                                           float* y, float* __restrict__ gates, float* __restrict__ cell,
-                                                           unsigned* flags, unsigned* status, int T, int B) {
-    constexpr int H = 64 * KQ4;
-    constexpr int ublocks = H >> 2;
-    __shared__ float red[4][RT * 16][17];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int dir = blockIdx.x / ublocks, ub = blockIdx.x % ublocks, unit0 = ub * 4;
-    const int lr = lane & 15, q = lane >> 4;
-    const int kbase = wave * (H >> 2) + q * 4;
-    const float* whh = dir ? whh_r : whh_f;
-    unsigned* dflags = flags + dir * 128;                    // this direction's arrival flags: one word per workgroup
-
-    // resident operands: this lane's W_hh fragment (gate row lr>>2, unit lr&3, k = kbase + 16 i + e)
-    f32x4 wv[KQ4];
-    {
-        const f32x4* wp = (const f32x4*)(whh + ((long)(lr >> 2) * H + unit0 + (lr & 3)) * H + kbase);
-#pragma unroll
-        for (int i = 0; i < KQ4; ++i) wv[i] = wp[i * 4];
-    }
-    const bool cellthr = tid < B * 4;
-    const int cb_ = tid >> 2, cu = tid & 3, unit = unit0 + cu;
-    const int len_b = cellthr ? lens[cb_] : 0;
-    float cstate = 0.f;
-    bool timed_out = false;
-    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, T * B * 2 * H * 4, 0x00020000);
-
-    for (int step = 0; step < T; ++step) {
-        const int t = dir == 0 ? step : T - 1 - step;
-        const int tprev = dir == 0 ? t - 1 : t + 1;
-        // x-projection (plain loads: an earlier kernel wrote it), issued ahead of the wait so HBM latency hides under it
-        float xp[4] = {0.f, 0.f, 0.f, 0.f};
-        if (cellthr) {
-            const float* xrow = xproj + (((long)dir * T + t) * B + cb_) * 4 * H + unit;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) xp[g] = xrow[(long)g * H];
-        }
-        f32x4 acc[RT];
-#pragma unroll
-        for (int i = 0; i < RT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (step > 0) {
-            if (wave == 3 && !timed_out) {
-                unsigned spins = 0;
-                for (;;) {
-                    unsigned f0 = (unsigned)step, f1 = (unsigned)step;
-                    if (lane < ublocks) f0 = __hip_atomic_load(dflags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (lane + 64 < ublocks) f1 = __hip_atomic_load(dflags + lane + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (__all(f0 >= (unsigned)step && f1 >= (unsigned)step)) break;
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1u << 22)) {                                    // ~seconds: give up, flag it, keep going
-                        if (lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        timed_out = true;
-                        break;
-                    }
-                }
-            }
-            __syncthreads();
-            const int hrow0 = (tprev * B) * 2 * H + dir * H + kbase;
-            f32x4 hv[RT][KQ4];
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                const int b = rt * 16 + lr;
-                const int off = (hrow0 + (b < B ? b : 0) * 2 * H) * 4;
-#pragma unroll
-                for (int i = 0; i < KQ4; ++i) {
-                    const u32x4_t raw = __builtin_amdgcn_raw_buffer_load_b128(yrsrc, off + i * 64, 0, 16);      // aux 16 = sc1
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = (b < B) ? __uint_as_float(raw[e]) : 0.f;
-                    hv[rt][i] = v;
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < KQ4; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt)
-                        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[rt][i][e], wv[i][e], acc[rt], 0, 0, 0);
-        }
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) red[wave][rt * 16 + q * 4 + r][lr] = acc[rt][r];
-        __syncthreads();
-
-        if (cellthr) {
-            const int b = cb_, u = cu;
-            const bool active = t < len_b;
-            const long sidx = (((long)dir * T + t) * B + b) * H + unit;
-            float pre[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                pre[g] = ((red[0][b][g * 4 + u] + red[1][b][g * 4 + u]) + (red[2][b][g * 4 + u] + red[3][b][g * 4 + u])) + xp[g];
-            float* yo = y + ((long)t * B + b) * 2 * H + dir * H + unit;
-            f32x4* go = (f32x4*)(gates + sidx * 4);
-            float h = 0.f;
-            if (active) {
-                const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
-                const float c = fg * cstate + ig * gg;
-                h = og * tanhf(c);
-                *go = (f32x4){ig, fg, gg, og};
-                cell[sidx] = c;
-                cstate = c;
-            } else {
-                *go = (f32x4){0.f, 0.f, 0.f, 0.f};
-                cell[sidx] = 0.f;
-                cstate = 0.f;
-            }
-            if (step == T - 1 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
-                h = __uint_as_float(0x7FC00000u);                                        // a hand-off timed out: fail loudly
-            __hip_atomic_store(yo, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // write-through (sc1) payload
-        }
-        // publish: every storing wave drains its stores, then one lane raises this workgroup's flag
-        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(dflags + ub, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-template <int KQ4>
-void launch_fwd_persistent(int rt, hipStream_t s, const float* xproj, const float* wf, const float* wr, const int32_t* lens,
-                           float* y, float* gates, float* cell, unsigned* flags, unsigned* status, int T, int B) {
-    const dim3 grid(2 * 16 * KQ4);
-    switch (rt) {
-        case 1: lstm_fwd_persistent<KQ4, 1><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, flags, status, T, B); break;
-        case 2: lstm_fwd_persistent<KQ4, 2><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, flags, status, T, B); break;
-        case 3: lstm_fwd_persistent<KQ4, 3><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, flags, status, T, B); break;
-        default: lstm_fwd_persistent<KQ4, 4><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, flags, status, T, B); break;
-    }
-}
 
 // ------------------------------------------------------------------------------------------------ chain sweeps
 // The recurrence never couples batch rows, so (direction, tile of 16 batch rows) is an independent chain: <= 8 of them.
@@ -454,7 +319,7 @@ void launch_fwd_persistent(int rt, hipStream_t s, const float* xproj, const floa
 // XCD does the chain switch its payload and flag stores from write-through (sc1) to plain stores.  Plain stores stay
 // in that XCD's L2, which is the coherence point of all its CUs, and the consumer's sc1 loads (L1 bypassed,
 // L2 served) then hit them at L2 latency instead of making a fabric round trip per step.  With any other placement the
-// chain runs the write-through protocol of lstm_fwd_persistent unchanged, so results never depend on placement.
+// chain runs the write-through protocol described above unchanged, so results never depend on placement.
 __device__ __forceinline__ unsigned xcc_id() {
     unsigned x;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
@@ -936,145 +801,9 @@ __global__ __launch_bounds__(64 * NW) void lstm_bwd_step_fast(const float* __res
     }
 }
 
-// Backward chain sweep: the write-through hand-off of lstm_fwd_persistent with dgates_{t+-1} as the payload and the
-// chain layout of lstm_fwd_chain (blockIdx = member*8 + chain, so a chain's 32 workgroups share an XCD's L2 for their
-// common reads).  A workgroup (chain, 16 units) keeps its 16 x 4H slice of W_hh^T in registers (128 VGPRs per lane at
-// H = 512; the per-step kernel re-fetches those 128 KB per workgroup per step), carries dc in a register, and regroups
-// dgates through LDS so that every hand-off store is one 16-byte write-through store (scalar sc1 stores are one fabric
-// write each).  Same MFMA order as lstm_bwd_step_fast: bit-identical.  Measured 6.4 us/step vs 10.2 per-step launches.
-template <int NCH>
-__global__ __launch_bounds__(256) void lstm_bwd_persistent(const float* __restrict__ dy, const float* __restrict__ whht_f,
-                                                           const float* __restrict__ whht_r, const int32_t* __restrict__ lens,
-                                                           const float* __restrict__ gates, const float* __restrict__ cell,
-                                                           float* dgates, unsigned* flags, unsigned* status, int T, int B, int RT) {
-    constexpr int H = 128 * NCH;
-    constexpr int CH = NCH;
-    constexpr int ublocks = H / 16;
-    __shared__ float lds[4 * 16 * 17 + 4 * 16 * 20];
-    float (*red)[16][17] = (float (*)[16][17])lds;
-    float (*xch)[16][20] = (float (*)[16][20])(lds + 4 * 16 * 17);      // [gate][row][unit], rows padded to 80 B
-    // chain = (direction, batch tile) = blockIdx % 8, member = 16-unit block = blockIdx / 8 (see "chain sweeps" above)
-    const int chain = blockIdx.x & 7, ub = blockIdx.x >> 3;
-    if (chain >= 2 * RT) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int dir = chain / RT, bt = chain % RT, unit0 = ub * 16;
-    const int lr = lane & 15, q = lane >> 4;
-    const int nbase = wave * H + q * 4;                                   // wave = gate block of the 4H reduction
-    unsigned* cflags = flags + chain * 32;                                // this chain's arrival flags: one word per workgroup
-
-    f32x4 bw[CH][8];
-    {
-        const float* whht = dir ? whht_r : whht_f;
-        const f32x4* bp = (const f32x4*)(whht + (long)(unit0 + lr) * 4 * H + nbase);
-#pragma unroll
-        for (int c = 0; c < CH; ++c)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) bw[c][i] = bp[c * 32 + i * 4];
-    }
-    const int b0 = bt * 16;
-    const int eb = b0 + (tid >> 4), ej = tid & 15, eunit = unit0 + ej;
-    const bool ev = eb < B;
-    const int ebs = ev ? eb : b0;
-    const int len = lens[ebs];
-    float dcar = 0.f;
-    bool timed_out = false;
-    const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc((void*)dgates, 0, 2 * T * B * 4 * H * 4, 0x00020000);
-    const int arow = b0 + lr;
-    const bool bv = arow < B;
-    // regroup-store role of this thread: row tid>>4, gate (tid>>2)&3, units 4*(tid&3)..+3
-    const int sb = b0 + (tid >> 4), sg = (tid >> 2) & 3, su = (tid & 3) * 4;
-
-    for (int step = 0; step < T; ++step) {
-        const int t = dir == 0 ? T - 1 - step : step;
-        const int tv = dir == 0 ? t + 1 : t - 1;
-        const bool act = ev && t < len;
-        // epilogue operands (written by earlier kernels: plain loads), issued ahead of the wait
-        float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, c = 0.f, cprev = 0.f, dyv = 0.f;
-        if (act) {
-            const long sidx = (((long)dir * T + t) * B + ebs) * H + eunit;
-            const f32x4 gv = *(const f32x4*)(gates + sidx * 4);
-            ig = gv[0];
-            fg = gv[1];
-            gg = gv[2];
-            og = gv[3];
-            c = cell[sidx];
-            const int tp = dir == 0 ? t - 1 : t + 1;
-            cprev = (tp >= 0 && tp < len) ? cell[(((long)dir * T + tp) * B + ebs) * H + eunit] : 0.f;
-            dyv = dy[((long)t * B + ebs) * 2 * H + dir * H + eunit];
-        }
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (step > 0) {
-            if (wave == 3 && !timed_out) {
-                unsigned spins = 0;
-                for (;;) {
-                    unsigned f0 = (unsigned)step;
-                    if (lane < ublocks) f0 = __hip_atomic_load(cflags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (__all(f0 >= (unsigned)step)) break;
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1u << 22)) {
-                        if (lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        timed_out = true;
-                        break;
-                    }
-                }
-            }
-            __syncthreads();
-            // A rows past B are clamped to a valid row and never masked: row r of A only reaches row r of the product,
-            // which the epilogue ignores (masking the loaded values made hipcc serialise the 32 loads, one round trip each)
-            const int off = ((((dir * T + tv) * B) + (bv ? arow : b0)) * 4 * H + nbase) * 4;
-            u32x4_t av[CH][8];
-#pragma unroll
-            for (int cc = 0; cc < CH; ++cc)
-#pragma unroll
-                for (int i = 0; i < 8; ++i) av[cc][i] = __builtin_amdgcn_raw_buffer_load_b128(grsrc, off + cc * 512 + i * 64, 0, 16);      // aux 16 = sc1
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int cc = 0; cc < CH; ++cc)
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-#pragma unroll
-                    for (int e = 0; e < 4; e += 2) {
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av[cc][i][e]), bw[cc][i][e], acc, 0, 0, 0);
-                        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av[cc][i][e + 1]), bw[cc][i][e + 1], acc2, 0, 0, 0);
-                    }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave][q * 4 + r][lr] = acc[r] + acc2[r];
-        __syncthreads();
-
-        float dg[4] = {0.f, 0.f, 0.f, 0.f};
-        if (act) {
-            const int bl = tid >> 4;
-            float rs = 0.f;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) rs += red[w][bl][ej];
-            dcar = lstm_cell_grad(dyv + rs, dcar, ig, fg, gg, og, c, cprev, dg);
-        } else {
-            dcar = 0.f;
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) xch[g][tid >> 4][ej] = dg[g];
-        __syncthreads();
-        if (sb < B) {
-            const f32x4 v = *(const f32x4*)&xch[sg][tid >> 4][su];
-            u32x4_t raw;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) raw[e] = __float_as_uint(v[e]);
-            if (step == T - 1 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
-                raw = (u32x4_t){0x7FC00000u, 0x7FC00000u, 0x7FC00000u, 0x7FC00000u};        // a hand-off timed out: fail loudly
-            const int soff = ((((dir * T + t) * B) + sb) * 4 * H + sg * H + unit0 + su) * 4;
-            // write-through (sc1) payload, 16 B.  (Keeping the lines in the XCD's L2 with sc0/plain/nt stores when the
-            // chain sits on one XCD, as the forward sweep does, measured 6.6 vs 6.4 us per step here: not used.)
-            __builtin_amdgcn_raw_buffer_store_b128(raw, grsrc, soff, 0, 16);
-        }
-        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): every storing wave drains before the flag
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(cflags + ub, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-// Backward chain sweep, second form ("K-owner").  lstm_bwd_persistent spends 4.7 of its 6.3 us per step loading the
-// chain's dgates (128 KB per workgroup, 32 times the same bytes per XCD) before and under its MFMAs.  Here a workgroup
+// Backward chain sweep, "K-owner" form.  The obvious (N-owner) form - every workgroup loads the chain's dgates_{t+-1},
+// 128 KB per workgroup and 32 times the same bytes per XCD, and multiplies them with its 16 x 4H slice of W_hh^T - spent
+// 4.7 of its 6.3 us per step on that load (measured, then removed from the tree).  Here a workgroup
 // multiplies the dgates it has just produced itself (16 rows x 64 gate-units, straight from LDS) with its 64 x H slice of
 // W_hh and hands out PARTIAL sums instead: out[row][n] for all H units, one 1-KB block per consumer.  The exchange is
 // then 32 KB written and 32 KB read per workgroup per step, the reads are 32 fully coalesced dword loads per thread
@@ -1441,8 +1170,7 @@ extern "C" int vocr_lstm_fwd_range(const float* xproj, const float* whh_fwd, con
     VOCR_CHECK_ARG(xproj && whh_fwd && whh_rev && lens && y && gates && cell && workspace, "vocr_lstm_fwd: null pointer");
     VOCR_CHECK_ARG(t > 0 && b > 0 && b <= 64 && h > 0 && h % 16 == 0, "vocr_lstm_fwd: need 1<=B<=64 and H%%16==0 (B=%d H=%d)", b, h);
     VOCR_CHECK_ARG(0 <= step_begin && step_begin < step_end && step_end <= t, "vocr_lstm_fwd: bad step range [%d, %d) of %d", step_begin, step_end, t);
-    const bool whole = step_begin == 0 && step_end == t;
-    hipStream_t s = (hipStream_t)stream;
+        hipStream_t s = (hipStream_t)stream;
     const int rt = (b + 15) / 16;
     const bool fast = (h == 64 || h == 128 || h == 256 || h == 512) && aligned16(whh_fwd) && aligned16(whh_rev) && aligned16(y) &&
                       aligned16(gates);
@@ -1450,7 +1178,7 @@ extern "C" int vocr_lstm_fwd_range(const float* xproj, const float* whh_fwd, con
     const dim3 grid(2 * (h / 4));
     // persistent sweep by default (VOCR_LSTM_PERSISTENT: bit 0 forward, bit 1 backward; 0 = one launch per step)
     static const int persistent_mode = getenv("VOCR_LSTM_PERSISTENT") ? atoi(getenv("VOCR_LSTM_PERSISTENT")) : 3;
-    if (fast && (persistent_mode & 1) && !(persistent_mode & 4) && 8 * (h / 16) <= resident_workgroup_capacity()) {
+    if (fast && (persistent_mode & 1) && 8 * (h / 16) <= resident_workgroup_capacity()) {
         // chain sweep.  arrival flags: [chain <= 8][32 workgroups] at [0..255], XCC ids at [256..511]; status words at [512..]
         unsigned* flags = (unsigned*)workspace;
         unsigned* status = flags + 512;
@@ -1475,23 +1203,6 @@ extern "C" int vocr_lstm_fwd_range(const float* xproj, const float* whh_fwd, con
         if (h == 64) VOCR_CHAIN(1); else if (h == 128) VOCR_CHAIN(2); else if (h == 256) VOCR_CHAIN(4); else VOCR_CHAIN(8);
 #undef VOCR_CHAIN
         VOCR_CHECK_LAUNCH("vocr_lstm_fwd(chain)");
-        return VOCR_OK;
-    }
-    if (fast && whole && (persistent_mode & 1) && (int)grid.x <= resident_workgroup_capacity() && h >= 64) {
-        // arrival flags: [dir][128 workgroups]; status words at [512..]
-        unsigned* flags = (unsigned*)workspace;
-        unsigned* status = flags + 512;
-        if (hipMemsetAsync(flags, 0, 520 * sizeof(unsigned), s) != hipSuccess) {
-            vocr_set_error("vocr_lstm_fwd: memset failed");
-            return VOCR_ELAUNCH;
-        }
-        switch (h) {
-            case 64: launch_fwd_persistent<1>(rt, s, xproj, whh_fwd, whh_rev, lens, y, gates, cell, flags, status, t, b); break;
-            case 128: launch_fwd_persistent<2>(rt, s, xproj, whh_fwd, whh_rev, lens, y, gates, cell, flags, status, t, b); break;
-            case 256: launch_fwd_persistent<4>(rt, s, xproj, whh_fwd, whh_rev, lens, y, gates, cell, flags, status, t, b); break;
-            default: launch_fwd_persistent<8>(rt, s, xproj, whh_fwd, whh_rev, lens, y, gates, cell, flags, status, t, b); break;
-        }
-        VOCR_CHECK_LAUNCH("vocr_lstm_fwd(persistent)");
         return VOCR_OK;
     }
     for (int step = step_begin; step < step_end; ++step) {
@@ -1554,35 +1265,28 @@ extern "C" int vocr_lstm_bwd_bias(const float* dy, const float* whht_fwd, const 
             return VOCR_ELAUNCH;
         }
         const dim3 g(8 * (h / 16));
-        if (!(persistent_mode & 16)) {
-            // K-owner form: partial sums [parity][chain][consumer][producer][16 x 16] behind the flags/status words
-            float* partials = (float*)((char*)workspace + 4096);
-            const int nt8 = (b + 7) / 8;
-            if (2 * nt8 <= 8 && !(persistent_mode & 32) && (h == 512 || h == 256)) {      // 8-row chains on all 8 XCDs, 4x4x1 MFMA
-                const int fwt8 = (persistent_mode & 8) ? 1 : 0;
-                float* bpart = dbias ? (float*)((char*)workspace + 4096 + ((size_t)16 << 20)) : nullptr;     // [chain][4H]
-                if (h == 512)
-                    lstm_bwd_kowner8<4><<<g, 512, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, bpart, t, b, nt8, fwt8);
-                else
-                    lstm_bwd_kowner8<2><<<g, 512, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, bpart, t, b, nt8, fwt8);
-                VOCR_CHECK_LAUNCH("vocr_lstm_bwd(k-owner, 8-row chains)");
-                if (dbias) {
-                    lstm_bias_combine_kernel<<<dim3(vocr_cdiv(4 * h, 256), 2), 256, 0, s>>>(bpart, dbias, 4 * h, nt8);
-                    VOCR_CHECK_LAUNCH("vocr_lstm_bwd(bias combine)");
-                }
-                return VOCR_OK;
+        // K-owner form: partial sums [parity][chain][consumer][producer][16 x 16] behind the flags/status words
+        float* partials = (float*)((char*)workspace + 4096);
+        const int nt8 = (b + 7) / 8;
+        if (2 * nt8 <= 8 && !(persistent_mode & 32) && (h == 512 || h == 256)) {      // 8-row chains on all 8 XCDs, 4x4x1 MFMA
+            const int fwt8 = (persistent_mode & 8) ? 1 : 0;
+            float* bpart = dbias ? (float*)((char*)workspace + 4096 + ((size_t)16 << 20)) : nullptr;     // [chain][4H]
+            if (h == 512)
+                lstm_bwd_kowner8<4><<<g, 512, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, bpart, t, b, nt8, fwt8);
+            else
+                lstm_bwd_kowner8<2><<<g, 512, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, bpart, t, b, nt8, fwt8);
+            VOCR_CHECK_LAUNCH("vocr_lstm_bwd(k-owner, 8-row chains)");
+            if (dbias) {
+                lstm_bias_combine_kernel<<<dim3(vocr_cdiv(4 * h, 256), 2), 256, 0, s>>>(bpart, dbias, 4 * h, nt8);
+                VOCR_CHECK_LAUNCH("vocr_lstm_bwd(bias combine)");
             }
-            const int fwt = (persistent_mode & 8) ? 1 : 0;       // experiments: write-through hand-off even on one XCD
-            if (h == 128) lstm_bwd_kowner<1><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, t, b, rt, fwt);
-            else if (h == 256) lstm_bwd_kowner<2><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, t, b, rt, fwt);
-            else lstm_bwd_kowner<4><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, t, b, rt, fwt);
-            VOCR_CHECK_LAUNCH("vocr_lstm_bwd(k-owner)");
-            return lstm_bias_by_colsum(dgates, dbias, t, b, h, stream);
+            return VOCR_OK;
         }
-        if (h == 128) lstm_bwd_persistent<1><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, flags, status, t, b, rt);
-        else if (h == 256) lstm_bwd_persistent<2><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, flags, status, t, b, rt);
-        else lstm_bwd_persistent<4><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, flags, status, t, b, rt);
-        VOCR_CHECK_LAUNCH("vocr_lstm_bwd(persistent)");
+        const int fwt = (persistent_mode & 8) ? 1 : 0;       // experiments: write-through hand-off even on one XCD
+        if (h == 128) lstm_bwd_kowner<1><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, t, b, rt, fwt);
+        else if (h == 256) lstm_bwd_kowner<2><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, t, b, rt, fwt);
+        else lstm_bwd_kowner<4><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, t, b, rt, fwt);
+        VOCR_CHECK_LAUNCH("vocr_lstm_bwd(k-owner)");
         return lstm_bias_by_colsum(dgates, dbias, t, b, h, stream);
     }
     for (int step = 0; step < t; ++step) {
