@@ -117,7 +117,11 @@ int vocr_dropout_fwd(const float* x, float* out, float* mask, size_t count, floa
  * whh_fwd / whh_rev [4H][H] (the two directions' weight_hh), lens[B] int32 (device, descending).  Outputs y[T][B][2H] (zeros past lens),
  * gates[dir][T][B][H][4] (post-activation i,f,g,o interleaved per unit, 16-byte aligned) and cell[dir][T][B][H]
  * for backward.  h_{t-1}/c_{t-1} are read back from y/cell, so the sweep keeps no separate state.
- * workspace: vocr_lstm_workspace_bytes.  Supports B <= 64, H % 16 == 0. */
+ * workspace: vocr_lstm_workspace_bytes (256-byte aligned device memory; contents need not be preserved between calls).
+ * Supports B <= 64, H % 16 == 0.  For H in {64,128,256,512} a whole sweep is ONE persistent launch whose workgroups
+ * hand h_t (forward) / partial sums (backward) to each other through memory: it needs its grid (<= one workgroup per CU)
+ * co-resident, so do not run two sweeps concurrently on one device; a hand-off that times out (seconds) poisons the
+ * output with NaN instead of hanging.  VOCR_LSTM_PERSISTENT=0 selects one launch per time step instead. */
 size_t vocr_lstm_workspace_bytes(int t, int b, int h);
 int vocr_lstm_fwd(const float* xproj, const float* whh_fwd, const float* whh_rev, const int32_t* lens, float* y,
                   float* gates, float* cell, void* workspace, int t, int b, int h, void* stream);
