@@ -264,11 +264,33 @@ __global__ __launch_bounds__(512) void pool_bwd_lds_kernel(const float* __restri
     __shared__ __attribute__((aligned(16))) float pl[CAP];
     const long plane = blockIdx.x;
     const int tid = threadIdx.x;
-    for (int i = tid; i < in_plane; i += 512) pl[i] = 0.f;
-    __syncthreads();
     const float* dp = dout + plane * out_plane;
     const int32_t* ip = idx + plane * out_plane;
-    for (int o = tid; o < out_plane; o += 512) atomicAdd(&pl[ip[o]], dp[o]);
+    // the first batch of (gradient, winner index) pairs is fetched before the LDS image is cleared, so its latency hides
+    constexpr int U = 4;
+    float v[U];
+    int ix[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int o = tid + u * 512;
+        v[u] = o < out_plane ? dp[o] : 0.f;
+        ix[u] = o < out_plane ? ip[o] : 0;
+    }
+    for (int i = tid * 4; i < CAP; i += 512 * 4) *(f32x4*)(pl + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    for (int base = tid;; ) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (base + u * 512 < out_plane) atomicAdd(&pl[ix[u]], v[u]);
+        base += U * 512;
+        if (base >= out_plane) break;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int o = base + u * 512;
+            v[u] = o < out_plane ? dp[o] : 0.f;
+            ix[u] = o < out_plane ? ip[o] : 0;
+        }
+    }
     __syncthreads();
     float* xp = dx + plane * (long)in_plane;
     if ((in_plane & 3) == 0 && ((((uintptr_t)dx) & 15) == 0)) {
@@ -423,9 +445,12 @@ extern "C" int vocr_fracpool2x2_bwd(const float* dout, const int32_t* idx, float
     VOCR_CHECK_ARG(dout && idx && dx && n > 0 && c > 0 && (long)n * c <= 65535, "vocr_fracpool2x2_bwd: bad argument");
     hipStream_t s = (hipStream_t)stream;
     const long in_plane = (long)h * w;
-    if (in_plane <= 18432) {
+    static const int use_lds = getenv("VOCR_POOL_LDS") ? atoi(getenv("VOCR_POOL_LDS")) : 1;      // experiments
+    if (use_lds && in_plane <= 8192) {
+        pool_bwd_lds_kernel<8192><<<(unsigned)(n * c), 512, 0, s>>>(dout, idx, dx, (int)in_plane, oh * ow);
+    } else if (use_lds && in_plane <= 18432) {
         pool_bwd_lds_kernel<18432><<<(unsigned)(n * c), 512, 0, s>>>(dout, idx, dx, (int)in_plane, oh * ow);
-    } else if (in_plane <= 36864) {
+    } else if (use_lds && in_plane <= 36864) {
         pool_bwd_lds_kernel<36864><<<(unsigned)(n * c), 512, 0, s>>>(dout, idx, dx, (int)in_plane, oh * ow);
     } else {
         if (hipMemsetAsync(dx, 0, (size_t)n * c * in_plane * sizeof(float), s) != hipSuccess) {
