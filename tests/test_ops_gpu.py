@@ -243,7 +243,8 @@ def test_bilstm_layer(dev, T, B, D, H, lens):
         _close(p.grad, r, 1e-3, 5e-5 * float(r.abs().max()) + 1e-6, "lstm d" + nm)
 
 
-@pytest.mark.parametrize("T,B,H", [(40, 20, 128), (25, 5, 64), (33, 32, 512), (12, 40, 256), (9, 64, 128), (21, 27, 256), (15, 7, 512)])
+@pytest.mark.parametrize("T,B,H", [(40, 20, 128), (25, 5, 64), (33, 32, 512), (12, 40, 256), (9, 64, 128), (21, 27, 256), (15, 7, 512),
+                                   (1, 1, 256), (2, 3, 512), (3, 64, 512)])
 def test_persistent_sweeps_match_per_step_launches(dev, T, B, H):
     """Persistent sweeps (weights in registers, flag hand-off with sc1 payload): bit-identical to one launch per step,
     forward (y, gates, cell) and backward (dgates)."""
