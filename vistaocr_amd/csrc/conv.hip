@@ -701,10 +701,13 @@ extern "C" int vocr_conv3x3_fwd(const float* x, const float* wpack, const float*
     const bool vec = (cout % 4 == 0) && ((((uintptr_t)wpack) & 15) == 0);
     const float* zp = zero_page_ptr();
     VOCR_CHECK_ARG(zp != nullptr, "vocr_conv3x3_fwd: no device zero page");
-    // full-size workgroups (128co x 4 segments or 64co x 8 segments); fewer than 6 of them per CU -> half-size (measured)
+    // full-size workgroups (128co x 4 segments or 64co x 8 segments); fewer than 12 of them per CU -> half-size (measured:
+    // 6 was the break-even while every launch ran alone; with the data-gradient launches sharing the chip with the
+    // weight-gradient kernel the half-size ones win up to 9 per CU, +0.4 % on the step)
     const int co_tiles = cout > 64 ? vocr_cdiv(cout, 128) : 1;
     const long full_wgs = (long)vocr_cdiv(nseg, cout > 64 ? 4 : 8) * co_tiles;
-    const bool small = full_wgs < 6l * 256;
+    static const int tile_mode = getenv("VOCR_CONV_TILE") ? atoi(getenv("VOCR_CONV_TILE")) : 0;     // experiments: 1 half, 2 full
+    const bool small = tile_mode == 1 ? true : tile_mode == 2 ? false : full_wgs < 12l * 256;
 #define VOCR_CONV(CO_T, SPWV, NSEG)                                                                                          \
     do {                                                                                                                    \
         dim3 grid(vocr_cdiv(nseg, NSEG), co_tiles);                                                                         \
