@@ -115,10 +115,33 @@ def train(batch, model, criterion, optimizer):
     optimizer.zero_grad()
     model_output, model_output_actual_lengths = model(input_tensor, input_widths)
     loss = criterion(model_output, target, model_output_actual_lengths, target_widths)
+    # The float the reference returns is known as soon as the forward pass is done: its copy to pinned host memory is
+    # queued HERE, ahead of the backward kernels, and only that copy is waited for at the end.  The host then gets the
+    # value while the device is still busy with this step's backward + Adam and starts queueing the next step at once
+    # (with loss.item() after optimizer.step() the device ran dry at the start of every step: 23.6 vs 22.2 ms/step).
+    ev = None
+    if loss.is_cuda:
+        host = _pinned_scalar(loss.device)
+        host.copy_(loss.detach().reshape(-1)[:1], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
     loss.backward()
     optimizer.all_reduce_grads()
     optimizer.step()
-    return loss.data[0].item()
+    if ev is None:
+        return loss.data[0].item()
+    ev.synchronize()
+    return float(host[0])
+
+
+_PINNED = {}
+
+
+def _pinned_scalar(device):
+    key = str(device)
+    if key not in _PINNED:
+        _PINNED[key] = torch.empty(1, dtype=torch.float32).pin_memory()
+    return _PINNED[key]
 
 
 def train_async(batch, model, criterion, optimizer):
