@@ -1178,7 +1178,9 @@ extern "C" int vocr_lstm_fwd_range(const float* xproj, const float* whh_fwd, con
     const dim3 grid(2 * (h / 4));
     // persistent sweep by default (VOCR_LSTM_PERSISTENT: bit 0 forward, bit 1 backward; 0 = one launch per step)
     static const int persistent_mode = getenv("VOCR_LSTM_PERSISTENT") ? atoi(getenv("VOCR_LSTM_PERSISTENT")) : 3;
-    if (fast && (persistent_mode & 1) && 8 * (h / 16) <= resident_workgroup_capacity()) {
+    // the chain kernels address y through a buffer descriptor with 32-bit byte offsets
+    const bool fits32 = (long)t * b * 2 * h * 4 < (1l << 31);
+    if (fast && fits32 && (persistent_mode & 1) && 8 * (h / 16) <= resident_workgroup_capacity()) {
         // chain sweep.  arrival flags: [chain <= 8][32 workgroups] at [0..255], XCC ids at [256..511]; status words at [512..]
         unsigned* flags = (unsigned*)workspace;
         unsigned* status = flags + 512;
