@@ -80,6 +80,11 @@ int vocr_bn_relu_bwd(const float* da, const float* y, const float* mean, const f
 /* samples[n][c][2] (u_w, u_h) as ATen's _random_samples; idx = flat h*W+w of the winner (int32) */
 int vocr_fracpool2x2_fwd(const float* x, const float* samples, float* out, int32_t* idx,
                          int n, int c, int h, int w, int oh, int ow, void* stream);
+/* BatchNorm-apply + ReLU + the same pooling in one pass over the conv output y (vocr_bn_relu_apply followed by
+ * vocr_fracpool2x2_fwd, bit for bit), for layers whose activation is only ever consumed by the pool. */
+int vocr_bn_relu_fracpool2x2_fwd(const float* y, const float* mean, const float* invstd, const float* gamma,
+                                 const float* beta, const float* samples, float* out, int32_t* idx,
+                                 int n, int c, int h, int w, int oh, int ow, void* stream);
 /* dx[n][c][h][w] = sum of dout over the windows whose winner is that pixel; every element of dx is written
  * (no zero-fill needed) */
 int vocr_fracpool2x2_bwd(const float* dout, const int32_t* idx, float* dx,

@@ -298,6 +298,39 @@ def test_persistent_sweeps_match_per_step_launches(dev, T, B, H):
             assert torch.equal(a, b), "%s (mode %s) differs: max |diff| %.3e at %d of %d" % (nm, mode, float((a - b).abs().max()), int((a != b).sum()), a.numel())
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w", [(3, 5, 8, 30, 75), (2, 64, 64, 15, 42)])
+def test_fused_bn_relu_fracpool_equals_the_two_separate_passes(dev, n, cin, cout, h, w):
+    """ConvBnReluFn with pool_samples (one pass: BN-apply + ReLU + FractionalMaxPool) == ConvBnReluFn then FracPoolFn, bit for
+    bit, forward and backward."""
+    import math
+    from vistaocr_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = (torch.rand(n, cin, h, w, generator=g) - 0.3).to(dev)
+    wt = ((torch.rand(cout, cin, 3, 3, generator=g) - 0.5) * 0.2).to(dev)
+    bias = (torch.rand(cout, generator=g) - 0.5).to(dev)
+    gamma = (torch.rand(cout, generator=g) - 0.3).to(dev)          # some negative scales: max does not commute with BN
+    beta = (torch.rand(cout, generator=g) - 0.5).to(dev)
+    u = torch.rand(n, cout, 2, generator=g).to(dev)
+    oh, ow = math.floor(h * 0.5), math.floor(w * 0.7)
+    dout = (torch.rand(n, cout, oh, ow, generator=g) - 0.5).to(dev)
+    res = []
+    for fused in (False, True):
+        leaves = [t.clone().requires_grad_(True) for t in (x, wt, bias, gamma, beta)]
+        rm, rv = torch.zeros(cout, device=dev), torch.ones(cout, device=dev)
+        if fused:
+            out = ops.ConvBnReluFn.apply(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], rm, rv, True, 1e-5, 0.1, False, u, oh, ow)
+        else:
+            a = ops.ConvBnReluFn.apply(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], rm, rv, True, 1e-5, 0.1, False)
+            out = ops.FracPoolFn.apply(a, u, oh, ow)
+        out.backward(dout)
+        res.append([out.detach().cpu()] + [t.grad.cpu() for t in leaves] + [rm.cpu(), rv.cpu()])
+    for nm, a, b in zip(("out", "dx", "dw", "dbias", "dgamma", "dbeta", "running_mean", "running_var"), res[0], res[1]):
+        if nm == "dbias":       # exactly zero in exact arithmetic (bias in front of batch-stat BN): float-atomic rounding noise only
+            assert float((a - b).abs().max()) < 1e-3
+            continue
+        assert torch.equal(a, b), "%s differs: max |diff| %.3e" % (nm, float((a - b).abs().max()))
+
+
 @pytest.mark.parametrize("T,B,H", [(33, 32, 512), (21, 27, 256), (12, 40, 256), (17, 9, 128)])
 def test_lstm_backward_bias_gradient_is_the_column_sum_of_dgates(dev, T, B, H):
     """vocr_lstm_bwd_bias: dbias[dir] accumulated inside the sweep (8-row K-owner kernel) or by column sums (other paths)."""

@@ -31,6 +31,7 @@ SIGNATURES = {
     "vocr_bn_relu_apply": (I, [P, P, P, P, P, P, I, I, I, P]),
     "vocr_bn_relu_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, P, P]),
     "vocr_fracpool2x2_fwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
+    "vocr_bn_relu_fracpool2x2_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "vocr_fracpool2x2_bwd": (I, [P, P, P, I, I, I, I, I, I, P]),
     "vocr_relu_maxpool2_fwd": (I, [P, P, P, I, I, I, I, P]),
     "vocr_relu_maxpool2_bwd": (I, [P, P, P, P, I, I, I, I, P]),

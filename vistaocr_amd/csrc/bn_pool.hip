@@ -254,6 +254,43 @@ __global__ __launch_bounds__(256) void pool_bwd_scatter_kernel(const float* __re
     }
 }
 
+// BatchNorm-apply + ReLU + fractional max pool in one pass over the conv output: where a pooling layer follows, the
+// activation a = relu(bn(y)) itself is needed by nobody (the backward recomputes it from y, the next layer reads the
+// pooled tensor), so it is never written.  Same arithmetic per element as bn_relu_apply_kernel and the same window /
+// first-maximum rule as fracpool_fwd_kernel.
+__global__ __launch_bounds__(256) void bn_relu_fracpool_fwd_kernel(const float* __restrict__ y, const float* __restrict__ mean,
+                                                                   const float* __restrict__ invstd,
+                                                                   const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta,
+                                                                   const float* __restrict__ samples, float* __restrict__ out,
+                                                                   int32_t* __restrict__ idx, int C, int H, int W, int OH, int OW,
+                                                                   float alpha_h, float alpha_w) {
+    const long plane = blockIdx.y;
+    const int c = (int)(plane % C);
+    const float mu = mean[c], is = invstd[c], g = gamma[c], b = beta[c];
+    const float uw = samples[plane * 2], uh = samples[plane * 2 + 1];
+    const float* yp = y + plane * (long)H * W;
+    const int total = OH * OW;
+    for (int o = blockIdx.x * 256 + threadIdx.x; o < total; o += gridDim.x * 256) {
+        const int oh = o / OW, ow = o % OW;
+        const int hs = frac_start(oh, uh, alpha_h, H, OH);
+        const int ws = frac_start(ow, uw, alpha_w, W, OW);
+        int best = hs * W + ws;
+        float mv = -INFINITY;
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int dw = 0; dw < 2; ++dw) {
+                const int p = (hs + dh) * W + ws + dw;
+                const float t = (yp[p] - mu) * is * g + b;
+                const float v = t > 0.f ? t : 0.f;
+                if (v > mv || v != v) { mv = v; best = p; }
+            }
+        out[plane * total + o] = mv;
+        idx[plane * total + o] = best;
+    }
+}
+
 // Same gradient with the input plane assembled in LDS: one workgroup per (n, c) plane zeroes an LDS image, adds its
 // outputs' gradients there (ds_add_f32; <= 2 contributions per pixel, so the order cannot matter) and writes the plane out
 // once, in full lines.  No zero-fill pass over dx and no global atomics: 250 MB instead of ~550 MB of traffic for the
@@ -437,6 +474,20 @@ extern "C" int vocr_fracpool2x2_fwd(const float* x, const float* samples, float*
     fracpool_fwd_kernel<<<plane_grid((long)n * c, (long)oh * ow), 256, 0, (hipStream_t)stream>>>(x, samples, out, idx, h, w, oh,
                                                                                              ow, alpha_h, alpha_w);
     VOCR_CHECK_LAUNCH("vocr_fracpool2x2_fwd");
+    return VOCR_OK;
+}
+
+extern "C" int vocr_bn_relu_fracpool2x2_fwd(const float* y, const float* mean, const float* invstd, const float* gamma,
+                                            const float* beta, const float* samples, float* out, int32_t* idx, int n, int c,
+                                            int h, int w, int oh, int ow, void* stream) {
+    VOCR_CHECK_ARG(y && mean && invstd && gamma && beta && samples && out && idx, "vocr_bn_relu_fracpool2x2_fwd: null pointer");
+    VOCR_CHECK_ARG(n > 0 && c > 0 && h >= 2 && w >= 2 && oh >= 1 && ow >= 1 && oh <= h - 1 && ow <= w - 1 && (long)n * c <= 65535,
+                   "vocr_bn_relu_fracpool2x2_fwd: bad shape h=%d w=%d oh=%d ow=%d", h, w, oh, ow);
+    const float alpha_h = oh > 1 ? (float)(h - 2) / (float)(oh - 1) : 0.f;
+    const float alpha_w = ow > 1 ? (float)(w - 2) / (float)(ow - 1) : 0.f;
+    bn_relu_fracpool_fwd_kernel<<<plane_grid((long)n * c, (long)oh * ow), 256, 0, (hipStream_t)stream>>>(
+        y, mean, invstd, gamma, beta, samples, out, idx, c, h, w, oh, ow, alpha_h, alpha_w);
+    VOCR_CHECK_LAUNCH("vocr_bn_relu_fracpool2x2_fwd");
     return VOCR_OK;
 }
 

@@ -218,8 +218,12 @@ class CnnOcrModel(nn.Module):
             conv = getattr(self.rapid_ds, "%02d-conv" % i)
             a = ops.ConvReluPoolFn.apply(a, conv.weight, conv.bias, self.conv_dtype == "fp16")
         pool_i = 0
-        for step in self._plan:
+        fused_pool = False
+        for si, step in enumerate(self._plan):
             if step == "pool":
+                if fused_pool:                      # already applied inside the conv layer before it
+                    fused_pool = False
+                    continue
                 n, c, h, w = a.shape
                 oh, ow = math.floor(h * 0.5), math.floor(w * 0.7)
                 if self.pool_samples is not None:
@@ -230,8 +234,19 @@ class CnnOcrModel(nn.Module):
                 pool_i += 1
                 continue
             conv, bn = step
+            u, oh, ow = None, 0, 0
+            if si + 1 < len(self._plan) and self._plan[si + 1] == "pool":
+                # the pooling layer that follows is fused into this layer's BatchNorm + ReLU pass
+                n, h, w = a.shape[0], a.shape[2], a.shape[3]
+                oh, ow = math.floor(h * 0.5), math.floor(w * 0.7)
+                if self.pool_samples is not None:
+                    u = self.pool_samples[pool_i].to(dev)
+                else:
+                    u = torch.rand(n, conv.weight.shape[0], 2, dtype=torch.float32, device=dev)
+                pool_i += 1
+                fused_pool = True
             a = ops.ConvBnReluFn.apply(a, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                       self.training, bn.eps, bn.momentum, self.conv_dtype == "fp16")
+                                       self.training, bn.eps, bn.momentum, self.conv_dtype == "fp16", u, oh, ow)
             if self.training:
                 bn.num_batches_tracked += 1
         b, c, h, w = a.shape

@@ -142,7 +142,10 @@ class ConvBnReluFn(torch.autograd.Function):
     """Conv2d(k3,p1) -> BatchNorm2d -> ReLU (reference ConvBNReLU, src/models/cnnlstm.py:263-266)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, training, eps, momentum, f16=False):
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, training, eps, momentum, f16=False,
+                pool_samples=None, pool_oh=0, pool_ow=0):
+        """With `pool_samples` (N, C, 2) the FractionalMaxPool2d that follows this layer (cnnlstm.py:127,130) is applied in
+        the same pass as BatchNorm + ReLU and the pooled tensor is returned: the unpooled activation is needed by nobody."""
         _need_gpu(x, weight, bias, gamma, beta, running_mean, running_var)
         x = _f32c(x)
         n, cin, h, w = x.shape
@@ -163,22 +166,39 @@ class ConvBnReluFn(torch.autograd.Function):
                  _p(running_var), _p(ws), _stream())
         else:
             call("vocr_bn_eval_stats", _p(running_mean), _p(running_var), cout, eps, _p(mean), _p(invstd), _stream())
-        out = torch.empty_like(y)
-        call("vocr_bn_relu_apply", _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(out), n, cout, h * w, _stream())
+        ctx.pool = None
+        idx = None
+        if pool_samples is not None:
+            samples = _f32c(pool_samples)
+            if tuple(samples.shape) != (n, cout, 2):
+                raise RuntimeError("fractional pool samples must have shape (N, C, 2)")
+            out = torch.empty(n, cout, pool_oh, pool_ow, dtype=torch.float32, device=x.device)
+            idx = torch.empty(n, cout, pool_oh, pool_ow, dtype=torch.int32, device=x.device)
+            call("vocr_bn_relu_fracpool2x2_fwd", _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(samples), _p(out), _p(idx),
+                 n, cout, h, w, pool_oh, pool_ow, _stream())
+            ctx.pool = (pool_oh, pool_ow)
+        else:
+            out = torch.empty_like(y)
+            call("vocr_bn_relu_apply", _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(out), n, cout, h * w, _stream())
         ctx.training = training
         ctx.prefs = (weight, bias, gamma, beta)
-        ctx.save_for_backward(x, y, mean, invstd, gamma, beta, pd)
+        ctx.save_for_backward(x, y, mean, invstd, gamma, beta, pd, idx)
         return out
 
     @staticmethod
     def backward(ctx, da):
         if not ctx.training:
             raise RuntimeError("vistaocr_amd: backward through eval-mode BatchNorm is not part of the reference path")
-        x, y, mean, invstd, gamma, beta, pd = ctx.saved_tensors
+        x, y, mean, invstd, gamma, beta, pd, idx = ctx.saved_tensors
         da = _f32c(da)
         n, cin, h, w = x.shape
         cout = y.shape[1]
         lib = _lib.load()
+        if ctx.pool is not None:            # gradient of the fused pooling first: back to the full plane
+            oh, ow = ctx.pool
+            dfull = torch.empty(n, cout, h, w, dtype=torch.float32, device=da.device)
+            call("vocr_fracpool2x2_bwd", _p(da), _p(idx), _p(dfull), n, cout, h, w, oh, ow, _stream())
+            da = dfull
         dy = torch.empty_like(y)
         sinks = _sinks(ctx.prefs)
         if sinks is not None:
@@ -209,8 +229,8 @@ class ConvBnReluFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = conv3x3_forward_f16(dy, pd, None, cin) if ctx.f16 else conv3x3_forward(dy, pd, None, cin)
         if sinks is not None:
-            return dx, None, None, None, None, None, None, None, None, None, None
-        return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None
+            return (dx,) + (None,) * 13
+        return (dx, dw, dbias, dgamma, dbeta) + (None,) * 9
 
 
 class ConvReluPoolFn(torch.autograd.Function):
