@@ -26,6 +26,12 @@ extern "C" {
 #define VOCR_EINVAL     -1   /* bad argument (shape, null pointer, unsupported size) */
 #define VOCR_ELAUNCH    -2   /* HIP launch error */
 #define VOCR_ENODEVICE  -3   /* no gfx950 device visible */
+#define VOCR_ECOMM      -4   /* RCCL missing or a collective failed */
+
+/* "health" words: an optional caller-owned int32[2] in device memory, zeroed once by the caller and then sticky.
+ *   health[0] != 0: a hand-off inside a persistent LSTM sweep timed out (that sweep's output is NaN-poisoned);
+ *   health[1] != 0: a NaN gradient reached vocr_clamp_adam / vocr_clamp (the reference's clamp_ propagates NaN too).
+ * The host reads it whenever it synchronises anyway (vistaocr_amd.train() copies it next to the loss). */
 
 const char* vocr_last_error(void);
 int  vocr_abi_version(void);
@@ -54,12 +60,14 @@ int vocr_conv3x3_f16_fwd(const float* x, const void* wpack, const float* bias, f
                          int n, int cin, int h, int w, int cout, void* stream);
 int vocr_conv3x3_wgrad_f16(const float* x, const float* dy, float* dw, void* workspace,
                            int n, int cin, int h, int w, int cout, void* stream);
-/* per-channel sum over (n,h,w): conv bias gradient.  out[c] */
-int vocr_channel_sum(const float* x, float* out, int n, int c, int hw, void* stream);
+/* per-channel sum over (n,h,w): conv bias gradient.  out[c].  workspace (vocr_channel_sum_workspace_bytes, may be NULL =
+ * one workgroup per channel) holds per-chunk partial sums that are added in a fixed order: bitwise reproducible. */
+size_t vocr_channel_sum_workspace_bytes(int n, int c, int hw);
+int vocr_channel_sum(const float* x, float* out, int n, int c, int hw, void* workspace, void* stream);
 
 /* ---- BatchNorm2d + ReLU — src/models/cnnlstm.py:265-266 -------------------------------------------------- */
 /* training statistics: mean[c], invstd[c] (biased var, eps) and running-stat update (momentum, unbiased var).
- * running_mean/var may be NULL.  workspace: 2*c*nchunk doubles, see vocr_bn_workspace_bytes. */
+ * running_mean/var may be NULL.  workspace: 3*c*nchunk doubles, see vocr_bn_workspace_bytes. */
 size_t vocr_bn_workspace_bytes(int n, int c, int hw);
 int vocr_bn_train_stats(const float* y, int n, int c, int hw, float eps, float momentum,
                         float* mean, float* invstd, float* running_mean, float* running_var,
@@ -71,7 +79,8 @@ int vocr_bn_eval_stats(const float* running_mean, const float* running_var, int 
 int vocr_bn_relu_apply(const float* y, const float* mean, const float* invstd, const float* gamma,
                        const float* beta, float* out, int n, int c, int hw, void* stream);
 /* given da = dL/d(out): dgamma, dbeta and dy = dL/d(y) (training-mode batch-stat backward through ReLU);
- * dconv_bias (may be NULL) receives sum_{n,h,w} dy per channel = the gradient of the conv bias in front. */
+ * dconv_bias (may be NULL) receives sum_{n,h,w} dy per channel = the gradient of the conv bias in front (rounding
+ * noise around zero, from the fixed-order reduction: no float atomics anywhere in this call). */
 int vocr_bn_relu_bwd(const float* da, const float* y, const float* mean, const float* invstd,
                      const float* gamma, const float* beta, float* dy, float* dgamma, float* dbeta,
                      float* dconv_bias, int n, int c, int hw, void* workspace, void* stream);
@@ -98,12 +107,17 @@ int vocr_relu_maxpool2_bwd(const float* dout, const float* out, const int32_t* i
 /* ---- dense layers: bridge Linear+ReLU, LSTM input projections, prob Linear — cnnlstm.py:143-154,278,294 -- */
 /* C[M,N] (ldc) = op(A)[M,K] * op(B)[K,N] (+ bias[N]) (relu) — row-major.
  * transa=0: A is [M,K] lda;  transa=1: A is stored [K,M] lda.   transb=0: B is [K,N] ldb;  transb=1: B is [N,K] ldb.
- * accumulate!=0: C += result (split-K uses float atomics; C must hold the addend or zeros). */
+ * accumulate!=0: C += result.  Long-K products with few output tiles (the weight gradients) are split along K: each
+ * slice writes its own [M][N] slab into `workspace` (vocr_gemm_workspace_bytes; 16-byte aligned; may be NULL or smaller
+ * = fewer or no slices) and the slabs are added in slice order — results are bitwise reproducible run to run. */
+size_t vocr_gemm_workspace_bytes(int m, int n, int k, int has_bias_or_relu);
 int vocr_gemm(int transa, int transb, int m, int n, int k,
               const float* a, int lda, const float* b, int ldb, float* c, int ldc,
-              const float* bias, int relu, int accumulate, void* stream);
-/* out[N] = sum over M rows of x[M,N] (bias gradients) */
-int vocr_colsum(const float* x, float* out, int m, int n, void* stream);
+              const float* bias, int relu, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* out[N] = sum over M rows of x[M,N] (bias gradients); partial rows in `workspace` (vocr_colsum_workspace_bytes, may be
+ * NULL = one workgroup per 64 columns), added in a fixed order */
+size_t vocr_colsum_workspace_bytes(int m, int n);
+int vocr_colsum(const float* x, float* out, int m, int n, void* workspace, void* stream);
 /* dz = (out > 0) ? dy : 0  (ReLU backward, elementwise) */
 int vocr_relu_bwd(const float* dy, const float* out, float* dz, size_t count, void* stream);
 /* bchw -> (w,b,c*h) and back — cnn_output.permute(3,0,1,2).contiguous(), cnnlstm.py:276 */
@@ -126,24 +140,26 @@ int vocr_dropout_fwd(const float* x, float* out, float* mask, size_t count, floa
  * Supports B <= 64, H % 16 == 0.  For H in {64,128,256,512} a whole sweep is ONE persistent launch whose workgroups
  * hand h_t (forward) / partial sums (backward) to each other through memory: it needs its grid (<= one workgroup per CU)
  * co-resident, so do not run two sweeps concurrently on one device; a hand-off that times out (seconds) poisons the
- * output with NaN instead of hanging.  VOCR_LSTM_PERSISTENT=0 selects one launch per time step instead. */
+ * output with NaN instead of hanging.  VOCR_LSTM_PERSISTENT=0 selects one launch per time step instead.
+ * `health` (may be NULL): see the note on health words at the top; with NULL the timeout flag lives in the workspace. */
 size_t vocr_lstm_workspace_bytes(int t, int b, int h);
 int vocr_lstm_fwd(const float* xproj, const float* whh_fwd, const float* whh_rev, const int32_t* lens, float* y,
-                  float* gates, float* cell, void* workspace, int t, int b, int h, void* stream);
+                  float* gates, float* cell, void* workspace, int t, int b, int h, int32_t* health, void* stream);
 /* Steps [step_begin, step_end) of the same sweep (step s is time s for the forward direction, T-1-s for the reverse
  * one): a later range resumes from the h (in y) and c (in cell) an earlier call left.  Lets the host overlap the
  * x-projection GEMM of the later time steps with the first half of the sweep.  vocr_lstm_fwd == range [0, t). */
 int vocr_lstm_fwd_range(const float* xproj, const float* whh_fwd, const float* whh_rev, const int32_t* lens, float* y,
                         float* gates, float* cell, void* workspace, int t, int b, int h, int step_begin, int step_end,
-                        void* stream);
+                        int32_t* health, void* stream);
 /* dy[T][B][2H] -> dgates[dir][T][B][4H] (gradient w.r.t. pre-activation gates = w.r.t. xproj).
  * whht_* are the TRANSPOSED recurrent weights [H][4H] (vocr_bchw_to_wbch with b=1 transposes a matrix). */
 int vocr_lstm_bwd(const float* dy, const float* whht_fwd, const float* whht_rev, const int32_t* lens, const float* gates,
-                  const float* cell, float* dgates, void* workspace, int t, int b, int h, void* stream);
+                  const float* cell, float* dgates, void* workspace, int t, int b, int h, int32_t* health, void* stream);
 /* Same, and dbias[dir][4H] = sum over (t, b) of dgates[dir] (the gradient of b_ih and of b_hh): accumulated inside the
  * sweep where the kernel supports it, else by column sums afterwards.  dbias may be NULL. */
 int vocr_lstm_bwd_bias(const float* dy, const float* whht_fwd, const float* whht_rev, const int32_t* lens, const float* gates,
-                       const float* cell, float* dgates, float* dbias, void* workspace, int t, int b, int h, void* stream);
+                       const float* cell, float* dgates, float* dbias, void* workspace, int t, int b, int h, int32_t* health,
+                       void* stream);
 
 /* ---- CTC: warpctc_pytorch.CTCLoss — src/train_cnn_lstm.py:358,138 ------------------------------------------ */
 /* logits[T][B][V] pre-softmax, blank = 0.  labels flat int32 (device), label_offsets[B], label_lens[B],
@@ -164,9 +180,24 @@ int vocr_greedy_collapse(const int32_t* idx, const float* maxv, const int32_t* l
                          int32_t* out_labels, int32_t* out_counts, int t, int b, float thresh, void* stream);
 
 /* ---- optimiser: grad clamp + torch.optim.Adam — src/train_cnn_lstm.py:143-149,363 -------------------------- */
-/* g = clamp(g*grad_scale, -clamp, clamp) (+ wd*p); Adam(m, v); step is the 1-based step count. */
+/* g = clamp(g*grad_scale, -clamp, clamp) (+ wd*p); Adam(m, v); step is the 1-based step count.  A NaN gradient stays NaN
+ * (torch's clamp_ propagates NaN) and sets health[1] (health may be NULL). */
 int vocr_clamp_adam(float* p, const float* g, float* m, float* v, size_t count, float lr, float beta1, float beta2,
-                    float eps, float weight_decay, float clamp, float grad_scale, int step, void* stream);
+                    float eps, float weight_decay, float clamp, float grad_scale, int step, int32_t* health, void* stream);
+/* in place x = clamp(x, -clamp, clamp), NaN preserved: `param.grad.data.clamp_(min=-5, max=5)` (train_cnn_lstm.py:143-145)
+ * for callers that keep their own optimiser (torch.optim.Adam). */
+int vocr_clamp(float* x, size_t count, float clamp, int32_t* health, void* stream);
+
+/* ---- data-parallel exchange: nn.DataParallel's gradient reduction — cnnlstm.py:198-199, train_cnn_lstm.py:333 ---- */
+/* One process per GPU; the only collective of the path is a SUM all-reduce of the flat fp32 gradient before the clamp.
+ * Thin RCCL wrapper (xGMI inside a node) for hosts that do not use torch.distributed; RCCL is dlopen'ed on first use.
+ * Rank 0 calls vocr_comm_unique_id and hands the 128 bytes to every rank (any transport); every rank then calls
+ * vocr_comm_create(device = its GPU).  The handle is the only object the library ever allocates. */
+typedef struct vocr_comm vocr_comm;
+int vocr_comm_unique_id(void* id128);
+int vocr_comm_create(vocr_comm** out, const void* id128, int nranks, int rank, int device);
+int vocr_allreduce_sum_f32(vocr_comm* comm, float* buf, size_t count, void* stream);   /* in place, stream-ordered */
+int vocr_comm_destroy(vocr_comm* comm);
 
 #ifdef __cplusplus
 }

@@ -293,6 +293,57 @@ def run_host_logic():
     print("host_logic  scheduler traces + collater batch saved")
 
 
+def run_ref_checkpoint(CnnOcrModel, alphabet):
+    """A checkpoint exactly as the reference writes it (src/train_cnn_lstm.py:427-438) from a model trained with the
+    reference's defaults gpu=True, multigpu=True: the hyper-parameter dict pickles the reference's own
+    `alphabet.Alphabet` instance, the CNN keys carry nn.DataParallel's `cnn.module.` prefix, the optimiser state is
+    torch.optim.Adam's.  Stored gzip-compressed (tests/golden/ref_checkpoint.pth.gz); to keep it small the five large
+    conv weights keep one entry in sixteen (the file pins FORMAT interop; numerics are pinned by the other goldens).
+    Expected outputs: the reference model's eval-mode logits / greedy strings on a fixed closed-form batch."""
+    import gzip
+    import io
+    hp = dict(input_line_height=30, rds_line_height=30, lstm_input_dim=16, num_lstm_layers=1,
+              num_lstm_hidden_units=16, p_lstm_dropout=0.5, num_in_channels=1)
+    V = len(alphabet)
+    sd_np = cf.closed_form_state(hp, V)
+    for k in ("cnn.7.weight", "cnn.10.weight", "cnn.14.weight", "cnn.17.weight", "cnn.20.weight"):
+        flat = sd_np[k].reshape(-1)
+        keep = (np.arange(flat.size) % 16) == 3
+        sd_np[k] = (flat * keep * np.float32(4.0)).reshape(sd_np[k].shape).astype(np.float32)
+    model = build_ref_model(CnnOcrModel, hp, alphabet, sd_np)
+    # what a gpu=True, multigpu=True run holds: DataParallel around the CNN (cnnlstm.py:198-199) and those kwargs in the
+    # hyper-parameter dict (cnnlstm.py:80: self.hyper_params = kwargs.copy())
+    model.cnn = torch.nn.DataParallel(model.cnn)
+    model.hyper_params = dict(hp, alphabet=alphabet, gpu=True, multigpu=True, verbose=False)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=0.0)
+    B, widths = 2, [120, 90]
+    x, w, tgt, tl = cf.closed_form_batch(B, 1, 30, widths, V, [4, 3], seed=2)
+    s1, s2 = cf.closed_form_pool_samples(B)
+    pools = [m for m in model.cnn.module if isinstance(m, torch.nn.FractionalMaxPool2d)]
+    pools[0]._random_samples = torch.from_numpy(s1)
+    pools[1]._random_samples = torch.from_numpy(s2)
+    model.eval()
+    with torch.no_grad():
+        logits, lens = model(torch.from_numpy(x), torch.from_numpy(w))
+    strs_ux = model.decode_without_lm(logits, lens, uxxxx=True)
+    for pl in pools:                   # the injected samples are test plumbing, not part of a trained model's state
+        pl._random_samples = None
+    ckpt = {'iteration': 1234, 'state_dict': model.state_dict(), 'optimizer': opt.state_dict(),
+            'model_hyper_params': model.get_hyper_params(), 'rtl': False, 'cur_lr': 1e-3, 'val_loss': 1.5,
+            'val_cer': 0.25, 'val_wer': 0.5, 'line_height': 30}
+    assert any(k.startswith("cnn.module.") for k in ckpt['state_dict'])
+    buf = io.BytesIO()
+    torch.save(ckpt, buf)
+    with gzip.GzipFile(os.path.join(OUT, "ref_checkpoint.pth.gz"), "wb", mtime=0) as fh:
+        fh.write(buf.getvalue())
+    np.savez_compressed(os.path.join(OUT, "ref_checkpoint_expect.npz"), widths=w, lens=lens.numpy(), logits=logits.numpy(),
+                        strings_uxxxx=np.array(strs_ux, dtype=object), batch_seed=np.int64(2),
+                        margin=np.float64(top2_margin(logits, lens)), n_keys=np.int64(len(ckpt['state_dict'])))
+    print("ref_checkpoint  %d keys, %.0f KB gz, margin %.3g, strings %s" %
+          (len(ckpt['state_dict']), os.path.getsize(os.path.join(OUT, "ref_checkpoint.pth.gz")) / 1024.0,
+           top2_margin(logits, lens), strs_ux))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -305,6 +356,9 @@ def main():
         json.dump({"train": [], "validation": [], "test": []}, fh)     # french.py:14-19 wants a desc.json
     fre = Alphabet(FrenchAlphabet(None, fh.name).idx_to_alphabet, left_to_right=True)
     os.unlink(fh.name)
+    if len(sys.argv) > 1 and sys.argv[1] == "ref_checkpoint":          # regenerate this one fixture only
+        run_ref_checkpoint(CnnOcrModel, eng)
+        return
     np.savez_compressed(os.path.join(OUT, "alphabets.npz"),
                         english=np.array(eng.char_array, dtype=object),
                         arabic=np.array(ara.char_array, dtype=object),
@@ -337,6 +391,7 @@ def main():
     run_train2(CnnOcrModel, eng, small, 4, [200, 200, 160, 120], [8, 8, 6, 4])
     run_decode_edges(CnnOcrModel, ArgmaxDecoder, eng)
     run_host_logic()
+    run_ref_checkpoint(CnnOcrModel, eng)
     # no bytecode may be left in the read-only reference tree
     for d in (REF, os.path.join(REF, "models")):
         assert not os.path.exists(os.path.join(d, "__pycache__")), d

@@ -17,8 +17,8 @@ dy = torch.randn(T * B, 2 * H, device=dev) * 0.01
 dg = torch.empty(2, T * B, 4 * H, device=dev)
 wtf, wtr = ops.transpose2d(wf), ops.transpose2d(wr)
 s = torch.cuda.current_stream().cuda_stream
-def fwd(): call("vocr_lstm_fwd", xproj.data_ptr(), wf.data_ptr(), wr.data_ptr(), lens.data_ptr(), y.data_ptr(), gates.data_ptr(), cell.data_ptr(), ws.data_ptr(), T, B, H, s)
-def bwd(): call("vocr_lstm_bwd", dy.data_ptr(), wtf.data_ptr(), wtr.data_ptr(), lens.data_ptr(), gates.data_ptr(), cell.data_ptr(), dg.data_ptr(), ws.data_ptr(), T, B, H, s)
+def fwd(): call("vocr_lstm_fwd", xproj.data_ptr(), wf.data_ptr(), wr.data_ptr(), lens.data_ptr(), y.data_ptr(), gates.data_ptr(), cell.data_ptr(), ws.data_ptr(), T, B, H, None, s)
+def bwd(): call("vocr_lstm_bwd", dy.data_ptr(), wtf.data_ptr(), wtr.data_ptr(), lens.data_ptr(), gates.data_ptr(), cell.data_ptr(), dg.data_ptr(), ws.data_ptr(), T, B, H, None, s)
 for name, fn in (("fwd", fwd), ("bwd", bwd)):
     for _ in range(2): fn()
     torch.cuda.synchronize(); t0 = time.perf_counter()

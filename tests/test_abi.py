@@ -23,15 +23,15 @@ def test_library_builds_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "libvocr.so does not export %s" % name
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
-    assert lib.vocr_abi_version() == 1
+    assert lib.vocr_abi_version() == 2
 
 
 def test_argument_validation_without_gpu():
     from vistaocr_amd import _lib
     lib = _lib.load()
-    rc = lib.vocr_gemm(0, 0, 0, 4, 4, None, 4, None, 4, None, 4, None, 0, 0, None)
+    rc = lib.vocr_gemm(0, 0, 0, 4, 4, None, 4, None, 4, None, 4, None, 0, 0, None, 0, None)
     assert rc == -1 and b"vocr_gemm" in lib.vocr_last_error()
-    rc = lib.vocr_lstm_fwd(None, None, None, None, None, None, None, None, 4, 4, 16, None)
+    rc = lib.vocr_lstm_fwd(None, None, None, None, None, None, None, None, 4, 4, 16, None, None)
     assert rc == -1
     assert lib.vocr_conv3x3_wgrad_workspace_bytes(32, 256, 7, 294, 256) > 0
     assert lib.vocr_ctc_workspace_bytes(294, 32, 96, 20) > 0

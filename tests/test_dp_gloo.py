@@ -79,7 +79,7 @@ def _worker_buckets(rank, world, port, q):
     ok = opt._split == n_cnn and 0 < n_cnn < opt.flat_g.numel()
     opt.zero_grad()
     opt.flat_g[opt._split:] = float(rank + 1)          # sequence-side gradients are final ...
-    for fn in ops.BACKWARD_HOOKS["sequence_grads_ready"]:
+    for fn in m._vocr_hooks["sequence_grads_ready"]:
         fn()                                            # ... the backward fires the hook: tail all-reduce starts
     ok = ok and opt._tail_work is not None
     opt.flat_g[:opt._split] = float(10 * (rank + 1))   # CNN gradients arrive later

@@ -90,6 +90,59 @@ def test_checkpoint_roundtrip_schema(tmp_path):
         assert torch.equal(v, m2.state_dict()[k])
 
 
+def _ref_checkpoint(tmp_path):
+    import gzip
+    path = os.path.join(tmp_path, "ref-best_model.pth")
+    with gzip.open(os.path.join(gu.GOLDEN, "ref_checkpoint.pth.gz"), "rb") as src, open(path, "wb") as dst:
+        dst.write(src.read())
+    return path
+
+
+def test_reference_written_checkpoint_loads(tmp_path):
+    """tests/golden/ref_checkpoint.pth.gz was written by the REFERENCE's own classes (oracle/gen_golden.py
+    run_ref_checkpoint: train_cnn_lstm.py:427-438 schema, pickled `alphabet.Alphabet`, DataParallel 'cnn.module.' keys,
+    torch.optim.Adam state).  A plain torch.load cannot even unpickle it here (no top-level module `alphabet`);
+    FromSavedWeights must — without leaving anything in sys.modules."""
+    import sys
+    import vistaocr_amd as va
+    from vistaocr_amd import checkpoint
+    path = _ref_checkpoint(tmp_path)
+    with pytest.raises(ModuleNotFoundError):
+        torch.load(path, map_location="cpu", weights_only=False)
+    w = checkpoint.load(path)
+    assert "alphabet" not in sys.modules
+    assert set(w) == {"iteration", "state_dict", "optimizer", "model_hyper_params", "rtl", "cur_lr", "val_loss", "val_cer",
+                      "val_wer", "line_height"}
+    al = w["model_hyper_params"]["alphabet"]
+    assert isinstance(al, va.Alphabet) and len(al) == 96 and al.left_to_right is True
+    assert al.idx_to_char == va.english_alphabet().idx_to_char and al.char_to_idx == va.english_alphabet().char_to_idx
+    assert sum(k.startswith("cnn.module.") for k in w["state_dict"]) == 49          # 7 x (conv w,b + BN 5 entries)
+    m = va.CnnOcrModel.FromSavedWeights(path, verbose=False, gpu=False)
+    exp = gu.load("ref_checkpoint_expect")
+    assert len(m.state_dict()) == int(exp["n_keys"]) and m.rtl is False and m.num_lstm_hidden_units == 16
+    for k, v in checkpoint.strip_dataparallel_prefix(w["state_dict"]).items():
+        assert torch.equal(m.state_dict()[k], v), k
+    # and back: a snapshot this build writes names the alphabet class the reference's way and re-adds the prefix
+    from vistaocr_amd.loop import save_snapshot
+
+    class _Opt:
+        def state_dict(self):
+            return {}
+    m.hyper_params["gpu"] = True
+    out = os.path.join(tmp_path, "ours-cur_snapshot.pth")
+    save_snapshot(out, 5, m, _Opt(), False, 1e-3, 1.0, 0.5, 0.9, 30)
+    import zipfile
+    z = zipfile.ZipFile(out)
+    pkl = z.read([n for n in z.namelist() if n.endswith("data.pkl")][0])
+    assert b"alphabet\nAlphabet\n" in pkl and b"vistaocr_amd" not in pkl
+    w2 = checkpoint.load(out)
+    assert sorted(w2["state_dict"]) == sorted(w["state_dict"])
+    m.hyper_params["gpu"] = False
+    m2 = va.CnnOcrModel.FromSavedWeights(out, verbose=False, gpu=False)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, m2.state_dict()[k])
+
+
 def test_textutils_and_edit_distance_kat():
     from vistaocr_amd import textutils as tu
     assert tu.uxxxx_to_utf8("u0061 u0062 u0020 u0063") == "ab c"

@@ -90,7 +90,8 @@ def test_fit_control_flow_and_checkpoint_schema(tmp_path):
     assert [v[0] for v in hist["val"]] == [4, 8, 12, 16, 20, 24]          # validation every 4 iterations
     assert hist["lr_drops"] == [16, 24] and hist["stopped_early"]          # patience 1: drop at 16, exhausted at 24
     assert abs(opt.param_groups[0]["lr"] - 1e-4) < 1e-12
-    ck = torch.load(prefix + "-best_model.pth", map_location="cpu", weights_only=False)
+    from vistaocr_amd import checkpoint
+    ck = checkpoint.load(prefix + "-best_model.pth")
     assert set(ck) == {"iteration", "state_dict", "optimizer", "model_hyper_params", "rtl", "cur_lr", "val_loss", "val_cer", "val_wer", "line_height"}
     assert ck["iteration"] == 8 and abs(ck["val_wer"] - 0.8) < 1e-12       # best = second validation
     # after the LR drop at iteration 16 the best weights (iteration 8 -> w0 + 8) were reloaded before training went on

@@ -265,11 +265,11 @@ def test_persistent_sweeps_match_per_step_launches(dev, T, B, H):
         "y = torch.empty(T * B, 2 * H, device=dev); gt = torch.empty(2, T * B, 4 * H, device=dev); c = torch.empty(2, T * B, H, device=dev)\n"
         "dg = torch.full((2, T * B, 4 * H), float('nan'), device=dev)\n"
         "ws = torch.zeros(lib.vocr_lstm_workspace_bytes(T, B, H) // 4 + 16, device=dev); s = torch.cuda.current_stream().cuda_stream\n"
-        "call('vocr_lstm_fwd', xp.data_ptr(), wf.data_ptr(), wr.data_ptr(), lens.data_ptr(), y.data_ptr(), gt.data_ptr(), c.data_ptr(), ws.data_ptr(), T, B, H, s)\n"
+        "call('vocr_lstm_fwd', xp.data_ptr(), wf.data_ptr(), wr.data_ptr(), lens.data_ptr(), y.data_ptr(), gt.data_ptr(), c.data_ptr(), ws.data_ptr(), T, B, H, None, s)\n"
         "torch.cuda.synchronize(); st = int(ws.view(torch.int32)[512])\n"
         "if H >= 128:\n"
         "    wtf, wtr = ops.transpose2d(wf), ops.transpose2d(wr)\n"
-        "    call('vocr_lstm_bwd', dy.data_ptr(), wtf.data_ptr(), wtr.data_ptr(), lens.data_ptr(), gt.data_ptr(), c.data_ptr(), dg.data_ptr(), ws.data_ptr(), T, B, H, s)\n"
+        "    call('vocr_lstm_bwd', dy.data_ptr(), wtf.data_ptr(), wtr.data_ptr(), lens.data_ptr(), gt.data_ptr(), c.data_ptr(), dg.data_ptr(), ws.data_ptr(), T, B, H, None, s)\n"
         "    torch.cuda.synchronize(); st |= int(ws.view(torch.int32)[512]) if int(sys.argv[2]) & 2 else 0\n"
         "print('STATUS', st); torch.save((y.cpu(), gt.cpu(), c.cpu(), dg.cpu()), sys.argv[1])\n"
     ) % (root, T, B, H)
@@ -351,10 +351,10 @@ def test_lstm_backward_bias_gradient_is_the_column_sum_of_dgates(dev, T, B, H):
     db = torch.full((2, 4 * H), float("nan"), device=dev)
     ws = torch.zeros(lib.vocr_lstm_workspace_bytes(T, B, H) // 4 + 16, device=dev)
     call("vocr_lstm_fwd", xp.data_ptr(), wf.data_ptr(), wr.data_ptr(), lens.data_ptr(), y.data_ptr(), gt.data_ptr(), c.data_ptr(),
-         ws.data_ptr(), T, B, H, s)
+         ws.data_ptr(), T, B, H, None, s)
     wtf, wtr = ops.transpose2d(wf), ops.transpose2d(wr)
     call("vocr_lstm_bwd_bias", dy.data_ptr(), wtf.data_ptr(), wtr.data_ptr(), lens.data_ptr(), gt.data_ptr(), c.data_ptr(),
-         dg.data_ptr(), db.data_ptr(), ws.data_ptr(), T, B, H, s)
+         dg.data_ptr(), db.data_ptr(), ws.data_ptr(), T, B, H, None, s)
     torch.cuda.synchronize()
     ref = dg.double().sum(dim=1)
     assert float((db.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-6       # fp32 summation-order tolerance
@@ -380,7 +380,7 @@ def test_lstm_forward_step_ranges_resume_bit_exactly(dev, T, B, H, cut):
         ws = torch.zeros(lib.vocr_lstm_workspace_bytes(T, B, H) // 4 + 16, device=dev)
         for a, b in ranges:
             call("vocr_lstm_fwd_range", xp.data_ptr(), wf.data_ptr(), wr.data_ptr(), lens.data_ptr(), y.data_ptr(), gt.data_ptr(),
-                 c.data_ptr(), ws.data_ptr(), T, B, H, a, b, s)
+                 c.data_ptr(), ws.data_ptr(), T, B, H, a, b, None, s)
         torch.cuda.synchronize()
         outs.append((y.cpu(), gt.cpu(), c.cpu()))
     for nm, a, b in zip(("y", "gates", "cell"), outs[0], outs[1]):

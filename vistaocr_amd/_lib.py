@@ -24,7 +24,8 @@ SIGNATURES = {
     "vocr_conv3x3_f16_pack_weights": (I, [P, P, P, I, I, P]),
     "vocr_conv3x3_f16_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
     "vocr_conv3x3_wgrad_f16": (I, [P, P, P, P, I, I, I, I, I, P]),
-    "vocr_channel_sum": (I, [P, P, I, I, I, P]),
+    "vocr_channel_sum_workspace_bytes": (Z, [I, I, I]),
+    "vocr_channel_sum": (I, [P, P, I, I, I, P, P]),
     "vocr_bn_workspace_bytes": (Z, [I, I, I]),
     "vocr_bn_train_stats": (I, [P, I, I, I, F, F, P, P, P, P, P, P]),
     "vocr_bn_eval_stats": (I, [P, P, I, F, P, P, P]),
@@ -35,8 +36,10 @@ SIGNATURES = {
     "vocr_fracpool2x2_bwd": (I, [P, P, P, I, I, I, I, I, I, P]),
     "vocr_relu_maxpool2_fwd": (I, [P, P, P, I, I, I, I, P]),
     "vocr_relu_maxpool2_bwd": (I, [P, P, P, P, I, I, I, I, P]),
-    "vocr_gemm": (I, [I, I, I, I, I, P, I, P, I, P, I, P, I, I, P]),
-    "vocr_colsum": (I, [P, P, I, I, P]),
+    "vocr_gemm_workspace_bytes": (Z, [I, I, I, I]),
+    "vocr_gemm": (I, [I, I, I, I, I, P, I, P, I, P, I, P, I, I, P, Z, P]),
+    "vocr_colsum_workspace_bytes": (Z, [I, I]),
+    "vocr_colsum": (I, [P, P, I, I, P, P]),
     "vocr_relu_bwd": (I, [P, P, P, Z, P]),
     "vocr_bchw_to_wbch": (I, [P, P, I, I, I, I, P]),
     "vocr_wbch_to_bchw": (I, [P, P, I, I, I, I, P]),
@@ -45,15 +48,20 @@ SIGNATURES = {
     "vocr_scale_dev": (I, [P, P, P, Z, P]),
     "vocr_dropout_fwd": (I, [P, P, P, Z, F, U64, P]),
     "vocr_lstm_workspace_bytes": (Z, [I, I, I]),
-    "vocr_lstm_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, P]),
-    "vocr_lstm_fwd_range": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
-    "vocr_lstm_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, P]),
-    "vocr_lstm_bwd_bias": (I, [P, P, P, P, P, P, P, P, P, I, I, I, P]),
+    "vocr_lstm_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, P, P]),
+    "vocr_lstm_fwd_range": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, P, P]),
+    "vocr_lstm_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, P, P]),
+    "vocr_lstm_bwd_bias": (I, [P, P, P, P, P, P, P, P, P, I, I, I, P, P]),
     "vocr_ctc_workspace_bytes": (Z, [I, I, I, I]),
     "vocr_ctc_loss_grad": (I, [P, P, P, P, P, P, P, P, I, I, I, I, P]),
     "vocr_argmax_rows": (I, [P, P, P, I, I, P]),
     "vocr_greedy_collapse": (I, [P, P, P, P, P, P, I, I, F, P]),
-    "vocr_clamp_adam": (I, [P, P, P, P, Z, F, F, F, F, F, F, F, I, P]),
+    "vocr_clamp_adam": (I, [P, P, P, P, Z, F, F, F, F, F, F, F, I, P, P]),
+    "vocr_clamp": (I, [P, Z, F, P, P]),
+    "vocr_comm_unique_id": (I, [P]),
+    "vocr_comm_create": (I, [ctypes.POINTER(P), P, I, I, I]),
+    "vocr_allreduce_sum_f32": (I, [P, P, Z, P]),
+    "vocr_comm_destroy": (I, [P]),
 }
 
 _lib = None

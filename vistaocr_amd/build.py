@@ -7,7 +7,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-SOURCES = ["gemm.hip", "conv.hip", "conv_f16.hip", "bn_pool.hip", "lstm.hip", "ctc.hip", "misc.cpp"]
+SOURCES = ["gemm.hip", "conv.hip", "conv_f16.hip", "bn_pool.hip", "lstm.hip", "ctc.hip", "misc.cpp", "comm.cpp"]
 LIB = os.path.join(CSRC, "libvocr.so")
 ARCH = "gfx950"
 
@@ -48,7 +48,7 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(cc, SOURCES))
-    r = subprocess.run([hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs, capture_output=True, text=True)
+    r = subprocess.run([hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs + ["-ldl"], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stderr)
     return LIB

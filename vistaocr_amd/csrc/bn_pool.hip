@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
     const float mu = mean[c], is = invstd[c], g = gamma[c], b = beta[c];
     const long total = (long)N * HW;
     const long beg = j * per, end = min(total, beg + per);
-    double s1 = 0.0, s2 = 0.0;
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
     for (long e = beg + (long)threadIdx.x * V; e < end; e += 256 * V) {
         const long a = chan_addr(e, c, C, HW);
         const vec yv = *(const vec*)(y + a);
@@ -143,26 +143,37 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
             const float dz = o > 0.f ? vget<V>(dv, k) : 0.f;
             s1 += (double)dz;
             s2 += (double)dz * (double)xh;
+            s3 += (double)xh;
         }
     }
     block_reduce2(s1, s2, red);
+    __syncthreads();
+    double dummy = 0.0;
+    block_reduce2(s3, dummy, red);
     if (threadIdx.x == 0) {
-        part[((long)c * nchunk + j) * 2] = s1;
-        part[((long)c * nchunk + j) * 2 + 1] = s2;
+        part[((long)c * nchunk + j) * 3] = s1;
+        part[((long)c * nchunk + j) * 3 + 1] = s2;
+        part[((long)c * nchunk + j) * 3 + 2] = s3;
     }
 }
 
-__global__ void bn_bwd_final_kernel(const double* __restrict__ part, int C, int nchunk, float* __restrict__ dgamma,
-                                    float* __restrict__ dbeta) {
+// Also the gradient of the conv bias in front of the BatchNorm: sum over (n,h,w) of dy = g*is*(dz - mean(dz) - xh*mean(dz*xh))
+// = -g*is*mean(dz*xh)*sum(xh); sum(xh) is the fp32 rounding residue of the batch mean, so this is rounding noise around
+// zero exactly as in the reference, but summed in a fixed order (it used to be float atomics over the dy planes).
+__global__ void bn_bwd_final_kernel(const double* __restrict__ part, int C, int nchunk, double inv_count,
+                                    const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dconv_bias) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
     for (int j = 0; j < nchunk; ++j) {
-        s1 += part[((long)c * nchunk + j) * 2];
-        s2 += part[((long)c * nchunk + j) * 2 + 1];
+        s1 += part[((long)c * nchunk + j) * 3];
+        s2 += part[((long)c * nchunk + j) * 3 + 1];
+        s3 += part[((long)c * nchunk + j) * 3 + 2];
     }
     dbeta[c] = (float)s1;
     dgamma[c] = (float)s2;
+    if (dconv_bias) dconv_bias[c] = (float)(-(double)gamma[c] * (double)invstd[c] * (s2 * inv_count) * s3);
 }
 
 template <int V>
@@ -173,10 +184,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ beta,
                                                            const float* __restrict__ dgamma,
                                                            const float* __restrict__ dbeta, float* __restrict__ dy,
-                                                           float* __restrict__ dconv_bias, int C, long HW,
-                                                           float inv_count) {
+                                                           int C, long HW, float inv_count) {
     typedef typename VecT<V>::type vec;
-    __shared__ float redf[4];
     const long plane = blockIdx.y;
     const int c = (int)(plane % C);
     const float mu = mean[c], is = invstd[c], g = gamma[c], b = beta[c];
@@ -185,7 +194,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const vec* dp = (const vec*)(da + plane * HW);
     vec* op = (vec*)(dy + plane * HW);
     const long nv = HW / V;
-    float acc = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
         const vec yv = yp[i], dv = dp[i];
         vec o;
@@ -194,17 +202,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             const float xh = (vget<V>(yv, k) - mu) * is;
             const float ov = xh * g + b;
             const float dz = ov > 0.f ? vget<V>(dv, k) : 0.f;
-            const float v = gs * (dz - k1 - xh * k2);
-            vset<V>(o, k, v);
-            acc += v;
+            vset<V>(o, k, gs * (dz - k1 - xh * k2));
         }
         op[i] = o;
-    }
-    if (dconv_bias) {     // gradient of the conv bias in front of the BN = sum of dy (zero up to rounding); fused here
-        acc = wave_sum(acc);
-        if ((threadIdx.x & 63) == 0) redf[threadIdx.x >> 6] = acc;
-        __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(dconv_bias + c, (redf[0] + redf[1]) + (redf[2] + redf[3]));
     }
 }
 
@@ -387,7 +387,7 @@ static inline long chunk_len(long per_channel, int nchunk) {
 
 extern "C" size_t vocr_bn_workspace_bytes(int n, int c, int hw) {
     if (n <= 0 || c <= 0 || hw <= 0) return 0;
-    return (size_t)c * bn_nchunk((long)n * hw) * 2 * sizeof(double);
+    return (size_t)c * bn_nchunk((long)n * hw) * 3 * sizeof(double);
 }
 
 extern "C" int vocr_bn_train_stats(const float* y, int n, int c, int hw, float eps, float momentum, float* mean,
@@ -448,17 +448,14 @@ extern "C" int vocr_bn_relu_bwd(const float* da, const float* y, const float* me
     else if (V == 2) bn_bwd_partial_kernel<2><<<dim3(c, nchunk), 256, 0, s>>>(da, y, mean, invstd, gamma, beta, (double*)workspace, n, c, hw, nchunk, per);
     else bn_bwd_partial_kernel<1><<<dim3(c, nchunk), 256, 0, s>>>(da, y, mean, invstd, gamma, beta, (double*)workspace, n, c, hw, nchunk, per);
     VOCR_CHECK_LAUNCH("vocr_bn_relu_bwd(partial)");
-    bn_bwd_final_kernel<<<vocr_cdiv(c, 64), 64, 0, s>>>((const double*)workspace, c, nchunk, dgamma, dbeta);
+    bn_bwd_final_kernel<<<vocr_cdiv(c, 64), 64, 0, s>>>((const double*)workspace, c, nchunk, 1.0 / (double)((long)n * hw), gamma, invstd,
+                                                        dgamma, dbeta, dconv_bias);
     VOCR_CHECK_LAUNCH("vocr_bn_relu_bwd(final)");
-    if (dconv_bias && hipMemsetAsync(dconv_bias, 0, (size_t)c * sizeof(float), s) != hipSuccess) {
-        vocr_set_error("vocr_bn_relu_bwd: memset failed");
-        return VOCR_ELAUNCH;
-    }
     const dim3 grid = plane_grid((long)n * c, hw / V);
     const float inv_count = 1.0f / (float)((long)n * hw);
-    if (V == 4) bn_bwd_apply_kernel<4><<<grid, 256, 0, s>>>(da, y, mean, invstd, gamma, beta, dgamma, dbeta, dy, dconv_bias, c, hw, inv_count);
-    else if (V == 2) bn_bwd_apply_kernel<2><<<grid, 256, 0, s>>>(da, y, mean, invstd, gamma, beta, dgamma, dbeta, dy, dconv_bias, c, hw, inv_count);
-    else bn_bwd_apply_kernel<1><<<grid, 256, 0, s>>>(da, y, mean, invstd, gamma, beta, dgamma, dbeta, dy, dconv_bias, c, hw, inv_count);
+    if (V == 4) bn_bwd_apply_kernel<4><<<grid, 256, 0, s>>>(da, y, mean, invstd, gamma, beta, dgamma, dbeta, dy, c, hw, inv_count);
+    else if (V == 2) bn_bwd_apply_kernel<2><<<grid, 256, 0, s>>>(da, y, mean, invstd, gamma, beta, dgamma, dbeta, dy, c, hw, inv_count);
+    else bn_bwd_apply_kernel<1><<<grid, 256, 0, s>>>(da, y, mean, invstd, gamma, beta, dgamma, dbeta, dy, c, hw, inv_count);
     VOCR_CHECK_LAUNCH("vocr_bn_relu_bwd(apply)");
     return VOCR_OK;
 }

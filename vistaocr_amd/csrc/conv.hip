@@ -624,7 +624,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
-// per-channel sum over (n, h*w): grid (C, chunks); double accumulation inside a workgroup, float atomics across
+// per-channel sum over (n, h*w): grid (C, chunks); double accumulation inside a workgroup; with more than one chunk the
+// partial sums go to part[chunk][C] and channel_sum_final_kernel adds them in chunk order (reproducible, no atomics)
 __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int N, int C,
                                                           long HW, int nchunk) {
     __shared__ double red[4];
@@ -641,9 +642,16 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float v = (float)((red[0] + red[1]) + (red[2] + red[3]));
-        if (nchunk > 1) atomicAdd(out + c, v); else out[c] = v;
+        out[(long)j * C + c] = (float)((red[0] + red[1]) + (red[2] + red[3]));
     }
+}
+
+__global__ void channel_sum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int C, int nchunk) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float v = part[c];
+    for (int j = 1; j < nchunk; ++j) v += part[(long)j * C + c];
+    out[c] = v;
 }
 
 const float* zero_page_ptr() {
@@ -775,17 +783,27 @@ extern "C" int vocr_conv3x3_wgrad_f16(const float* x, const float* dy, float* dw
     return VOCR_OK;
 }
 
-extern "C" int vocr_channel_sum(const float* x, float* out, int n, int c, int hw, void* stream) {
-    VOCR_CHECK_ARG(x && out && n > 0 && c > 0 && hw > 0, "vocr_channel_sum: bad argument");
-    hipStream_t s = (hipStream_t)stream;
+static inline int channel_sum_chunks(int n, int hw) {
     long nchunk = ((long)n * hw + 16383) / 16384;
     if (nchunk > 64) nchunk = 64;
-    if (nchunk < 1) nchunk = 1;
-    if (nchunk > 1 && hipMemsetAsync(out, 0, (size_t)c * sizeof(float), s) != hipSuccess) {
-        vocr_set_error("vocr_channel_sum: memset failed");
-        return VOCR_ELAUNCH;
-    }
-    channel_sum_kernel<<<dim3(c, (unsigned)nchunk), 256, 0, s>>>(x, out, n, c, hw, (int)nchunk);
+    return (int)(nchunk < 1 ? 1 : nchunk);
+}
+
+extern "C" size_t vocr_channel_sum_workspace_bytes(int n, int c, int hw) {
+    if (n <= 0 || c <= 0 || hw <= 0) return 0;
+    const int nchunk = channel_sum_chunks(n, hw);
+    return nchunk > 1 ? (size_t)nchunk * c * sizeof(float) : 0;
+}
+
+extern "C" int vocr_channel_sum(const float* x, float* out, int n, int c, int hw, void* workspace, void* stream) {
+    VOCR_CHECK_ARG(x && out && n > 0 && c > 0 && hw > 0, "vocr_channel_sum: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int nchunk = workspace ? channel_sum_chunks(n, hw) : 1;
+    channel_sum_kernel<<<dim3(c, (unsigned)nchunk), 256, 0, s>>>(x, nchunk > 1 ? (float*)workspace : out, n, c, hw, nchunk);
     VOCR_CHECK_LAUNCH("vocr_channel_sum");
+    if (nchunk > 1) {
+        channel_sum_final_kernel<<<vocr_cdiv(c, 64), 64, 0, s>>>((const float*)workspace, out, c, nchunk);
+        VOCR_CHECK_LAUNCH("vocr_channel_sum(final)");
+    }
     return VOCR_OK;
 }

@@ -228,15 +228,22 @@ __global__ void greedy_collapse_kernel(const int32_t* __restrict__ idx, const fl
     out_counts[b] = n;
 }
 
+// NaN policy: grad.clamp_(-5, 5) of the reference propagates NaN (torch.clamp), so a NaN gradient must reach the
+// weights and the next loss instead of being turned into a finite +-clamp update by fminf/fmaxf; the first NaN seen is
+// also recorded in the caller's health word (health[1]) so the host can fail the step without an extra sync.
+__device__ __forceinline__ float clamp_keep_nan(float x, float c) { return (x != x) ? x : fminf(fmaxf(x, -c), c); }
+
 __global__ __launch_bounds__(256) void clamp_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                          float* __restrict__ m, float* __restrict__ v, size_t n, float lr,
                                                          float omb1, float beta2, float omb2, float eps, float wd, float clampv,
-                                                         float gscale, float step_size, float bc2_sqrt) {
+                                                         float gscale, float step_size, float bc2_sqrt, int32_t* health) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
+    bool bad = false;
     for (; i < n; i += stride) {
         float gr = g[i] * gscale;
-        gr = fminf(fmaxf(gr, -clampv), clampv);
+        bad |= (gr != gr);
+        gr = clamp_keep_nan(gr, clampv);
         const float pv = p[i];
         if (wd != 0.f) gr = gr + wd * pv;
         const float mo = m[i];
@@ -247,6 +254,24 @@ __global__ __launch_bounds__(256) void clamp_adam_kernel(float* __restrict__ p, 
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
         p[i] = pv - step_size * (mi / denom);
     }
+    if (health && bad) health[1] = 1;
+}
+
+// in-place elementwise clamp (the reference's `param.grad.data.clamp_(min=-5, max=5)` loop) for optimisers that are not
+// FlatClampAdam; NaN stays NaN
+__global__ void clamp_kernel(float* __restrict__ x, size_t n, float c, int vec, int32_t* health) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n4 = vec ? n / 4 : 0;
+    bool bad = false;
+    for (size_t q = i; q < n4; q += stride) {
+        f32x4 t = ((f32x4*)x)[q];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { bad |= (t[k] != t[k]); t[k] = clamp_keep_nan(t[k], c); }
+        ((f32x4*)x)[q] = t;
+    }
+    for (size_t e = n4 * 4 + i; e < n; e += stride) { bad |= (x[e] != x[e]); x[e] = clamp_keep_nan(x[e], c); }
+    if (health && bad) health[1] = 1;
 }
 
 }  // namespace
@@ -301,7 +326,7 @@ extern "C" int vocr_greedy_collapse(const int32_t* idx, const float* maxv, const
 
 extern "C" int vocr_clamp_adam(float* p, const float* g, float* m, float* v, size_t count, float lr, float beta1,
                                float beta2, float eps, float weight_decay, float clamp, float grad_scale, int step,
-                               void* stream) {
+                               int32_t* health, void* stream) {
     VOCR_CHECK_ARG(p && g && m && v && step >= 1, "vocr_clamp_adam: bad argument");
     if (count == 0) return VOCR_OK;
     // bias corrections in double on the host, exactly the scalars torch.optim.Adam derives per step
@@ -313,7 +338,18 @@ extern "C" int vocr_clamp_adam(float* p, const float* g, float* m, float* v, siz
     size_t gsz = (count + 255) / 256;
     if (gsz > 4096) gsz = 4096;
     clamp_adam_kernel<<<(int)gsz, 256, 0, (hipStream_t)stream>>>(p, g, m, v, count, lr, omb1, beta2, omb2, eps, weight_decay, clamp,
-                                                                grad_scale, step_size, bc2_sqrt);
+                                                                grad_scale, step_size, bc2_sqrt, health);
     VOCR_CHECK_LAUNCH("vocr_clamp_adam");
+    return VOCR_OK;
+}
+
+extern "C" int vocr_clamp(float* x, size_t count, float clamp, int32_t* health, void* stream) {
+    VOCR_CHECK_ARG(x && clamp >= 0.f, "vocr_clamp: bad argument");
+    if (count == 0) return VOCR_OK;
+    size_t gsz = (count / 4 + 255) / 256;
+    if (gsz > 2048) gsz = 2048;
+    if (gsz < 1) gsz = 1;
+    clamp_kernel<<<(int)gsz, 256, 0, (hipStream_t)stream>>>(x, count, clamp, ((((uintptr_t)x) & 15) == 0) ? 1 : 0, health);
+    VOCR_CHECK_LAUNCH("vocr_clamp");
     return VOCR_OK;
 }

@@ -21,7 +21,7 @@ template <int BM, int BN, int WM, int WN, bool A_KCONTIG, bool B_NCONTIG, bool V
 __global__ __launch_bounds__(256) void gemm_f32_kernel(
     int M, int N, int K, const float* __restrict__ A, long sam, long sak, const float* __restrict__ B, long sbk,
     long sbn, float* __restrict__ C, int ldc, const float* __restrict__ bias, int relu, int accumulate,
-    int k_per_split, const float* __restrict__ zp) {
+    int k_per_split, const float* __restrict__ zp, float* __restrict__ slab) {
     // LDS tiles are K-major: As[k][m], Bs[k][n].  Pitch ≡ 2 (mod 32) keeps the transposing scalar stores of a
     // k-contiguous operand at most 2-way conflicted; a multiple of 4 keeps 16-byte stores of an m-contiguous one aligned.
     constexpr int PA = BM + ((VEC && !A_KCONTIG) ? 4 : 2);
@@ -166,7 +166,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
     }
 
     // epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const bool atomic = gridDim.z > 1;
+    // split-K: every K-slice stores its partial tile into its own dense [M][N] slab; splitk_reduce_kernel adds the slabs
+    // in slice order (bitwise reproducible; float atomics into C were neither reproducible nor faster: 1.3 TB/s)
+    const bool split = gridDim.z > 1;
+    float* const sl = split ? slab + (long)blockIdx.z * M * N : nullptr;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -180,8 +183,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
                 if (gm >= M) continue;
                 float v = acc[i][j][r] + bv;
                 float* cp = C + (long)gm * ldc + gn;
-                if (atomic) {
-                    atomicAdd(cp, v);
+                if (split) {
+                    sl[(long)gm * N + gn] = v;
                 } else {
                     if (accumulate) v += *cp;
                     if (relu) v = fmaxf(v, 0.f);
@@ -194,15 +197,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
 template <int BM, int BN, int WM, int WN, bool VEC>
 void launch_cfg(int ta, int tb, dim3 grid, hipStream_t s, int M, int N, int K, const float* A, long sam, long sak,
                 const float* B, long sbk, long sbn, float* C, int ldc, const float* bias, int relu, int acc, int kps,
-                const float* zp) {
+                const float* zp, float* slab) {
     if (!ta && !tb)
-        gemm_f32_kernel<BM, BN, WM, WN, true, true, VEC><<<grid, 256, 0, s>>>(M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, relu, acc, kps, zp);
+        gemm_f32_kernel<BM, BN, WM, WN, true, true, VEC><<<grid, 256, 0, s>>>(M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, relu, acc, kps, zp, slab);
     else if (!ta && tb)
-        gemm_f32_kernel<BM, BN, WM, WN, true, false, VEC><<<grid, 256, 0, s>>>(M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, relu, acc, kps, zp);
+        gemm_f32_kernel<BM, BN, WM, WN, true, false, VEC><<<grid, 256, 0, s>>>(M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, relu, acc, kps, zp, slab);
     else if (ta && !tb)
-        gemm_f32_kernel<BM, BN, WM, WN, false, true, VEC><<<grid, 256, 0, s>>>(M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, relu, acc, kps, zp);
+        gemm_f32_kernel<BM, BN, WM, WN, false, true, VEC><<<grid, 256, 0, s>>>(M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, relu, acc, kps, zp, slab);
     else
-        gemm_f32_kernel<BM, BN, WM, WN, false, false, VEC><<<grid, 256, 0, s>>>(M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, relu, acc, kps, zp);
+        gemm_f32_kernel<BM, BN, WM, WN, false, false, VEC><<<grid, 256, 0, s>>>(M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, relu, acc, kps, zp, slab);
 }
 
 const float* gemm_zero_page() {
@@ -217,7 +220,36 @@ const float* gemm_zero_page() {
     return zp[dev];
 }
 
-// out[n] += sum of rows [r0, r1) of x[:, n]; grid (N/64 column tiles, row splits); float atomics combine splits
+// C[m][n] (+)= sum over K-slices of slab[z][m][n], slices added in order z = 0, 1, ...
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ C, int M, int N,
+                                                            int ldc, int splits, int accumulate, int vec) {
+    const long plane = (long)M * N;
+    const long stride = (long)gridDim.x * 256;
+    if (vec) {
+        const int n4 = N / 4;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)M * n4; i += stride) {
+            const int m = (int)(i / n4), c4 = (int)(i % n4);
+            const float* sp = slab + (long)m * N + c4 * 4;
+            f32x4 v = *(const f32x4*)sp;
+            for (int z = 1; z < splits; ++z) v += *(const f32x4*)(sp + z * plane);
+            f32x4* cp = (f32x4*)(C + (long)m * ldc + c4 * 4);
+            if (accumulate) v += *cp;
+            *cp = v;
+        }
+    } else {
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < plane; i += stride) {
+            const int m = (int)(i / N), n = (int)(i % N);
+            float v = slab[i];
+            for (int z = 1; z < splits; ++z) v += slab[i + z * plane];
+            float* cp = C + (long)m * ldc + n;
+            if (accumulate) v += *cp;
+            *cp = v;
+        }
+    }
+}
+
+// partial[split][n] = sum of rows [r0, r1) of x[:, n]; grid (N/64 column tiles, row splits).  With one split the sum goes
+// straight to out; otherwise colsum_final_kernel adds the partial rows in split order (no float atomics: reproducible).
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int M, int N,
                                                      int rows_per_split) {
     __shared__ float red[4][64];
@@ -232,10 +264,15 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     }
     red[wave][lane] = s0 + s1;
     __syncthreads();
-    if (wave == 0 && n < N) {
-        const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-        if (gridDim.y > 1) atomicAdd(out + n, v); else out[n] = v;
-    }
+    if (wave == 0 && n < N) out[(long)blockIdx.y * N + n] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int N, int splits) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float v = part[n];
+    for (int z = 1; z < splits; ++z) v += part[(long)z * N + n];
+    out[n] = v;
 }
 
 // elementwise glue: 16-byte main loop (count4 = count/4 vectors) + scalar tail, grid-stride
@@ -340,73 +377,118 @@ __global__ void bchw_to_wbch_kernel(const float* __restrict__ x, float* __restri
 
 }  // namespace
 
+namespace {
+struct GemmPlan { bool big, half; int bm, bn, splits, kps; };
+
+// tile and split-K choice; max_splits = 1 forbids split-K (no workspace)
+GemmPlan gemm_plan(int m, int n, int k, bool has_epilogue, int max_splits) {
+    GemmPlan p;
+    const long tiles128 = (long)vocr_cdiv(m, 128) * vocr_cdiv(n, 128);
+    const bool can_split = !has_epilogue && k >= 1024 && max_splits > 1;
+    // 128x128 tiles (32 FLOP per LDS-staged byte) whenever they can fill the chip, possibly with split-K
+    p.big = m >= 96 && n >= 96 && (tiles128 >= 192 || (can_split && tiles128 * (k / 512) >= 128));
+    // 128x64 tiles when there are fewer than 6 full tiles per CU and no split-K: twice as many half-size workgroups let
+    // the dispatcher balance the last partial round (measured 104 TF at 4.6 tiles/CU vs 118 TF at exactly 4)
+    p.half = p.big && tiles128 < 6 * 256 && !(can_split && tiles128 < 384) && n >= 64;
+    p.bm = p.big ? 128 : 64;
+    p.bn = p.big ? (p.half ? 64 : 128) : 64;
+    const long tiles = (long)vocr_cdiv(m, p.bm) * vocr_cdiv(n, p.bn);
+    int splits = 1;
+    if (can_split && tiles < 384) {
+        splits = (int)((512 + tiles - 1) / tiles);
+        const int maxs = k / 512;
+        if (splits > maxs) splits = maxs;
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+    }
+    p.kps = vocr_cdiv(vocr_cdiv(k, splits), BK) * BK;
+    p.splits = vocr_cdiv(k, p.kps);
+    return p;
+}
+}  // namespace
+
+extern "C" size_t vocr_gemm_workspace_bytes(int m, int n, int k, int has_bias_or_relu) {
+    if (m <= 0 || n <= 0 || k <= 0) return 0;
+    const GemmPlan p = gemm_plan(m, n, k, has_bias_or_relu != 0, 1 << 30);
+    return p.splits > 1 ? (size_t)p.splits * m * n * sizeof(float) : 0;
+}
+
 extern "C" int vocr_gemm(int transa, int transb, int m, int n, int k, const float* a, int lda, const float* b, int ldb,
-                         float* c, int ldc, const float* bias, int relu, int accumulate, void* stream) {
+                         float* c, int ldc, const float* bias, int relu, int accumulate, void* workspace,
+                         size_t workspace_bytes, void* stream) {
     VOCR_CHECK_ARG(m > 0 && n > 0 && k > 0, "vocr_gemm: bad shape m=%d n=%d k=%d", m, n, k);
     VOCR_CHECK_ARG(a && b && c, "vocr_gemm: null pointer");
     VOCR_CHECK_ARG(lda >= (transa ? m : k) && ldb >= (transb ? k : n) && ldc >= n, "vocr_gemm: bad leading dimension");
     hipStream_t s = (hipStream_t)stream;
     const long sam = transa ? 1 : lda, sak = transa ? lda : 1;
     const long sbk = transb ? 1 : ldb, sbn = transb ? ldb : 1;
-    const long tiles128 = (long)vocr_cdiv(m, 128) * vocr_cdiv(n, 128);
-    const bool can_split = !bias && !relu && k >= 1024;
-    // 128x128 tiles (32 FLOP per LDS-staged byte) whenever they can fill the chip, possibly with split-K
-    const bool big = m >= 96 && n >= 96 && (tiles128 >= 192 || (can_split && tiles128 * (k / 512) >= 128));
-    // 128x64 tiles when there are fewer than 6 full tiles per CU and no split-K: twice as many half-size workgroups let
-    // the dispatcher balance the last partial round (measured 104 TF at 4.6 tiles/CU vs 118 TF at exactly 4)
-    const bool half = big && tiles128 < 6 * 256 && !(can_split && tiles128 < 384) && n >= 64;
-    const int bm = big ? 128 : 64;
-    const int bn = big ? (half ? 64 : 128) : 64;
-    const long tiles = (long)vocr_cdiv(m, bm) * vocr_cdiv(n, bn);
-    int splits = 1;
-    if (can_split && tiles < 384) {
-        splits = (int)((512 + tiles - 1) / tiles);
-        const int maxs = k / 512;
-        if (splits > maxs) splits = maxs;
-        if (splits < 1) splits = 1;
-    }
-    int kps = vocr_cdiv(vocr_cdiv(k, splits), BK) * BK;
-    splits = vocr_cdiv(k, kps);
-    if (splits > 1 && !accumulate) {
-        if (hipMemset2DAsync(c, (size_t)ldc * sizeof(float), 0, (size_t)n * sizeof(float), (size_t)m, s) != hipSuccess) {
-            vocr_set_error("vocr_gemm: memset failed");
-            return VOCR_ELAUNCH;
-        }
-    }
-    dim3 grid(vocr_cdiv(n, bn), vocr_cdiv(m, bm), splits);
+    // split-K needs room for one [m][n] slab per K-slice; with less workspace the slices shrink, with none K is not split
+    const size_t slab_bytes = (size_t)m * n * sizeof(float);
+    const int max_splits = (workspace && (((uintptr_t)workspace) & 15) == 0) ? (int)(workspace_bytes / slab_bytes > 4096 ? 4096 : workspace_bytes / slab_bytes) : 1;
+    const GemmPlan p = gemm_plan(m, n, k, bias != nullptr || relu != 0, max_splits < 1 ? 1 : max_splits);
+    const bool big = p.big, half = p.half;
+    const int kps = p.kps, splits = p.splits;
+    float* slab = splits > 1 ? (float*)workspace : nullptr;
+    dim3 grid(vocr_cdiv(n, p.bn), vocr_cdiv(m, p.bm), splits);
     const float* zp = gemm_zero_page();
     VOCR_CHECK_ARG(zp != nullptr, "vocr_gemm: no device zero page");
     const bool vec = ((((uintptr_t)a) | ((uintptr_t)b)) & 15) == 0 && lda % 4 == 0 && ldb % 4 == 0 && m % 4 == 0 && n % 4 == 0 &&
                      k % 4 == 0;
     if (big && half) {
-        if (vec) launch_cfg<128, 64, 64, 32, true>(transa, transb, grid, s, m, n, k, a, sam, sak, b, sbk, sbn, c, ldc, bias, relu, accumulate, kps, zp);
-        else launch_cfg<128, 64, 64, 32, false>(transa, transb, grid, s, m, n, k, a, sam, sak, b, sbk, sbn, c, ldc, bias, relu, accumulate, kps, zp);
+        if (vec) launch_cfg<128, 64, 64, 32, true>(transa, transb, grid, s, m, n, k, a, sam, sak, b, sbk, sbn, c, ldc, bias, relu, accumulate, kps, zp, slab);
+        else launch_cfg<128, 64, 64, 32, false>(transa, transb, grid, s, m, n, k, a, sam, sak, b, sbk, sbn, c, ldc, bias, relu, accumulate, kps, zp, slab);
     } else if (big) {
-        if (vec) launch_cfg<128, 128, 64, 64, true>(transa, transb, grid, s, m, n, k, a, sam, sak, b, sbk, sbn, c, ldc, bias, relu, accumulate, kps, zp);
-        else launch_cfg<128, 128, 64, 64, false>(transa, transb, grid, s, m, n, k, a, sam, sak, b, sbk, sbn, c, ldc, bias, relu, accumulate, kps, zp);
+        if (vec) launch_cfg<128, 128, 64, 64, true>(transa, transb, grid, s, m, n, k, a, sam, sak, b, sbk, sbn, c, ldc, bias, relu, accumulate, kps, zp, slab);
+        else launch_cfg<128, 128, 64, 64, false>(transa, transb, grid, s, m, n, k, a, sam, sak, b, sbk, sbn, c, ldc, bias, relu, accumulate, kps, zp, slab);
     } else {
-        if (vec) launch_cfg<64, 64, 32, 32, true>(transa, transb, grid, s, m, n, k, a, sam, sak, b, sbk, sbn, c, ldc, bias, relu, accumulate, kps, zp);
-        else launch_cfg<64, 64, 32, 32, false>(transa, transb, grid, s, m, n, k, a, sam, sak, b, sbk, sbn, c, ldc, bias, relu, accumulate, kps, zp);
+        if (vec) launch_cfg<64, 64, 32, 32, true>(transa, transb, grid, s, m, n, k, a, sam, sak, b, sbk, sbn, c, ldc, bias, relu, accumulate, kps, zp, slab);
+        else launch_cfg<64, 64, 32, 32, false>(transa, transb, grid, s, m, n, k, a, sam, sak, b, sbk, sbn, c, ldc, bias, relu, accumulate, kps, zp, slab);
     }
     VOCR_CHECK_LAUNCH("vocr_gemm");
+    if (splits > 1) {
+        const int rvec = (n % 4 == 0 && ldc % 4 == 0 && (((uintptr_t)c) & 15) == 0) ? 1 : 0;
+        long work = rvec ? (long)m * (n / 4) : (long)m * n;
+        long g = (work + 255) / 256;
+        if (g > 4096) g = 4096;
+        splitk_reduce_kernel<<<(int)g, 256, 0, s>>>(slab, c, m, n, ldc, splits, accumulate, rvec);
+        VOCR_CHECK_LAUNCH("vocr_gemm(split-K reduce)");
+    }
     return VOCR_OK;
 }
 
-extern "C" int vocr_colsum(const float* x, float* out, int m, int n, void* stream) {
-    VOCR_CHECK_ARG(x && out && m > 0 && n > 0, "vocr_colsum: bad argument");
-    hipStream_t s = (hipStream_t)stream;
+namespace {
+int colsum_splits(int m, int n, int* rows_per_split) {
     const int ctiles = vocr_cdiv(n, 64);
     int splits = vocr_cdiv(1024, ctiles);
+    if (splits > 64) splits = 64;
     if (splits > vocr_cdiv(m, 32)) splits = vocr_cdiv(m, 32);
     if (splits < 1) splits = 1;
     const int rps = vocr_cdiv(m, splits);
-    splits = vocr_cdiv(m, rps);
-    if (splits > 1 && hipMemsetAsync(out, 0, (size_t)n * sizeof(float), s) != hipSuccess) {
-        vocr_set_error("vocr_colsum: memset failed");
-        return VOCR_ELAUNCH;
-    }
-    colsum_kernel<<<dim3(ctiles, splits), 256, 0, s>>>(x, out, m, n, rps);
+    *rows_per_split = rps;
+    return vocr_cdiv(m, rps);
+}
+}  // namespace
+
+extern "C" size_t vocr_colsum_workspace_bytes(int m, int n) {
+    if (m <= 0 || n <= 0) return 0;
+    int rps;
+    const int splits = colsum_splits(m, n, &rps);
+    return splits > 1 ? (size_t)splits * n * sizeof(float) : 0;
+}
+
+extern "C" int vocr_colsum(const float* x, float* out, int m, int n, void* workspace, void* stream) {
+    VOCR_CHECK_ARG(x && out && m > 0 && n > 0, "vocr_colsum: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    int rps;
+    int splits = colsum_splits(m, n, &rps);
+    if (!workspace) { splits = 1; rps = m; }       // no room for partial rows: one workgroup per column tile
+    const int ctiles = vocr_cdiv(n, 64);
+    colsum_kernel<<<dim3(ctiles, splits), 256, 0, s>>>(x, splits > 1 ? (float*)workspace : out, m, n, rps);
     VOCR_CHECK_LAUNCH("vocr_colsum");
+    if (splits > 1) {
+        colsum_final_kernel<<<vocr_cdiv(n, 256), 256, 0, s>>>((const float*)workspace, out, n, splits);
+        VOCR_CHECK_LAUNCH("vocr_colsum(final)");
+    }
     return VOCR_OK;
 }
 

@@ -1161,12 +1161,14 @@ extern "C" size_t vocr_lstm_workspace_bytes(int t, int b, int h) {
     // dc carry [2][B][H] (+ spare); 4 KiB of arrival flags / status; 16 MiB of partial-sum blocks for the backward chain
     // sweep (2 parities x 8 chains x 32 consumers x 32 producers x 1 KiB)
     // + per-chain bias-gradient rows [8][4H]
-    return (size_t)6 * 2 * b * h * sizeof(float) + 4096 + ((size_t)16 << 20) + (size_t)8 * 4 * h * sizeof(float);
+    // + 64 partial rows [4H] for the fixed-order column sums of the bias gradient (paths without in-sweep accumulation)
+    return (size_t)6 * 2 * b * h * sizeof(float) + 4096 + ((size_t)16 << 20) + (size_t)8 * 4 * h * sizeof(float) +
+           (size_t)64 * 4 * h * sizeof(float);
 }
 
 extern "C" int vocr_lstm_fwd_range(const float* xproj, const float* whh_fwd, const float* whh_rev, const int32_t* lens, float* y,
                                    float* gates, float* cell, void* workspace, int t, int b, int h, int step_begin, int step_end,
-                                   void* stream) {
+                                   int32_t* health, void* stream) {
     VOCR_CHECK_ARG(xproj && whh_fwd && whh_rev && lens && y && gates && cell && workspace, "vocr_lstm_fwd: null pointer");
     VOCR_CHECK_ARG(t > 0 && b > 0 && b <= 64 && h > 0 && h % 16 == 0, "vocr_lstm_fwd: need 1<=B<=64 and H%%16==0 (B=%d H=%d)", b, h);
     VOCR_CHECK_ARG(0 <= step_begin && step_begin < step_end && step_end <= t, "vocr_lstm_fwd: bad step range [%d, %d) of %d", step_begin, step_end, t);
@@ -1183,7 +1185,8 @@ extern "C" int vocr_lstm_fwd_range(const float* xproj, const float* whh_fwd, con
     if (fast && fits32 && (persistent_mode & 1) && 8 * (h / 16) <= resident_workgroup_capacity()) {
         // chain sweep.  arrival flags: [chain <= 8][32 workgroups] at [0..255], XCC ids at [256..511]; status words at [512..]
         unsigned* flags = (unsigned*)workspace;
-        unsigned* status = flags + 512;
+        // a hand-off timeout is recorded in the caller's sticky health word (health[0]) when one is given
+        unsigned* status = health ? (unsigned*)health : flags + 512;
         if (hipMemsetAsync(flags, 0, 520 * sizeof(unsigned), s) != hipSuccess) {
             vocr_set_error("vocr_lstm_fwd: memset failed");
             return VOCR_ELAUNCH;
@@ -1224,23 +1227,25 @@ extern "C" int vocr_lstm_fwd_range(const float* xproj, const float* whh_fwd, con
 }
 
 extern "C" int vocr_lstm_fwd(const float* xproj, const float* whh_fwd, const float* whh_rev, const int32_t* lens, float* y,
-                             float* gates, float* cell, void* workspace, int t, int b, int h, void* stream) {
-    return vocr_lstm_fwd_range(xproj, whh_fwd, whh_rev, lens, y, gates, cell, workspace, t, b, h, 0, t, stream);
+                             float* gates, float* cell, void* workspace, int t, int b, int h, int32_t* health, void* stream) {
+    return vocr_lstm_fwd_range(xproj, whh_fwd, whh_rev, lens, y, gates, cell, workspace, t, b, h, 0, t, health, stream);
 }
 
-extern "C" int vocr_colsum(const float* x, float* out, int m, int n, void* stream);
+extern "C" int vocr_colsum(const float* x, float* out, int m, int n, void* workspace, void* stream);
 
 extern "C" int vocr_lstm_bwd(const float* dy, const float* whht_fwd, const float* whht_rev, const int32_t* lens,
                              const float* gates, const float* cell, float* dgates, void* workspace, int t, int b, int h,
-                             void* stream) {
-    return vocr_lstm_bwd_bias(dy, whht_fwd, whht_rev, lens, gates, cell, dgates, nullptr, workspace, t, b, h, stream);
+                             int32_t* health, void* stream) {
+    return vocr_lstm_bwd_bias(dy, whht_fwd, whht_rev, lens, gates, cell, dgates, nullptr, workspace, t, b, h, health, stream);
 }
 
 // every path but the 8-row K-owner kernel: bias gradient = column sums of the finished dgates
-static int lstm_bias_by_colsum(const float* dgates, float* dbias, int t, int b, int h, void* stream) {
+static int lstm_bias_by_colsum(const float* dgates, float* dbias, void* workspace, int t, int b, int h, void* stream) {
     if (!dbias) return VOCR_OK;
+    // partial rows live in the last 64 x 4H floats of the LSTM workspace (vocr_lstm_workspace_bytes)
+    void* cws = (char*)workspace + (size_t)6 * 2 * b * h * sizeof(float) + 4096 + ((size_t)16 << 20) + (size_t)8 * 4 * h * sizeof(float);
     for (int dir = 0; dir < 2; ++dir) {
-        const int rc = vocr_colsum(dgates + (size_t)dir * t * b * 4 * h, dbias + (size_t)dir * 4 * h, t * b, 4 * h, stream);
+        const int rc = vocr_colsum(dgates + (size_t)dir * t * b * 4 * h, dbias + (size_t)dir * 4 * h, t * b, 4 * h, cws, stream);
         if (rc != VOCR_OK) return rc;
     }
     return VOCR_OK;
@@ -1248,7 +1253,7 @@ static int lstm_bias_by_colsum(const float* dgates, float* dbias, int t, int b, 
 
 extern "C" int vocr_lstm_bwd_bias(const float* dy, const float* whht_fwd, const float* whht_rev, const int32_t* lens,
                                   const float* gates, const float* cell, float* dgates, float* dbias, void* workspace, int t,
-                                  int b, int h, void* stream) {
+                                  int b, int h, int32_t* health, void* stream) {
     const float* whh_fwd = whht_fwd;
     const float* whh_rev = whht_rev;
     VOCR_CHECK_ARG(dy && whh_fwd && whh_rev && lens && gates && cell && dgates && workspace, "vocr_lstm_bwd: null pointer");
@@ -1261,7 +1266,7 @@ extern "C" int vocr_lstm_bwd_bias(const float* dy, const float* whht_fwd, const 
     if (fast && (persistent_mode & 2) && 8 * (h / 16) <= resident_workgroup_capacity() && aligned16(gates)) {
         // arrival flags: [chain <= 8][32 workgroups] at [0..255]; status words at [512..]
         unsigned* flags = (unsigned*)workspace;
-        unsigned* status = flags + 512;
+        unsigned* status = health ? (unsigned*)health : flags + 512;
         if (hipMemsetAsync(flags, 0, 520 * sizeof(unsigned), s) != hipSuccess) {
             vocr_set_error("vocr_lstm_bwd: memset failed");
             return VOCR_ELAUNCH;
@@ -1289,7 +1294,7 @@ extern "C" int vocr_lstm_bwd_bias(const float* dy, const float* whht_fwd, const 
         else if (h == 256) lstm_bwd_kowner<2><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, t, b, rt, fwt);
         else lstm_bwd_kowner<4><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, t, b, rt, fwt);
         VOCR_CHECK_LAUNCH("vocr_lstm_bwd(k-owner)");
-        return lstm_bias_by_colsum(dgates, dbias, t, b, h, stream);
+        return lstm_bias_by_colsum(dgates, dbias, workspace, t, b, h, stream);
     }
     for (int step = 0; step < t; ++step) {
         if (fast) {
@@ -1306,5 +1311,5 @@ extern "C" int vocr_lstm_bwd_bias(const float* dy, const float* whht_fwd, const 
         }
     }
     VOCR_CHECK_LAUNCH("vocr_lstm_bwd");
-    return lstm_bias_by_colsum(dgates, dbias, t, b, h, stream);
+    return lstm_bias_by_colsum(dgates, dbias, workspace, t, b, h, stream);
 }

@@ -175,10 +175,18 @@ def test_on_val(val_dataloader, model, criterion):
 
 
 def save_snapshot(path, iteration, model, optimizer, rtl, cur_lr, val_loss, val_cer, val_wer, line_height):
-    """The checkpoint dictionary of src/train_cnn_lstm.py:427-438 (FromSavedWeights reads it back)."""
-    torch.save({"iteration": iteration, "state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
-                "optimizer": optimizer.state_dict(), "model_hyper_params": model.get_hyper_params(), "rtl": rtl,
-                "cur_lr": cur_lr, "val_loss": val_loss, "val_cer": val_cer, "val_wer": val_wer, "line_height": line_height}, path)
+    """The checkpoint dictionary of src/train_cnn_lstm.py:427-438, readable by this build's and by the reference's
+    FromSavedWeights: the alphabet is pickled under the reference's class path (checkpoint.save) and, for a model built
+    with the reference's default multigpu=True, the CNN keys carry nn.DataParallel's 'cnn.module.' prefix the reference's
+    strict load expects (this build strips it again on load).  `optimizer` state is whatever the optimiser reports."""
+    from . import checkpoint
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    hp = dict(model.get_hyper_params())
+    if hp.get("multigpu", True) and hp.get("gpu", True):
+        sd = checkpoint.add_dataparallel_prefix(sd)
+    checkpoint.save({"iteration": iteration, "state_dict": sd, "optimizer": optimizer.state_dict(), "model_hyper_params": hp,
+                     "rtl": rtl, "cur_lr": cur_lr, "val_loss": val_loss, "val_cer": val_cer, "val_wer": val_wer,
+                     "line_height": line_height}, path)
 
 
 def fit(model, criterion, optimizer, train_dataloader, validation_dataloader, train_fn, snapshot_prefix, batch_size,
@@ -215,8 +223,9 @@ def fit(model, criterion, optimizer, train_dataloader, validation_dataloader, tr
                 hist["stopped_early"] = True
                 return hist
             if lowered:
-                weights = torch.load(best_model_path, map_location="cpu", weights_only=False)
-                model.load_state_dict(weights["state_dict"])
+                from . import checkpoint
+                weights = checkpoint.load(best_model_path, map_location="cpu")
+                model.load_state_dict(checkpoint.strip_dataparallel_prefix(weights["state_dict"]))
     return hist
 
 

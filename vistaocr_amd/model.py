@@ -86,7 +86,8 @@ class CnnOcrModel(nn.Module):
     @classmethod
     def FromSavedWeights(cls, weight_file, verbose=True, gpu=None):
         """src/models/cnnlstm.py:40-71 — same checkpoint dict schema (written at train_cnn_lstm.py:427-438)."""
-        weights = torch.load(weight_file, map_location=lambda storage, loc: storage, weights_only=False)
+        from . import checkpoint
+        weights = checkpoint.load(weight_file, map_location=lambda storage, loc: storage)
         if verbose:
             logger.info("Loading model from: %s" % weight_file)
             logger.info("\tFrom iteration: %d" % weights["iteration"])
@@ -100,7 +101,7 @@ class CnnOcrModel(nn.Module):
         model.rtl = weights["rtl"] if "rtl" in weights else True
         sd = weights["state_dict"]
         # checkpoints written with multigpu=True carry DataParallel's 'cnn.module.' prefix (utils/decode.py:58-71)
-        sd = {(k.replace("cnn.module.", "cnn.", 1) if k.startswith("cnn.module.") else k): v for k, v in sd.items()}
+        sd = checkpoint.strip_dataparallel_prefix(sd)
         model.load_state_dict(sd, strict=True)
         return model
 
@@ -176,6 +177,8 @@ class CnnOcrModel(nn.Module):
         self.dropout_masks = None         # list of [T,B,2H] pre-scaled masks or None -> drawn on device
         self._dropout_calls = 0
         self.dropout_seed = 0x5EED
+        # backward milestones of THIS model (train.make_optimizer registers the data-parallel bucket start here)
+        self._vocr_hooks = {"sequence_grads_ready": []}
 
         if self.verbose:
             total = sum(p.numel() for p in self.parameters())
@@ -250,7 +253,7 @@ class CnnOcrModel(nn.Module):
             if self.training:
                 bn.num_batches_tracked += 1
         b, c, h, w = a.shape
-        feat = ops.PermuteBchwToWbchFn.apply(a)                                   # [w*b, c*h]
+        feat = ops.PermuteBchwToWbchFn.apply(a, self._vocr_hooks)                                   # [w*b, c*h]
         br = getattr(self.bridge_layer, "0")
         lstm_in = ops.LinearFn.apply(feat, br.weight, br.bias, True)              # [w*b, D]
 

@@ -34,54 +34,100 @@ def _f32c(t):
 # ---- side stream: weight-gradient GEMMs of an LSTM layer run concurrently with the next (latency-bound) sweep
 import os as _os
 # Measured on MI355X (bench.py): with one launch per LSTM step the overlap bought nothing (the GEMM delayed every step
-# launch as much as it hid); with the persistent chain sweeps, which keep 4 of the 8 XCDs idle, it is worth +4 %
-# (1102 -> 1146 img/s).  A persistent sweep never waits on these GEMMs, so co-scheduling cannot deadlock it.
-_SIDE = {"stream": None, "pending": False, "enabled": _os.environ.get("VOCR_SIDE_STREAM", "1") == "1"}
+# launch as much as it hid); with the persistent chain sweeps it is worth +4 % (1102 -> 1146 img/s).  A persistent sweep
+# never waits on these GEMMs, so co-scheduling cannot deadlock it.
+# One low-priority side stream per DEVICE (like the allocator's pools): it carries no model state, only "work was queued
+# on it since the last join".
+_SIDE_ENABLED = _os.environ.get("VOCR_SIDE_STREAM", "1") == "1"
+_SIDE = {}
 
 
-def side_stream():
-    if _SIDE["stream"] is None:
-        import os
+def _side(device=None):
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    st = _SIDE.get(idx)
+    if st is None:
         lo, hi = torch.cuda.Stream.priority_range()        # (lowest priority value, highest priority value)
-        _SIDE["stream"] = torch.cuda.Stream(priority=lo) if os.environ.get("VOCR_SIDE_LOWPRIO", "1") == "1" else torch.cuda.Stream()
-    return _SIDE["stream"]
+        with torch.cuda.device(idx):
+            stream = torch.cuda.Stream(priority=lo) if _os.environ.get("VOCR_SIDE_LOWPRIO", "1") == "1" else torch.cuda.Stream()
+        st = _SIDE[idx] = {"stream": stream, "pending": False}
+    return st
 
 
-def join_side_stream():
-    """Make the current stream wait for every weight-gradient GEMM issued on the side stream."""
-    if _SIDE["pending"]:
-        torch.cuda.current_stream().wait_stream(_SIDE["stream"])
-        _SIDE["pending"] = False
+def side_stream(device=None):
+    return _side(device)["stream"]
 
 
-# ---- direct gradient sinks: when an optimiser has pre-attached a gradient buffer to every parameter (FlatClampAdam's
-# flat buffer, zeroed once per step), the backward kernels write weight gradients straight into it instead of
-# returning fresh tensors for autograd to add (saves ~56 small add kernels and allocations per step).  Valid because
-# every parameter of the model is used exactly once per forward.
-DIRECT_GRADS = {"enabled": False}
+def mark_side_pending(device=None):
+    _side(device)["pending"] = True
 
 
+def join_side_stream(device=None):
+    """Make the current stream wait for every weight-gradient kernel issued on this device's side stream."""
+    if not torch.cuda.is_available():
+        return
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    st = _SIDE.get(idx)
+    if st is not None and st["pending"]:
+        torch.cuda.current_stream(idx).wait_stream(st["stream"])
+        st["pending"] = False
+
+
+# ---- health words (include/vocr.h): one sticky int32[2] per device.  [0]: a persistent LSTM sweep's hand-off timed out,
+# [1]: a NaN gradient reached the optimiser.  The kernels set them; train() reads them next to the loss (no extra sync).
+_HEALTH = {}
+
+
+def health(device):
+    idx = torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    h = _HEALTH.get(idx)
+    if h is None:
+        h = _HEALTH[idx] = torch.zeros(2, dtype=torch.int32, device=torch.device("cuda", idx))
+    return h
+
+
+def check_health(values):
+    """Raise if the two health words (any int sequence) report a failure."""
+    if int(values[0]) != 0:
+        raise RuntimeError("vistaocr_amd: a hand-off inside a persistent LSTM sweep timed out (its output is NaN-poisoned); "
+                           "is another persistent sweep running on this GPU?  VOCR_LSTM_PERSISTENT=0 selects per-step launches")
+    if int(values[1]) != 0:
+        raise RuntimeError("vistaocr_amd: a NaN gradient reached the optimiser (the reference's clamp_ would propagate it too)")
+
+
+# ---- direct gradient sinks: an optimiser that owns a persistent gradient buffer per parameter (FlatClampAdam's flat
+# buffer, zeroed once per step) marks ITS parameters (p._vocr_sink_owner = the optimiser).  The backward kernels then
+# write weight gradients straight into p.grad instead of returning fresh tensors for autograd to add (saves ~56 small
+# add kernels and allocations per step).  Valid because every parameter is used exactly once per forward; the owner
+# refuses a second backward before zero_grad() (direct stores overwrite, they do not accumulate).  Parameters of other
+# models / optimisers in the same process are untouched: there is no module-level switch.
 def _sinks(params):
-    """The .grad buffers of `params` if direct mode is on and every one is attached and contiguous, else None."""
-    if not DIRECT_GRADS["enabled"]:
-        return None
+    """The .grad buffers of `params` if every one is owned by the same direct-gradient optimiser, else None."""
+    owner = None
     out = []
     for p in params:
+        o = getattr(p, "_vocr_sink_owner", None)
         g = p.grad
-        if g is None or not g.is_contiguous() or g.dtype != torch.float32:
+        if o is None or (owner is not None and o is not owner) or g is None or not g.is_cuda or not g.is_contiguous() \
+                or g.dtype != torch.float32:
             return None
+        owner = o
         out.append(g)
+    if owner is None or not owner.owns_grads(params):
+        return None
+    owner.note_direct_write(params)
     return out
 
 
-# ---- backward milestones: callbacks fired from inside the backward pass (used to start the data-parallel
-# all-reduce of the sequence-side gradients while the CNN backward is still running)
-BACKWARD_HOOKS = {"sequence_grads_ready": []}
-
-
-def _fire(name):
-    for fn in BACKWARD_HOOKS.get(name, ()):
-        fn()
+def _fire(hooks, name):
+    """Backward milestones: callbacks registered on the MODEL (model._vocr_hooks), fired from inside its backward pass
+    (used to start the data-parallel all-reduce of the sequence-side gradients while the CNN backward is running)."""
+    if hooks:
+        for fn in hooks.get(name, ()):
+            fn()
 
 
 def _ws(nbytes, device):
@@ -134,7 +180,9 @@ def conv3x3_wgrad(x, dy, out=None, f16=False):
 def channel_sum(x, out=None):
     n, c, h, w = x.shape
     out = out if out is not None else torch.empty(c, dtype=torch.float32, device=x.device)
-    call("vocr_channel_sum", _p(x), _p(out), n, c, h * w, _stream())
+    nb = _lib.load().vocr_channel_sum_workspace_bytes(n, c, h * w)
+    ws = _ws(nb, x.device) if nb else None
+    call("vocr_channel_sum", _p(x), _p(out), n, c, h * w, _p(ws), _stream())
     return out
 
 
@@ -213,7 +261,7 @@ class ConvBnReluFn(torch.autograd.Function):
             join_side_stream()          # first layer = last backward op: everything issued on the side stream is done after this
         call("vocr_bn_relu_bwd", _p(da), _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(dy), _p(dgamma), _p(dbeta),
              _p(dbias), n, cout, h * w, _p(ws), _stream())
-        if sinks is not None and _SIDE["enabled"] and ctx.needs_input_grad[0] and _os.environ.get("VOCR_CONV_OVERLAP", "1") == "1":
+        if sinks is not None and _SIDE_ENABLED and ctx.needs_input_grad[0] and _os.environ.get("VOCR_CONV_OVERLAP", "1") == "1":
             # weight gradient (off the critical path, written straight into the optimiser's buffer) on the low-priority side
             # stream beside the data gradient: each kernel's last partial round of workgroups is filled by the other's
             side = side_stream()
@@ -222,7 +270,7 @@ class ConvBnReluFn(torch.autograd.Function):
                 t_.record_stream(side)
             with torch.cuda.stream(side):
                 conv3x3_wgrad(x, dy, out=dw, f16=ctx.f16)
-            _SIDE["pending"] = True
+            mark_side_pending()
         else:
             dw = conv3x3_wgrad(x, dy, out=dw, f16=ctx.f16)
         dx = None
@@ -310,14 +358,19 @@ class FracPoolFn(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------------------------ dense layers
 def gemm(ta, tb, m, n, k, a, lda, b, ldb, c, ldc, bias=None, relu=False, accumulate=False):
+    # split-K slabs (long-K weight gradients): summed in a fixed order by the library, so results are reproducible
+    nb = _lib.load().vocr_gemm_workspace_bytes(m, n, k, int(bias is not None or relu))
+    ws = _ws(nb, c.device) if nb else None
     call("vocr_gemm", int(ta), int(tb), m, n, k, _p(a), lda, _p(b), ldb, _p(c), ldc, _p(bias), int(relu), int(accumulate),
-         _stream())
+         _p(ws), nb, _stream())
 
 
 def colsum(x2d, out=None):
     m, n = x2d.shape
     out = out if out is not None else torch.empty(n, dtype=torch.float32, device=x2d.device)
-    call("vocr_colsum", _p(x2d), _p(out), m, n, _stream())
+    nb = _lib.load().vocr_colsum_workspace_bytes(m, n)
+    ws = _ws(nb, x2d.device) if nb else None
+    call("vocr_colsum", _p(x2d), _p(out), m, n, _p(ws), _stream())
     return out
 
 
@@ -333,13 +386,14 @@ class PermuteBchwToWbchFn(torch.autograd.Function):
     """cnn_output.permute(3, 0, 1, 2).contiguous().view(-1, c*h) (src/models/cnnlstm.py:275-278)."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, hooks=None):
         _need_gpu(x)
         x = _f32c(x)
         b, c, h, w = x.shape
         out = torch.empty(w * b, c * h, dtype=torch.float32, device=x.device)
         call("vocr_bchw_to_wbch", _p(x), _p(out), b, c, h, w, _stream())
         ctx.shape = (b, c, h, w)
+        ctx.hooks = hooks
         return out
 
     @staticmethod
@@ -347,10 +401,10 @@ class PermuteBchwToWbchFn(torch.autograd.Function):
         b, c, h, w = ctx.shape
         dout = _f32c(dout)
         # everything above the CNN (bridge, LSTM, prob) has produced its gradients by now
-        _fire("sequence_grads_ready")
+        _fire(ctx.hooks, "sequence_grads_ready")
         dx = torch.empty(b, c, h, w, dtype=torch.float32, device=dout.device)
         call("vocr_wbch_to_bchw", _p(dout), _p(dx), b, c, h, w, _stream())
-        return dx
+        return dx, None
 
 
 class LinearFn(torch.autograd.Function):
@@ -463,7 +517,7 @@ class BiLstmLayerFn(torch.autograd.Function):
             gemm(0, 1, r1 - r0, G, din, x[r0:r1], din, w_ih_r if d else w_ih_f, din, xproj[d][r0:r1], G, bias=bsum[d])
 
         Th = T // 2
-        if _SIDE["enabled"] and Th >= 16 and Th * B * din >= (1 << 20) and _os.environ.get("VOCR_XPROJ_SPLIT", "0") == "1":
+        if _SIDE_ENABLED and Th >= 16 and Th * B * din >= (1 << 20) and _os.environ.get("VOCR_XPROJ_SPLIT", "0") == "1":
             # Opt-in (VOCR_XPROJ_SPLIT=1): only the x-projection of the rows the sweep's first half needs (forward
             # direction: t < Th; reverse direction: t >= T - Th) runs ahead of it; the other halves run on the side
             # stream under steps [0, Th) and steps [Th, T) start when they are done (vocr_lstm_fwd_range).  Worth
@@ -479,14 +533,14 @@ class BiLstmLayerFn(torch.autograd.Function):
                 xgemm(0, Th * B, T * B)
                 xgemm(1, 0, (T - Th) * B)
             args = (_p(xproj), _p(w_hh_f), _p(w_hh_r), _p(lens_dev), _p(y), _p(gates), _p(cell), _p(ws), T, B, H)
-            call("vocr_lstm_fwd_range", *args, 0, Th, _stream())
+            call("vocr_lstm_fwd_range", *args, 0, Th, _p(health(dev)), _stream())
             torch.cuda.current_stream().wait_stream(side)
-            call("vocr_lstm_fwd_range", *args, Th, T, _stream())
+            call("vocr_lstm_fwd_range", *args, Th, T, _p(health(dev)), _stream())
         else:
             xgemm(0, 0, T * B)
             xgemm(1, 0, T * B)
             call("vocr_lstm_fwd", _p(xproj), _p(w_hh_f), _p(w_hh_r), _p(lens_dev), _p(y), _p(gates), _p(cell), _p(ws), T, B, H,
-                 _stream())
+                 _p(health(dev)), _stream())
         ctx.dims = (T, B, H, din)
         ctx.b_refs = (b_ih_f, b_hh_f, b_ih_r, b_hh_r)
         ctx.save_for_backward(x, lens_dev, y, gates, cell, w_ih_f, w_hh_f, w_ih_r, w_hh_r)
@@ -504,7 +558,7 @@ class BiLstmLayerFn(torch.autograd.Function):
         wt_f, wt_r = transpose2d(w_hh_f), transpose2d(w_hh_r)            # [H][4H]: contiguous B operand for the sweep
         dbias = torch.empty(2, 4 * H, dtype=torch.float32, device=dev)          # gradient of b_ih (= of b_hh), both directions
         call("vocr_lstm_bwd_bias", _p(dy), _p(wt_f), _p(wt_r), _p(lens_dev), _p(gates), _p(cell), _p(dg), _p(dbias), _p(ws),
-             T, B, H, _stream())
+             T, B, H, _p(health(dev)), _stream())
         G = 4 * H
         # critical path first: dx feeds the layer below
         dx = None
@@ -537,14 +591,14 @@ class BiLstmLayerFn(torch.autograd.Function):
             dbh_f.copy_(dbias[0])
             dbh_r.copy_(dbias[1])
 
-        if direct and _SIDE["enabled"] and _os.environ.get("VOCR_LSTM_DW_OVERLAP", "1") == "1":
+        if direct and _SIDE_ENABLED and _os.environ.get("VOCR_LSTM_DW_OVERLAP", "1") == "1":
             side = side_stream()
             side.wait_stream(torch.cuda.current_stream())
             for t_ in (dg, x, y, dbias):
                 t_.record_stream(side)
             with torch.cuda.stream(side):
                 weight_grads(sinks)
-            _SIDE["pending"] = True
+            mark_side_pending()
             return (dx, None, None, None) + (None,) * 8
         if direct:
             weight_grads(sinks)
@@ -607,4 +661,13 @@ def greedy_collapse(idx, mx, lens_dev, canon_dev, thresh):
 def clamp_adam(p, g, m, v, lr, beta1, beta2, eps, weight_decay, clamp, grad_scale, step):
     _need_gpu(p, g, m, v)
     call("vocr_clamp_adam", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
-         float(weight_decay), float(clamp), float(grad_scale), int(step), _stream())
+         float(weight_decay), float(clamp), float(grad_scale), int(step), _p(health(p.device)), _stream())
+
+
+def clamp_(x, clamp):
+    """In-place x.clamp_(-clamp, clamp) on the device, NaN preserved (train_cnn_lstm.py:143-145)."""
+    _need_gpu(x)
+    if not x.is_contiguous() or x.dtype != torch.float32:
+        raise RuntimeError("vistaocr_amd.clamp_: need a contiguous fp32 tensor")
+    call("vocr_clamp", _p(x), x.numel(), float(clamp), _p(health(x.device)), _stream())
+    return x

@@ -1,14 +1,25 @@
-"""train() step of the reference (src/train_cnn_lstm.py:131-150) with the optimiser side fused for MI355X:
-all parameters live in ONE flat fp32 buffer (params / grads / Adam moments), so zero_grad is one memset, the
-data-parallel exchange is one RCCL all-reduce over xGMI on the flat gradient, and clamp(+-5) + Adam is one
-HBM-streaming kernel (vocr_clamp_adam) instead of ~150 small launches.
+"""train() step of the reference (src/train_cnn_lstm.py:131-150).
 
-Data parallelism: one process per GPU, full replica, per-rank batch; gradients are SUMMED
-across ranks before the clamp (the reference's loss is a batch SUM, so this equals one big batch of B*N)."""
+Two optimiser paths behind the same train(batch, model, criterion, optimizer) call:
+  * any torch.optim optimiser (the reference passes torch.optim.Adam, train_cnn_lstm.py:363): gradients are clamped to
+    [-5, 5] on the device (vocr_clamp, NaN preserved like torch's clamp_) and optimizer.step() runs as given;
+  * FlatClampAdam (the fast path, `make_optimizer(model)`): all parameters live in ONE flat fp32 buffer (params / grads /
+    Adam moments), so zero_grad is one memset, the data-parallel exchange is one RCCL all-reduce over xGMI on the flat
+    gradient, and clamp(+-5) + Adam is one HBM-streaming kernel (vocr_clamp_adam) instead of ~150 small launches.
+
+Data parallelism: one process per GPU, full replica, per-rank batch; gradients are SUMMED across ranks
+before the clamp (the reference's loss is a batch SUM, so this equals one big batch of B*N)."""
+import os
+
 import torch
 import torch.distributed as dist
 
 from . import ops
+
+
+def _dp_active(group=None):
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or
+                                                              os.environ.get("VOCR_FORCE_DIST") == "1")
 
 
 class FlatClampAdam(object):
@@ -26,6 +37,7 @@ class FlatClampAdam(object):
         self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._offsets = {}
         off = 0
         with torch.no_grad():
             for p in self.params:
@@ -33,24 +45,43 @@ class FlatClampAdam(object):
                 self.flat_p[off:off + k].copy_(p.data.reshape(-1))
                 p.data = self.flat_p[off:off + k].view_as(p)          # parameter storage now aliases the flat buffer
                 p.grad = self.flat_g[off:off + k].view_as(p)          # autograd accumulates in place into the flat grads
+                self._offsets[id(p)] = off
+                # every parameter now owns a persistent gradient buffer that zero_grad() clears once per step: the backward
+                # kernels may write its gradient straight there (ops._sinks).  The mark is per PARAMETER, so other models
+                # and optimisers in the process are unaffected.
+                if dev.type == "cuda":
+                    p._vocr_sink_owner = self
                 off += k
         self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, clamp=clamp)]
         self.step_count = 0
-        # every parameter now owns a persistent gradient buffer that zero_grad() clears once per step: let the backward
-        # kernels write weight gradients straight into it (each parameter is used once per forward)
-        ops.DIRECT_GRADS["enabled"] = dev.type == "cuda"
+        self._written = set()            # parameters whose gradient a backward kernel stored directly since zero_grad()
         # Two all-reduce buckets: [0, split) = parameters whose gradients appear last (rapid_ds + cnn), [split, n) =
         # bridge + LSTM + prob (88 % of the bytes at H=512), final as soon as the backward reaches the CNN, so their
-        # exchange over xGMI is launched there and hides under the CNN backward.
-        self._split = 0
+        # exchange over xGMI is launched there and hides under the CNN backward (make_optimizer registers the hook).
+        self._split = int(named_split) if named_split is not None else 0
         self._tail_work = None
-        if named_split is not None:
-            self._split = int(named_split)
-        if self._split > 0:
-            ops.BACKWARD_HOOKS["sequence_grads_ready"] = [self._start_tail_allreduce]
+
+    # ---- direct-gradient bookkeeping (ops._sinks)
+    def owns_grads(self, params):
+        base = self.flat_g.data_ptr()
+        for p in params:
+            off = self._offsets.get(id(p))
+            if off is None or p.grad.data_ptr() != base + off * 4:
+                return False
+        return True
+
+    def note_direct_write(self, params):
+        for p in params:
+            if id(p) in self._written:
+                raise RuntimeError("vistaocr_amd.FlatClampAdam: second backward() before zero_grad(): the backward kernels "
+                                   "store weight gradients directly into the flat buffer (they do not accumulate). Call "
+                                   "optimizer.zero_grad() between backward passes, or use a torch.optim optimiser for "
+                                   "gradient accumulation.")
+            self._written.add(id(p))
 
     def zero_grad(self, set_to_none=False):
         self.flat_g.zero_()
+        self._written.clear()
         off = 0
         for p in self.params:                                         # re-attach if someone set .grad = None
             k = p.numel()
@@ -58,24 +89,20 @@ class FlatClampAdam(object):
                 p.grad = self.flat_g[off:off + k].view_as(p)
             off += k
 
-    @staticmethod
-    def _dp_active(group=None):
-        import os
-        return dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or
-                                                                  os.environ.get("VOCR_FORCE_DIST") == "1")
+    _dp_active = staticmethod(_dp_active)
 
     def _start_tail_allreduce(self):
         """Backward hook: bridge/LSTM/prob gradients are final -> start their all-reduce asynchronously."""
-        if self._split > 0 and self._tail_work is None and self._dp_active():
+        if self._split > 0 and self._tail_work is None and _dp_active():
             if self.flat_g.is_cuda:
-                ops.join_side_stream()
+                ops.join_side_stream(self.flat_g.device)
             self._tail_work = dist.all_reduce(self.flat_g[self._split:], op=dist.ReduceOp.SUM, async_op=True)
 
     def all_reduce_grads(self, group=None):
         """Sum gradients over data-parallel ranks (RCCL over xGMI when the backend is 'nccl')."""
         if self.flat_g.is_cuda:
-            ops.join_side_stream()
-        if not self._dp_active(group):
+            ops.join_side_stream(self.flat_g.device)
+        if not _dp_active(group):
             return
         if self._tail_work is not None:                 # tail bucket already in flight since mid-backward
             dist.all_reduce(self.flat_g[:self._split], op=dist.ReduceOp.SUM, group=group)
@@ -86,10 +113,14 @@ class FlatClampAdam(object):
 
     def step(self, grad_scale=1.0):
         g = self.param_groups[0]
-        ops.join_side_stream()
+        ops.join_side_stream(self.flat_g.device)
         self.step_count += 1
         ops.clamp_adam(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, g["lr"], g["betas"][0], g["betas"][1],
                        g["eps"], g["weight_decay"], g["clamp"], grad_scale, self.step_count)
+
+    def check_health(self):
+        """Synchronising check of the device health words (LSTM hand-off timeout, NaN gradient)."""
+        ops.check_health(ops.health(self.flat_g.device).cpu().tolist())
 
     def state_dict(self):
         return dict(step=self.step_count, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, param_groups=self.param_groups)
@@ -102,14 +133,36 @@ class FlatClampAdam(object):
 
 
 def make_optimizer(model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clamp=5.0):
-    """FlatClampAdam over model.parameters() with the bucket boundary placed after the CNN parameters."""
+    """FlatClampAdam over model.parameters() with the bucket boundary placed after the CNN parameters; the model's
+    "sequence gradients are final" backward milestone starts the big bucket's all-reduce."""
     n_cnn = sum(p.numel() for p in list(model.rapid_ds.parameters()) + list(model.cnn.parameters()) if p.requires_grad)
-    return FlatClampAdam(model.parameters(), lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, clamp=clamp, named_split=n_cnn)
+    opt = FlatClampAdam(model.parameters(), lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, clamp=clamp, named_split=n_cnn)
+    hooks = getattr(model, "_vocr_hooks", None)
+    if hooks is not None and n_cnn > 0:
+        hooks["sequence_grads_ready"] = [opt._start_tail_allreduce]
+    return opt
 
 
-def train(batch, model, criterion, optimizer):
-    """One optimisation step — src/train_cnn_lstm.py:131-150.  `optimizer` is a FlatClampAdam (it performs the
-    reference's clamp(-5, 5) inside its fused step); returns the batch-summed loss as a Python float."""
+GRAD_CLAMP = 5.0          # src/train_cnn_lstm.py:143-145
+
+
+def _generic_update(model, optimizer):
+    """The reference's own tail of train() for an optimiser that is not FlatClampAdam: (all-reduce,) clamp every
+    gradient to [-5, 5] on the device, optimizer.step()."""
+    grads = [p.grad for p in model.parameters() if p.grad is not None]
+    if grads and grads[0].is_cuda:
+        ops.join_side_stream(grads[0].device)
+    if _dp_active():
+        for g in grads:
+            dist.all_reduce(g, op=dist.ReduceOp.SUM)
+    for g in grads:
+        if not g.is_contiguous():
+            g.data = g.data.contiguous()
+        ops.clamp_(g.data, GRAD_CLAMP)
+    optimizer.step()
+
+
+def _step(batch, model, criterion, optimizer, want_float):
     input_tensor, target, input_widths, target_widths, metadata = batch
     input_tensor = input_tensor.cuda(non_blocking=True)
     optimizer.zero_grad()
@@ -119,39 +172,46 @@ def train(batch, model, criterion, optimizer):
     # queued HERE, ahead of the backward kernels, and only that copy is waited for at the end.  The host then gets the
     # value while the device is still busy with this step's backward + Adam and starts queueing the next step at once
     # (with loss.item() after optimizer.step() the device ran dry at the start of every step: 23.6 vs 22.2 ms/step).
+    # The device health words ride along: they cover the previous step's backward/optimiser and this step's forward.
     ev = None
-    if loss.is_cuda:
-        host = _pinned_scalar(loss.device)
+    if want_float and loss.is_cuda:
+        host, host_health = _pinned(loss.device)
         host.copy_(loss.detach().reshape(-1)[:1], non_blocking=True)
+        host_health.copy_(ops.health(loss.device), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
     loss.backward()
-    optimizer.all_reduce_grads()
-    optimizer.step()
+    if hasattr(optimizer, "all_reduce_grads"):
+        optimizer.all_reduce_grads()
+        optimizer.step()
+    else:
+        _generic_update(model, optimizer)
+    if not want_float:
+        return loss.detach()
     if ev is None:
         return loss.data[0].item()
     ev.synchronize()
+    ops.check_health(host_health.tolist())
     return float(host[0])
+
+
+def train(batch, model, criterion, optimizer):
+    """One optimisation step — src/train_cnn_lstm.py:131-150; returns the batch-summed loss as a Python float.
+    `optimizer` is a FlatClampAdam (clamp fused into its step) or any torch.optim optimiser (device clamp, then step())."""
+    return _step(batch, model, criterion, optimizer, True)
 
 
 _PINNED = {}
 
 
-def _pinned_scalar(device):
+def _pinned(device):
     key = str(device)
     if key not in _PINNED:
-        _PINNED[key] = torch.empty(1, dtype=torch.float32).pin_memory()
+        _PINNED[key] = (torch.empty(1, dtype=torch.float32).pin_memory(), torch.zeros(2, dtype=torch.int32).pin_memory())
     return _PINNED[key]
 
 
 def train_async(batch, model, criterion, optimizer):
-    """Same step without the device->host sync of the returned float (returns the loss tensor)."""
-    input_tensor, target, input_widths, target_widths, metadata = batch
-    input_tensor = input_tensor.cuda(non_blocking=True)
-    optimizer.zero_grad()
-    model_output, model_output_actual_lengths = model(input_tensor, input_widths)
-    loss = criterion(model_output, target, model_output_actual_lengths, target_widths)
-    loss.backward()
-    optimizer.all_reduce_grads()
-    optimizer.step()
-    return loss.detach()
+    """Same step without the device->host sync of the returned float (returns the loss tensor; no health check —
+    call optimizer.check_health() or train() now and then)."""
+    return _step(batch, model, criterion, optimizer, False)
