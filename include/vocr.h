@@ -66,12 +66,14 @@ size_t vocr_channel_sum_workspace_bytes(int n, int c, int hw);
 int vocr_channel_sum(const float* x, float* out, int n, int c, int hw, void* workspace, void* stream);
 
 /* ---- BatchNorm2d + ReLU — src/models/cnnlstm.py:265-266 -------------------------------------------------- */
-/* training statistics: mean[c], invstd[c] (biased var, eps) and running-stat update (momentum, unbiased var).
- * running_mean/var may be NULL.  workspace: 3*c*nchunk doubles, see vocr_bn_workspace_bytes. */
+/* training statistics: mean[c], invstd[c] (biased var, eps) and running-stat update (momentum, unbiased var);
+ * *num_batches_tracked (device int64) += 1; xhat_sum[c] = sum over the batch of (y-mean)*invstd (the rounding residue of the
+ * fp32 mean; the backward turns it into the conv-bias gradient).  running_mean/var, num_batches_tracked, xhat_sum may be NULL.
+ * workspace: 2*c*nchunk doubles, see vocr_bn_workspace_bytes. */
 size_t vocr_bn_workspace_bytes(int n, int c, int hw);
 int vocr_bn_train_stats(const float* y, int n, int c, int hw, float eps, float momentum,
                         float* mean, float* invstd, float* running_mean, float* running_var,
-                        void* workspace, void* stream);
+                        int64_t* num_batches_tracked, float* xhat_sum, void* workspace, void* stream);
 /* eval: mean/invstd from running stats */
 int vocr_bn_eval_stats(const float* running_mean, const float* running_var, int c, float eps,
                        float* mean, float* invstd, void* stream);
@@ -82,7 +84,7 @@ int vocr_bn_relu_apply(const float* y, const float* mean, const float* invstd, c
  * dconv_bias (may be NULL) receives sum_{n,h,w} dy per channel = the gradient of the conv bias in front (rounding
  * noise around zero, from the fixed-order reduction: no float atomics anywhere in this call). */
 int vocr_bn_relu_bwd(const float* da, const float* y, const float* mean, const float* invstd,
-                     const float* gamma, const float* beta, float* dy, float* dgamma, float* dbeta,
+                     const float* gamma, const float* beta, const float* xhat_sum, float* dy, float* dgamma, float* dbeta,
                      float* dconv_bias, int n, int c, int hw, void* workspace, void* stream);
 
 /* ---- FractionalMaxPool2d(2, output_ratio=(0.5,0.7)) — src/models/cnnlstm.py:127,130 --------------------- */
@@ -94,6 +96,15 @@ int vocr_fracpool2x2_fwd(const float* x, const float* samples, float* out, int32
 int vocr_bn_relu_fracpool2x2_fwd(const float* y, const float* mean, const float* invstd, const float* gamma,
                                  const float* beta, const float* samples, float* out, int32_t* idx,
                                  int n, int c, int h, int w, int oh, int ow, void* stream);
+/* Backward of vocr_bn_relu_fracpool2x2_fwd in one go: dout/idx are the pooled gradient and winner indices, samples the
+ * forward's; returns dy = dL/d(conv output), dgamma, dbeta, dconv_bias like vocr_bn_relu_bwd, without materialising the
+ * un-pooled gradient.  Needs window starts that strictly increase (vocr_bn_relu_fracpool2x2_bwd_supported: both
+ * (in-2)/(out-1) >= 1.01, true for the reference's 0.5 x 0.7 ratios); otherwise use vocr_fracpool2x2_bwd + vocr_bn_relu_bwd. */
+int vocr_bn_relu_fracpool2x2_bwd_supported(int h, int w, int oh, int ow);
+int vocr_bn_relu_fracpool2x2_bwd(const float* dout, const int32_t* idx, const float* samples, const float* y,
+                                 const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                 const float* xhat_sum, float* dy, float* dgamma, float* dbeta, float* dconv_bias,
+                                 int n, int c, int h, int w, int oh, int ow, void* workspace, void* stream);
 /* dx[n][c][h][w] = sum of dout over the windows whose winner is that pixel; every element of dx is written
  * (no zero-fill needed) */
 int vocr_fracpool2x2_bwd(const float* dout, const int32_t* idx, float* dx,

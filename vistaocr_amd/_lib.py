@@ -27,10 +27,12 @@ SIGNATURES = {
     "vocr_channel_sum_workspace_bytes": (Z, [I, I, I]),
     "vocr_channel_sum": (I, [P, P, I, I, I, P, P]),
     "vocr_bn_workspace_bytes": (Z, [I, I, I]),
-    "vocr_bn_train_stats": (I, [P, I, I, I, F, F, P, P, P, P, P, P]),
+    "vocr_bn_train_stats": (I, [P, I, I, I, F, F, P, P, P, P, P, P, P, P]),
     "vocr_bn_eval_stats": (I, [P, P, I, F, P, P, P]),
     "vocr_bn_relu_apply": (I, [P, P, P, P, P, P, I, I, I, P]),
-    "vocr_bn_relu_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, P, P]),
+    "vocr_bn_relu_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, P, P]),
+    "vocr_bn_relu_fracpool2x2_bwd_supported": (I, [I, I, I, I]),
+    "vocr_bn_relu_fracpool2x2_bwd": (I, [P] * 13 + [I] * 6 + [P, P]),
     "vocr_fracpool2x2_fwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
     "vocr_bn_relu_fracpool2x2_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "vocr_fracpool2x2_bwd": (I, [P, P, P, I, I, I, I, I, I, P]),
@@ -92,12 +94,21 @@ def check(rc, what):
 
 # optional per-entry-point HIP-event timing (bench.py's roofline leg): name -> list of (args, start, end)
 _TIMED = None
+_FILTER = {}
 
 
-def enable_timing(names):
-    """Record a HIP event pair on the current torch stream around every call of the named entry points."""
-    global _TIMED
-    _TIMED = {n: [] for n in names} if names else None
+def enable_timing(names, keep=False):
+    """Record a HIP event pair on the current torch stream around every call of the named entry points.  `names`: a list, or
+    a dict name -> predicate(args) selecting which calls to time; None switches it off.  keep=True keeps the records gathered
+    so far (used to time only some steps of a loop)."""
+    global _TIMED, _FILTER
+    old = _TIMED if keep and _TIMED is not None else {}
+    if not names:
+        _TIMED = {k: v for k, v in old.items()} if (keep and old) else None
+        _FILTER = {k: (lambda a: False) for k in (_TIMED or {})}
+        return
+    _FILTER = dict(names) if isinstance(names, dict) else {n: None for n in names}
+    _TIMED = {n: old.get(n, []) for n in _FILTER}
 
 
 def timing_records():
@@ -105,7 +116,7 @@ def timing_records():
 
 
 def call(name, *args):
-    if _TIMED is not None and name in _TIMED:
+    if _TIMED is not None and name in _TIMED and (_FILTER.get(name) is None or _FILTER[name](args)):
         import torch
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)

@@ -18,6 +18,20 @@ __device__ __forceinline__ long chan_addr(long e, int c, int C, long HW) {
     return (n * C + c) * HW + r;
 }
 
+// Walks the elements of one channel in steps of `step` without a 64-bit division per access (chan_addr's e / HW cost
+// more than the loads it addressed: the partial-reduction passes ran at 2.0-2.5 TB/s): one division at the start, then
+// the (plane, offset) pair is advanced incrementally.
+struct ChanWalk {
+    long n;
+    long r;
+    __device__ __forceinline__ ChanWalk(long e, long HW) : n(e / HW), r(e - (e / HW) * HW) {}
+    __device__ __forceinline__ long addr(int c, int C, long HW) const { return (n * C + c) * HW + r; }
+    __device__ __forceinline__ void advance(long step, long HW) {
+        r += step;
+        while (r >= HW) { r -= HW; ++n; }
+    }
+};
+
 __device__ __forceinline__ void block_reduce2(double& a, double& b, double* red) {
     a = wave_sum_d(a);
     b = wave_sum_d(b);
@@ -46,8 +60,9 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
     const long total = (long)N * HW;
     const long beg = j * per, end = min(total, beg + per);
     double s = 0.0, q = 0.0;
-    for (long e = beg + (long)threadIdx.x * V; e < end; e += 256 * V) {
-        const vec v = *(const vec*)(y + chan_addr(e, c, C, HW));
+    ChanWalk wk(beg + (long)threadIdx.x * V, HW);
+    for (long e = beg + (long)threadIdx.x * V; e < end; e += 256 * V, wk.advance(256 * V, HW)) {
+        const vec v = *(const vec*)(y + wk.addr(c, C, HW));
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             const double x = (double)vget<V>(v, i);
@@ -64,8 +79,10 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
 
 __global__ void bn_stats_final_kernel(const double* __restrict__ part, int C, int nchunk, long count, float eps,
                                       float momentum, float* __restrict__ mean, float* __restrict__ invstd,
-                                      float* __restrict__ rmean, float* __restrict__ rvar) {
+                                      float* __restrict__ rmean, float* __restrict__ rvar, long long* __restrict__ nbt,
+                                      float* __restrict__ xhat_sum) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt) *nbt += 1;            // BatchNorm2d.num_batches_tracked += 1 (was a separate torch kernel per layer)
     if (c >= C) return;
     double s = 0.0, q = 0.0;
     for (int j = 0; j < nchunk; ++j) {
@@ -77,6 +94,9 @@ __global__ void bn_stats_final_kernel(const double* __restrict__ part, int C, in
     if (var < 0.0) var = 0.0;
     mean[c] = (float)m;
     invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    // sum over the batch of xhat = (y - mean)*invstd with the fp32 mean the later passes use: the rounding residue of the
+    // mean, ~0.  The backward needs it for the gradient of the conv bias in front (see bn_bwd_final_kernel).
+    if (xhat_sum) xhat_sum[c] = (float)((s - (double)count * (double)mean[c]) * (double)invstd[c]);
     if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
     if (rvar) {
         const double unbiased = count > 1 ? var * (double)count / (double)(count - 1) : var;
@@ -131,49 +151,83 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
     const float mu = mean[c], is = invstd[c], g = gamma[c], b = beta[c];
     const long total = (long)N * HW;
     const long beg = j * per, end = min(total, beg + per);
-    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    for (long e = beg + (long)threadIdx.x * V; e < end; e += 256 * V) {
-        const long a = chan_addr(e, c, C, HW);
+    double s1 = 0.0, s2 = 0.0;
+    ChanWalk wk(beg + (long)threadIdx.x * V, HW);
+    for (long e = beg + (long)threadIdx.x * V; e < end; e += 256 * V, wk.advance(256 * V, HW)) {
+        const long a = wk.addr(c, C, HW);
         const vec yv = *(const vec*)(y + a);
         const vec dv = *(const vec*)(da + a);
+        // the V elements of one load are summed in fp32 first (<= 4 terms: exact to ~1 ulp), then carried in double:
+        // a quarter of the fp64 conversions/adds of the per-element form
+        float p1 = 0.f, p2 = 0.f;
 #pragma unroll
         for (int k = 0; k < V; ++k) {
             const float xh = (vget<V>(yv, k) - mu) * is;
             const float o = xh * g + b;
             const float dz = o > 0.f ? vget<V>(dv, k) : 0.f;
-            s1 += (double)dz;
-            s2 += (double)dz * (double)xh;
-            s3 += (double)xh;
+            p1 += dz;
+            p2 += dz * xh;
         }
+        s1 += (double)p1;
+        s2 += (double)p2;
     }
     block_reduce2(s1, s2, red);
-    __syncthreads();
-    double dummy = 0.0;
-    block_reduce2(s3, dummy, red);
     if (threadIdx.x == 0) {
-        part[((long)c * nchunk + j) * 3] = s1;
-        part[((long)c * nchunk + j) * 3 + 1] = s2;
-        part[((long)c * nchunk + j) * 3 + 2] = s3;
+        part[((long)c * nchunk + j) * 2] = s1;
+        part[((long)c * nchunk + j) * 2 + 1] = s2;
+    }
+}
+
+// The same two sums for a layer whose activation went straight into FractionalMaxPool2d (bn_relu_fracpool_fwd_kernel):
+// da is the scatter of the pooled gradient, so sum_p dz(p) f(p) = sum_o dout(o) [relu active at the winner] f(winner(o)):
+// one pass over the POOLED tensors (35 % of the plane) with a gather of y, instead of materialising da and reading it back.
+__global__ __launch_bounds__(256) void bn_pool_bwd_partial_kernel(const float* __restrict__ dout, const int32_t* __restrict__ idx,
+                                                                  const float* __restrict__ y, const float* __restrict__ mean,
+                                                                  const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, double* __restrict__ part, int N,
+                                                                  int C, long HW, long OP, int nchunk, long per) {
+    __shared__ double red[8];
+    const int c = blockIdx.x, j = blockIdx.y;
+    const float mu = mean[c], is = invstd[c], g = gamma[c], b = beta[c];
+    const long total = (long)N * OP;
+    const long beg = j * per, end = min(total, beg + per);
+    double s1 = 0.0, s2 = 0.0;
+    ChanWalk wk(beg + threadIdx.x, OP);
+    for (long e = beg + threadIdx.x; e < end; e += 256, wk.advance(256, OP)) {
+        const long plane = wk.n * C + c;
+        const float d = dout[plane * OP + wk.r];
+        const float yv = y[plane * HW + idx[plane * OP + wk.r]];
+        const float xh = (yv - mu) * is;
+        const float o = xh * g + b;
+        const float dz = o > 0.f ? d : 0.f;
+        s1 += (double)dz;
+        s2 += (double)(dz * xh);
+    }
+    block_reduce2(s1, s2, red);
+    if (threadIdx.x == 0) {
+        part[((long)c * nchunk + j) * 2] = s1;
+        part[((long)c * nchunk + j) * 2 + 1] = s2;
     }
 }
 
 // Also the gradient of the conv bias in front of the BatchNorm: sum over (n,h,w) of dy = g*is*(dz - mean(dz) - xh*mean(dz*xh))
-// = -g*is*mean(dz*xh)*sum(xh); sum(xh) is the fp32 rounding residue of the batch mean, so this is rounding noise around
-// zero exactly as in the reference, but summed in a fixed order (it used to be float atomics over the dy planes).
+// = -g*is*mean(dz*xh)*sum(xh); sum(xh) (xhat_sum, from the forward statistics pass) is the fp32 rounding residue of the batch
+// mean, so this is rounding noise around zero exactly as in the reference, but reproducible (it used to be float atomics over
+// the dy planes).
 __global__ void bn_bwd_final_kernel(const double* __restrict__ part, int C, int nchunk, double inv_count,
                                     const float* __restrict__ gamma, const float* __restrict__ invstd,
-                                    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dconv_bias) {
+                                    const float* __restrict__ xhat_sum, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                    float* __restrict__ dconv_bias) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    double s1 = 0.0, s2 = 0.0;
     for (int j = 0; j < nchunk; ++j) {
-        s1 += part[((long)c * nchunk + j) * 3];
-        s2 += part[((long)c * nchunk + j) * 3 + 1];
-        s3 += part[((long)c * nchunk + j) * 3 + 2];
+        s1 += part[((long)c * nchunk + j) * 2];
+        s2 += part[((long)c * nchunk + j) * 2 + 1];
     }
     dbeta[c] = (float)s1;
     dgamma[c] = (float)s2;
-    if (dconv_bias) dconv_bias[c] = (float)(-(double)gamma[c] * (double)invstd[c] * (s2 * inv_count) * s3);
+    if (dconv_bias) dconv_bias[c] = xhat_sum ? (float)(-(double)gamma[c] * (double)invstd[c] * (s2 * inv_count) * (double)xhat_sum[c]) : 0.f;
 }
 
 template <int V>
@@ -337,6 +391,72 @@ __global__ __launch_bounds__(512) void pool_bwd_lds_kernel(const float* __restri
     }
 }
 
+// dy of a pooled layer in ONE pass: gradient of FractionalMaxPool2d (gather form) + ReLU + batch-stat BatchNorm.
+// One workgroup per (n, c) plane.  The pooling windows are rebuilt from the samples with the forward's rule; because the
+// window starts are strictly increasing (alpha >= 1; the LAST window, pinned at in-2, is handled on its own since float32
+// rounding can make it coincide with its neighbour) every input column is the first column of at most one window and the
+// second column of at most one: two small inverse maps per axis in LDS.  A pixel then looks at its <= 9 candidate windows
+// and adds dout where the stored winner index is itself - no atomics, no LDS image of the plane, full occupancy, and the
+// BatchNorm backward is applied on the way out, so neither da nor a zero-filled plane ever goes to HBM.
+__global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float* __restrict__ dout, const int32_t* __restrict__ idx,
+                                                                const float* __restrict__ samples, const float* __restrict__ y,
+                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                                float* __restrict__ dy, int C, int H, int W, int OH, int OW,
+                                                                float alpha_h, float alpha_w, float inv_count) {
+    extern __shared__ int inv[];                 // wa[W], wb[W], ha[H], hb[H]
+    int* wa = inv;
+    int* wb = inv + W;
+    int* ha = inv + 2 * W;
+    int* hb = inv + 2 * W + H;
+    const long plane = blockIdx.x;
+    const int c = (int)(plane % C);
+    const int tid = threadIdx.x;
+    const float uw = samples[plane * 2], uh = samples[plane * 2 + 1];
+    for (int i = tid; i < 2 * W + 2 * H; i += 256) inv[i] = -1;
+    __syncthreads();
+    for (int o = tid; o < OW - 1; o += 256) {
+        const int st = frac_start(o, uw, alpha_w, W, OW);
+        wa[st] = o;
+        wb[st + 1] = o;
+    }
+    for (int o = tid; o < OH - 1; o += 256) {
+        const int st = frac_start(o, uh, alpha_h, H, OH);
+        ha[st] = o;
+        hb[st + 1] = o;
+    }
+    __syncthreads();
+    const float mu = mean[c], is = invstd[c], g = gamma[c], b = beta[c];
+    const float k1 = dbeta[c] * inv_count, k2 = dgamma[c] * inv_count, gs = g * is;
+    const float* dp = dout + plane * (long)OH * OW;
+    const int32_t* ip = idx + plane * (long)OH * OW;
+    const float* yp = y + plane * (long)H * W;
+    float* op = dy + plane * (long)H * W;
+    for (int h = 0; h < H; ++h) {
+        const int ohc[3] = {ha[h], hb[h], h >= H - 2 ? OH - 1 : -1};
+        for (int w = tid; w < W; w += 256) {
+            const int p = h * W + w;
+            const int owc[3] = {wa[w], wb[w], w >= W - 2 ? OW - 1 : -1};
+            float da = 0.f;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                if (ohc[a] < 0) continue;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    if (owc[q] < 0) continue;
+                    const int o = ohc[a] * OW + owc[q];
+                    if (ip[o] == p) da += dp[o];
+                }
+            }
+            const float xh = (yp[p] - mu) * is;
+            const float ov = xh * g + b;
+            const float dz = ov > 0.f ? da : 0.f;
+            op[p] = gs * (dz - k1 - xh * k2);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void relu_maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                                 int32_t* __restrict__ idx, int H, int W, int OH, int OW) {
     const long plane = blockIdx.y;
@@ -387,11 +507,12 @@ static inline long chunk_len(long per_channel, int nchunk) {
 
 extern "C" size_t vocr_bn_workspace_bytes(int n, int c, int hw) {
     if (n <= 0 || c <= 0 || hw <= 0) return 0;
-    return (size_t)c * bn_nchunk((long)n * hw) * 3 * sizeof(double);
+    return (size_t)c * bn_nchunk((long)n * hw) * 2 * sizeof(double);
 }
 
 extern "C" int vocr_bn_train_stats(const float* y, int n, int c, int hw, float eps, float momentum, float* mean,
-                                   float* invstd, float* running_mean, float* running_var, void* workspace, void* stream) {
+                                   float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                   float* xhat_sum, void* workspace, void* stream) {
     VOCR_CHECK_ARG(y && mean && invstd && workspace && n > 0 && c > 0 && hw > 0, "vocr_bn_train_stats: bad argument");
     hipStream_t s = (hipStream_t)stream;
     const int nchunk = bn_nchunk((long)n * hw);
@@ -402,7 +523,7 @@ extern "C" int vocr_bn_train_stats(const float* y, int n, int c, int hw, float e
     else bn_stats_partial_kernel<1><<<dim3(c, nchunk), 256, 0, s>>>(y, (double*)workspace, n, c, hw, nchunk, per);
     VOCR_CHECK_LAUNCH("vocr_bn_train_stats(partial)");
     bn_stats_final_kernel<<<vocr_cdiv(c, 64), 64, 0, s>>>((const double*)workspace, c, nchunk, (long)n * hw, eps, momentum,
-                                                          mean, invstd, running_mean, running_var);
+                                                          mean, invstd, running_mean, running_var, (long long*)num_batches_tracked, xhat_sum);
     VOCR_CHECK_LAUNCH("vocr_bn_train_stats(final)");
     return VOCR_OK;
 }
@@ -436,7 +557,7 @@ extern "C" int vocr_bn_relu_apply(const float* y, const float* mean, const float
 }
 
 extern "C" int vocr_bn_relu_bwd(const float* da, const float* y, const float* mean, const float* invstd,
-                                const float* gamma, const float* beta, float* dy, float* dgamma, float* dbeta,
+                                const float* gamma, const float* beta, const float* xhat_sum, float* dy, float* dgamma, float* dbeta,
                                 float* dconv_bias, int n, int c, int hw, void* workspace, void* stream) {
     VOCR_CHECK_ARG(da && y && mean && invstd && gamma && beta && dy && dgamma && dbeta && workspace, "vocr_bn_relu_bwd: null pointer");
     VOCR_CHECK_ARG(n > 0 && c > 0 && hw > 0 && (long)n * c <= 65535, "vocr_bn_relu_bwd: bad shape");
@@ -449,7 +570,7 @@ extern "C" int vocr_bn_relu_bwd(const float* da, const float* y, const float* me
     else bn_bwd_partial_kernel<1><<<dim3(c, nchunk), 256, 0, s>>>(da, y, mean, invstd, gamma, beta, (double*)workspace, n, c, hw, nchunk, per);
     VOCR_CHECK_LAUNCH("vocr_bn_relu_bwd(partial)");
     bn_bwd_final_kernel<<<vocr_cdiv(c, 64), 64, 0, s>>>((const double*)workspace, c, nchunk, 1.0 / (double)((long)n * hw), gamma, invstd,
-                                                        dgamma, dbeta, dconv_bias);
+                                                        xhat_sum, dgamma, dbeta, dconv_bias);
     VOCR_CHECK_LAUNCH("vocr_bn_relu_bwd(final)");
     const dim3 grid = plane_grid((long)n * c, hw / V);
     const float inv_count = 1.0f / (float)((long)n * hw);
@@ -457,6 +578,38 @@ extern "C" int vocr_bn_relu_bwd(const float* da, const float* y, const float* me
     else if (V == 2) bn_bwd_apply_kernel<2><<<grid, 256, 0, s>>>(da, y, mean, invstd, gamma, beta, dgamma, dbeta, dy, c, hw, inv_count);
     else bn_bwd_apply_kernel<1><<<grid, 256, 0, s>>>(da, y, mean, invstd, gamma, beta, dgamma, dbeta, dy, c, hw, inv_count);
     VOCR_CHECK_LAUNCH("vocr_bn_relu_bwd(apply)");
+    return VOCR_OK;
+}
+
+extern "C" int vocr_bn_relu_fracpool2x2_bwd_supported(int h, int w, int oh, int ow) {
+    if (h < 2 || w < 2 || oh < 2 || ow < 2 || oh > h - 1 || ow > w - 1) return 0;
+    // strictly increasing window starts need alpha comfortably above 1 (float32 interval arithmetic)
+    return ((float)(h - 2) / (float)(oh - 1) >= 1.01f && (float)(w - 2) / (float)(ow - 1) >= 1.01f && (2 * w + 2 * h) * 4 <= 64 * 1024) ? 1 : 0;
+}
+
+extern "C" int vocr_bn_relu_fracpool2x2_bwd(const float* dout, const int32_t* idx, const float* samples, const float* y,
+                                            const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                            const float* xhat_sum, float* dy, float* dgamma, float* dbeta, float* dconv_bias, int n,
+                                            int c, int h, int w, int oh, int ow, void* workspace, void* stream) {
+    VOCR_CHECK_ARG(dout && idx && samples && y && mean && invstd && gamma && beta && dy && dgamma && dbeta && workspace,
+                   "vocr_bn_relu_fracpool2x2_bwd: null pointer");
+    VOCR_CHECK_ARG(n > 0 && c > 0 && (long)n * c <= 65535 && vocr_bn_relu_fracpool2x2_bwd_supported(h, w, oh, ow),
+                   "vocr_bn_relu_fracpool2x2_bwd: unsupported shape h=%d w=%d oh=%d ow=%d", h, w, oh, ow);
+    hipStream_t s = (hipStream_t)stream;
+    const long op = (long)oh * ow, hw = (long)h * w;
+    const int nchunk = bn_nchunk((long)n * hw);                  // sized like the dense pass (same workspace)
+    const long per = ((long)n * op + nchunk - 1) / nchunk;
+    bn_pool_bwd_partial_kernel<<<dim3(c, nchunk), 256, 0, s>>>(dout, idx, y, mean, invstd, gamma, beta, (double*)workspace, n, c, hw, op,
+                                                              nchunk, per);
+    VOCR_CHECK_LAUNCH("vocr_bn_relu_fracpool2x2_bwd(partial)");
+    bn_bwd_final_kernel<<<vocr_cdiv(c, 64), 64, 0, s>>>((const double*)workspace, c, nchunk, 1.0 / (double)((long)n * hw), gamma, invstd,
+                                                        xhat_sum, dgamma, dbeta, dconv_bias);
+    VOCR_CHECK_LAUNCH("vocr_bn_relu_fracpool2x2_bwd(final)");
+    const float alpha_h = (float)(h - 2) / (float)(oh - 1), alpha_w = (float)(w - 2) / (float)(ow - 1);
+    bn_pool_bwd_apply_kernel<<<(unsigned)(n * c), 256, (size_t)(2 * w + 2 * h) * sizeof(int), s>>>(
+        dout, idx, samples, y, mean, invstd, gamma, beta, dgamma, dbeta, dy, c, h, w, oh, ow, alpha_h, alpha_w,
+        1.0f / (float)((long)n * hw));
+    VOCR_CHECK_LAUNCH("vocr_bn_relu_fracpool2x2_bwd(apply)");
     return VOCR_OK;
 }
 

@@ -33,7 +33,54 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
     if (pd) pd[(long)(co * 9 + (8 - tap)) * cin + ci] = v;   // (2-kh)*3+(2-kw) = 8 - tap
 }
 
-struct SegInfo { long base; int h; int w0; int valid; };
+// Segment geometry.  A SEGMENT is one MFMA N-tile: 32 lane positions over a 34-wide halo patch row.  An image row of
+// W pixels gives FS = W/32 full segments (one sub-row: 34 patch columns, 32 outputs); the RW = W%32 pixels left over at
+// the right edge of RR consecutive image rows share ONE remainder segment: its 34 patch columns are RR sub-rows of
+// RW+2 columns (left halo, RW pixels, zero right pad), RR = floor(34/(RW+2)), so lane position q is pixel (q/(RW+2),
+// q%(RW+2)) and the B operand of tap kw is still patch[q + kw].  The MFMA loops do not know the difference; only the
+// loaders' per-lane offsets and the store masks do.  (A remainder used to cost a whole segment per row: 8 % of the MFMA
+// work at W = 294, 6 % at W = 420.)
+struct SegGeom { int FS, RW, RR, per_img, nseg; };
+struct SegInfo { long base; int n; int h; int w0; int valid; int rows; int pw; int ow; };
+
+__host__ __device__ inline SegGeom seg_geom(int N, int H, int W) {
+    SegGeom g;
+    g.FS = W / SEGW;
+    g.RW = W % SEGW;
+    g.RR = g.RW ? (PROW / (g.RW + 2)) : 1;
+    if (g.RR > H) g.RR = H;
+    g.per_img = H * g.FS + (g.RW ? (H + g.RR - 1) / g.RR : 0);
+    g.nseg = N * g.per_img;
+    return g;
+}
+
+__device__ __forceinline__ SegInfo seg_decode(int gidx, const SegGeom& g, int H, long chw) {
+    SegInfo s;
+    s.valid = gidx < g.nseg;
+    const int gg = s.valid ? gidx : 0;
+    s.n = gg / g.per_img;
+    const int loc = gg - s.n * g.per_img;
+    const int nfull = H * g.FS;
+    if (loc < nfull) {
+        s.h = loc / g.FS;
+        s.w0 = (loc - s.h * g.FS) * SEGW;
+        s.rows = 1; s.pw = PROW; s.ow = SEGW;
+    } else {
+        s.h = (loc - nfull) * g.RR;
+        s.w0 = g.FS * SEGW;
+        s.rows = min(g.RR, H - s.h); s.pw = g.RW + 2; s.ow = g.RW;
+    }
+    s.base = (long)s.n * chw;
+    return s;
+}
+
+// XCD-aware workgroup order (cdna_hip_programming.md T1, bijective form): workgroups are dealt round-robin to the 8 XCDs,
+// so linear id b runs on XCD b % 8; giving XCD x the x-th contiguous slice of the work list keeps the rows h-1, h, h+1 of an
+// image (and both output-channel tiles of a pixel tile) in ONE XCD's L2 instead of three.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_slice_order(int b, int nwg) {
+    const int x = b & 7, q = nwg >> 3, r = nwg & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
 
 // Out-of-range operands are read from this zero page instead of being selected after the load: the ADDRESS is
 // selected, the load itself stays unconditional, so hipcc keeps all of a chunk's loads in flight together
@@ -49,13 +96,14 @@ __device__ __attribute__((aligned(16))) float g_zero_page[64];
 // a workgroup: at batch 32 the layers have only 4-7 full-size workgroups per CU and the last partial round costs 20 %
 // (measured 88 TF at 4.4 WG/CU vs 111 TF at 16 WG/CU); twice as many half-size workgroups let the hardware
 // dispatcher balance the tail.
-template <int CO_T, int SPWV, bool VECW>
+template <int CO_T, int SPWV, bool VECW, int WCO = 64>
 __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ in, const float* __restrict__ wpack,
                                                       const float* __restrict__ bias, float* __restrict__ out,
                                                       const float* __restrict__ zero_page, int N, int Cin, int H, int W,
-                                                      int Cout, int SW, int nseg_total) {
-    constexpr int WAVES_CO = CO_T / 64;
+                                                      int Cout, SegGeom geo, int co_tiles) {
+    constexpr int WAVES_CO = CO_T / WCO;                   // WCO = output channels per wave: 64 (two 32x32 accumulators) or 32
     constexpr int WAVES_PX = 4 / WAVES_CO;
+    constexpr int TM = WCO / 32;
     constexpr int NSEG = WAVES_PX * SPWV;
     constexpr int RPW = NSEG * 6;                          // halo rows staged per wave (NSEG*24 rows / 4 waves): 12, 24 or 48
     constexpr int SST = RPW >= 24 ? RPW / 24 : 1;          // segments a wave stages rows for
@@ -69,28 +117,20 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lk = lane >> 5;
-    const int co0 = blockIdx.y * CO_T;
-    const int seg0 = blockIdx.x * NSEG;
+    // work item v = (pixel tile, output-channel tile), channel tile fastest; XCD x takes the x-th contiguous slice
+    const int v = xcd_slice_order(blockIdx.x, gridDim.x);
+    const int co0 = (v % co_tiles) * CO_T;
+    const int seg0 = (v / co_tiles) * NSEG;
     const long HW = (long)H * W;
-    if (tid < NSEG) {
-        const int g = seg0 + tid;
-        SegInfo s;
-        s.valid = g < nseg_total;
-        const int gg = s.valid ? g : 0;
-        const int n = gg / (H * SW), rem = gg % (H * SW);
-        s.h = rem / SW;
-        s.w0 = (rem % SW) * SEGW;
-        s.base = (long)n * Cin * HW;
-        segs[tid] = s;
-    }
+    if (tid < NSEG) segs[tid] = seg_decode(seg0 + tid, geo, H, (long)Cin * HW);
     __syncthreads();
 
-    const int wco = (wave / WAVES_PX) * 64;
+    const int wco = (wave / WAVES_PX) * WCO;
     const int wsg = (wave % WAVES_PX) * SPWV;
 
-    f32x16 acc[2][SPWV];
+    f32x16 acc[TM][SPWV];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < SPWV; ++j)
 #pragma unroll
@@ -115,13 +155,14 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
 #pragma unroll
     for (int q = 0; q < SST; ++q) {
         const SegInfo sg = segs[st_seg0 + q];
-        const int ww = sg.w0 - 1 + lane;
-        const bool colok = sg.valid && lane < PROW && ww >= 0 && ww < W;
+        const int rr = lane / sg.pw, cc = lane - rr * sg.pw;          // patch column `lane` = sub-row rr, column cc
+        const int ww = sg.w0 - 1 + cc;
+        const bool colok = sg.valid && lane < PROW && rr < sg.rows && ww >= 0 && ww < W;
         const int loff = min(max(ww, 0), W - 1);
         p_base[q] = in + sg.base;
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
-            const int hh = sg.h + kh - 1;
+            const int hh = sg.h + rr + kh - 1;
             p_m[q][kh] = (colok && hh >= 0 && hh < H) ? 1.f : 0.f;
             p_off[q][kh] = min(max(hh, 0), H - 1) * W + loff;
         }
@@ -192,31 +233,34 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
         const int cnext = min(c + 1, nchunks - 1) * CI_C;     // branch-free prefetch (the last chunk re-loads itself, unused)
         // fragment reads run one k-step ahead of the MFMAs that consume them (hipcc otherwise emits
         // read -> lgkmcnt(0) -> MFMAs per step and exposes the LDS latency)
-        float a0 = wa[0], a1 = wa[32], b[SPWV];
+        float a[TM], b[SPWV];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = wa[32 * i];
 #pragma unroll
         for (int j = 0; j < SPWV; ++j) b[j] = pb[j * PSEG];
 #pragma unroll
         for (int ks = 0; ks < KC / 2; ++ks) {
             load_slice(cnext, ks);                  // next chunk's global loads ride between this chunk's MFMAs
-            float a0n = 0.f, a1n = 0.f, bn[SPWV];
+            float an[TM], bn[SPWV];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) an[i] = 0.f;
 #pragma unroll
             for (int j = 0; j < SPWV; ++j) bn[j] = 0.f;
             if (ks + 1 < KC / 2) {
                 const int kn = ks + 1;
                 const int offn = (kn / 9) * PCI + ((kn % 9) / 3) * PROW + (kn % 3);     // compile-time after unrolling
-                a0n = wa[kn * CO_T];
-                a1n = wa[kn * CO_T + 32];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) an[i] = wa[kn * CO_T + 32 * i];
 #pragma unroll
                 for (int j = 0; j < SPWV; ++j) bn[j] = pb[j * PSEG + offn];
             }
             __builtin_amdgcn_sched_barrier(0);      // next step's ds_reads are issued BEFORE this step's MFMAs
 #pragma unroll
-            for (int j = 0; j < SPWV; ++j) {
-                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[j], acc[0][j], 0, 0, 0);
-                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[j], acc[1][j], 0, 0, 0);
-            }
-            a0 = a0n;
-            a1 = a1n;
+            for (int j = 0; j < SPWV; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = an[i];
 #pragma unroll
             for (int j = 0; j < SPWV; ++j) b[j] = bn[j];
         }
@@ -230,11 +274,11 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
 #pragma unroll
     for (int j = 0; j < SPWV; ++j) {
         const SegInfo s = segs[wsg + j];
-        const int ww = s.w0 + li;
-        if (!s.valid || ww >= W) continue;
-        const long obase = (s.base / Cin) * Cout + (long)s.h * W + ww;   // n*Cout*HW + h*W + w
+        const int rr = li / s.pw, cc = li - rr * s.pw;                   // lane position -> (sub-row, column)
+        if (!s.valid || rr >= s.rows || cc >= s.ow) continue;
+        const long obase = (long)s.n * Cout * HW + (long)(s.h + rr) * W + s.w0 + cc;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wco + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
@@ -250,7 +294,7 @@ constexpr int WG_XCI = 3 * PROW + 1;  // 103
 __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             float* __restrict__ slab,
                                                             const float* __restrict__ zero_page, int N, int Cin, int H,
-                                                            int W, int Cout, int SW, int nseg_total, int segs_per_split) {
+                                                            int W, int Cout, SegGeom geo, int segs_per_split) {
     __shared__ float dyT[64 * WG_DYP];
     __shared__ float xp[64 * WG_XCI];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -268,9 +312,10 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restr
     constexpr int EDY = 64 * SEGW / 256;               // 8
     float rdy[EDY], rx[48];
 
+    const int nseg_total = geo.nseg;
     const int sbeg = split * segs_per_split;
     const int send = min(nseg_total, sbeg + segs_per_split);
-    const int dpx = tid & 31, dco = tid >> 5;           // dy loader: 32 pixels x 8 channels per pass
+    const int dpx = tid & 31, dco = tid >> 5;           // dy loader: 32 lane positions x 8 channels per pass
 
     // Loader: 32-bit element offsets from the tensor bases (host guarantees < 2^31 elements); everything that does not
     // depend on the segment is hoisted; the per-segment part is three scalars.  The 56 loads of segment g+1 are issued in
@@ -299,16 +344,21 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restr
     struct SegPos { int dy_off; int x_off[3]; float dy_ok; float row_ok[3]; };
     auto seg_pos = [&](int g) {
         SegPos p;
-        const int n = g / (H * SW), rem = g % (H * SW);
-        const int h = rem / SW, w0 = (rem % SW) * SEGW;
-        p.dy_ok = w0 + dpx < W ? 1.f : 0.f;
-        p.dy_off = n * Cout * (int)HW + h * W + min(w0 + dpx, W - 1);
-        const int ww = w0 - 1 + lane;
-        const bool colok = lane < PROW && ww >= 0 && ww < W;
+        const SegInfo sg = seg_decode(g, geo, H, 0);
+        const int n = sg.n, h = sg.h, w0 = sg.w0;
+        // dy sits at its lane POSITION (sub-row dr, column dc of the segment; gaps between sub-rows hold zeros), so that
+        // k-index q of the MFMA pairs dy[q] with patch[q + kw] exactly as in a full segment
+        const int dr = dpx / sg.pw, dc = dpx - dr * sg.pw;
+        const bool dok = dr < sg.rows && dc < sg.ow;
+        p.dy_ok = dok ? 1.f : 0.f;
+        p.dy_off = n * Cout * (int)HW + min(h + dr, H - 1) * W + min(w0 + dc, W - 1);
+        const int rr = lane / sg.pw, cc = lane - rr * sg.pw;
+        const int ww = w0 - 1 + cc;
+        const bool colok = lane < PROW && rr < sg.rows && ww >= 0 && ww < W;
         const int loff = min(max(ww, 0), W - 1);
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
-            const int hh = h + kh - 1;
+            const int hh = h + rr + kh - 1;
             p.row_ok[kh] = (colok && hh >= 0 && hh < H) ? 1.f : 0.f;
             p.x_off[kh] = n * Cin * (int)HW + min(max(hh, 0), H - 1) * W + loff;
         }
@@ -674,9 +724,10 @@ void launch_wgrad_reduce(const float* slab, float* dw, int cout, int cin, int sp
         wgrad_reduce_scalar_kernel<<<vocr_cdiv(total, 256), 256, 0, s>>>(slab, dw, cout, cin, splits);
 }
 
-int wgrad_splits(int n, int cin, int h, int w, int cout, int* segs_per_split) {
+// f16 = the fp16-operand kernel, which still enumerates one segment per 32-pixel piece of a row
+int wgrad_splits(int n, int cin, int h, int w, int cout, int* segs_per_split, bool f16 = false) {
     const int SW = vocr_cdiv(w, SEGW);
-    const long nseg = (long)n * h * SW;
+    const long nseg = (cin <= 3 || f16) ? (long)n * h * SW : (long)seg_geom(n, h, w).nseg;
     const int tiles = (cin <= 3 ? 1 : vocr_cdiv(cin, 64)) * vocr_cdiv(cout, 64);
     // the generic kernel holds one workgroup per CU (9 accumulators per wave): 256 slabs = one full round and a
     // 3x smaller slab than 768; the small-Cin kernel is light and streams, give it more
@@ -702,9 +753,9 @@ extern "C" int vocr_conv3x3_fwd(const float* x, const float* wpack, const float*
                                 int w, int cout, void* stream) {
     VOCR_CHECK_ARG(x && wpack && y, "vocr_conv3x3_fwd: null pointer");
     VOCR_CHECK_ARG(n > 0 && cin > 0 && h > 0 && w > 0 && cout > 0, "vocr_conv3x3_fwd: bad shape");
-    const int SW = vocr_cdiv(w, SEGW);
-    const long nseg = (long)n * h * SW;
-    VOCR_CHECK_ARG(nseg < (1l << 30), "vocr_conv3x3_fwd: too many segments");
+    VOCR_CHECK_ARG((long)n * h * vocr_cdiv(w, SEGW) < (1l << 30), "vocr_conv3x3_fwd: too many segments");
+    const SegGeom geo = seg_geom(n, h, w);
+    const long nseg = geo.nseg;
     hipStream_t s = (hipStream_t)stream;
     const bool vec = (cout % 4 == 0) && ((((uintptr_t)wpack) & 15) == 0);
     const float* zp = zero_page_ptr();
@@ -716,16 +767,17 @@ extern "C" int vocr_conv3x3_fwd(const float* x, const float* wpack, const float*
     const long full_wgs = (long)vocr_cdiv(nseg, cout > 64 ? 4 : 8) * co_tiles;
     static const int tile_mode = getenv("VOCR_CONV_TILE") ? atoi(getenv("VOCR_CONV_TILE")) : 0;     // experiments: 1 half, 2 full
     const bool small = tile_mode == 1 ? true : tile_mode == 2 ? false : full_wgs < 12l * 256;
-#define VOCR_CONV(CO_T, SPWV, NSEG)                                                                                          \
+    const bool tiny = tile_mode == 3;        // experiments: 32 output channels per wave (one accumulator), half the tile again
+#define VOCR_CONV(CO_T, SPWV, NSEG, WCO)                                                                                     \
     do {                                                                                                                    \
-        dim3 grid(vocr_cdiv(nseg, NSEG), co_tiles);                                                                         \
-        if (vec) conv3x3_kernel<CO_T, SPWV, true><<<grid, 256, 0, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, SW, (int)nseg);  \
-        else conv3x3_kernel<CO_T, SPWV, false><<<grid, 256, 0, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, SW, (int)nseg);     \
+        dim3 grid(vocr_cdiv(nseg, NSEG) * co_tiles);                                                                        \
+        if (vec) conv3x3_kernel<CO_T, SPWV, true, WCO><<<grid, 256, 0, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, geo, co_tiles);  \
+        else conv3x3_kernel<CO_T, SPWV, false, WCO><<<grid, 256, 0, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, geo, co_tiles);     \
     } while (0)
     if (cout > 64) {
-        if (small) VOCR_CONV(128, 1, 2); else VOCR_CONV(128, 2, 4);
+        if (tiny) VOCR_CONV(128, 1, 1, 32); else if (small) VOCR_CONV(128, 1, 2, 64); else VOCR_CONV(128, 2, 4, 64);
     } else {
-        if (small) VOCR_CONV(64, 1, 4); else VOCR_CONV(64, 2, 8);
+        if (tiny) VOCR_CONV(64, 1, 2, 32); else if (small) VOCR_CONV(64, 1, 4, 64); else VOCR_CONV(64, 2, 8, 64);
     }
 #undef VOCR_CONV
     VOCR_CHECK_LAUNCH("vocr_conv3x3_fwd");
@@ -735,8 +787,8 @@ extern "C" int vocr_conv3x3_fwd(const float* x, const float* wpack, const float*
 extern "C" size_t vocr_conv3x3_wgrad_workspace_bytes(int n, int cin, int h, int w, int cout) {
     if (n <= 0 || cin <= 0 || h <= 0 || w <= 0 || cout <= 0) return 0;
     int sps;
-    const int splits = wgrad_splits(n, cin, h, w, cout, &sps);
-    return (size_t)splits * 9 * cout * cin * sizeof(float);
+    const int a = wgrad_splits(n, cin, h, w, cout, &sps), b = wgrad_splits(n, cin, h, w, cout, &sps, true);   // f32 / fp16-operand kernels
+    return (size_t)(a > b ? a : b) * 9 * cout * cin * sizeof(float);
 }
 
 extern "C" int vocr_conv3x3_wgrad(const float* x, const float* dy, float* dw, void* workspace, int n, int cin, int h,
@@ -756,7 +808,7 @@ extern "C" int vocr_conv3x3_wgrad(const float* x, const float* dy, float* dw, vo
         conv3x3_wgrad_smallcin_kernel<<<grid, 128, 0, s>>>(x, dy, (float*)workspace, zp, n, cin, h, w, cout, SW, (int)nseg, sps);
     } else {
         dim3 grid(vocr_cdiv(cin, 64), vocr_cdiv(cout, 64), splits);
-        conv3x3_wgrad_kernel<<<grid, 256, 0, s>>>(x, dy, (float*)workspace, zp, n, cin, h, w, cout, SW, (int)nseg, sps);
+        conv3x3_wgrad_kernel<<<grid, 256, 0, s>>>(x, dy, (float*)workspace, zp, n, cin, h, w, cout, seg_geom(n, h, w), sps);
     }
     VOCR_CHECK_LAUNCH("vocr_conv3x3_wgrad");
     launch_wgrad_reduce((const float*)workspace, dw, cout, cin, splits, s);
@@ -773,7 +825,7 @@ extern "C" int vocr_conv3x3_wgrad_f16(const float* x, const float* dy, float* dw
     const int SW = vocr_cdiv(w, SEGW);
     const long nseg = (long)n * h * SW;
     int sps;
-    const int splits = wgrad_splits(n, cin, h, w, cout, &sps);
+    const int splits = wgrad_splits(n, cin, h, w, cout, &sps, true);
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(vocr_cdiv(cin, 64), vocr_cdiv(cout, 64), splits);
     conv3x3_wgrad_f16_kernel<<<grid, 256, 0, s>>>(x, dy, (float*)workspace, n, cin, h, w, cout, SW, (int)nseg, sps);

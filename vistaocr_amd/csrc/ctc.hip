@@ -126,6 +126,89 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(const float* __restr
     }
 }
 
+// The same sweeps for S = 2L+1 <= 64 (L <= 31: every BASELINE workload): one extended-label position per lane, the previous
+// row stays in a register and neighbours are fetched with wave shuffles (no LDS, no barrier), and the one global operand of
+// a step, lp[t][b][l'_s], does not depend on the recursion, so it is gathered PF steps ahead.  The generic kernel paid an
+// L2/HBM round trip per time step for it (0.73 us x 294 steps = 215 us on the critical path of every training step).
+// Same expressions in the same order per element as ctc_alpha_beta_kernel: results are bit-identical.
+__global__ __launch_bounds__(64) void ctc_alpha_beta64_kernel(const float* __restrict__ lp, const int32_t* __restrict__ labels,
+                                                              const int32_t* __restrict__ label_offsets,
+                                                              const int32_t* __restrict__ label_lens,
+                                                              const int32_t* __restrict__ act_lens, float* __restrict__ ab,
+                                                              float* __restrict__ nll, int T, int B, int V) {
+    constexpr int SP = 64, PF = 8;
+    const int b = blockIdx.x >> 1, dirn = blockIdx.x & 1;
+    const int lane = threadIdx.x;
+    const int L = label_lens[b], S = 2 * L + 1, Tb = act_lens[b];
+    const int32_t* lab = labels + label_offsets[b];
+    float* out = ab + ((long)(b * 2 + dirn) * T) * SP;
+    if (Tb <= 0) {
+        if (dirn == 0 && lane == 0) nll[b] = (S == 1) ? 0.f : INFINITY;
+        return;
+    }
+    const bool in = lane < S;
+    const int e = (in && (lane & 1)) ? lab[lane >> 1] : 0;
+    const int e_m2 = __shfl_up(e, 2, 64), e_p2 = __shfl_down(e, 2, 64);
+    const float* col = lp + (long)b * V + e;              // lp[t][b][e] = col[t * B * V]
+    const long tstride = (long)B * V;
+    float buf[PF];
+    if (dirn == 0) {
+        const bool skip = lane >= 2 && e != 0 && e != e_m2;
+        float v = NEG_INF;
+        if (lane == 0) v = lp[(long)b * V];
+        else if (lane == 1 && S > 1) v = col[0];
+        out[lane] = v;
+#pragma unroll
+        for (int k = 0; k < PF; ++k) buf[k] = col[(long)min(1 + k, Tb - 1) * tstride];
+        for (int t0 = 1; t0 < Tb; t0 += PF) {
+#pragma unroll
+            for (int k = 0; k < PF; ++k) {
+                const int t = t0 + k;
+                if (t < Tb) {                                   // wave-uniform
+                    const float lpe = buf[k];
+                    buf[k] = col[(long)min(t + PF, Tb - 1) * tstride];
+                    float a2 = __shfl_up(v, 1, 64), a3 = __shfl_up(v, 2, 64);
+                    if (lane < 1) a2 = NEG_INF;
+                    if (!skip) a3 = NEG_INF;
+                    const float l = lse3(v, a2, a3);
+                    v = (in && l != NEG_INF) ? l + lpe : NEG_INF;
+                    out[(long)t * SP + lane] = v;
+                }
+            }
+        }
+        const float a = __shfl(v, S - 1, 64);
+        const float c = S > 1 ? __shfl(v, S - 2, 64) : NEG_INF;
+        if (lane == 0) {
+            const float m = fmaxf(a, c);
+            nll[b] = (m == NEG_INF) ? INFINITY : -(logf(expf(a - m) + expf(c - m)) + m);
+        }
+    } else {
+        const bool skip = lane + 2 < S && e != 0 && e != e_p2;
+        float v = NEG_INF;
+        if (lane == S - 1) v = lp[((long)(Tb - 1) * B + b) * V];
+        else if (lane == S - 2 && S > 1) v = col[(long)(Tb - 1) * tstride];
+        out[(long)(Tb - 1) * SP + lane] = v;
+#pragma unroll
+        for (int k = 0; k < PF; ++k) buf[k] = col[(long)max(Tb - 2 - k, 0) * tstride];
+        for (int t0 = Tb - 2; t0 >= 0; t0 -= PF) {
+#pragma unroll
+            for (int k = 0; k < PF; ++k) {
+                const int t = t0 - k;
+                if (t >= 0) {
+                    const float lpe = buf[k];
+                    buf[k] = col[(long)max(t - PF, 0) * tstride];
+                    float b2 = __shfl_down(v, 1, 64), b3 = __shfl_down(v, 2, 64);
+                    if (lane >= 63) b2 = NEG_INF;
+                    if (!skip) b3 = NEG_INF;
+                    const float l = lse3(v, b2, b3);
+                    v = (in && l != NEG_INF) ? l + lpe : NEG_INF;
+                    out[(long)t * SP + lane] = v;
+                }
+            }
+        }
+    }
+}
+
 // one wave per (t,b): grad[v] = exp(lp[v]) - exp(lse_{s: l'_s = v}(alpha+beta) + nll - lp[v]); zero for t >= act_len
 __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__ lp, const int32_t* __restrict__ labels,
                                                        const int32_t* __restrict__ label_offsets,
@@ -299,7 +382,9 @@ extern "C" int vocr_ctc_loss_grad(const float* logits, const int32_t* labels, co
     log_softmax_rows_kernel<<<vocr_cdiv(rows, 4), 256, 0, s>>>(logits, lp, rows, v);
     VOCR_CHECK_LAUNCH("vocr_ctc_loss_grad(log_softmax)");
     const size_t smem = (size_t)(2 * (sp + 4) + sp) * sizeof(float);
-    ctc_alpha_beta_kernel<<<2 * b, 64, smem, s>>>(lp, labels, label_offsets, label_lens, act_lens, ab, nll, t, b, v, sp);
+    static const int generic_only = getenv("VOCR_CTC_GENERIC") ? atoi(getenv("VOCR_CTC_GENERIC")) : 0;      // tests: compare the two kernels
+    if (sp == 64 && !generic_only) ctc_alpha_beta64_kernel<<<2 * b, 64, 0, s>>>(lp, labels, label_offsets, label_lens, act_lens, ab, nll, t, b, v);
+    else ctc_alpha_beta_kernel<<<2 * b, 64, smem, s>>>(lp, labels, label_offsets, label_lens, act_lens, ab, nll, t, b, v, sp);
     VOCR_CHECK_LAUNCH("vocr_ctc_loss_grad(alpha_beta)");
     if (dlogits) {
         ctc_grad_kernel<<<vocr_cdiv(rows, 4), 256, (size_t)4 * v * sizeof(float), s>>>(lp, labels, label_offsets, label_lens,

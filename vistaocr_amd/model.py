@@ -249,9 +249,8 @@ class CnnOcrModel(nn.Module):
                 pool_i += 1
                 fused_pool = True
             a = ops.ConvBnReluFn.apply(a, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                       self.training, bn.eps, bn.momentum, self.conv_dtype == "fp16", u, oh, ow)
-            if self.training:
-                bn.num_batches_tracked += 1
+                                       self.training, bn.eps, bn.momentum, self.conv_dtype == "fp16", u, oh, ow,
+                                       bn.num_batches_tracked if self.training else None)
         b, c, h, w = a.shape
         feat = ops.PermuteBchwToWbchFn.apply(a, self._vocr_hooks)                                   # [w*b, c*h]
         br = getattr(self.bridge_layer, "0")

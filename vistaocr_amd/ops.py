@@ -191,7 +191,7 @@ class ConvBnReluFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, training, eps, momentum, f16=False,
-                pool_samples=None, pool_oh=0, pool_ow=0):
+                pool_samples=None, pool_oh=0, pool_ow=0, num_batches_tracked=None):
         """With `pool_samples` (N, C, 2) the FractionalMaxPool2d that follows this layer (cnnlstm.py:127,130) is applied in
         the same pass as BatchNorm + ReLU and the pooled tensor is returned: the unpooled activation is needed by nobody."""
         _need_gpu(x, weight, bias, gamma, beta, running_mean, running_var)
@@ -208,14 +208,16 @@ class ConvBnReluFn(torch.autograd.Function):
             y = conv3x3_forward(x, pf, bias, cout)
         mean = torch.empty(cout, dtype=torch.float32, device=x.device)
         invstd = torch.empty(cout, dtype=torch.float32, device=x.device)
+        xhat_sum = None
         if training:
             ws = _ws(lib.vocr_bn_workspace_bytes(n, cout, h * w), x.device)
+            xhat_sum = torch.empty(cout, dtype=torch.float32, device=x.device)
             call("vocr_bn_train_stats", _p(y), n, cout, h * w, eps, momentum, _p(mean), _p(invstd), _p(running_mean),
-                 _p(running_var), _p(ws), _stream())
+                 _p(running_var), _p(num_batches_tracked), _p(xhat_sum), _p(ws), _stream())
         else:
             call("vocr_bn_eval_stats", _p(running_mean), _p(running_var), cout, eps, _p(mean), _p(invstd), _stream())
         ctx.pool = None
-        idx = None
+        idx = samples = None
         if pool_samples is not None:
             samples = _f32c(pool_samples)
             if tuple(samples.shape) != (n, cout, 2):
@@ -230,23 +232,26 @@ class ConvBnReluFn(torch.autograd.Function):
             call("vocr_bn_relu_apply", _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(out), n, cout, h * w, _stream())
         ctx.training = training
         ctx.prefs = (weight, bias, gamma, beta)
-        ctx.save_for_backward(x, y, mean, invstd, gamma, beta, pd, idx)
+        ctx.save_for_backward(x, y, mean, invstd, gamma, beta, pd, idx, samples, xhat_sum)
         return out
 
     @staticmethod
     def backward(ctx, da):
         if not ctx.training:
             raise RuntimeError("vistaocr_amd: backward through eval-mode BatchNorm is not part of the reference path")
-        x, y, mean, invstd, gamma, beta, pd, idx = ctx.saved_tensors
+        x, y, mean, invstd, gamma, beta, pd, idx, samples, xhat_sum = ctx.saved_tensors
         da = _f32c(da)
         n, cin, h, w = x.shape
         cout = y.shape[1]
         lib = _lib.load()
-        if ctx.pool is not None:            # gradient of the fused pooling first: back to the full plane
+        fused_pool_bwd = False
+        if ctx.pool is not None:
             oh, ow = ctx.pool
-            dfull = torch.empty(n, cout, h, w, dtype=torch.float32, device=da.device)
-            call("vocr_fracpool2x2_bwd", _p(da), _p(idx), _p(dfull), n, cout, h, w, oh, ow, _stream())
-            da = dfull
+            fused_pool_bwd = bool(lib.vocr_bn_relu_fracpool2x2_bwd_supported(h, w, oh, ow)) and _os.environ.get("VOCR_POOL_BWD_FUSED", "1") == "1"
+            if not fused_pool_bwd:          # gradient of the fused pooling first: back to the full plane
+                dfull = torch.empty(n, cout, h, w, dtype=torch.float32, device=da.device)
+                call("vocr_fracpool2x2_bwd", _p(da), _p(idx), _p(dfull), n, cout, h, w, oh, ow, _stream())
+                da = dfull
         dy = torch.empty_like(y)
         sinks = _sinks(ctx.prefs)
         if sinks is not None:
@@ -259,8 +264,14 @@ class ConvBnReluFn(torch.autograd.Function):
         ws = _ws(lib.vocr_bn_workspace_bytes(n, cout, h * w), x.device)
         if not ctx.needs_input_grad[0]:
             join_side_stream()          # first layer = last backward op: everything issued on the side stream is done after this
-        call("vocr_bn_relu_bwd", _p(da), _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(dy), _p(dgamma), _p(dbeta),
-             _p(dbias), n, cout, h * w, _p(ws), _stream())
+        if fused_pool_bwd:
+            # pooled layer: pooling gradient (gather form) + ReLU + BatchNorm backward in one pass over the plane; the two
+            # BatchNorm sums come from the pooled tensors alone
+            call("vocr_bn_relu_fracpool2x2_bwd", _p(da), _p(idx), _p(samples), _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta),
+                 _p(xhat_sum), _p(dy), _p(dgamma), _p(dbeta), _p(dbias), n, cout, h, w, oh, ow, _p(ws), _stream())
+        else:
+            call("vocr_bn_relu_bwd", _p(da), _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(xhat_sum), _p(dy), _p(dgamma),
+                 _p(dbeta), _p(dbias), n, cout, h * w, _p(ws), _stream())
         if sinks is not None and _SIDE_ENABLED and ctx.needs_input_grad[0] and _os.environ.get("VOCR_CONV_OVERLAP", "1") == "1":
             # weight gradient (off the critical path, written straight into the optimiser's buffer) on the low-priority side
             # stream beside the data gradient: each kernel's last partial round of workgroups is filled by the other's
@@ -277,8 +288,8 @@ class ConvBnReluFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = conv3x3_forward_f16(dy, pd, None, cin) if ctx.f16 else conv3x3_forward(dy, pd, None, cin)
         if sinks is not None:
-            return (dx,) + (None,) * 13
-        return (dx, dw, dbias, dgamma, dbeta) + (None,) * 9
+            return (dx,) + (None,) * 14
+        return (dx, dw, dbias, dgamma, dbeta) + (None,) * 10
 
 
 class ConvReluPoolFn(torch.autograd.Function):
