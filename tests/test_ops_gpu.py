@@ -203,7 +203,10 @@ def test_relu_maxpool(dev):
         _close(a.grad, r.grad, 1e-4, 1e-4 * float(r.grad.abs().max()) + 1e-6, "rds " + nm)
 
 
-@pytest.mark.parametrize("m,n,k", [(100, 96, 1024), (9408, 128, 1792), (300, 2048, 128), (257, 166, 96), (64, 64, 4000), (1200, 384, 96)])
+# the last two shapes have more tiles than one round of resident workgroups, so their last partial round is cut along K into
+# tail-filling pieces (gemm.hip, ragged grid): 33x32 = 1056 tiles of 128x64 (288 cut in 2), 1100 tiles of 128x128 (76 cut in 6)
+@pytest.mark.parametrize("m,n,k", [(100, 96, 1024), (9408, 128, 1792), (300, 2048, 128), (257, 166, 96), (64, 64, 4000), (1200, 384, 96),
+                                   (4200, 2048, 256), (6400, 2816, 384)])
 def test_gemm_variants(dev, m, n, k):
     from vistaocr_amd import ops
     a = _rand((m, k), 1)

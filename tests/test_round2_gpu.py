@@ -259,7 +259,7 @@ def test_train_accepts_torch_optim_adam_like_the_reference():
         n_tot += d.numel()
         n_bad += int((d > 2e-6).sum())      # an element whose gradient is rounding noise around zero may step the other way
         assert float(d.max()) <= 4.1e-3, k
-    assert n_bad <= 1e-3 * n_tot, (n_bad, n_tot)
+    assert n_bad <= 1e-2 * n_tot, (n_bad, n_tot)
     # gradients of model_a were clamped in place on the device
     assert max(float(p.grad.abs().max()) for p in model_a.parameters()) <= 5.0
 

@@ -192,16 +192,46 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_partial_kernel(const float* _
     const long total = (long)N * OP;
     const long beg = j * per, end = min(total, beg + per);
     double s1 = 0.0, s2 = 0.0;
-    ChanWalk wk(beg + threadIdx.x, OP);
-    for (long e = beg + threadIdx.x; e < end; e += 256, wk.advance(256, OP)) {
-        const long plane = wk.n * C + c;
-        const float d = dout[plane * OP + wk.r];
-        const float yv = y[plane * HW + idx[plane * OP + wk.r]];
-        const float xh = (yv - mu) * is;
-        const float o = xh * g + b;
-        const float dz = o > 0.f ? d : 0.f;
-        s1 += (double)dz;
-        s2 += (double)(dz * xh);
+    // four strided outputs per thread and iteration: their (dout, idx) loads and then the four dependent gathers of y are
+    // in flight together (one output at a time was a chain of two memory latencies per element)
+    long wn[4], wr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const long e0 = beg + threadIdx.x + 256 * u;
+        wn[u] = e0 / OP;
+        wr[u] = e0 - wn[u] * OP;
+    }
+    for (long e = beg + threadIdx.x; e < end; e += 1024) {
+        float d[4], yv[4];
+        int ix[4];
+        bool ok[4];
+        long pl[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ok[u] = e + 256 * u < end;
+            pl[u] = (ok[u] ? wn[u] : 0) * C + c;
+            const long r = ok[u] ? wr[u] : 0;
+            d[u] = dout[pl[u] * OP + r];
+            ix[u] = idx[pl[u] * OP + r];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) yv[u] = y[pl[u] * HW + ix[u]];
+        float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float xh = (yv[u] - mu) * is;
+            const float o = xh * g + b;
+            const float dz = (ok[u] && o > 0.f) ? d[u] : 0.f;
+            p1 += dz;
+            p2 += dz * xh;
+        }
+        s1 += (double)p1;
+        s2 += (double)p2;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            wr[u] += 1024;
+            while (wr[u] >= OP) { wr[u] -= OP; ++wn[u]; }
+        }
     }
     block_reduce2(s1, s2, red);
     if (threadIdx.x == 0) {
@@ -392,12 +422,14 @@ __global__ __launch_bounds__(512) void pool_bwd_lds_kernel(const float* __restri
 }
 
 // dy of a pooled layer in ONE pass: gradient of FractionalMaxPool2d (gather form) + ReLU + batch-stat BatchNorm.
-// One workgroup per (n, c) plane.  The pooling windows are rebuilt from the samples with the forward's rule; because the
-// window starts are strictly increasing (alpha >= 1; the LAST window, pinned at in-2, is handled on its own since float32
-// rounding can make it coincide with its neighbour) every input column is the first column of at most one window and the
-// second column of at most one: two small inverse maps per axis in LDS.  A pixel then looks at its <= 9 candidate windows
-// and adds dout where the stored winner index is itself - no atomics, no LDS image of the plane, full occupancy, and the
-// BatchNorm backward is applied on the way out, so neither da nor a zero-filled plane ever goes to HBM.
+// One workgroup per (n, c) plane.  The pooling windows are rebuilt from the samples with the forward's rule.  The window
+// starts of outputs 0..out-2 are strictly increasing (alpha >= 1.01), so a column is the first column of at most one window
+// and the second column of at most one: two inverse maps per axis in LDS (wa: start == w, wb: start == w-1).  The LAST
+// window, pinned at in-2, is kept out of the maps and handled on its own (float32 rounding can make it coincide with its
+// neighbour).  A thread owns 4 consecutive pixels of a row: the windows that can have elected one of them are the <= 5 with
+// start in [w0-1, w0+3], in <= 2 window rows; their (winner index, gradient) pairs are fetched unconditionally (20
+// independent loads in flight per thread) and matched in registers.  No atomics, no LDS image of the plane, full occupancy;
+// the BatchNorm backward is applied on the way out, so neither da nor a zero-filled plane ever goes to HBM.
 __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float* __restrict__ dout, const int32_t* __restrict__ idx,
                                                                 const float* __restrict__ samples, const float* __restrict__ y,
                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -405,16 +437,16 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float* __r
                                                                 const float* __restrict__ dgamma, const float* __restrict__ dbeta,
                                                                 float* __restrict__ dy, int C, int H, int W, int OH, int OW,
                                                                 float alpha_h, float alpha_w, float inv_count) {
-    extern __shared__ int inv[];                 // wa[W], wb[W], ha[H], hb[H]
+    extern __shared__ int inv[];                 // wa[W + 4], wb[W + 4], ha[H], hb[H]
     int* wa = inv;
-    int* wb = inv + W;
-    int* ha = inv + 2 * W;
-    int* hb = inv + 2 * W + H;
+    int* wb = inv + W + 4;
+    int* ha = inv + 2 * W + 8;
+    int* hb = inv + 2 * W + 8 + H;
     const long plane = blockIdx.x;
     const int c = (int)(plane % C);
     const int tid = threadIdx.x;
     const float uw = samples[plane * 2], uh = samples[plane * 2 + 1];
-    for (int i = tid; i < 2 * W + 2 * H; i += 256) inv[i] = -1;
+    for (int i = tid; i < 2 * W + 8 + 2 * H; i += 256) inv[i] = -1;
     __syncthreads();
     for (int o = tid; o < OW - 1; o += 256) {
         const int st = frac_start(o, uw, alpha_w, W, OW);
@@ -431,29 +463,63 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float* __r
     const float k1 = dbeta[c] * inv_count, k2 = dgamma[c] * inv_count, gs = g * is;
     const float* dp = dout + plane * (long)OH * OW;
     const int32_t* ip = idx + plane * (long)OH * OW;
-    const float* yp = y + plane * (long)H * W;
-    float* op = dy + plane * (long)H * W;
-    for (int h = 0; h < H; ++h) {
-        const int ohc[3] = {ha[h], hb[h], h >= H - 2 ? OH - 1 : -1};
-        for (int w = tid; w < W; w += 256) {
-            const int p = h * W + w;
-            const int owc[3] = {wa[w], wb[w], w >= W - 2 ? OW - 1 : -1};
-            float da = 0.f;
+    const f32x4* yp = (const f32x4*)(y + plane * (long)H * W);
+    f32x4* op = (f32x4*)(dy + plane * (long)H * W);
+    const int GW = W >> 2, G = H * GW;
+    for (int gi = tid; gi < G; gi += 256) {
+        const int h = gi / GW, w0 = (gi - h * GW) << 2;
+        const f32x4 yv = yp[gi];
+        // candidate window rows (start == h, start == h-1) and columns (start == w0-1 .. w0+3); -1 = none
+        const int orow[2] = {ha[h], hb[h]};
+        const int ocol[5] = {wb[w0], wa[w0], wa[w0 + 1], wa[w0 + 2], wa[w0 + 3]};
+        float da[4] = {0.f, 0.f, 0.f, 0.f};
+        const int p0 = h * W + w0;
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                if (ohc[a] < 0) continue;
+        for (int r = 0; r < 2; ++r) {
+            // a wave's 64 pixel groups span at most two image rows, and with window strides >= 2 a row has ONE candidate
+            // window row: skip the other wave-uniformly (its loads were half of this kernel's address traffic)
+            if (!__any(orow[r] >= 0)) continue;
+            int wi[5];
+            float wd[5];
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    if (owc[q] < 0) continue;
-                    const int o = ohc[a] * OW + owc[q];
-                    if (ip[o] == p) da += dp[o];
+            for (int k = 0; k < 5; ++k) {
+                const int o = max(orow[r], 0) * OW + max(ocol[k], 0);       // clamped: the load is unconditional
+                wi[k] = ip[o];
+                wd[k] = dp[o];
+            }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const bool ok = orow[r] >= 0 && ocol[k] >= 0;
+                const int j = wi[k] - p0;                                    // winner relative to this thread's 4 pixels
+#pragma unroll
+                for (int q = 0; q < 4; ++q) da[q] += (ok && j == q) ? wd[k] : 0.f;
+            }
+        }
+        // the pinned last window row / column (rare: last two rows, last pixel group of a row)
+        if (h >= H - 2 || w0 + 3 >= W - 2) {
+            const int lr = h >= H - 2 ? OH - 1 : -1, lc = w0 + 3 >= W - 2 ? OW - 1 : -1;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int orr = r < 2 ? orow[r] : lr;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const int occ = k < 5 ? ocol[k] : lc;
+                    if ((r < 2 && k < 5) || orr < 0 || occ < 0) continue;   // regular x regular pairs were counted above
+                    const int o = orr * OW + occ;
+                    const int j = ip[o] - p0;
+                    if (j >= 0 && j < 4) da[j] += dp[o];
                 }
             }
-            const float xh = (yp[p] - mu) * is;
-            const float ov = xh * g + b;
-            const float dz = ov > 0.f ? da : 0.f;
-            op[p] = gs * (dz - k1 - xh * k2);
         }
+        f32x4 ov;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float xh = (yv[q] - mu) * is;
+            const float act = xh * g + b;
+            const float dz = act > 0.f ? da[q] : 0.f;
+            ov[q] = gs * (dz - k1 - xh * k2);
+        }
+        op[gi] = ov;
     }
 }
 
@@ -584,7 +650,9 @@ extern "C" int vocr_bn_relu_bwd(const float* da, const float* y, const float* me
 extern "C" int vocr_bn_relu_fracpool2x2_bwd_supported(int h, int w, int oh, int ow) {
     if (h < 2 || w < 2 || oh < 2 || ow < 2 || oh > h - 1 || ow > w - 1) return 0;
     // strictly increasing window starts need alpha comfortably above 1 (float32 interval arithmetic)
-    return ((float)(h - 2) / (float)(oh - 1) >= 1.01f && (float)(w - 2) / (float)(ow - 1) >= 1.01f && (2 * w + 2 * h) * 4 <= 64 * 1024) ? 1 : 0;
+    // ... and rows are processed as 16-byte pixel groups
+    return ((float)(h - 2) / (float)(oh - 1) >= 1.01f && (float)(w - 2) / (float)(ow - 1) >= 1.01f && w % 4 == 0 &&
+            (2 * w + 8 + 2 * h) * 4 <= 64 * 1024) ? 1 : 0;
 }
 
 extern "C" int vocr_bn_relu_fracpool2x2_bwd(const float* dout, const int32_t* idx, const float* samples, const float* y,
@@ -606,7 +674,7 @@ extern "C" int vocr_bn_relu_fracpool2x2_bwd(const float* dout, const int32_t* id
                                                         xhat_sum, dgamma, dbeta, dconv_bias);
     VOCR_CHECK_LAUNCH("vocr_bn_relu_fracpool2x2_bwd(final)");
     const float alpha_h = (float)(h - 2) / (float)(oh - 1), alpha_w = (float)(w - 2) / (float)(ow - 1);
-    bn_pool_bwd_apply_kernel<<<(unsigned)(n * c), 256, (size_t)(2 * w + 2 * h) * sizeof(int), s>>>(
+    bn_pool_bwd_apply_kernel<<<(unsigned)(n * c), 256, (size_t)(2 * w + 8 + 2 * h) * sizeof(int), s>>>(
         dout, idx, samples, y, mean, invstd, gamma, beta, dgamma, dbeta, dy, c, h, w, oh, ow, alpha_h, alpha_w,
         1.0f / (float)((long)n * hw));
     VOCR_CHECK_LAUNCH("vocr_bn_relu_fracpool2x2_bwd(apply)");

@@ -291,7 +291,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
 constexpr int WG_DYP = SEGW + 1;    // 33: odd pitch -> conflict-free reads across channels
 constexpr int WG_XCI = 3 * PROW + 1;  // 103
 
-__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void conv3x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             float* __restrict__ slab,
                                                             const float* __restrict__ zero_page, int N, int Cin, int H,
                                                             int W, int Cout, SegGeom geo, int segs_per_split) {
@@ -731,7 +732,8 @@ int wgrad_splits(int n, int cin, int h, int w, int cout, int* segs_per_split, bo
     const int tiles = (cin <= 3 ? 1 : vocr_cdiv(cin, 64)) * vocr_cdiv(cout, 64);
     // the generic kernel holds one workgroup per CU (9 accumulators per wave): 256 slabs = one full round and a
     // 3x smaller slab than 768; the small-Cin kernel is light and streams, give it more
-    long s = ((cin <= 3 ? 1024 : 256) + tiles - 1) / tiles;
+    static const int occ2 = getenv("VOCR_WGRAD_OCC2") ? atoi(getenv("VOCR_WGRAD_OCC2")) : 0;
+    long s = ((cin <= 3 ? 1024 : (occ2 ? 512 : 256)) + tiles - 1) / tiles;
     if (s > nseg) s = nseg;
     if (s < 1) s = 1;
     const int sps = (int)((nseg + s - 1) / s);
@@ -808,7 +810,9 @@ extern "C" int vocr_conv3x3_wgrad(const float* x, const float* dy, float* dw, vo
         conv3x3_wgrad_smallcin_kernel<<<grid, 128, 0, s>>>(x, dy, (float*)workspace, zp, n, cin, h, w, cout, SW, (int)nseg, sps);
     } else {
         dim3 grid(vocr_cdiv(cin, 64), vocr_cdiv(cout, 64), splits);
-        conv3x3_wgrad_kernel<<<grid, 256, 0, s>>>(x, dy, (float*)workspace, zp, n, cin, h, w, cout, seg_geom(n, h, w), sps);
+        static const int occ2 = getenv("VOCR_WGRAD_OCC2") ? atoi(getenv("VOCR_WGRAD_OCC2")) : 0;       // experiment: cap registers for 2 waves/SIMD
+        if (occ2) conv3x3_wgrad_kernel<2><<<grid, 256, 0, s>>>(x, dy, (float*)workspace, zp, n, cin, h, w, cout, seg_geom(n, h, w), sps);
+        else conv3x3_wgrad_kernel<1><<<grid, 256, 0, s>>>(x, dy, (float*)workspace, zp, n, cin, h, w, cout, seg_geom(n, h, w), sps);
     }
     VOCR_CHECK_LAUNCH("vocr_conv3x3_wgrad");
     launch_wgrad_reduce((const float*)workspace, dw, cout, cin, splits, s);

@@ -21,7 +21,7 @@ template <int BM, int BN, int WM, int WN, bool A_KCONTIG, bool B_NCONTIG, bool V
 __global__ __launch_bounds__(256) void gemm_f32_kernel(
     int M, int N, int K, const float* __restrict__ A, long sam, long sak, const float* __restrict__ B, long sbk,
     long sbn, float* __restrict__ C, int ldc, const float* __restrict__ bias, int relu, int accumulate,
-    int k_per_split, const float* __restrict__ zp, float* __restrict__ slab) {
+    int k_per_split, const float* __restrict__ zp, float* __restrict__ slab, int n_whole, int pieces_per_tile, int tiles_n) {
     // LDS tiles are K-major: As[k][m], Bs[k][n].  Pitch ≡ 2 (mod 32) keeps the transposing scalar stores of a
     // k-contiguous operand at most 2-way conflicted; a multiple of 4 keeps 16-byte stores of an m-contiguous one aligned.
     constexpr int PA = BM + ((VEC && !A_KCONTIG) ? 4 : 2);
@@ -35,9 +35,24 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kbeg = blockIdx.z * k_per_split;
-    const int kend = min(K, kbeg + k_per_split);
+    // 1-D ragged grid: the first n_whole workgroups each compute one whole output tile (in XCD-sliced order: an XCD works on
+    // a contiguous run of tiles, so the A row panel they share sits in ONE L2); the remaining tiles - fewer than one round
+    // of resident workgroups - are cut along K into pieces_per_tile short pieces that are dispatched LAST and fill the tail
+    // of the launch; a piece stores its partial tile into its own slab and splitk_reduce_kernel adds a tile's slabs in
+    // piece order (n_whole = 0: classic split-K of every tile, used for the long-K weight gradients).
+    int tile, kbeg, kend, piece = -1;
+    if ((int)blockIdx.x < n_whole) {
+        const int x = blockIdx.x & 7, q = n_whole >> 3, r = n_whole & 7;
+        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (blockIdx.x >> 3);
+        kbeg = 0;
+        kend = K;
+    } else {
+        piece = blockIdx.x - n_whole;
+        tile = n_whole + piece / pieces_per_tile;
+        kbeg = (piece % pieces_per_tile) * k_per_split;
+        kend = min(K, kbeg + k_per_split);
+    }
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
     const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
 
     f32x16 acc[TM][TN];
@@ -166,15 +181,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
     }
 
     // epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    // split-K: every K-slice stores its partial tile into its own dense [M][N] slab; splitk_reduce_kernel adds the slabs
-    // in slice order (bitwise reproducible; float atomics into C were neither reproducible nor faster: 1.3 TB/s)
-    const bool split = gridDim.z > 1;
-    float* const sl = split ? slab + (long)blockIdx.z * M * N : nullptr;
+    float* const sl = piece >= 0 ? slab + (long)piece * BM * BN : nullptr;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int gn = n0 + wn0 + j * 32 + li;
+            const int ln = wn0 + j * 32 + li, gn = n0 + ln;
+            if (piece >= 0) {                       // partial tile: tile-local [BM][BN] slab, every element (the reduce masks the edges)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sl[(wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * BN + ln] = acc[i][j][r];
+                continue;
+            }
             if (gn >= N) continue;
             const float bv = bias ? bias[gn] : 0.f;
 #pragma unroll
@@ -183,13 +200,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
                 if (gm >= M) continue;
                 float v = acc[i][j][r] + bv;
                 float* cp = C + (long)gm * ldc + gn;
-                if (split) {
-                    sl[(long)gm * N + gn] = v;
-                } else {
-                    if (accumulate) v += *cp;
-                    if (relu) v = fmaxf(v, 0.f);
-                    *cp = v;
-                }
+                if (accumulate) v += *cp;
+                if (relu) v = fmaxf(v, 0.f);
+                *cp = v;
             }
         }
 }
@@ -197,15 +210,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
 template <int BM, int BN, int WM, int WN, bool VEC>
 void launch_cfg(int ta, int tb, dim3 grid, hipStream_t s, int M, int N, int K, const float* A, long sam, long sak,
                 const float* B, long sbk, long sbn, float* C, int ldc, const float* bias, int relu, int acc, int kps,
-                const float* zp, float* slab) {
+                const float* zp, float* slab, int n_whole, int ppt, int tiles_n) {
     if (!ta && !tb)
-        gemm_f32_kernel<BM, BN, WM, WN, true, true, VEC><<<grid, 256, 0, s>>>(M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, relu, acc, kps, zp, slab);
+        gemm_f32_kernel<BM, BN, WM, WN, true, true, VEC><<<grid, 256, 0, s>>>(M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, relu, acc, kps, zp, slab, n_whole, ppt, tiles_n);
     else if (!ta && tb)
-        gemm_f32_kernel<BM, BN, WM, WN, true, false, VEC><<<grid, 256, 0, s>>>(M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, relu, acc, kps, zp, slab);
+        gemm_f32_kernel<BM, BN, WM, WN, true, false, VEC><<<grid, 256, 0, s>>>(M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, relu, acc, kps, zp, slab, n_whole, ppt, tiles_n);
     else if (ta && !tb)
-        gemm_f32_kernel<BM, BN, WM, WN, false, true, VEC><<<grid, 256, 0, s>>>(M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, relu, acc, kps, zp, slab);
+        gemm_f32_kernel<BM, BN, WM, WN, false, true, VEC><<<grid, 256, 0, s>>>(M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, relu, acc, kps, zp, slab, n_whole, ppt, tiles_n);
     else
-        gemm_f32_kernel<BM, BN, WM, WN, false, false, VEC><<<grid, 256, 0, s>>>(M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, relu, acc, kps, zp, slab);
+        gemm_f32_kernel<BM, BN, WM, WN, false, false, VEC><<<grid, 256, 0, s>>>(M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, relu, acc, kps, zp, slab, n_whole, ppt, tiles_n);
 }
 
 const float* gemm_zero_page() {
@@ -220,30 +233,30 @@ const float* gemm_zero_page() {
     return zp[dev];
 }
 
-// C[m][n] (+)= sum over K-slices of slab[z][m][n], slices added in order z = 0, 1, ...
+// The tiles that were cut along K: C tile (+)= sum over its pieces' slabs, added in piece order (bitwise reproducible;
+// float atomics into C were neither reproducible nor faster: 1.3 TB/s), then bias / ReLU.  grid.x = cut tiles.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ C, int M, int N,
-                                                            int ldc, int splits, int accumulate, int vec) {
-    const long plane = (long)M * N;
-    const long stride = (long)gridDim.x * 256;
-    if (vec) {
-        const int n4 = N / 4;
-        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)M * n4; i += stride) {
-            const int m = (int)(i / n4), c4 = (int)(i % n4);
-            const float* sp = slab + (long)m * N + c4 * 4;
-            f32x4 v = *(const f32x4*)sp;
-            for (int z = 1; z < splits; ++z) v += *(const f32x4*)(sp + z * plane);
-            f32x4* cp = (f32x4*)(C + (long)m * ldc + c4 * 4);
-            if (accumulate) v += *cp;
-            *cp = v;
-        }
-    } else {
-        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < plane; i += stride) {
-            const int m = (int)(i / N), n = (int)(i % N);
-            float v = slab[i];
-            for (int z = 1; z < splits; ++z) v += slab[i + z * plane];
-            float* cp = C + (long)m * ldc + n;
-            if (accumulate) v += *cp;
-            *cp = v;
+                                                            int ldc, int BM, int BN, int first_tile, int pieces_per_tile,
+                                                            int tiles_n, const float* __restrict__ bias, int relu, int accumulate) {
+    const int tile = first_tile + blockIdx.x;
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const float* sp = slab + (long)blockIdx.x * pieces_per_tile * BM * BN;
+    const int cols4 = BN >> 2;
+    for (int e = threadIdx.x; e < BM * cols4; e += 256) {
+        const int r = e / cols4, c = (e - r * cols4) << 2;
+        f32x4 v = *(const f32x4*)(sp + r * BN + c);
+        for (int z = 1; z < pieces_per_tile; ++z) v += *(const f32x4*)(sp + (long)z * BM * BN + r * BN + c);
+        const int gm = m0 + r;
+        if (gm >= M) continue;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int gn = n0 + c + k;
+            if (gn >= N) continue;
+            float x = v[k] + (bias ? bias[gn] : 0.f);
+            float* cp = C + (long)gm * ldc + gn;
+            if (accumulate) x += *cp;
+            if (relu) x = fmaxf(x, 0.f);
+            *cp = x;
         }
     }
 }
@@ -378,13 +391,24 @@ __global__ void bchw_to_wbch_kernel(const float* __restrict__ x, float* __restri
 }  // namespace
 
 namespace {
-struct GemmPlan { bool big, half; int bm, bn, splits, kps; };
+struct GemmPlan { bool big, half; int bm, bn, tiles_m, tiles_n, n_whole, ppt, kps, pieces; };
 
-// tile and split-K choice; max_splits = 1 forbids split-K (no workspace)
-GemmPlan gemm_plan(int m, int n, int k, bool has_epilogue, int max_splits) {
+int gemm_cu_count() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cus[dev]) {
+        hipDeviceProp_t prop;
+        cus[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return cus[dev];
+}
+
+// Tile shape and K cuts.  max_pieces_128 = how many 128x128 slabs the workspace can hold (0: none, K is never cut).
+GemmPlan gemm_plan(int m, int n, int k, bool has_epilogue, long max_pieces_128, bool allow_tail_fill) {
     GemmPlan p;
     const long tiles128 = (long)vocr_cdiv(m, 128) * vocr_cdiv(n, 128);
-    const bool can_split = !has_epilogue && k >= 1024 && max_splits > 1;
+    const bool can_split = !has_epilogue && k >= 1024 && max_pieces_128 > 1;
     // 128x128 tiles (32 FLOP per LDS-staged byte) whenever they can fill the chip, possibly with split-K
     p.big = m >= 96 && n >= 96 && (tiles128 >= 192 || (can_split && tiles128 * (k / 512) >= 128));
     // 128x64 tiles when there are fewer than 6 full tiles per CU and no split-K: twice as many half-size workgroups let
@@ -392,25 +416,57 @@ GemmPlan gemm_plan(int m, int n, int k, bool has_epilogue, int max_splits) {
     p.half = p.big && tiles128 < 6 * 256 && !(can_split && tiles128 < 384) && n >= 64;
     p.bm = p.big ? 128 : 64;
     p.bn = p.big ? (p.half ? 64 : 128) : 64;
-    const long tiles = (long)vocr_cdiv(m, p.bm) * vocr_cdiv(n, p.bn);
-    int splits = 1;
-    if (can_split && tiles < 384) {
-        splits = (int)((512 + tiles - 1) / tiles);
+    p.tiles_m = vocr_cdiv(m, p.bm);
+    p.tiles_n = vocr_cdiv(n, p.bn);
+    const long tiles = (long)p.tiles_m * p.tiles_n;
+    const long max_pieces = max_pieces_128 * (128l * 128) / ((long)p.bm * p.bn);
+    const int kt = vocr_cdiv(k, BK);                          // K tiles of one output tile
+    p.n_whole = (int)tiles;
+    p.ppt = 1;
+    p.kps = kt * BK;
+    if (can_split && tiles < 384) {                           // few tiles, long K: cut every tile (weight gradients)
+        int splits = (int)((512 + tiles - 1) / tiles);
         const int maxs = k / 512;
         if (splits > maxs) splits = maxs;
-        if (splits > max_splits) splits = max_splits;
-        if (splits < 1) splits = 1;
+        if ((long)splits * tiles > max_pieces) splits = (int)(max_pieces / tiles);
+        if (splits > 1) {
+            p.kps = vocr_cdiv(kt, splits) * BK;
+            p.ppt = vocr_cdiv(k, p.kps);
+            p.n_whole = 0;
+        }
+    } else if (allow_tail_fill && max_pieces > 1 && kt >= 4) {
+        // many tiles: whole tiles for every full round of resident workgroups, the last partial round cut into pieces
+        const int occ = p.bm == 64 ? 4 : (p.bn == 64 ? 3 : 2);                  // workgroups per CU (LDS: 34 / 50 / 66.5 KB)
+        const long slots = (long)gemm_cu_count() * occ;
+        const long left = tiles % slots;
+        if (tiles > slots && left > 0 && left * 10 < slots * 9) {
+            long ppt = slots / left;
+            if (ppt > kt / 2) ppt = kt / 2;                                      // a piece covers at least two K tiles
+            if (ppt * left > max_pieces) ppt = max_pieces / left;
+            if (ppt > 1) {
+                p.kps = vocr_cdiv(kt, (int)ppt) * BK;
+                p.ppt = vocr_cdiv(k, p.kps);
+                p.n_whole = (int)(tiles - left);
+            }
+        }
     }
-    p.kps = vocr_cdiv(vocr_cdiv(k, splits), BK) * BK;
-    p.splits = vocr_cdiv(k, p.kps);
+    if (p.ppt <= 1) { p.n_whole = (int)tiles; p.ppt = 1; p.kps = kt * BK; }
+    p.pieces = p.ppt > 1 ? (int)(tiles - p.n_whole) * p.ppt : 0;
     return p;
+}
+
+bool gemm_tail_fill_enabled() {
+    // measured on the BASELINE shapes (scripts/gemm_bench.py): no gain over whole tiles only (412 vs 412 us on the 9408x2048x1024
+    // projection: with 9 half-size tiles per CU the dispatcher already balances the last round), so it is opt-in
+    static const int on = getenv("VOCR_GEMM_TAILFILL") ? atoi(getenv("VOCR_GEMM_TAILFILL")) : 0;
+    return on != 0;
 }
 }  // namespace
 
 extern "C" size_t vocr_gemm_workspace_bytes(int m, int n, int k, int has_bias_or_relu) {
     if (m <= 0 || n <= 0 || k <= 0) return 0;
-    const GemmPlan p = gemm_plan(m, n, k, has_bias_or_relu != 0, 1 << 30);
-    return p.splits > 1 ? (size_t)p.splits * m * n * sizeof(float) : 0;
+    const GemmPlan p = gemm_plan(m, n, k, has_bias_or_relu != 0, 1l << 40, gemm_tail_fill_enabled());
+    return (size_t)p.pieces * p.bm * p.bn * sizeof(float);
 }
 
 extern "C" int vocr_gemm(int transa, int transb, int m, int n, int k, const float* a, int lda, const float* b, int ldb,
@@ -422,35 +478,33 @@ extern "C" int vocr_gemm(int transa, int transb, int m, int n, int k, const floa
     hipStream_t s = (hipStream_t)stream;
     const long sam = transa ? 1 : lda, sak = transa ? lda : 1;
     const long sbk = transb ? 1 : ldb, sbn = transb ? ldb : 1;
-    // split-K needs room for one [m][n] slab per K-slice; with less workspace the slices shrink, with none K is not split
-    const size_t slab_bytes = (size_t)m * n * sizeof(float);
-    const int max_splits = (workspace && (((uintptr_t)workspace) & 15) == 0) ? (int)(workspace_bytes / slab_bytes > 4096 ? 4096 : workspace_bytes / slab_bytes) : 1;
-    const GemmPlan p = gemm_plan(m, n, k, bias != nullptr || relu != 0, max_splits < 1 ? 1 : max_splits);
+    // K cuts need room for one tile-sized slab per piece; with less workspace there are fewer pieces, with none K is never cut
+    const long max_pieces_128 = (workspace && (((uintptr_t)workspace) & 15) == 0) ? (long)(workspace_bytes / (128 * 128 * sizeof(float))) : 0;
+    const GemmPlan p = gemm_plan(m, n, k, bias != nullptr || relu != 0, max_pieces_128, gemm_tail_fill_enabled());
     const bool big = p.big, half = p.half;
-    const int kps = p.kps, splits = p.splits;
-    float* slab = splits > 1 ? (float*)workspace : nullptr;
-    dim3 grid(vocr_cdiv(n, p.bn), vocr_cdiv(m, p.bm), splits);
+    const int kps = p.kps;
+    float* slab = p.pieces > 0 ? (float*)workspace : nullptr;
+    dim3 grid(p.n_whole + p.pieces);
     const float* zp = gemm_zero_page();
     VOCR_CHECK_ARG(zp != nullptr, "vocr_gemm: no device zero page");
     const bool vec = ((((uintptr_t)a) | ((uintptr_t)b)) & 15) == 0 && lda % 4 == 0 && ldb % 4 == 0 && m % 4 == 0 && n % 4 == 0 &&
                      k % 4 == 0;
+#define VOCR_GEMM_ARGS transa, transb, grid, s, m, n, k, a, sam, sak, b, sbk, sbn, c, ldc, bias, relu, accumulate, kps, zp, slab, p.n_whole, p.ppt, p.tiles_n
     if (big && half) {
-        if (vec) launch_cfg<128, 64, 64, 32, true>(transa, transb, grid, s, m, n, k, a, sam, sak, b, sbk, sbn, c, ldc, bias, relu, accumulate, kps, zp, slab);
-        else launch_cfg<128, 64, 64, 32, false>(transa, transb, grid, s, m, n, k, a, sam, sak, b, sbk, sbn, c, ldc, bias, relu, accumulate, kps, zp, slab);
+        if (vec) launch_cfg<128, 64, 64, 32, true>(VOCR_GEMM_ARGS);
+        else launch_cfg<128, 64, 64, 32, false>(VOCR_GEMM_ARGS);
     } else if (big) {
-        if (vec) launch_cfg<128, 128, 64, 64, true>(transa, transb, grid, s, m, n, k, a, sam, sak, b, sbk, sbn, c, ldc, bias, relu, accumulate, kps, zp, slab);
-        else launch_cfg<128, 128, 64, 64, false>(transa, transb, grid, s, m, n, k, a, sam, sak, b, sbk, sbn, c, ldc, bias, relu, accumulate, kps, zp, slab);
+        if (vec) launch_cfg<128, 128, 64, 64, true>(VOCR_GEMM_ARGS);
+        else launch_cfg<128, 128, 64, 64, false>(VOCR_GEMM_ARGS);
     } else {
-        if (vec) launch_cfg<64, 64, 32, 32, true>(transa, transb, grid, s, m, n, k, a, sam, sak, b, sbk, sbn, c, ldc, bias, relu, accumulate, kps, zp, slab);
-        else launch_cfg<64, 64, 32, 32, false>(transa, transb, grid, s, m, n, k, a, sam, sak, b, sbk, sbn, c, ldc, bias, relu, accumulate, kps, zp, slab);
+        if (vec) launch_cfg<64, 64, 32, 32, true>(VOCR_GEMM_ARGS);
+        else launch_cfg<64, 64, 32, 32, false>(VOCR_GEMM_ARGS);
     }
+#undef VOCR_GEMM_ARGS
     VOCR_CHECK_LAUNCH("vocr_gemm");
-    if (splits > 1) {
-        const int rvec = (n % 4 == 0 && ldc % 4 == 0 && (((uintptr_t)c) & 15) == 0) ? 1 : 0;
-        long work = rvec ? (long)m * (n / 4) : (long)m * n;
-        long g = (work + 255) / 256;
-        if (g > 4096) g = 4096;
-        splitk_reduce_kernel<<<(int)g, 256, 0, s>>>(slab, c, m, n, ldc, splits, accumulate, rvec);
+    if (p.pieces > 0) {
+        const int cut_tiles = p.pieces / p.ppt;
+        splitk_reduce_kernel<<<cut_tiles, 256, 0, s>>>(slab, c, m, n, ldc, p.bm, p.bn, p.n_whole, p.ppt, p.tiles_n, bias, relu, accumulate);
         VOCR_CHECK_LAUNCH("vocr_gemm(split-K reduce)");
     }
     return VOCR_OK;

@@ -216,6 +216,14 @@ class CnnOcrModel(nn.Module):
             raise RuntimeError("vistaocr_amd.CnnOcrModel.forward needs the model on an MI355X (model.cuda()); "
                                "there is no CPU fallback")
         x = x.to(dev, non_blocking=True)
+        # weight-only preparation (conv packs of layers 2.., LSTM bias sums and W_hh transposes) on the idle side stream
+        prep = None
+        if self.conv_dtype == "fp32":
+            convs = [st[0].weight for st in self._plan if st != "pool"][1:]
+            layers = [(self.lstm.layer(l, "")[1], self.lstm.layer(l, "")[2], self.lstm.layer(l, "")[3],
+                       self.lstm.layer(l, "_reverse")[1], self.lstm.layer(l, "_reverse")[2], self.lstm.layer(l, "_reverse")[3])
+                      for l in range(self.num_lstm_layers)]
+            prep = ops.forward_prep(convs, layers, torch.is_grad_enabled())
         a = x
         for i in range(self.num_rds_layers):
             conv = getattr(self.rapid_ds, "%02d-conv" % i)
@@ -250,7 +258,7 @@ class CnnOcrModel(nn.Module):
                 fused_pool = True
             a = ops.ConvBnReluFn.apply(a, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                        self.training, bn.eps, bn.momentum, self.conv_dtype == "fp16", u, oh, ow,
-                                       bn.num_batches_tracked if self.training else None)
+                                       bn.num_batches_tracked if self.training else None, prep)
         b, c, h, w = a.shape
         feat = ops.PermuteBchwToWbchFn.apply(a, self._vocr_hooks)                                   # [w*b, c*h]
         br = getattr(self.bridge_layer, "0")
@@ -274,7 +282,7 @@ class CnnOcrModel(nn.Module):
         for l in range(self.num_lstm_layers):
             f = self.lstm.layer(l, "")
             r = self.lstm.layer(l, "_reverse")
-            hseq = ops.BiLstmLayerFn.apply(hseq, lens_dev, T, b, f[0], f[1], f[2], f[3], r[0], r[1], r[2], r[3])
+            hseq = ops.BiLstmLayerFn.apply(hseq, lens_dev, T, b, f[0], f[1], f[2], f[3], r[0], r[1], r[2], r[3], prep)
             if l < self.num_lstm_layers - 1:
                 if self.dropout_masks is not None:
                     hseq = ops.MulMaskFn.apply(hseq, self.dropout_masks[l].to(dev).reshape(T * b, -1))
