@@ -96,6 +96,11 @@ __device__ __attribute__((aligned(16))) float g_zero_page[64];
 // a workgroup: at batch 32 the layers have only 4-7 full-size workgroups per CU and the last partial round costs 20 %
 // (measured 88 TF at 4.4 WG/CU vs 111 TF at 16 WG/CU); twice as many half-size workgroups let the hardware
 // dispatcher balance the tail.
+#ifdef VOCR_CONV_STAMPS        // diagnostic build only (scripts/conv_stamp.hip): phase stamps of one workgroup, never in libvocr.so
+__device__ unsigned long long* g_stamp_out;
+#define VOCR_STAMP(t) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); } while (0)
+#endif
+
 template <int CO_T, int SPWV, bool VECW, int WCO = 64>
 __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ in, const float* __restrict__ wpack,
                                                       const float* __restrict__ bias, float* __restrict__ out,
@@ -111,8 +116,12 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
     constexpr int C4 = CO_T / 4;                           // float4 columns of the weight tile
     constexpr int RPP = 256 / C4;                          // weight rows per pass: 8 or 16
     constexpr int EA = (KC + RPP - 1) / RPP;               // 9 or 5 passes
-    __shared__ __attribute__((aligned(16))) float Wt[KC * CO_T];
-    __shared__ float P[NSEG * PSEG];
+    // Every staging store below is UNCONDITIONAL (weight rows padded to EA*RPP, halo lanes >= 34 land in a dummy tail of P).
+    // With a store under `if (r < KC)` / `if (lane < PROW)`, LLVM's sink pass moved the global LOADS that only feed it into
+    // that block, i.e. behind the end-of-chunk barrier: every chunk then waited out a full memory round trip with the matrix
+    // pipe idle (a lone workgroup took 107 us per tile for 62 us of MFMA work).
+    __shared__ __attribute__((aligned(16))) float Wt[EA * RPP * CO_T];
+    __shared__ float P[NSEG * PSEG + 64];
     __shared__ SegInfo segs[NSEG];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -209,30 +218,39 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
 #pragma unroll
         for (int e = 0; e < EA; ++e) {
             const int r = wr0 + e * RPP;
-            if (r < KC) *(f32x4*)(Wt + r * CO_T + wc4 * 4) = ra[e];
+            *(f32x4*)(Wt + r * CO_T + wc4 * 4) = ra[e];                                // rows >= KC: padding, never read
         }
-        if (lane < PROW) {
 #pragma unroll
-            for (int q = 0; q < SST; ++q)
+        for (int q = 0; q < SST; ++q)
 #pragma unroll
-                for (int j = 0; j < ROWS; ++j) {
-                    const int ci = st_ci0 + j / 3, kh = j % 3;
-                    const float cm = (ci0 + ci) < Cin ? 1.f : 0.f;                     // wave-uniform
-                    P[(st_seg0 + q) * PSEG + ci * PCI + kh * PROW + lane] = rp[q * ROWS + j] * (p_m[q][kh] * cm);
-                }
-        }
+            for (int j = 0; j < ROWS; ++j) {
+                const int ci = st_ci0 + j / 3, kh = j % 3;
+                const float cm = (ci0 + ci) < Cin ? 1.f : 0.f;                         // wave-uniform
+                const int dst = lane < PROW ? (st_seg0 + q) * PSEG + ci * PCI + kh * PROW + lane : NSEG * PSEG + lane;
+                P[dst] = rp[q * ROWS + j] * (p_m[q][kh] * cm);
+            }
     };
 
     const int nchunks = (Cin + CI_C - 1) / CI_C;
+#ifdef VOCR_CONV_STAMPS
+    unsigned long long st_begin, st0, st1, st2, st3, st4, sum_k = 0, sum_b1 = 0, sum_st = 0, sum_b2 = 0, st_pro;
+    VOCR_STAMP(st_begin);
+#endif
     load_chunk(0);
     store_chunk(0);
     __syncthreads();
+#ifdef VOCR_CONV_STAMPS
+    VOCR_STAMP(st_pro);
+#endif
     const float* wa = Wt + wco + li + lk * (KC / 2) * CO_T;
     const float* pb = P + wsg * PSEG + li + lk * (CI_C / 2) * PCI;
     for (int c = 0; c < nchunks; ++c) {
         const int cnext = min(c + 1, nchunks - 1) * CI_C;     // branch-free prefetch (the last chunk re-loads itself, unused)
         // fragment reads run one k-step ahead of the MFMAs that consume them (hipcc otherwise emits
         // read -> lgkmcnt(0) -> MFMAs per step and exposes the LDS latency)
+#ifdef VOCR_CONV_STAMPS
+        VOCR_STAMP(st0);
+#endif
         float a[TM], b[SPWV];
 #pragma unroll
         for (int i = 0; i < TM; ++i) a[i] = wa[32 * i];
@@ -264,12 +282,29 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
 #pragma unroll
             for (int j = 0; j < SPWV; ++j) b[j] = bn[j];
         }
+#ifdef VOCR_CONV_STAMPS
+        VOCR_STAMP(st1);
+#endif
         __syncthreads();
-        if (c + 1 < nchunks) {
-            store_chunk((c + 1) * CI_C);
-            __syncthreads();
-        }
+#ifdef VOCR_CONV_STAMPS
+        VOCR_STAMP(st2);
+#endif
+        // unconditional (the last iteration stores its own re-loaded chunk, which nobody reads): under `if (c + 1 < nchunks)`
+        // the compiler sank the chunk's last weight load into that block, behind the barrier
+        store_chunk(cnext);
+#ifdef VOCR_CONV_STAMPS
+        VOCR_STAMP(st3);
+#endif
+        __syncthreads();
+#ifdef VOCR_CONV_STAMPS
+        VOCR_STAMP(st4);
+        sum_k += st1 - st0; sum_b1 += st2 - st1; sum_st += st3 - st2; sum_b2 += st4 - st3;
+#endif
     }
+#ifdef VOCR_CONV_STAMPS
+    unsigned long long st_loop_end;
+    VOCR_STAMP(st_loop_end);
+#endif
 
 #pragma unroll
     for (int j = 0; j < SPWV; ++j) {
@@ -285,19 +320,272 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
                 if (co < Cout) out[obase + (long)co * HW] = acc[i][j][r] + (bias ? bias[co] : 0.f);
             }
     }
+#ifdef VOCR_CONV_STAMPS
+    unsigned long long st_end;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    VOCR_STAMP(st_end);
+    if (tid == 0 && g_stamp_out && blockIdx.x < 4096) {
+        unsigned long long* o = g_stamp_out + (size_t)blockIdx.x * 8;
+        o[0] = st_end - st_begin; o[1] = sum_k; o[2] = sum_b1; o[3] = sum_st; o[4] = sum_b2; o[5] = st_pro - st_begin; o[6] = st_end - st_loop_end;
+    }
+#endif
+}
+
+// ---------------------------------------------------------------- forward / data gradient, LDS-DMA form
+// Same implicit GEMM, same tiles and segments as conv3x3_kernel; what changes is how the operands reach LDS.  Phase stamps of
+// conv3x3_kernel (scripts/conv_stamp.hip) showed a workgroup spending 14-18 % of its life in store_chunk - 37 KB of packed
+// weights per 8-channel chunk going global -> VGPR -> ds_write_b128, the LDS write port being the limit - between two
+// barriers with its matrix pipe idle.  Here the K loop runs over HALF chunks of 4 input channels (36 K rows), ping-pong
+// between two LDS buffers of half the size (same LDS footprint, same occupancy):
+//   * the weights of half-chunk h+1 are written into the idle buffer by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no
+//     ds_write instructions; the 36 x CO_T tile is 36 consecutive rows of wpack, one 1-KiB DMA = 2 or 4 rows) while the MFMAs
+//     of half-chunk h read the other buffer;
+//   * the halo rows of h+1 still pass through registers (they need the border masks) but are loaded at the top of
+//     half-chunk h and stored at its end into the idle buffer: 3-24 ds_write_b32 per wave instead of a store phase;
+//   * ONE barrier per half-chunk (__syncthreads drains the DMA: vmcnt(0)), none between store and use.
+// K order inside a half-chunk: MFMA step ks multiplies k = ks (lanes 0-31) and k = ks + 18 (lanes 32-63), i.e. channels
+// c and c + 2 of the four.  Cin is padded to a multiple of 8 with zero weights (rows past Cin*9 come from the zero page).
+// Needs Cout % 4 == 0 and a 16-byte aligned weight pack (the DMA moves 16 bytes per lane).
+constexpr int CI_H = 4;
+constexpr int KH_ROWS = CI_H * 9;      // 36
+constexpr int PSEGH = CI_H * PCI;      // 408 floats of halo patch per segment and half-chunk
+
+template <int CO_T, int SPWV, int WCO>
+__global__ __launch_bounds__(256) void conv3x3_dma_kernel(const float* __restrict__ in, const float* __restrict__ wpack,
+                                                          const float* __restrict__ bias, float* __restrict__ out,
+                                                          const float* __restrict__ zero_page, int N, int Cin, int H, int W,
+                                                          int Cout, SegGeom geo, int co_tiles) {
+    constexpr int WAVES_CO = CO_T / WCO;
+    constexpr int WAVES_PX = 4 / WAVES_CO;
+    constexpr int TM = WCO / 32;
+    constexpr int NSEG = WAVES_PX * SPWV;
+    constexpr int WBUF = KH_ROWS * CO_T;                     // floats per weight buffer
+    constexpr int PBUF = NSEG * PSEGH;                       // floats per halo buffer
+    constexpr int ROWS_W = NSEG * 3;                         // halo rows a wave stages per half-chunk (NSEG*12 rows / 4 waves)
+    constexpr int SSTH = ROWS_W >= 12 ? ROWS_W / 12 : 1;     // segments a wave stages rows for
+    constexpr int ROWSH = ROWS_W >= 12 ? 12 : ROWS_W;        // rows per staged segment
+    constexpr int LPR = CO_T / 4;                            // lanes per weight row in one DMA (32 or 16)
+    constexpr int RPI = 64 / LPR;                            // weight rows per DMA instruction (2 or 4)
+    constexpr int NDMA = KH_ROWS / RPI;                      // DMA instructions per half-chunk (18 or 9)
+    constexpr int DPW = (NDMA + 3) / 4;                      // ... per wave
+    // ONE LDS object (a second one beside an LDS-DMA target makes hipcc drain vmcnt before every ds_read):
+    // Wt[2][36][CO_T] | P[2][NSEG][4][3][34] | 64 dummy floats (halo lanes >= 34) | NSEG x 8 ints of segment geometry
+    __shared__ __attribute__((aligned(16))) float lds[2 * WBUF + 2 * PBUF + 64 + NSEG * 8];
+    float* const Wt = lds;
+    float* const P = lds + 2 * WBUF;
+    constexpr int DUMMY = 2 * PBUF;                          // offset into P of the dummy tail
+    int* const segw = (int*)(lds + 2 * WBUF + 2 * PBUF + 64);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lk = lane >> 5;
+    const int v = xcd_slice_order(blockIdx.x, gridDim.x);
+    const int co0 = (v % co_tiles) * CO_T;
+    const int seg0 = (v / co_tiles) * NSEG;
+    const long HW = (long)H * W;
+    if (tid < NSEG) {
+        const SegInfo s = seg_decode(seg0 + tid, geo, H, 0);
+        int* o = segw + tid * 8;
+        o[0] = s.n; o[1] = s.h; o[2] = s.w0; o[3] = s.valid; o[4] = s.rows; o[5] = s.pw; o[6] = s.ow;
+    }
+    __syncthreads();
+
+    const int wco = (wave / WAVES_PX) * WCO;
+    const int wsg = (wave % WAVES_PX) * SPWV;
+    f32x16 acc[TM][SPWV];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < SPWV; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- halo loader state: this wave stages rows [wave*ROWS_W, (wave+1)*ROWS_W) of the (segment, ci, kh) rows
+    const int st_seg0 = (wave * ROWS_W) / 12;
+    const int st_ci0 = ((wave * ROWS_W) % 12) / 3;
+    int p_off[SSTH][3];
+    float p_m[SSTH][3];
+    const float* p_base[SSTH];
+#pragma unroll
+    for (int q = 0; q < SSTH; ++q) {
+        const int* sg = segw + (st_seg0 + q) * 8;
+        const int pw = sg[5];
+        const int rr = lane / pw, cc = lane - rr * pw;
+        const int ww = sg[2] - 1 + cc;
+        const bool colok = sg[3] && lane < PROW && rr < sg[4] && ww >= 0 && ww < W;
+        const int loff = min(max(ww, 0), W - 1);
+        p_base[q] = in + (long)sg[0] * Cin * HW;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int hh = sg[1] + rr + kh - 1;
+            p_m[q][kh] = (colok && hh >= 0 && hh < H) ? 1.f : 0.f;
+            p_off[q][kh] = min(max(hh, 0), H - 1) * W + loff;
+        }
+    }
+    float rp[SSTH * ROWSH];
+    auto load_patch = [&](int ci0) {
+#pragma unroll
+        for (int q = 0; q < SSTH; ++q)
+#pragma unroll
+            for (int j = 0; j < ROWSH; ++j) {
+                const int ci = st_ci0 + j / 3, kh = j % 3;
+                const float* cb = p_base[q] + (long)min(ci0 + ci, Cin - 1) * HW;      // wave-uniform
+                rp[q * ROWSH + j] = cb[p_off[q][kh]];
+            }
+    };
+    auto store_patch = [&](int ci0, int buf) {
+#pragma unroll
+        for (int q = 0; q < SSTH; ++q)
+#pragma unroll
+            for (int j = 0; j < ROWSH; ++j) {
+                const int ci = st_ci0 + j / 3, kh = j % 3;
+                const float cm = (ci0 + ci) < Cin ? 1.f : 0.f;                         // wave-uniform
+                const int dst = lane < PROW ? buf * PBUF + (st_seg0 + q) * PSEGH + ci * PCI + kh * PROW + lane : DUMMY + lane;
+                P[dst] = rp[q * ROWSH + j] * (p_m[q][kh] * cm);
+            }
+    };
+    // ---- weight DMA: instruction q of a half-chunk moves rows [q*RPI, (q+1)*RPI) x CO_T floats = 1 KiB
+    const int Ktot = Cin * 9;
+    const int drow = lane / LPR, dcol = (lane % LPR) * 4;
+    const bool dcol_ok = co0 + dcol < Cout;
+    auto dma_weights = [&](int ci0, int buf) {
+#pragma unroll
+        for (int d = 0; d < DPW; ++d) {
+            const int q = wave + 4 * d;                                               // wave-uniform
+            if (q < NDMA) {
+                const int gk = ci0 * 9 + q * RPI + drow;
+                const float* src = (gk < Ktot && dcol_ok) ? wpack + (long)gk * Cout + co0 + dcol : zero_page;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(Wt + buf * WBUF + q * 256), 16, 0, 0);
+            }
+        }
+    };
+    auto kloop = [&](int buf) {
+        const float* wa = Wt + buf * WBUF + wco + li + lk * (KH_ROWS / 2) * CO_T;
+        const float* pb = P + buf * PBUF + wsg * PSEGH + li + lk * (CI_H / 2) * PCI;
+        float a[TM], b[SPWV];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = wa[32 * i];
+#pragma unroll
+        for (int j = 0; j < SPWV; ++j) b[j] = pb[j * PSEGH];
+#pragma unroll
+        for (int ks = 0; ks < KH_ROWS / 2; ++ks) {
+            float an[TM], bn[SPWV];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) an[i] = 0.f;
+#pragma unroll
+            for (int j = 0; j < SPWV; ++j) bn[j] = 0.f;
+            if (ks + 1 < KH_ROWS / 2) {
+                const int kn = ks + 1;
+                const int offn = (kn / 9) * PCI + ((kn % 9) / 3) * PROW + (kn % 3);     // compile-time after unrolling
+#pragma unroll
+                for (int i = 0; i < TM; ++i) an[i] = wa[kn * CO_T + 32 * i];
+#pragma unroll
+                for (int j = 0; j < SPWV; ++j) bn[j] = pb[j * PSEGH + offn];
+            }
+            __builtin_amdgcn_sched_barrier(0);      // next step's ds_reads are issued BEFORE this step's MFMAs
+#pragma unroll
+            for (int j = 0; j < SPWV; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = an[i];
+#pragma unroll
+            for (int j = 0; j < SPWV; ++j) b[j] = bn[j];
+        }
+    };
+
+    const int nh = ((Cin + 2 * CI_H - 1) / (2 * CI_H)) * 2;          // half-chunks, padded to an even count (zero weights)
+#ifdef VOCR_CONV_STAMPS
+    unsigned long long st_begin, t0, t1, t2, t3, t4, sum_bar = 0, sum_issue = 0, sum_k = 0, sum_st = 0, st_pro;
+    VOCR_STAMP(st_begin);
+#define VOCR_PHASE(tA, tB, acc_) do { VOCR_STAMP(tB); acc_ += tB - tA; } while (0)
+#else
+#define VOCR_PHASE(tA, tB, acc_) do { } while (0)
+#endif
+    dma_weights(0, 0);
+    load_patch(0);
+    store_patch(0, 0);
+#ifdef VOCR_CONV_STAMPS
+    VOCR_STAMP(st_pro);
+    t4 = st_pro;
+#endif
+    for (int h = 0; h < nh; h += 2) {
+        __syncthreads();                            // buffer 0 complete (DMA drained: vmcnt(0)), buffer 1 free
+        VOCR_PHASE(t4, t0, sum_bar);
+        // the next half-chunk's DMAs and halo loads are issued here in one go: spread between the k-steps they measured
+        // slower (733 vs 707 us on the 256->256 layer: an LDS-DMA instruction holds the in-order wave for 100-450 cycles)
+        dma_weights((h + 1) * CI_H, 1);
+        load_patch((h + 1) * CI_H);
+        VOCR_PHASE(t0, t1, sum_issue);
+        kloop(0);
+        VOCR_PHASE(t1, t2, sum_k);
+        store_patch((h + 1) * CI_H, 1);
+        VOCR_PHASE(t2, t3, sum_st);
+        __syncthreads();                            // buffer 1 complete, buffer 0 free
+        VOCR_PHASE(t3, t0, sum_bar);
+        dma_weights((h + 2) * CI_H, 0);             // past the last channel: zero page / masked rows, never used
+        load_patch((h + 2) * CI_H);
+        VOCR_PHASE(t0, t1, sum_issue);
+        kloop(1);
+        VOCR_PHASE(t1, t2, sum_k);
+        store_patch((h + 2) * CI_H, 0);
+        VOCR_PHASE(t2, t4, sum_st);
+    }
+#ifdef VOCR_CONV_STAMPS
+    unsigned long long st_loop_end;
+    VOCR_STAMP(st_loop_end);
+#endif
+
+    // bias of this lane's 16*TM output channels, gathered with all loads in flight (a `bias ? bias[co] : 0` inside the store
+    // loop became 32 load -> wait -> store round trips)
+    float bv[TM][16];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bv[i][r] = 0.f;
+    if (bias) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bv[i][r] = bias[min(co0 + wco + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk, Cout - 1)];
+    }
+#pragma unroll
+    for (int j = 0; j < SPWV; ++j) {
+        const int* sg = segw + (wsg + j) * 8;
+        const int pw = sg[5];
+        const int rr = li / pw, cc = li - rr * pw;
+        if (!sg[3] || rr >= sg[4] || cc >= sg[6]) continue;
+        const long obase = (long)sg[0] * Cout * HW + (long)(sg[1] + rr) * W + sg[2] + cc;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wco + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (co < Cout) out[obase + (long)co * HW] = acc[i][j][r] + bv[i][r];
+            }
+    }
+#ifdef VOCR_CONV_STAMPS
+    unsigned long long st_end;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    VOCR_STAMP(st_end);
+    if (tid == 0 && g_stamp_out && blockIdx.x < 4096) {
+        unsigned long long* o = g_stamp_out + (size_t)blockIdx.x * 8;
+        o[0] = st_end - st_begin; o[1] = sum_k; o[2] = sum_bar; o[3] = sum_st; o[4] = sum_issue; o[5] = st_pro - st_begin; o[6] = st_end - st_loop_end;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------- weight gradient
 constexpr int WG_DYP = SEGW + 1;    // 33: odd pitch -> conflict-free reads across channels
 constexpr int WG_XCI = 3 * PROW + 1;  // 103
 
-template <int MINW>
-__global__ __launch_bounds__(256, MINW) void conv3x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             float* __restrict__ slab,
                                                             const float* __restrict__ zero_page, int N, int Cin, int H,
                                                             int W, int Cout, SegGeom geo, int segs_per_split) {
     __shared__ float dyT[64 * WG_DYP];
-    __shared__ float xp[64 * WG_XCI];
+    __shared__ float xp[64 * WG_XCI + 64];              // + dummy tail for lanes >= 34 (unconditional stores, see conv3x3_kernel)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lk = lane >> 5;
     const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64, split = blockIdx.z;
@@ -377,6 +665,10 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_wgrad_kernel(const float* _
     auto store_seg = [&](const SegPos& p) {
 #pragma unroll
         for (int e = 0; e < EDY; ++e) dyT[(dco + 8 * e) * WG_DYP + dpx] = rdy[e] * (dy_m[e] * p.dy_ok);
+        // NOTE: with the stores under `if (lane < PROW)` LLVM sinks the 48 x loads of load_slice into this block, i.e. they
+        // are issued in one burst behind the end-of-segment barrier.  That is the FASTER arrangement here (725 vs 780 us on
+        // the 256->256 layer with the loads kept between the k-steps): this kernel runs one wave per SIMD, so every VMEM
+        // issue slot inside the MFMA loop is a bubble nobody fills, while the burst's latency is paid once per segment.
         if (lane < PROW) {
 #pragma unroll
             for (int ci = 0; ci < 16; ++ci)
@@ -732,8 +1024,8 @@ int wgrad_splits(int n, int cin, int h, int w, int cout, int* segs_per_split, bo
     const int tiles = (cin <= 3 ? 1 : vocr_cdiv(cin, 64)) * vocr_cdiv(cout, 64);
     // the generic kernel holds one workgroup per CU (9 accumulators per wave): 256 slabs = one full round and a
     // 3x smaller slab than 768; the small-Cin kernel is light and streams, give it more
-    static const int occ2 = getenv("VOCR_WGRAD_OCC2") ? atoi(getenv("VOCR_WGRAD_OCC2")) : 0;
-    long s = ((cin <= 3 ? 1024 : (occ2 ? 512 : 256)) + tiles - 1) / tiles;
+    // (capping the registers for two workgroups per CU spills 26 dwords per lane into the loop: 78-90 TF instead of 98-107)
+    long s = ((cin <= 3 ? 1024 : 256) + tiles - 1) / tiles;
     if (s > nseg) s = nseg;
     if (s < 1) s = 1;
     const int sps = (int)((nseg + s - 1) / s);
@@ -769,14 +1061,26 @@ extern "C" int vocr_conv3x3_fwd(const float* x, const float* wpack, const float*
     const long full_wgs = (long)vocr_cdiv(nseg, cout > 64 ? 4 : 8) * co_tiles;
     static const int tile_mode = getenv("VOCR_CONV_TILE") ? atoi(getenv("VOCR_CONV_TILE")) : 0;     // experiments: 1 half, 2 full
     const bool small = tile_mode == 1 ? true : tile_mode == 2 ? false : full_wgs < 12l * 256;
-    const bool tiny = tile_mode == 3;        // experiments: 32 output channels per wave (one accumulator), half the tile again
+    const bool tiny = tile_mode == 3;
+    static const int lds_pad = getenv("VOCR_CONV_LDS_PAD") ? atoi(getenv("VOCR_CONV_LDS_PAD")) : 0;   // experiments: extra LDS = fewer workgroups per CU        // experiments: 32 output channels per wave (one accumulator), half the tile again
 #define VOCR_CONV(CO_T, SPWV, NSEG, WCO)                                                                                     \
     do {                                                                                                                    \
         dim3 grid(vocr_cdiv(nseg, NSEG) * co_tiles);                                                                        \
-        if (vec) conv3x3_kernel<CO_T, SPWV, true, WCO><<<grid, 256, 0, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, geo, co_tiles);  \
-        else conv3x3_kernel<CO_T, SPWV, false, WCO><<<grid, 256, 0, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, geo, co_tiles);     \
+        if (vec) conv3x3_kernel<CO_T, SPWV, true, WCO><<<grid, 256, lds_pad, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, geo, co_tiles);  \
+        else conv3x3_kernel<CO_T, SPWV, false, WCO><<<grid, 256, lds_pad, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, geo, co_tiles);     \
     } while (0)
-    if (cout > 64) {
+    static const int use_dma = getenv("VOCR_CONV_DMA") ? atoi(getenv("VOCR_CONV_DMA")) : 1;
+    if (use_dma && vec && !tiny) {
+        // LDS-DMA form (weights by global_load_lds into ping-pong half-chunk buffers)
+#define VOCR_CONV_DMA_LAUNCH(CO_T, SPWV, NSEG)                                                                              \
+        conv3x3_dma_kernel<CO_T, SPWV, 64><<<dim3(vocr_cdiv(nseg, NSEG) * co_tiles), 256, lds_pad, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, geo, co_tiles)
+        if (cout > 64) {
+            if (small) VOCR_CONV_DMA_LAUNCH(128, 1, 2); else VOCR_CONV_DMA_LAUNCH(128, 2, 4);
+        } else {
+            if (small) VOCR_CONV_DMA_LAUNCH(64, 1, 4); else VOCR_CONV_DMA_LAUNCH(64, 2, 8);
+        }
+#undef VOCR_CONV_DMA_LAUNCH
+    } else if (cout > 64) {
         if (tiny) VOCR_CONV(128, 1, 1, 32); else if (small) VOCR_CONV(128, 1, 2, 64); else VOCR_CONV(128, 2, 4, 64);
     } else {
         if (tiny) VOCR_CONV(64, 1, 2, 32); else if (small) VOCR_CONV(64, 1, 4, 64); else VOCR_CONV(64, 2, 8, 64);
@@ -810,9 +1114,7 @@ extern "C" int vocr_conv3x3_wgrad(const float* x, const float* dy, float* dw, vo
         conv3x3_wgrad_smallcin_kernel<<<grid, 128, 0, s>>>(x, dy, (float*)workspace, zp, n, cin, h, w, cout, SW, (int)nseg, sps);
     } else {
         dim3 grid(vocr_cdiv(cin, 64), vocr_cdiv(cout, 64), splits);
-        static const int occ2 = getenv("VOCR_WGRAD_OCC2") ? atoi(getenv("VOCR_WGRAD_OCC2")) : 0;       // experiment: cap registers for 2 waves/SIMD
-        if (occ2) conv3x3_wgrad_kernel<2><<<grid, 256, 0, s>>>(x, dy, (float*)workspace, zp, n, cin, h, w, cout, seg_geom(n, h, w), sps);
-        else conv3x3_wgrad_kernel<1><<<grid, 256, 0, s>>>(x, dy, (float*)workspace, zp, n, cin, h, w, cout, seg_geom(n, h, w), sps);
+        conv3x3_wgrad_kernel<<<grid, 256, 0, s>>>(x, dy, (float*)workspace, zp, n, cin, h, w, cout, seg_geom(n, h, w), sps);
     }
     VOCR_CHECK_LAUNCH("vocr_conv3x3_wgrad");
     launch_wgrad_reduce((const float*)workspace, dw, cout, cin, splits, s);

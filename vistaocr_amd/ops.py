@@ -297,7 +297,11 @@ class ConvBnReluFn(torch.autograd.Function):
         fused_pool_bwd = False
         if ctx.pool is not None:
             oh, ow = ctx.pool
-            fused_pool_bwd = bool(lib.vocr_bn_relu_fracpool2x2_bwd_supported(h, w, oh, ow)) and _os.environ.get("VOCR_POOL_BWD_FUSED", "1") == "1"
+            # Opt-in (VOCR_POOL_BWD_FUSED=1): pooling gradient + ReLU + BatchNorm backward in one gather pass.  Alone on the
+            # chip it beats the three passes (139 vs 167 us per layer), but beside the weight-gradient kernel on the side
+            # stream its address/VALU work gets starved (370-420 us) and the step is unchanged (21.34 vs 21.42 ms): the CNN
+            # backward is bound by the dgrad + wgrad MFMA work, not by these passes.
+            fused_pool_bwd = bool(lib.vocr_bn_relu_fracpool2x2_bwd_supported(h, w, oh, ow)) and _os.environ.get("VOCR_POOL_BWD_FUSED", "0") == "1"
             if not fused_pool_bwd:          # gradient of the fused pooling first: back to the full plane
                 dfull = torch.empty(n, cout, h, w, dtype=torch.float32, device=da.device)
                 call("vocr_fracpool2x2_bwd", _p(da), _p(idx), _p(dfull), n, cout, h, w, oh, ow, _stream())
