@@ -75,9 +75,28 @@ def test_scale_sizes_and_bicubic_properties():
     out = ds.Scale(new_h=32)(ramp).astype(np.int64)
     assert out.shape == (32, 50)
     assert np.all(np.abs(out[:, 2:-2] - (np.arange(50) * 4 + 1)[None, 2:-2]) <= 1)
+    outc = ds.Scale(new_h=32, interpolation="cubic")(ramp).astype(np.int64)          # the bicubic fallback keeps a ramp too
+    assert np.all(np.abs(outc[:, 2:-2] - (np.arange(50) * 4 + 1)[None, 2:-2]) <= 1)
+    # exact bilinear value at a known position: 2x upsampling of [0, 100] samples 0.25 / 0.75 of the way
+    up = ds.Scale(new_w=4, preserve_aspect_ratio=False)(np.array([[0, 100]], dtype=np.uint8))
+    assert up.tolist() == [[0, 25, 75, 100]]
     rgba = np.zeros((30, 20, 4), dtype=np.uint8)
     assert ds.ToTensor()(rgba[:, :, :3]).shape == (3, 30, 20)
     assert np.array_equal(ds.InvertBlackWhite()(np.array([[0, 1, 255]], dtype=np.uint8)), np.array([[255, 254, 0]], dtype=np.uint8))
+
+
+def test_decode_pipeline_follows_the_models_channel_count():
+    """src/decode_testset.py:48-65: InvertBlackWhite only for single-channel models; ConvertGray only with --cvtGray;
+    grey conversion = OpenCV's integer BGR2GRAY formula."""
+    bgr = np.zeros((30, 40, 3), dtype=np.uint8)
+    bgr[:, :, 0], bgr[:, :, 1], bgr[:, :, 2] = 10, 200, 90
+    t3 = ds.decode_transforms(30, num_in_channels=3)(bgr)
+    assert t3.shape == (3, 30, 40) and abs(float(t3[1, 0, 0]) - 200 / 255) < 1e-6          # colour model: not inverted
+    t1 = ds.decode_transforms(30, num_in_channels=1, cvt_gray=True)(bgr)
+    grey = (10 * 1868 + 200 * 9617 + 90 * 4899 + 8192) >> 14
+    assert grey == 145 and t1.shape == (1, 30, 40) and abs(float(t1[0, 0, 0]) - (255 - grey) / 255) < 1e-6
+    assert ds.ConvertColor()(np.full((5, 6), 9, dtype=np.uint8)).shape == (5, 6, 3)
+    assert ds.ConvertGray()(np.full((5, 6), 9, dtype=np.uint8)).shape == (5, 6)
 
 
 def test_lmdb_store_fails_loudly_without_its_modules(tmp_path):

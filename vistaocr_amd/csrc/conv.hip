@@ -1069,6 +1069,11 @@ extern "C" int vocr_conv3x3_fwd(const float* x, const float* wpack, const float*
         if (vec) conv3x3_kernel<CO_T, SPWV, true, WCO><<<grid, 256, lds_pad, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, geo, co_tiles);  \
         else conv3x3_kernel<CO_T, SPWV, false, WCO><<<grid, 256, lds_pad, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, geo, co_tiles);     \
     } while (0)
+    // VOCR_CONV_DMA=0: the register-staged kernel.  (A producer/consumer variant - two extra loader waves per workgroup, the
+    // four MFMA waves doing nothing but fragment reads and MFMAs between barriers - was built and measured SLOWER, 907-1020
+    // vs 708 us on the 256->256 layer: with double buffering the loaders can only run one half-chunk ahead, so their
+    // load -> land -> store latency (an LDS-DMA takes ~1.1 us from issue to landed) sits on the critical path of every
+    // half-chunk instead of hiding behind the issuing wave's own MFMAs; a third buffer does not fit three workgroups per CU.)
     static const int use_dma = getenv("VOCR_CONV_DMA") ? atoi(getenv("VOCR_CONV_DMA")) : 1;
     if (use_dma && vec && !tiny) {
         // LDS-DMA form (weights by global_load_lds into ping-pong half-chunk buffers)

@@ -97,9 +97,10 @@ class Scale:
     """src/imagetransforms.py:453-492, the `new_h` / `new_w` form: the other side follows the aspect ratio with the
     reference's truncation `int(w * float(new_h / h))`; a non-positive result falls back to width 1."""
 
-    def __init__(self, new_h=None, new_w=None, preserve_aspect_ratio=True):
+    def __init__(self, new_h=None, new_w=None, preserve_aspect_ratio=True, interpolation="linear"):
         assert isinstance(new_h, int) or isinstance(new_w, int)
         self.new_h, self.new_w, self.preserve_aspect_ratio = new_h, new_w, preserve_aspect_ratio
+        self.interpolation = interpolation          # only read by the no-OpenCV fallback: "linear" (default) or "cubic"
 
     def target_size(self, h, w):
         nh, nw = self.new_h or h, self.new_w or w
@@ -118,9 +119,59 @@ class Scale:
             return img
         try:
             import cv2
+            # the reference's own call, argument for argument (src/imagetransforms.py:492): the interpolation flag is passed
+            # POSITIONALLY, i.e. into cv2.resize's third parameter `dst`, so OpenCV resamples with its default, INTER_LINEAR
             return cv2.resize(img, (nw, nh), cv2.INTER_CUBIC)          # pragma: no cover - cv2 absent in the build image
         except ImportError:
-            return _resize_bicubic(img, nw, max(nh, 1))
+            # without OpenCV: bilinear with OpenCV's half-pixel sample positions (what the call above effectively does);
+            # "parity unpinned" - cv2's uint8 path uses 11-bit fixed-point weights, this one float64 + round-to-nearest
+            return _resize_bilinear(img, nw, max(nh, 1)) if self.interpolation == "linear" else _resize_bicubic(img, nw, max(nh, 1))
+
+
+def _resize_bilinear(img, new_w, new_h):
+    src = img.astype(np.float64)
+    h, w = src.shape[:2]
+
+    def taps(n_out, n_in):
+        pos = (np.arange(n_out) + 0.5) * (n_in / n_out) - 0.5
+        base = np.floor(pos).astype(np.int64)
+        frac = pos - base
+        i0 = np.clip(base, 0, n_in - 1)
+        i1 = np.clip(base + 1, 0, n_in - 1)
+        return i0, i1, frac
+
+    y0, y1, fy = taps(new_h, h)
+    x0, x1, fx = taps(new_w, w)
+    fy = fy.reshape((-1,) + (1,) * (src.ndim - 1))
+    rows = src[y0] * (1.0 - fy) + src[y1] * fy                                            # [new_h, w, ...]
+    fxs = fx.reshape((1, -1) + (1,) * (src.ndim - 2))
+    out = rows[:, x0] * (1.0 - fxs) + rows[:, x1] * fxs
+    if img.dtype == np.uint8:
+        out = np.clip(np.rint(out), 0, 255).astype(np.uint8)
+    return out
+
+
+class ConvertGray:
+    """src/imagetransforms.py:408-413 (cv2.COLOR_BGR2GRAY on 3-channel images, anything else passes through).  OpenCV's
+    uint8 formula restated exactly: (B*1868 + G*9617 + R*4899 + 8192) >> 14  (= 0.114 B + 0.587 G + 0.299 R)."""
+
+    def __call__(self, img):
+        if img.ndim == 3 and img.shape[2] == 3:
+            if img.dtype == np.uint8:
+                v = img.astype(np.int64)
+                return ((v[:, :, 0] * 1868 + v[:, :, 1] * 9617 + v[:, :, 2] * 4899 + 8192) >> 14).astype(np.uint8)
+            return (0.114 * img[:, :, 0] + 0.587 * img[:, :, 1] + 0.299 * img[:, :, 2]).astype(img.dtype)
+        return img
+
+
+class ConvertColor:
+    """src/imagetransforms.py:415-420 (cv2.COLOR_GRAY2BGR on anything that is not already 3-channel)."""
+
+    def __call__(self, img):
+        if img.ndim == 3 and img.shape[2] == 3:
+            return img
+        g = img if img.ndim == 2 else img[:, :, 0]
+        return np.stack([g, g, g], axis=2)
 
 
 class InvertBlackWhite:
@@ -140,10 +191,17 @@ class ToTensor:
         return torch.from_numpy(np.ascontiguousarray(pic.transpose((2, 0, 1)))).float().div(255)
 
 
-def decode_transforms(line_height, num_in_channels=1):
-    """The inference-time pipeline of src/decode_testset.py:48-65 for a model's line height."""
-    del num_in_channels          # the grey/colour conversion steps of the reference need cv2; images are used as stored
-    return Compose([Scale(new_h=line_height), InvertBlackWhite(), ToTensor()])
+def decode_transforms(line_height, num_in_channels=1, cvt_gray=False):
+    """The inference-time pipeline of src/decode_testset.py:48-65: [ConvertGray if --cvtGray] -> Scale(new_h = the model's
+    line height) -> [InvertBlackWhite only for single-channel models] -> ToTensor."""
+    steps = []
+    if cvt_gray:
+        steps.append(ConvertGray())
+    steps.append(Scale(new_h=line_height))
+    if num_in_channels == 1:
+        steps.append(InvertBlackWhite())
+    steps.append(ToTensor())
+    return Compose(steps)
 
 
 # ---------------------------------------------------------------------------------------------------- dataset
