@@ -262,7 +262,7 @@ def run_rank(args):
     # un-timed pass below
     CONV_FWD_ONLY = {"vocr_conv3x3_fwd": lambda a: a[2] is not None}
     _lib.enable_timing(CONV_FWD_ONLY)
-    dt, final_loss = timed(batch_dev, args.steps, event_every=4)
+    dt, final_loss = timed(batch_dev, args.steps, event_every=args.event_every)
     conv_recs = _lib.timing_records().get("vocr_conv3x3_fwd", [])
     _lib.enable_timing(None)
     dt_h2d, _ = timed(batch_host, args.steps)
@@ -354,9 +354,10 @@ def main():
         return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--event-every", type=int, default=4, help="HIP events around the dominant kernel in every n-th timed step (0: none)")
     ap.add_argument("--hidden", type=int, default=512)
     ap.add_argument("--conv-dtype", default="fp32", choices=["fp32", "fp16"],
                     help="fp16 = BASELINE config 5's fp16-operand conv MFMA (fp32 accumulate); the headline metric is fp32")
