@@ -1,0 +1,41 @@
+// Diagnostic build (never shipped): the 8-row forward chain sweep of lstm.hip with s_memtime stamps around the phases
+// of a time step.  usage: lstm_stamp
+#define VOCR_LSTM_STAMPS 1
+#include "../vistaocr_amd/csrc/lstm.hip"
+#include <vector>
+#include <cstdio>
+#include <cstdlib>
+void vocr_set_error(const char*, ...) {}
+extern "C" int vocr_colsum(const float*, float*, int, int, void*, void*) { return 0; }
+int main() {
+    const int T = 294, B = 32, H = 512;
+    float *xproj, *wf, *wr, *y, *gates, *cell; int32_t* lens; void* ws; unsigned long long* dbg;
+    hipMalloc(&xproj, (size_t)2 * T * B * 4 * H * 4); hipMalloc(&wf, (size_t)4 * H * H * 4); hipMalloc(&wr, (size_t)4 * H * H * 4);
+    hipMalloc(&y, (size_t)T * B * 2 * H * 4); hipMalloc(&gates, (size_t)2 * T * B * 4 * H * 4); hipMalloc(&cell, (size_t)2 * T * B * H * 4);
+    hipMalloc(&lens, B * 4); hipMalloc(&ws, vocr_lstm_workspace_bytes(T, B, H) + 256); hipMalloc(&dbg, 256 * 2 * 8 * 8);
+    hipMemset(xproj, 0, (size_t)2 * T * B * 4 * H * 4); hipMemset(wf, 0, (size_t)4 * H * H * 4); hipMemset(wr, 0, (size_t)4 * H * H * 4);
+    hipMemset(dbg, 0, 256 * 2 * 8 * 8);
+    std::vector<int32_t> hl(B, T); hipMemcpy(lens, hl.data(), B * 4, hipMemcpyHostToDevice);
+    hipMemcpyToSymbol(HIP_SYMBOL(g_lstm_stamp_out), &dbg, sizeof(dbg));
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0, nullptr);
+        int rc = vocr_lstm_fwd(xproj, wf, wr, lens, y, gates, cell, ws, T, B, H, nullptr, nullptr);
+        hipEventRecord(e1, nullptr); hipDeviceSynchronize(); hipEventElapsedTime(&ms, e0, e1);
+        if (rc) { printf("rc %d\n", rc); return 1; }
+    }
+    std::vector<unsigned long long> h(256 * 2 * 8);
+    hipMemcpy(h.data(), dbg, 256 * 2 * 8 * 8, hipMemcpyDeviceToHost);
+    const char* names[8] = {"poll", "barrier after poll", "h loads landed", "LDS stage + MFMA + partials to LDS", "barrier", "reduce + cell + stores issued",
+                            "vmcnt(0) drain", "final barrier + flag + loop top"};
+    printf("sweep %.3f ms = %.2f us per step (stamped build: an extra vmcnt(0) after the h loads)\n", ms, ms * 1e3 / T);
+    for (int w = 0; w < 2; ++w) {
+        double s[8] = {0}, tot = 0;
+        for (int b = 0; b < 256; ++b) for (int k = 0; k < 8; ++k) s[k] += (double)h[(b * 2 + w) * 8 + k] / 256 / T;
+        for (int k = 0; k < 8; ++k) tot += s[k];
+        printf("wave %d, s_memtime ticks per step (total %.1f => one tick = %.2f ns):\n", w ? 7 : 0, tot, ms * 1e6 / T / tot);
+        for (int k = 0; k < 8; ++k) printf("   %-38s %8.1f  %5.1f %%\n", names[k], s[k], 100 * s[k] / tot);
+    }
+    return 0;
+}

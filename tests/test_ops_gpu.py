@@ -40,7 +40,10 @@ def _close(a, b, rtol, atol, what="", max_bad_frac=0.0):
 # a multiple of that), 1 (11 rows per remainder segment), 15 / 16 (2 rows / 1 row), W < 32 (only remainder segments), H = 1
 @pytest.mark.parametrize("n,cin,h,w,cout", [(2, 1, 30, 70, 64), (2, 64, 15, 45, 64), (1, 64, 15, 97, 128), (2, 128, 7, 33, 256),
                                             (1, 16, 9, 40, 64), (1, 3, 12, 31, 16), (2, 72, 7, 294, 128), (1, 64, 15, 420, 64),
-                                            (3, 8, 13, 65, 32), (2, 16, 5, 47, 64), (1, 8, 6, 48, 16), (2, 8, 1, 38, 8), (1, 8, 3, 15, 8)])
+                                            (3, 8, 13, 65, 32), (2, 16, 5, 47, 64), (1, 8, 6, 48, 16), (2, 8, 1, 38, 8), (1, 8, 3, 15, 8),
+                                            # more than 256 workgroup tiles with a short last round: conv3x3_tail_kernel computes it
+                                            # (326 tiles of 128co x 2 segments, the last one half empty; 297 of 64co x 4; 293 with Cout = 72)
+                                            (5, 20, 7, 294, 256), (6, 12, 15, 420, 64), (9, 8, 7, 294, 72)])
 def test_conv3x3_fwd_dgrad_wgrad(dev, n, cin, h, w, cout):
     from vistaocr_amd import ops
     x = _rand((n, cin, h, w), 1)

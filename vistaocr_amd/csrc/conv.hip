@@ -576,6 +576,92 @@ __global__ __launch_bounds__(256) void conv3x3_dma_kernel(const float* __restric
 #endif
 }
 
+// ---------------------------------------------------------------- last partial round of the forward / data-gradient kernel
+// A launch of the kernel above takes ceil(workgroups / 256 CUs) rounds of equal length (scripts/conv_occ.py: a clean
+// staircase), so the 32 workgroups left over from 2080 cost the 7x294 layers a ninth round with 7/8 of the chip idle
+// (-8.7 % over the forward stack with the partial round simply dropped).  Those leftover workgroup tiles are computed here
+// instead, cut into their 32-channel x 32-pixel MFMA tiles (8 or 16 per workgroup tile -> 256+ pieces = every CU busy for
+// one short round).  One piece = one workgroup of 8 waves that split K: wave w and lane half lk take input channels
+// 2*(8*s + w) + lk, s = 0, 1, ...; operands go global -> register -> MFMA directly (the weight pack row and the halo
+// row are both 32 consecutive floats: two coalesced 128-byte reads per MFMA, all L2 hits), three steps of 9 taps in
+// flight; the eight partial tiles are added through LDS in a fixed order (deterministic; the summation order differs
+// from the main kernel's single accumulator, like any other tiling change).
+constexpr int TAIL_WAVES = 8;
+__global__ __launch_bounds__(64 * TAIL_WAVES) void conv3x3_tail_kernel(const float* __restrict__ in, const float* __restrict__ wpack,
+                                                                       const float* __restrict__ bias, float* __restrict__ out,
+                                                                       const float* __restrict__ zero_page, int Cin, int H, int W, int Cout,
+                                                                       SegGeom geo, int co_tiles, int co_t, int nseg_wg, int first_tile) {
+    __shared__ float red[TAIL_WAVES][16][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lk = lane >> 5;
+    const int cosub = co_t / 32, ppw = cosub * nseg_wg;
+    const int v = first_tile + blockIdx.x / ppw, sub = blockIdx.x % ppw;
+    const int co_base = (v % co_tiles) * co_t + (sub % cosub) * 32;
+    const SegInfo sg = seg_decode((v / co_tiles) * nseg_wg + sub / cosub, geo, H, 0);
+    if (!sg.valid || co_base >= Cout) return;                           // whole workgroup: no barrier is skipped by part of it
+    const long HW = (long)H * W;
+    const int rr = li / sg.pw, cc = li - rr * sg.pw;
+    const bool pix_ok = rr < sg.rows && cc < sg.ow;                     // lane position li is an output pixel
+    // the nine taps of this lane's pixel: offsets inside a channel plane (clamped) and 0/1 masks
+    int toff[9];
+    float tm[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int hh = sg.h + rr + t / 3 - 1, ww = sg.w0 + cc + t % 3 - 1;
+        tm[t] = (rr < sg.rows && cc < sg.pw && hh >= 0 && hh < H && ww >= 0 && ww < W) ? 1.f : 0.f;
+        toff[t] = min(max(hh, 0), H - 1) * W + min(max(ww, 0), W - 1);
+    }
+    const float* xin = in + (long)sg.n * Cin * HW;
+    const int co = co_base + li;
+    const bool co_ok = co < Cout;
+    const int nsteps = (Cin + 2 * TAIL_WAVES - 1) / (2 * TAIL_WAVES);
+    constexpr int DEPTH = 3;
+    float a[DEPTH][9], b[DEPTH][9];
+    auto loads = [&](int s, float (&av)[9], float (&bv)[9]) {
+        const int ci = 2 * (TAIL_WAVES * s + wave) + lk;
+        const bool ok = ci < Cin && s < nsteps;
+        const float* wrow = (ok && co_ok) ? wpack + (long)ci * 9 * Cout + co : zero_page;
+        const long wstride = (ok && co_ok) ? Cout : 0;
+        const float* xc = xin + (long)min(ci, Cin - 1) * HW;
+        const float cm = ok ? 1.f : 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            av[t] = wrow[t * wstride];
+            bv[t] = xc[toff[t]] * (tm[t] * cm);
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) loads(d, a[d], b[d]);
+    for (int s0 = 0; s0 < nsteps; s0 += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            if (s0 + d < nsteps) {                                                       // wave-uniform
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[d][t], b[d][t], acc, 0, 0, 0);
+                loads(s0 + d + DEPTH, a[d], b[d]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+    // thread (wave, lane) finishes registers 2*wave, 2*wave + 1 of lane's column
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int r = 2 * wave + q;
+        float sum = 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < TAIL_WAVES; ++w8) sum += red[w8][r][lane];
+        const int oc = co_base + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (pix_ok && oc < Cout)
+            out[(long)sg.n * Cout * HW + (long)oc * HW + (long)(sg.h + rr) * W + sg.w0 + cc] = sum + (bias ? bias[oc] : 0.f);
+    }
+}
+
 // ---------------------------------------------------------------- weight gradient
 constexpr int WG_DYP = SEGW + 1;    // 33: odd pitch -> conflict-free reads across channels
 constexpr int WG_XCI = 3 * PROW + 1;  // 103
@@ -1043,6 +1129,17 @@ extern "C" int vocr_conv3x3_pack_weights(const float* w, float* wpack_fwd, float
     return VOCR_OK;
 }
 
+static int conv_cu_count() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cus[dev]) {
+        hipDeviceProp_t prop;
+        cus[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return cus[dev];
+}
+
 extern "C" int vocr_conv3x3_fwd(const float* x, const float* wpack, const float* bias, float* y, int n, int cin, int h,
                                 int w, int cout, void* stream) {
     VOCR_CHECK_ARG(x && wpack && y, "vocr_conv3x3_fwd: null pointer");
@@ -1075,10 +1172,21 @@ extern "C" int vocr_conv3x3_fwd(const float* x, const float* wpack, const float*
     // load -> land -> store latency (an LDS-DMA takes ~1.1 us from issue to landed) sits on the critical path of every
     // half-chunk instead of hiding behind the issuing wave's own MFMAs; a third buffer does not fit three workgroups per CU.)
     static const int use_dma = getenv("VOCR_CONV_DMA") ? atoi(getenv("VOCR_CONV_DMA")) : 1;
+    // VOCR_CONV_TAIL: 1 (default) the last partial round goes to conv3x3_tail_kernel, 0 one launch as before,
+    // 2 EXPERIMENT (wrong results): the partial round is dropped - the upper bound of what the tail kernel can buy
+    static const int tail_mode = getenv("VOCR_CONV_TAIL") ? atoi(getenv("VOCR_CONV_TAIL")) : 1;
+    const int ncu = conv_cu_count();
     if (use_dma && vec && !tiny) {
         // LDS-DMA form (weights by global_load_lds into ping-pong half-chunk buffers)
 #define VOCR_CONV_DMA_LAUNCH(CO_T, SPWV, NSEG)                                                                              \
-        conv3x3_dma_kernel<CO_T, SPWV, 64><<<dim3(vocr_cdiv(nseg, NSEG) * co_tiles), 256, lds_pad, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, geo, co_tiles)
+        do {                                                                                                                \
+            const int tiles = vocr_cdiv(nseg, NSEG) * co_tiles, rem = tiles % ncu;                                         \
+            const bool cut = tail_mode && tiles > ncu && rem > 0 && rem <= ncu / 2;                                        \
+            const int n_main = cut ? tiles - rem : tiles;                                                                   \
+            conv3x3_dma_kernel<CO_T, SPWV, 64><<<dim3(n_main), 256, lds_pad, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, geo, co_tiles);   \
+            if (cut && tail_mode == 1)                                                                                      \
+                conv3x3_tail_kernel<<<dim3(rem * (CO_T / 32) * NSEG), 64 * TAIL_WAVES, 0, s>>>(x, wpack, bias, y, zp, cin, h, w, cout, geo, co_tiles, CO_T, NSEG, n_main); \
+        } while (0)
         if (cout > 64) {
             if (small) VOCR_CONV_DMA_LAUNCH(128, 1, 2); else VOCR_CONV_DMA_LAUNCH(128, 2, 4);
         } else {

@@ -15,6 +15,15 @@
 
 namespace {
 
+#ifdef VOCR_LSTM_STAMPS        // diagnostic build only (scripts/lstm_stamp.hip): phase stamps of the chain sweeps, never in libvocr.so
+__device__ unsigned long long* g_lstm_stamp_out;
+#define LSTM_STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[k] += now_ - st_last; st_last = now_; } while (0)
+#define LSTM_STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime()
+#else
+#define LSTM_STAMP(k) do { } while (0)
+#define LSTM_STAMP_DECL do { } while (0)
+#endif
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // grid.x = 2 * (H/4); 256 threads
@@ -587,8 +596,10 @@ __global__ __launch_bounds__(512) void lstm_fwd_chain8(const float* __restrict__
     float xn[4] = {0.f, 0.f, 0.f, 0.f};
     if (tid < 128) x_loads(s0, xn);
 
+    LSTM_STAMP_DECL;
     for (int step = s0; step < s1; ++step) {
         const int t = dir == 0 ? step : T - 1 - step;
+        LSTM_STAMP(7);
         const int tprev = dir == 0 ? t - 1 : t + 1;
         float xp[4];
 #pragma unroll
@@ -611,7 +622,9 @@ __global__ __launch_bounds__(512) void lstm_fwd_chain8(const float* __restrict__
                     }
                 }
             }
+            LSTM_STAMP(0);          // poll (wave 7) 
             __syncthreads();
+            LSTM_STAMP(1);
             const int toff = tprev * B * 2 * H * 4;
             u32x4_t pv[NP];
             if (local) {            // one XCD: plain loads of the L2-resident hand-off (see lstm_fwd_chain)
@@ -624,6 +637,10 @@ __global__ __launch_bounds__(512) void lstm_fwd_chain8(const float* __restrict__
             if (tid < 128) x_loads(step + 1 < T ? step + 1 : step, xn);
 #pragma unroll
             for (int j = 0; j < NP; ++j) *(u32x4_t*)(hst + pdst[j]) = pv[j];
+#ifdef VOCR_LSTM_STAMPS
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            LSTM_STAMP(2);          // h loads landed
+#endif
             // same wave writes and reads its staging rows: the LDS counter orders them, no barrier
             f32x4 hv[NL];
 #pragma unroll
@@ -641,7 +658,9 @@ __global__ __launch_bounds__(512) void lstm_fwd_chain8(const float* __restrict__
         for (int I = 0; I < 2; ++I)
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[wave][4 * rg + r][32 * I + 4 * cg + li] = acc[I][r];
+        LSTM_STAMP(3);              // LDS stage + MFMA + partial tile to LDS
         __syncthreads();
+        LSTM_STAMP(4);
 
         if (cellthr) {
             const bool active = t < len_b;
@@ -673,13 +692,21 @@ __global__ __launch_bounds__(512) void lstm_fwd_chain8(const float* __restrict__
             if (local) __hip_atomic_store(yo, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // stays in this XCD's L2
             else __hip_atomic_store(yo, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                // write-through (sc1)
         }
+        LSTM_STAMP(5);              // reduce + cell update + stores issued (waves 0, 1)
         __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): every storing wave drains before the flag
+        LSTM_STAMP(6);
         __syncthreads();
         if (tid == 0) {
             if (local) __hip_atomic_store(cflags + member, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             else __hip_atomic_store(cflags + member, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+#ifdef VOCR_LSTM_STAMPS
+    if (lane == 0 && (wave == 0 || wave == 7) && g_lstm_stamp_out) {
+        unsigned long long* o = g_lstm_stamp_out + ((size_t)blockIdx.x * 2 + (wave == 7)) * 8;
+        for (int k = 0; k < 8; ++k) o[k] = st_acc[k];
+    }
+#endif
 }
 
 // Gradient of one LSTM cell; shared by the per-step and the persistent backward kernels so both contract the same
