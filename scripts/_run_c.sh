@@ -1,4 +1,7 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_ops_gpu.py -x -q -m gpu -k "conv3x3_fwd_dgrad" 2>&1 | tail -5
-SWEEP=0 python scripts/conv_bench.py
-echo ---- no tail; VOCR_CONV_TAIL=0 SWEEP=0 python scripts/conv_bench.py
+python -m pytest tests -q -m gpu 2>&1 | tail -4
+python scripts/lstm_bench.py
+python bench.py --no-cpu-baseline 2>/dev/null | python -c "
+import sys, json
+j = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print(j['value'], j['ms_per_step'], 'h2d', j['h2d_inclusive']['ms_per_step'], 'conv', j['roofline']['achieved'], j['roofline']['frac'], j['ms_per_step_by_entry_point'])"

@@ -94,7 +94,7 @@ def test_forward_loss_labels_vs_reference_goldens(name, alpha):
             # recompute dlogits alone
             lg2 = logits.detach().clone().requires_grad_(True)
             va.CTCLoss()(lg2, torch.from_numpy(tgt), lens, torch.from_numpy(tl)).backward()
-            np.testing.assert_allclose(lg2.grad.cpu().numpy(), g["dlogits"], rtol=2e-3, atol=2e-5)
+            np.testing.assert_allclose(lg2.grad.cpu().numpy(), g["dlogits"], rtol=2e-3, atol=5e-5)   # fp32 log-space alpha/beta at loss ~500: one ulp is 3e-5
 
 
 def test_train_two_steps_vs_reference():

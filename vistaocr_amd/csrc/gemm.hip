@@ -234,30 +234,39 @@ const float* gemm_zero_page() {
 }
 
 // The tiles that were cut along K: C tile (+)= sum over its pieces' slabs, added in piece order (bitwise reproducible;
-// float atomics into C were neither reproducible nor faster: 1.3 TB/s), then bias / ReLU.  grid.x = cut tiles.
+// float atomics into C were neither reproducible nor faster: 1.3 TB/s), then bias / ReLU.  grid.x = cut tiles x
+// (BM*BN/1024) blocks: one 16-byte column group per thread, four pieces' loads in flight.  (One block per tile with a
+// serial piece loop left each thread with a single load in flight: 120-345 us for 14-16 tiles on a busy chip.)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ C, int M, int N,
                                                             int ldc, int BM, int BN, int first_tile, int pieces_per_tile,
                                                             int tiles_n, const float* __restrict__ bias, int relu, int accumulate) {
-    const int tile = first_tile + blockIdx.x;
-    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-    const float* sp = slab + (long)blockIdx.x * pieces_per_tile * BM * BN;
     const int cols4 = BN >> 2;
-    for (int e = threadIdx.x; e < BM * cols4; e += 256) {
-        const int r = e / cols4, c = (e - r * cols4) << 2;
-        f32x4 v = *(const f32x4*)(sp + r * BN + c);
-        for (int z = 1; z < pieces_per_tile; ++z) v += *(const f32x4*)(sp + (long)z * BM * BN + r * BN + c);
-        const int gm = m0 + r;
-        if (gm >= M) continue;
+    const int sub = (BM * cols4) >> 8;                       // blocks per tile
+    const int t = blockIdx.x / sub, e = (blockIdx.x - t * sub) * 256 + threadIdx.x;
+    const int tile = first_tile + t;
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const long tsz = (long)BM * BN;
+    const int r = e / cols4, c = (e - r * cols4) << 2;
+    const float* sp = slab + (long)t * pieces_per_tile * tsz + r * BN + c;
+    f32x4 v = *(const f32x4*)sp;
+    int z = 1;
+    for (; z + 4 <= pieces_per_tile; z += 4) {
+        const f32x4 a = *(const f32x4*)(sp + (long)z * tsz), b = *(const f32x4*)(sp + (long)(z + 1) * tsz);
+        const f32x4 c2 = *(const f32x4*)(sp + (long)(z + 2) * tsz), d = *(const f32x4*)(sp + (long)(z + 3) * tsz);
+        v += a; v += b; v += c2; v += d;                    // same order as a serial loop
+    }
+    for (; z < pieces_per_tile; ++z) v += *(const f32x4*)(sp + (long)z * tsz);
+    const int gm = m0 + r;
+    if (gm >= M) return;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int gn = n0 + c + k;
-            if (gn >= N) continue;
-            float x = v[k] + (bias ? bias[gn] : 0.f);
-            float* cp = C + (long)gm * ldc + gn;
-            if (accumulate) x += *cp;
-            if (relu) x = fmaxf(x, 0.f);
-            *cp = x;
-        }
+    for (int k = 0; k < 4; ++k) {
+        const int gn = n0 + c + k;
+        if (gn >= N) continue;
+        float x = v[k] + (bias ? bias[gn] : 0.f);
+        float* cp = C + (long)gm * ldc + gn;
+        if (accumulate) x += *cp;
+        if (relu) x = fmaxf(x, 0.f);
+        *cp = x;
     }
 }
 
@@ -504,7 +513,7 @@ extern "C" int vocr_gemm(int transa, int transb, int m, int n, int k, const floa
     VOCR_CHECK_LAUNCH("vocr_gemm");
     if (p.pieces > 0) {
         const int cut_tiles = p.pieces / p.ppt;
-        splitk_reduce_kernel<<<cut_tiles, 256, 0, s>>>(slab, c, m, n, ldc, p.bm, p.bn, p.n_whole, p.ppt, p.tiles_n, bias, relu, accumulate);
+        splitk_reduce_kernel<<<cut_tiles * ((p.bm * p.bn) >> 10), 256, 0, s>>>(slab, c, m, n, ldc, p.bm, p.bn, p.n_whole, p.ppt, p.tiles_n, bias, relu, accumulate);
         VOCR_CHECK_LAUNCH("vocr_gemm(split-K reduce)");
     }
     return VOCR_OK;

@@ -24,7 +24,8 @@ __device__ unsigned long long* g_lstm_stamp_out;
 #define LSTM_STAMP_DECL do { } while (0)
 #endif
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_exp_f32 and v_rcp_f32 (1 ulp each): an IEEE division is ten dependent instructions on the latency-bound path of every time step
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // grid.x = 2 * (H/4); 256 threads
 __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(const float* __restrict__ xproj, const float* __restrict__ whh_f,
@@ -537,9 +538,10 @@ __global__ __launch_bounds__(512) void lstm_fwd_chain8(const float* __restrict__
     constexpr int KW = H / 8;                         // k per wave
     constexpr int NL = KW / 4;                        // 16-byte loads per lane per step
     constexpr int HP = KW + 4;                        // staging row pitch: 16-byte reads of 8 rows hit distinct banks
-    __shared__ float lds[8 * 8 * 65 + 4 + 8 * 8 * HP];
+    __shared__ float lds[8 * 8 * 65 + 4 + 8 * 8 * HP + 8 * 64];
     float (*red)[8][65] = (float (*)[8][65])lds;
     float* hst = lds + 8 * 8 * 65 + 4 + wave_of(threadIdx.x) * 8 * HP;      // this wave's h_{t-1}[8 rows][its KW k]
+    float (*actb)[64] = (float (*)[64])(lds + 8 * 8 * 65 + 4 + 8 * 8 * HP);  // activated gates [row][gate*16 + unit]
     const int chain = blockIdx.x & 7, member = blockIdx.x >> 3;
     if (chain >= 2 * NT8) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -561,6 +563,13 @@ __global__ __launch_bounds__(512) void lstm_fwd_chain8(const float* __restrict__
 #pragma unroll
         for (int i = 0; i < NL; ++i) wv[I][i] = wp[i];
     }
+    // epilogue in two phases: (A) every thread reduces and activates ONE pre-activation - wave w takes gate w & 3 of rows
+    // 4*(w >> 2) .. +3, so a wave evaluates a single activation function on all 64 lanes - and leaves it in LDS; (B) the
+    // 128 cell threads (waves 0, 1: row = tid >> 4, unit = tid & 15) pick up their four gates and do the cell update.
+    // (Two waves doing reduction + five activations per thread took 0.5 of the 2.8 us step with six waves waiting.)
+    const int egate = __builtin_amdgcn_readfirstlane(wave) & 3;             // scalar: the activation below is a uniform branch
+    const int erow = 4 * (wave >> 2) + (lane >> 4), ecol = egate * 16 + (lane & 15);
+    const bool erowok = erow < nrows;
     const int bl = (tid >> 4) & 7, cu = tid & 15, cb_ = b0 + bl, unit = unit0 + cu;
     const bool cellthr = tid < 128 && bl < nrows;
     const int len_b = cellthr ? lens[cb_] : 0;
@@ -586,25 +595,20 @@ __global__ __launch_bounds__(512) void lstm_fwd_chain8(const float* __restrict__
     }
     const float* hrd = hst + (4 * rg + li) * HP;
 
-    const int xb = cellthr ? cb_ : b0;
-    auto x_loads = [&](int st, float (&xv)[4]) {
+    const int xb = erowok ? b0 + erow : b0;
+    auto x_load = [&](int st) {
         const int tt = dir == 0 ? st : T - 1 - st;
-        const float* xrow = xproj + (((long)dir * T + tt) * B + xb) * 4 * H + unit;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) xv[g] = xrow[(long)g * H];
+        return xproj[(((long)dir * T + tt) * B + xb) * 4 * H + (long)egate * H + unit0 + (lane & 15)];
     };
-    float xn[4] = {0.f, 0.f, 0.f, 0.f};
-    if (tid < 128) x_loads(s0, xn);
+    float xn = x_load(s0);
 
     LSTM_STAMP_DECL;
     for (int step = s0; step < s1; ++step) {
         const int t = dir == 0 ? step : T - 1 - step;
         LSTM_STAMP(7);
         const int tprev = dir == 0 ? t - 1 : t + 1;
-        float xp[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) xp[g] = xn[g];
-        if (step == 0 && tid < 128) x_loads(T > 1 ? 1 : 0, xn);
+        const float xp = xn;
+        if (step == 0) xn = x_load(T > 1 ? 1 : 0);
         f32x4 acc[2];
         acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (step > 0) {
@@ -634,7 +638,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_chain8(const float* __restrict__
 #pragma unroll
                 for (int j = 0; j < NP; ++j) pv[j] = __builtin_amdgcn_raw_buffer_load_b128(yrsrc, toff + poff[j], 0, 16);      // aux 16 = sc1
             }
-            if (tid < 128) x_loads(step + 1 < T ? step + 1 : step, xn);
+            xn = x_load(step + 1 < T ? step + 1 : step);
 #pragma unroll
             for (int j = 0; j < NP; ++j) *(u32x4_t*)(hst + pdst[j]) = pv[j];
 #ifdef VOCR_LSTM_STAMPS
@@ -662,21 +666,20 @@ __global__ __launch_bounds__(512) void lstm_fwd_chain8(const float* __restrict__
         __syncthreads();
         LSTM_STAMP(4);
 
+        {
+            const float pre = (((red[0][erow][ecol] + red[1][erow][ecol]) + (red[2][erow][ecol] + red[3][erow][ecol])) +
+                               ((red[4][erow][ecol] + red[5][erow][ecol]) + (red[6][erow][ecol] + red[7][erow][ecol]))) + xp;
+            actb[erow][ecol] = egate == 2 ? tanhf(pre) : sigmoidf_(pre);           // wave-uniform choice
+        }
+        __syncthreads();
         if (cellthr) {
             const bool active = t < len_b;
             const long sidx = (((long)dir * T + t) * B + cb_) * H + unit;
-            float pre[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int col = g * 16 + cu;
-                pre[g] = (((red[0][bl][col] + red[1][bl][col]) + (red[2][bl][col] + red[3][bl][col])) +
-                          ((red[4][bl][col] + red[5][bl][col]) + (red[6][bl][col] + red[7][bl][col]))) + xp[g];
-            }
             float* yo = y + ((long)t * B + cb_) * 2 * H + dir * H + unit;
             f32x4* go = (f32x4*)(gates + sidx * 4);
             float h = 0.f;
             if (active) {
-                const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
+                const float ig = actb[bl][cu], fg = actb[bl][16 + cu], gg = actb[bl][32 + cu], og = actb[bl][48 + cu];
                 const float c = fg * cstate + ig * gg;
                 h = og * tanhf(c);
                 *go = (f32x4){ig, fg, gg, og};
