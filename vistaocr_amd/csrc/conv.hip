@@ -666,31 +666,60 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void conv3x3_tail_kernel(const flo
 constexpr int WG_DYP = SEGW + 1;    // 33: odd pitch -> conflict-free reads across channels
 constexpr int WG_XCI = 3 * PROW + 1;  // 103
 
-__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+#ifndef VOCR_WGRAD_XCD
+#define VOCR_WGRAD_XCD 1
+#endif
+// TM = 32-channel dy fragments per wave: the workgroup tile is 64*TM output channels x 64 input channels x 9 taps; with TM = 2 a
+// halo fragment feeds two MFMAs and the x rows are staged once for 128 output channels (18 accumulators = 288 registers: one
+// wave per SIMD only, i.e. MODE 0 / 1).
+template <int MODE, int TM = 1>        // MODE 0: one LDS buffer, 1: two buffers, 2: two buffers + four loader waves (512 threads)
+__global__ __launch_bounds__(MODE == 2 ? 512 : 256) void conv3x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             float* __restrict__ slab,
                                                             const float* __restrict__ zero_page, int N, int Cin, int H,
                                                             int W, int Cout, SegGeom geo, int segs_per_split) {
-    __shared__ float dyT[64 * WG_DYP];
-    __shared__ float xp[64 * WG_XCI + 64];              // + dummy tail for lanes >= 34 (unconditional stores, see conv3x3_kernel)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // MODE 1: two LDS buffers; the 56 loads of segment g+1 are issued in ONE burst in front of the k-steps of segment g and
+    // stored into the idle buffer behind them (one barrier per segment).  Measured SLOWER than MODE 0 (769 vs 723 us on the
+    // 256->256 layer): what a segment pays outside its 144 MFMAs is not load latency but VMEM ISSUE - a CU takes one wave
+    // load per ~18 cycles once its queue is full, 224 dword loads per segment - and an in-order wave cannot issue MFMAs
+    // while it is stuck there, wherever the burst is placed.
+    // MODE 2: the issue moves to four LOADER waves (one per SIMD, waves 4-7): they fetch and stage segment g+1 while the
+    // four MFMA waves run nothing but fragment reads and MFMAs on segment g; one barrier per segment joins them.
+    constexpr bool DB = MODE >= 1, PC = MODE == 2;
+    constexpr int NB = DB ? 2 : 1;
+    constexpr int COT = 64 * TM;                        // output channels per workgroup
+    constexpr int XPB = 64 * WG_XCI + 64;               // + dummy tail for lanes >= 34 (unconditional stores, see conv3x3_kernel)
+    __shared__ float dyT[NB * COT * WG_DYP];
+    __shared__ float xp[NB * XPB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = !PC || wave_all >= 4, mfma_wave = !PC || wave_all < 4;
+    const int wave = wave_all & 3;                      // role-local wave index
     const int li = lane & 31, lk = lane >> 5;
-    const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64, split = blockIdx.z;
-    const int wco = (wave >> 1) * 32, wci = (wave & 1) * 32;
+    // Workgroup -> (channel tile, split): the 16 (ci, co) tiles of one split read the same pixels of x and dy, so they are
+    // placed on ONE XCD (linear id b runs on XCD b % 8): a line then comes from HBM / Infinity Cache once and from that
+    // XCD's L2 for the other tiles.  (The loads of a segment are bound by line fetches: ~64 outstanding per CU x latency.)
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (VOCR_WGRAD_XCD && (gridDim.z & 7) == 0) {
+        const int nxy = gridDim.x * gridDim.y;
+        const int b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int k = b & 7, slot = b >> 3;
+        bz = k + 8 * (slot / nxy);
+        const int xy = slot - (slot / nxy) * nxy;
+        bx = xy % gridDim.x;
+        by = xy / gridDim.x;
+    }
+    static_assert(TM == 1 || MODE != 2, "18 accumulators do not fit two waves per SIMD");
+    const int ci0 = bx * 64, co0 = by * COT, split = bz;
+    const int wco = (wave >> 1) * 32 * TM, wci = (wave & 1) * 32;
     const long HW = (long)H * W;
 
-    f32x16 acc[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-    constexpr int EDY = 64 * SEGW / 256;               // 8
+    constexpr int EDY = COT * SEGW / 256;              // 8 per 64 channels
     float rdy[EDY], rx[48];
 
     const int nseg_total = geo.nseg;
     const int sbeg = split * segs_per_split;
     const int send = min(nseg_total, sbeg + segs_per_split);
-    const int dpx = tid & 31, dco = tid >> 5;           // dy loader: 32 lane positions x 8 channels per pass
+    const int dpx = tid & 31, dco = (tid & 255) >> 5;   // dy loader: 32 lane positions x 8 channels per pass
 
     // Loader: 32-bit element offsets from the tensor bases (host guarantees < 2^31 elements); everything that does not
     // depend on the segment is hoisted; the per-segment part is three scalars.  The 56 loads of segment g+1 are issued in
@@ -719,6 +748,9 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restr
     struct SegPos { int dy_off; int x_off[3]; float dy_ok; float row_ok[3]; };
     auto seg_pos = [&](int g) {
         SegPos p;
+#ifdef VOCR_WGRAD_SAMESEG       // diagnostic: every segment reads the same lines (is the loader bound by line fetches or by issue?)
+        g = sbeg;
+#endif
         const SegInfo sg = seg_decode(g, geo, H, 0);
         const int n = sg.n, h = sg.h, w0 = sg.w0;
         // dy sits at its lane POSITION (sub-row dr, column dc of the segment; gaps between sub-rows hold zeros), so that
@@ -740,7 +772,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restr
         return p;
     };
     // slice q (0..15) of the loads of one segment: dy pass q/2 (even q) and x rows [3q, 3q+3)
-    auto load_slice = [&](const SegPos& p, int q) {
+    auto load_slice_into = [&](const SegPos& p, int q, float* rdy, float* rx) {
         if ((q & 1) == 0) rdy[q >> 1] = dy_cb[q >> 1][p.dy_off];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -748,9 +780,20 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restr
             rx[r] = x_cb[r / 3][p.x_off[r % 3]];
         }
     };
-    auto store_seg = [&](const SegPos& p) {
+    auto load_slice = [&](const SegPos& p, int q) { load_slice_into(p, q, rdy, rx); };
+    auto store_seg_from = [&](const SegPos& p, int buf, const float* rdy, const float* rx) {
+        float* const dyTb = dyT + buf * (COT * WG_DYP);
+        float* const xpb = xp + buf * XPB;
 #pragma unroll
-        for (int e = 0; e < EDY; ++e) dyT[(dco + 8 * e) * WG_DYP + dpx] = rdy[e] * (dy_m[e] * p.dy_ok);
+        for (int e = 0; e < EDY; ++e) dyTb[(dco + 8 * e) * WG_DYP + dpx] = rdy[e] * (dy_m[e] * p.dy_ok);
+        if (DB) {               // unconditional stores (lanes >= 34 hit the dummy tail): the loads stay where they were issued
+#pragma unroll
+            for (int ci = 0; ci < 16; ++ci)
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+                    xpb[lane < PROW ? (wave * 16 + ci) * WG_XCI + kh * PROW + lane : 64 * WG_XCI + lane] = rx[ci * 3 + kh] * (x_m[ci] * p.row_ok[kh]);
+            return;
+        }
         // NOTE: with the stores under `if (lane < PROW)` LLVM sinks the 48 x loads of load_slice into this block, i.e. they
         // are issued in one burst behind the end-of-segment barrier.  That is the FASTER arrangement here (725 vs 780 us on
         // the 256->256 layer with the loads kept between the k-steps): this kernel runs one wave per SIMD, so every VMEM
@@ -760,57 +803,206 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restr
             for (int ci = 0; ci < 16; ++ci)
 #pragma unroll
                 for (int kh = 0; kh < 3; ++kh)
-                    xp[(wave * 16 + ci) * WG_XCI + kh * PROW + lane] = rx[ci * 3 + kh] * (x_m[ci] * p.row_ok[kh]);
+                    xpb[(wave * 16 + ci) * WG_XCI + kh * PROW + lane] = rx[ci * 3 + kh] * (x_m[ci] * p.row_ok[kh]);
         }
     };
+    auto store_seg = [&](const SegPos& p, int buf) { store_seg_from(p, buf, rdy, rx); };
 
-    if (sbeg < send) {
+    if (PC && !mfma_wave) {
+        // Loader role (waves 4-7), kept apart from the MFMA role's code so that the accumulators are not live here.
+        // What was measured on the way (s_memtime stamps, scripts/wgrad_stamp.hip; 256->256 layer; wait of the MFMA waves per
+        // segment beside 8900 cycles of MFMAs): 56 dword loads per loader wave 3450; 34 dword loads (this form) 2550; 10
+        // 16-byte loads 3900; 34 loads that all hit one L1 line 1530; 34 LDS READS instead of the loads 2800; the whole
+        // address arithmetic and all LDS stores but no loads 70; scalar-only addressing (buffer loads, no VALU) 3700;
+        // all 16 tiles of a split on one XCD -1 %; LDS-DMA gather (global_load_lds_dword, 35 per wave) 10800.  So neither
+        // instruction count, cache, VALU nor LDS-store issue is the limit: beside a wave that keeps the matrix pipe full,
+        // data RETURNING to the partner wave (VMEM or LDS, into VGPRs or as DMA) arrives about once per 300 cycles per
+        // SIMD; the loader is bound by the number of registers it has to receive (34 x 300 > 8900), the MFMA wave's
+        // own fragment reads are not.  What helps is fewer returned registers: a halo row is 34 floats = 34 of 64 lanes,
+        // so two rows' first 32 columns share one load (lanes 0-31: channel c, lanes 32-63: channel c + 8) and the two
+        // right-hand halo columns of all 48 rows take two more: 26 instead of 48 x loads.
+        // Software pipeline over two register sets: the loads of segment g+2 are in flight while segment g+1 is written
+        // to LDS and while this wave waits at the barrier.
+        const int nsegs = send - sbeg;
+        const int half = lane >> 5, q32 = lane & 31;
+        int cbv[8];
+        float xmv[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int gci = ci0 + wave * 16 + c + 8 * half;
+            cbv[c] = min(gci, Cin - 1) * (int)HW;
+            xmv[c] = gci < Cin ? 1.f : 0.f;
+        }
+        struct LPos { int r0, r1, r2, b0, h0, h1; float k0, k1, k2, dk, hk0, hk1; };
+        auto lpos = [&](int g) {
+            LPos p;
+#ifdef VOCR_WGRAD_SAMESEG
+            g = sbeg;
+#endif
+            const SegInfo sg = seg_decode(g, geo, H, 0);
+            const int n = sg.n, h = sg.h, w0 = sg.w0;
+            const int img = n * Cin * (int)HW;
+            const int dr = dpx / sg.pw, dc = dpx - dr * sg.pw;
+            p.dk = (dr < sg.rows && dc < sg.ow) ? 1.f : 0.f;
+            p.b0 = n * Cout * (int)HW + min(h + dr, H - 1) * W + min(w0 + dc, W - 1);
+            const int rr = q32 / sg.pw, cc = q32 - rr * sg.pw, ww = w0 - 1 + cc;
+            const bool colok = rr < sg.rows && ww >= 0 && ww < W;
+            const int loff = min(max(ww, 0), W - 1);
+            int ro[3], ho[2];
+            float rk[3], hk[2];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int hh = h + rr + kh - 1;
+                rk[kh] = (colok && hh >= 0 && hh < H) ? 1.f : 0.f;
+                ro[kh] = img + min(max(hh, 0), H - 1) * W + loff;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int t = lane + 64 * j, row = min(t >> 1, 47), ci = row / 3, kh = row - 3 * ci, qq = 32 + (t & 1);
+                const int rr2 = qq / sg.pw, cc2 = qq - rr2 * sg.pw, ww2 = w0 - 1 + cc2, hh = h + rr2 + kh - 1;
+                const int gci = ci0 + wave * 16 + ci;
+                hk[j] = (t < 96 && gci < Cin && rr2 < sg.rows && ww2 >= 0 && ww2 < W && hh >= 0 && hh < H) ? 1.f : 0.f;
+                ho[j] = img + min(gci, Cin - 1) * (int)HW + min(max(hh, 0), H - 1) * W + min(max(ww2, 0), W - 1);
+            }
+            p.r0 = ro[0]; p.r1 = ro[1]; p.r2 = ro[2]; p.k0 = rk[0]; p.k1 = rk[1]; p.k2 = rk[2];
+            p.h0 = ho[0]; p.h1 = ho[1]; p.hk0 = hk[0]; p.hk1 = hk[1];
+            return p;
+        };
+        // register set layout (34 floats): [0,8) dy, [8,32) x rows (r = 3*c + kh), [32,34) right-hand halo
+        auto lload = [&](const LPos& p, float* rs) {
+#pragma unroll
+            for (int e = 0; e < EDY; ++e) rs[e] = dy_cb[e][p.b0];
+#pragma unroll
+            for (int r = 0; r < 24; ++r) rs[8 + r] = x[(r % 3 == 0 ? p.r0 : r % 3 == 1 ? p.r1 : p.r2) + cbv[r / 3]];
+            rs[32] = x[p.h0];
+            rs[33] = x[p.h1];
+        };
+        auto lstore = [&](const LPos& p, int buf, const float* rs) {
+            float* const dyTb = dyT + buf * (COT * WG_DYP);
+            float* const xpb = xp + buf * XPB;
+#pragma unroll
+            for (int e = 0; e < EDY; ++e) dyTb[(dco + 8 * e) * WG_DYP + dpx] = rs[e] * (dy_m[e] * p.dk);
+#pragma unroll
+            for (int r = 0; r < 24; ++r)
+                xpb[(wave * 16 + r / 3 + 8 * half) * WG_XCI + (r % 3) * PROW + q32] = rs[8 + r] * (xmv[r / 3] * (r % 3 == 0 ? p.k0 : r % 3 == 1 ? p.k1 : p.k2));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int t = lane + 64 * j, row = min(t >> 1, 47), ci = row / 3, kh = row - 3 * ci;
+                xpb[t < 96 ? (wave * 16 + ci) * WG_XCI + kh * PROW + 32 + (t & 1) : 64 * WG_XCI + lane] = rs[32 + j] * (j == 0 ? p.hk0 : p.hk1);
+            }
+        };
+        float rsA[34], rsB[34];
+        LPos pa = lpos(sbeg), pb = lpos(min(sbeg + 1, send - 1));
+        if (nsegs > 0) {
+            lload(pa, rsA);
+            lload(pb, rsB);
+            lstore(pa, 0, rsA);
+        }
+        __syncthreads();
+        // invariant at the top of iteration i (segment sbeg+i being multiplied from buffer i&1): set B holds segment i+1
+        for (int i = 0; i < nsegs; i += 2) {
+            pa = lpos(min(sbeg + i + 2, send - 1));
+            lload(pa, rsA);                                                  // segment i+2 -> set A
+            if (i + 1 < nsegs) lstore(pb, 1, rsB);                          // segment i+1 -> buffer 1
+            __syncthreads();
+            if (i + 1 >= nsegs) break;
+            pb = lpos(min(sbeg + i + 3, send - 1));
+            lload(pb, rsB);                                                  // segment i+3 -> set B
+            if (i + 2 < nsegs) lstore(pa, 0, rsA);                          // segment i+2 -> buffer 0
+            __syncthreads();
+        }
+        return;
+    }
+    f32x16 acc[TM][9];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
+
+    if (sbeg < send && loader) {
         const SegPos p0 = seg_pos(sbeg);
 #pragma unroll
         for (int q = 0; q < 16; ++q) load_slice(p0, q);
-        store_seg(p0);
+        store_seg(p0, 0);
     }
     __syncthreads();
+#ifdef VOCR_CONV_STAMPS
+    unsigned long long m0, m1, m2, sm_k = 0, sm_bar = 0;
+#endif
     for (int g = sbeg; g < send; ++g) {
+#ifdef VOCR_CONV_STAMPS
+        VOCR_STAMP(m0);
+#endif
+        const int cur = DB ? ((g - sbeg) & 1) : 0;
         const SegPos pn = seg_pos(min(g + 1, send - 1));      // branch-free: the last iteration re-loads its own segment (unused)
-        const float* ap = dyT + (wco + li) * WG_DYP + lk;
-        const float* bp = xp + (wci + li) * WG_XCI + lk;
+        const float* ap = dyT + cur * (COT * WG_DYP) + (wco + li) * WG_DYP + lk;
+        const float* bp = xp + cur * XPB + (wci + li) * WG_XCI + lk;
+        if (DB && !PC) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) load_slice(pn, q);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         // fragment reads run one k-step ahead of their MFMAs (one wave per SIMD: nothing else hides the LDS latency)
-        float a = ap[0], b[9];
+        float a[TM], b[9];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = ap[32 * i * WG_DYP];
 #pragma unroll
         for (int t = 0; t < 9; ++t) b[t] = bp[(t / 3) * PROW + (t % 3)];
 #pragma unroll
         for (int ks = 0; ks < SEGW / 2; ++ks) {
-            load_slice(pn, ks);
-            float an = 0.f, bn[9];
+            if (!DB) load_slice(pn, ks);
+            float an[TM], bn[9];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) an[i] = 0.f;
 #pragma unroll
             for (int t = 0; t < 9; ++t) bn[t] = 0.f;
             if (ks + 1 < SEGW / 2) {
-                an = ap[2 * (ks + 1)];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) an[i] = ap[32 * i * WG_DYP + 2 * (ks + 1)];
 #pragma unroll
                 for (int t = 0; t < 9; ++t) bn[t] = bp[(t / 3) * PROW + (t % 3) + 2 * (ks + 1)];
             }
             __builtin_amdgcn_sched_barrier(0);      // loads of the next segment and next step's ds_reads stay above the MFMAs
 #pragma unroll
-            for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[t], acc[t], 0, 0, 0);
-            a = an;
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[t], acc[i][t], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = an[i];
 #pragma unroll
             for (int t = 0; t < 9; ++t) b[t] = bn[t];
         }
+#ifdef VOCR_CONV_STAMPS
+        VOCR_STAMP(m1);
+#endif
+        if (!DB) __syncthreads();
+        if (!PC) store_seg(pn, cur ^ (DB ? 1 : 0));
         __syncthreads();
-        store_seg(pn);
-        __syncthreads();
+#ifdef VOCR_CONV_STAMPS
+        VOCR_STAMP(m2);
+        sm_k += m1 - m0; sm_bar += m2 - m1;
+#endif
     }
+#ifdef VOCR_CONV_STAMPS
+    if (tid == 0 && g_stamp_out && blockIdx.x == 0 && blockIdx.y == 0) {
+        unsigned long long* o = g_stamp_out + (size_t)blockIdx.z * 8;
+        o[0] = sm_k; o[1] = sm_bar; o[2] = send - sbeg;
+    }
+#endif
     // slab[split][tap][co][ci]  (ci contiguous -> coalesced stores)
     const long plane = (long)Cout * Cin;
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co0 + wco + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            const int ci = ci0 + wci + li;
-            if (co < Cout && ci < Cin) slab[((long)split * 9 + t) * plane + (long)co * Cin + ci] = acc[t][r];
-        }
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wco + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const int ci = ci0 + wci + li;
+                if (co < Cout && ci < Cin) slab[((long)split * 9 + t) * plane + (long)co * Cin + ci] = acc[i][t][r];
+            }
 }
 
 // Weight gradient for Cin <= 3 (the first layer: grey or RGB lines).  The generic kernel would spend a 32-wide
@@ -911,7 +1103,20 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f16_kernel(const float* __r
     __shared__ __attribute__((aligned(16))) _Float16 xH[3 * 64 * 3 * WH_P];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lk = lane >> 5;
-    const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64, split = blockIdx.z;
+    // Workgroup -> (channel tile, split): the 16 (ci, co) tiles of one split read the same pixels of x and dy, so they are
+    // placed on ONE XCD (linear id b runs on XCD b % 8): a line then comes from HBM / Infinity Cache once and from that
+    // XCD's L2 for the other tiles.  (The loads of a segment are bound by line fetches: ~64 outstanding per CU x latency.)
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (VOCR_WGRAD_XCD && (gridDim.z & 7) == 0) {
+        const int nxy = gridDim.x * gridDim.y;
+        const int b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int k = b & 7, slot = b >> 3;
+        bz = k + 8 * (slot / nxy);
+        const int xy = slot - (slot / nxy) * nxy;
+        bx = xy % gridDim.x;
+        by = xy / gridDim.x;
+    }
+    const int ci0 = bx * 64, co0 = by * 64, split = bz;
     const int wco = (wave >> 1) * 32, wci = (wave & 1) * 32;
     const long HW = (long)H * W;
 
@@ -1104,10 +1309,17 @@ void launch_wgrad_reduce(const float* slab, float* dw, int cout, int cin, int sp
 }
 
 // f16 = the fp16-operand kernel, which still enumerates one segment per 32-pixel piece of a row
+// output channels per workgroup of the generic f32 kernel.  VOCR_WGRAD_TM=2 (experiment): 128, two dy fragments per wave -
+// measured 1117 vs 680 us on the 256->256 layer: 288 accumulator registers plus the staging registers spill.
+int wgrad_cot(int cin, int cout, bool f16 = false) {
+    static const int tm = getenv("VOCR_WGRAD_TM") ? atoi(getenv("VOCR_WGRAD_TM")) : 1;
+    return (!f16 && cin > 3 && cout >= 128 && tm == 2) ? 128 : 64;
+}
+
 int wgrad_splits(int n, int cin, int h, int w, int cout, int* segs_per_split, bool f16 = false) {
     const int SW = vocr_cdiv(w, SEGW);
     const long nseg = (cin <= 3 || f16) ? (long)n * h * SW : (long)seg_geom(n, h, w).nseg;
-    const int tiles = (cin <= 3 ? 1 : vocr_cdiv(cin, 64)) * vocr_cdiv(cout, 64);
+    const int tiles = (cin <= 3 ? 1 : vocr_cdiv(cin, 64)) * vocr_cdiv(cout, wgrad_cot(cin, cout, f16));
     // the generic kernel holds one workgroup per CU (9 accumulators per wave): 256 slabs = one full round and a
     // 3x smaller slab than 768; the small-Cin kernel is light and streams, give it more
     // (capping the registers for two workgroups per CU spills 26 dwords per lane into the loop: 78-90 TF instead of 98-107)
@@ -1226,8 +1438,13 @@ extern "C" int vocr_conv3x3_wgrad(const float* x, const float* dy, float* dw, vo
         dim3 grid(1, vocr_cdiv(cout, 64), splits);
         conv3x3_wgrad_smallcin_kernel<<<grid, 128, 0, s>>>(x, dy, (float*)workspace, zp, n, cin, h, w, cout, SW, (int)nseg, sps);
     } else {
-        dim3 grid(vocr_cdiv(cin, 64), vocr_cdiv(cout, 64), splits);
-        conv3x3_wgrad_kernel<<<grid, 256, 0, s>>>(x, dy, (float*)workspace, zp, n, cin, h, w, cout, seg_geom(n, h, w), sps);
+        const int cot = wgrad_cot(cin, cout);
+        dim3 grid(vocr_cdiv(cin, 64), vocr_cdiv(cout, cot), splits);
+        static const int mode = getenv("VOCR_WGRAD_MODE") ? atoi(getenv("VOCR_WGRAD_MODE")) : 2;
+        if (cot == 128) conv3x3_wgrad_kernel<0, 2><<<grid, 256, 0, s>>>(x, dy, (float*)workspace, zp, n, cin, h, w, cout, seg_geom(n, h, w), sps);
+        else if (mode == 2) conv3x3_wgrad_kernel<2><<<grid, 512, 0, s>>>(x, dy, (float*)workspace, zp, n, cin, h, w, cout, seg_geom(n, h, w), sps);
+        else if (mode == 1) conv3x3_wgrad_kernel<1><<<grid, 256, 0, s>>>(x, dy, (float*)workspace, zp, n, cin, h, w, cout, seg_geom(n, h, w), sps);
+        else conv3x3_wgrad_kernel<0><<<grid, 256, 0, s>>>(x, dy, (float*)workspace, zp, n, cin, h, w, cout, seg_geom(n, h, w), sps);
     }
     VOCR_CHECK_LAUNCH("vocr_conv3x3_wgrad");
     launch_wgrad_reduce((const float*)workspace, dw, cout, cin, splits, s);
