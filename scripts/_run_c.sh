@@ -1,6 +1,5 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|FAILED|Error" | tail -5
-for i in 1 2; do python bench.py --no-cpu-baseline 2>/dev/null | python -c "
-import sys, json
-j = json.loads(sys.stdin.read().strip().splitlines()[-1])
-print(j['value'], j['ms_per_step'], 'h2d', j['h2d_inclusive']['ms_per_step'], 'conv', j['roofline']['achieved'], j['roofline']['frac'], j['ms_per_step_by_entry_point'])"; done
+export TMPDIR=/tmp
+mkdir -p gpurun_out/r02b
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r02b/trace -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/r02b/bench_profiled.json 2> gpurun_out/r02b/err.txt
+tail -c 600 gpurun_out/r02b/bench_profiled.json
