@@ -1,5 +1,4 @@
 cd $GRAFT_REPO_ROOT
-export TMPDIR=/tmp
-mkdir -p gpurun_out/r02b
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r02b/trace -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/r02b/bench_profiled.json 2> gpurun_out/r02b/err.txt
-tail -c 600 gpurun_out/r02b/bench_profiled.json
+python -m pytest tests/test_ops_gpu.py -q -m gpu -k "conv" 2>&1 | grep -E "passed|failed|Error" | tail -3
+SWEEP=0 python scripts/conv_bench.py
+echo "--- separate tail launch"; VOCR_CONV_TAIL=3 SWEEP=0 python scripts/conv_bench.py | tail -6

@@ -331,6 +331,103 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
 #endif
 }
 
+// ---------------------------------------------------------------- last partial round of the forward / data-gradient kernel
+// A launch of the kernel above takes ceil(workgroups / 256 CUs) rounds of equal length (scripts/conv_occ.py: a clean
+// staircase), so the 32 workgroups left over from 2080 cost the 7x294 layers a ninth round with 7/8 of the chip idle
+// (-8.7 % over the forward stack with the partial round simply dropped).  Those leftover workgroup tiles are computed here
+// instead, cut into their 32-channel x 32-pixel MFMA tiles (8 or 16 per workgroup tile -> 256+ pieces = every CU busy for
+// one short round).  One piece = one workgroup of 8 waves that split K: wave w and lane half lk take input channels
+// 2*(8*s + w) + lk, s = 0, 1, ...; operands go global -> register -> MFMA directly (the weight pack row and the halo
+// row are both 32 consecutive floats: two coalesced 128-byte reads per MFMA, all L2 hits), three steps of 9 taps in
+// flight; the eight partial tiles are added through LDS in a fixed order (deterministic; the summation order differs
+// from the main kernel's single accumulator, like any other tiling change).
+// One piece, computed by a workgroup of TAIL_WAVES waves; red = TAIL_WAVES x 16 x 64 floats of LDS.  Called from the kernel of
+// its own below (8 waves) and from conv3x3_dma_kernel (4 waves: there the pieces are the FIRST workgroups of the launch, so
+// they run beside the first full tiles instead of in a round of their own after the last).
+template <int TAIL_WAVES>
+__device__ __forceinline__ void conv3x3_tail_piece(float* __restrict__ red_, int piece, const float* __restrict__ in,
+                                                   const float* __restrict__ wpack, const float* __restrict__ bias, float* __restrict__ out,
+                                                   const float* __restrict__ zero_page, int Cin, int H, int W, int Cout,
+                                                   const SegGeom& geo, int co_tiles, int co_t, int nseg_wg, int first_tile) {
+    float (*red)[16][64] = (float (*)[16][64])red_;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lk = lane >> 5;
+    const int cosub = co_t / 32, ppw = cosub * nseg_wg;
+    const int v = first_tile + piece / ppw, sub = piece % ppw;
+    const int co_base = (v % co_tiles) * co_t + (sub % cosub) * 32;
+    const SegInfo sg = seg_decode((v / co_tiles) * nseg_wg + sub / cosub, geo, H, 0);
+    if (!sg.valid || co_base >= Cout) return;                           // whole workgroup: no barrier is skipped by part of it
+    const long HW = (long)H * W;
+    const int rr = li / sg.pw, cc = li - rr * sg.pw;
+    const bool pix_ok = rr < sg.rows && cc < sg.ow;                     // lane position li is an output pixel
+    // the nine taps of this lane's pixel: offsets inside a channel plane (clamped) and 0/1 masks
+    int toff[9];
+    float tm[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int hh = sg.h + rr + t / 3 - 1, ww = sg.w0 + cc + t % 3 - 1;
+        tm[t] = (rr < sg.rows && cc < sg.pw && hh >= 0 && hh < H && ww >= 0 && ww < W) ? 1.f : 0.f;
+        toff[t] = min(max(hh, 0), H - 1) * W + min(max(ww, 0), W - 1);
+    }
+    const float* xin = in + (long)sg.n * Cin * HW;
+    const int co = co_base + li;
+    const bool co_ok = co < Cout;
+    const int nsteps = (Cin + 2 * TAIL_WAVES - 1) / (2 * TAIL_WAVES);
+    constexpr int DEPTH = 3;
+    float a[DEPTH][9], b[DEPTH][9];
+    auto loads = [&](int s, float (&av)[9], float (&bv)[9]) {
+        const int ci = 2 * (TAIL_WAVES * s + wave) + lk;
+        const bool ok = ci < Cin && s < nsteps;
+        const float* wrow = (ok && co_ok) ? wpack + (long)ci * 9 * Cout + co : zero_page;
+        const long wstride = (ok && co_ok) ? Cout : 0;
+        const float* xc = xin + (long)min(ci, Cin - 1) * HW;
+        const float cm = ok ? 1.f : 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            av[t] = wrow[t * wstride];
+            bv[t] = xc[toff[t]] * (tm[t] * cm);
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) loads(d, a[d], b[d]);
+    for (int s0 = 0; s0 < nsteps; s0 += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            if (s0 + d < nsteps) {                                                       // wave-uniform
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[d][t], b[d][t], acc, 0, 0, 0);
+                loads(s0 + d + DEPTH, a[d], b[d]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+    // thread (wave, lane) finishes 16 / TAIL_WAVES registers of lane's column
+#pragma unroll
+    for (int q = 0; q < 16 / TAIL_WAVES; ++q) {
+        const int r = (16 / TAIL_WAVES) * wave + q;
+        float sum = 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < TAIL_WAVES; ++w8) sum += red[w8][r][lane];
+        const int oc = co_base + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (pix_ok && oc < Cout)
+            out[(long)sg.n * Cout * HW + (long)oc * HW + (long)(sg.h + rr) * W + sg.w0 + cc] = sum + (bias ? bias[oc] : 0.f);
+    }
+}
+
+__global__ __launch_bounds__(512) void conv3x3_tail_kernel(const float* __restrict__ in, const float* __restrict__ wpack,
+                                                           const float* __restrict__ bias, float* __restrict__ out,
+                                                           const float* __restrict__ zero_page, int Cin, int H, int W, int Cout,
+                                                           SegGeom geo, int co_tiles, int co_t, int nseg_wg, int first_tile) {
+    __shared__ float red[8 * 16 * 64];
+    conv3x3_tail_piece<8>(red, blockIdx.x, in, wpack, bias, out, zero_page, Cin, H, W, Cout, geo, co_tiles, co_t, nseg_wg, first_tile);
+}
+
 // ---------------------------------------------------------------- forward / data gradient, LDS-DMA form
 // Same implicit GEMM, same tiles and segments as conv3x3_kernel; what changes is how the operands reach LDS.  Phase stamps of
 // conv3x3_kernel (scripts/conv_stamp.hip) showed a workgroup spending 14-18 % of its life in store_chunk - 37 KB of packed
@@ -354,7 +451,7 @@ template <int CO_T, int SPWV, int WCO>
 __global__ __launch_bounds__(256) void conv3x3_dma_kernel(const float* __restrict__ in, const float* __restrict__ wpack,
                                                           const float* __restrict__ bias, float* __restrict__ out,
                                                           const float* __restrict__ zero_page, int N, int Cin, int H, int W,
-                                                          int Cout, SegGeom geo, int co_tiles) {
+                                                          int Cout, SegGeom geo, int co_tiles, int n_tail, int first_tail_tile) {
     constexpr int WAVES_CO = CO_T / WCO;
     constexpr int WAVES_PX = 4 / WAVES_CO;
     constexpr int TM = WCO / 32;
@@ -376,10 +473,14 @@ __global__ __launch_bounds__(256) void conv3x3_dma_kernel(const float* __restric
     constexpr int DUMMY = 2 * PBUF;                          // offset into P of the dummy tail
     int* const segw = (int*)(lds + 2 * WBUF + 2 * PBUF + 64);
 
+    if ((int)blockIdx.x < n_tail) {                          // pieces of the last partial round of tiles (conv3x3_tail_piece)
+        conv3x3_tail_piece<4>(lds, blockIdx.x, in, wpack, bias, out, zero_page, Cin, H, W, Cout, geo, co_tiles, CO_T, NSEG, first_tail_tile);
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lk = lane >> 5;
-    const int v = xcd_slice_order(blockIdx.x, gridDim.x);
+    const int v = xcd_slice_order(blockIdx.x - n_tail, gridDim.x - n_tail);
     const int co0 = (v % co_tiles) * CO_T;
     const int seg0 = (v / co_tiles) * NSEG;
     const long HW = (long)H * W;
@@ -574,92 +675,6 @@ __global__ __launch_bounds__(256) void conv3x3_dma_kernel(const float* __restric
         o[0] = st_end - st_begin; o[1] = sum_k; o[2] = sum_bar; o[3] = sum_st; o[4] = sum_issue; o[5] = st_pro - st_begin; o[6] = st_end - st_loop_end;
     }
 #endif
-}
-
-// ---------------------------------------------------------------- last partial round of the forward / data-gradient kernel
-// A launch of the kernel above takes ceil(workgroups / 256 CUs) rounds of equal length (scripts/conv_occ.py: a clean
-// staircase), so the 32 workgroups left over from 2080 cost the 7x294 layers a ninth round with 7/8 of the chip idle
-// (-8.7 % over the forward stack with the partial round simply dropped).  Those leftover workgroup tiles are computed here
-// instead, cut into their 32-channel x 32-pixel MFMA tiles (8 or 16 per workgroup tile -> 256+ pieces = every CU busy for
-// one short round).  One piece = one workgroup of 8 waves that split K: wave w and lane half lk take input channels
-// 2*(8*s + w) + lk, s = 0, 1, ...; operands go global -> register -> MFMA directly (the weight pack row and the halo
-// row are both 32 consecutive floats: two coalesced 128-byte reads per MFMA, all L2 hits), three steps of 9 taps in
-// flight; the eight partial tiles are added through LDS in a fixed order (deterministic; the summation order differs
-// from the main kernel's single accumulator, like any other tiling change).
-constexpr int TAIL_WAVES = 8;
-__global__ __launch_bounds__(64 * TAIL_WAVES) void conv3x3_tail_kernel(const float* __restrict__ in, const float* __restrict__ wpack,
-                                                                       const float* __restrict__ bias, float* __restrict__ out,
-                                                                       const float* __restrict__ zero_page, int Cin, int H, int W, int Cout,
-                                                                       SegGeom geo, int co_tiles, int co_t, int nseg_wg, int first_tile) {
-    __shared__ float red[TAIL_WAVES][16][64];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31, lk = lane >> 5;
-    const int cosub = co_t / 32, ppw = cosub * nseg_wg;
-    const int v = first_tile + blockIdx.x / ppw, sub = blockIdx.x % ppw;
-    const int co_base = (v % co_tiles) * co_t + (sub % cosub) * 32;
-    const SegInfo sg = seg_decode((v / co_tiles) * nseg_wg + sub / cosub, geo, H, 0);
-    if (!sg.valid || co_base >= Cout) return;                           // whole workgroup: no barrier is skipped by part of it
-    const long HW = (long)H * W;
-    const int rr = li / sg.pw, cc = li - rr * sg.pw;
-    const bool pix_ok = rr < sg.rows && cc < sg.ow;                     // lane position li is an output pixel
-    // the nine taps of this lane's pixel: offsets inside a channel plane (clamped) and 0/1 masks
-    int toff[9];
-    float tm[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int hh = sg.h + rr + t / 3 - 1, ww = sg.w0 + cc + t % 3 - 1;
-        tm[t] = (rr < sg.rows && cc < sg.pw && hh >= 0 && hh < H && ww >= 0 && ww < W) ? 1.f : 0.f;
-        toff[t] = min(max(hh, 0), H - 1) * W + min(max(ww, 0), W - 1);
-    }
-    const float* xin = in + (long)sg.n * Cin * HW;
-    const int co = co_base + li;
-    const bool co_ok = co < Cout;
-    const int nsteps = (Cin + 2 * TAIL_WAVES - 1) / (2 * TAIL_WAVES);
-    constexpr int DEPTH = 3;
-    float a[DEPTH][9], b[DEPTH][9];
-    auto loads = [&](int s, float (&av)[9], float (&bv)[9]) {
-        const int ci = 2 * (TAIL_WAVES * s + wave) + lk;
-        const bool ok = ci < Cin && s < nsteps;
-        const float* wrow = (ok && co_ok) ? wpack + (long)ci * 9 * Cout + co : zero_page;
-        const long wstride = (ok && co_ok) ? Cout : 0;
-        const float* xc = xin + (long)min(ci, Cin - 1) * HW;
-        const float cm = ok ? 1.f : 0.f;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            av[t] = wrow[t * wstride];
-            bv[t] = xc[toff[t]] * (tm[t] * cm);
-        }
-    };
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) loads(d, a[d], b[d]);
-    for (int s0 = 0; s0 < nsteps; s0 += DEPTH) {
-#pragma unroll
-        for (int d = 0; d < DEPTH; ++d) {
-            if (s0 + d < nsteps) {                                                       // wave-uniform
-#pragma unroll
-                for (int t = 0; t < 9; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[d][t], b[d][t], acc, 0, 0, 0);
-                loads(s0 + d + DEPTH, a[d], b[d]);
-            }
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
-    __syncthreads();
-    // thread (wave, lane) finishes registers 2*wave, 2*wave + 1 of lane's column
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int r = 2 * wave + q;
-        float sum = 0.f;
-#pragma unroll
-        for (int w8 = 0; w8 < TAIL_WAVES; ++w8) sum += red[w8][r][lane];
-        const int oc = co_base + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (pix_ok && oc < Cout)
-            out[(long)sg.n * Cout * HW + (long)oc * HW + (long)(sg.h + rr) * W + sg.w0 + cc] = sum + (bias ? bias[oc] : 0.f);
-    }
 }
 
 // ---------------------------------------------------------------- weight gradient
@@ -1386,8 +1401,9 @@ extern "C" int vocr_conv3x3_fwd(const float* x, const float* wpack, const float*
     // load -> land -> store latency (an LDS-DMA takes ~1.1 us from issue to landed) sits on the critical path of every
     // half-chunk instead of hiding behind the issuing wave's own MFMAs; a third buffer does not fit three workgroups per CU.)
     static const int use_dma = getenv("VOCR_CONV_DMA") ? atoi(getenv("VOCR_CONV_DMA")) : 1;
-    // VOCR_CONV_TAIL: 1 (default) the last partial round goes to conv3x3_tail_kernel, 0 one launch as before,
-    // 2 EXPERIMENT (wrong results): the partial round is dropped - the upper bound of what the tail kernel can buy
+    // VOCR_CONV_TAIL: 1 (default) the last partial round of tiles is cut into pieces that lead the same launch, 3 the pieces
+    // run as conv3x3_tail_kernel behind the launch, 0 one launch of whole tiles as before,
+    // 2 EXPERIMENT (wrong results): the partial round is dropped - the upper bound of what the pieces can buy
     static const int tail_mode = getenv("VOCR_CONV_TAIL") ? atoi(getenv("VOCR_CONV_TAIL")) : 1;
     const int ncu = conv_cu_count();
     if (use_dma && vec && !tiny) {
@@ -1397,9 +1413,10 @@ extern "C" int vocr_conv3x3_fwd(const float* x, const float* wpack, const float*
             const int tiles = vocr_cdiv(nseg, NSEG) * co_tiles, rem = tiles % ncu;                                         \
             const bool cut = tail_mode && tiles > ncu && rem > 0 && rem <= ncu / 2;                                        \
             const int n_main = cut ? tiles - rem : tiles;                                                                   \
-            conv3x3_dma_kernel<CO_T, SPWV, 64><<<dim3(n_main), 256, lds_pad, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, geo, co_tiles);   \
-            if (cut && tail_mode == 1)                                                                                      \
-                conv3x3_tail_kernel<<<dim3(rem * (CO_T / 32) * NSEG), 64 * TAIL_WAVES, 0, s>>>(x, wpack, bias, y, zp, cin, h, w, cout, geo, co_tiles, CO_T, NSEG, n_main); \
+            const int n_tail = (cut && tail_mode == 1) ? rem * (CO_T / 32) * NSEG : 0;                                       \
+            conv3x3_dma_kernel<CO_T, SPWV, 64><<<dim3(n_tail + n_main), 256, lds_pad, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, geo, co_tiles, n_tail, n_main);   \
+            if (cut && tail_mode == 3)                                                                                      \
+                conv3x3_tail_kernel<<<dim3(rem * (CO_T / 32) * NSEG), 512, 0, s>>>(x, wpack, bias, y, zp, cin, h, w, cout, geo, co_tiles, CO_T, NSEG, n_main); \
         } while (0)
         if (cout > 64) {
             if (small) VOCR_CONV_DMA_LAUNCH(128, 1, 2); else VOCR_CONV_DMA_LAUNCH(128, 2, 4);
