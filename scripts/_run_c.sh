@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_ops_gpu.py -q -m gpu -k "conv" 2>&1 | grep -E "passed|failed|Error" | tail -3
-SWEEP=0 python scripts/conv_bench.py
-echo "--- separate tail launch"; VOCR_CONV_TAIL=3 SWEEP=0 python scripts/conv_bench.py | tail -6
+export TMPDIR=/tmp
+mkdir -p gpurun_out/r02c
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r02c/trace -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/r02c/bench_profiled.json 2> gpurun_out/r02c/err.txt
