@@ -171,3 +171,38 @@ def test_textutils_and_edit_distance_kat():
     assert cer == 0.25 and wer == 0.5
     import vistaocr_amd as va
     assert tu.form_target_transcription([1, 2, 63], va.english_alphabet()) == "u0061 u0062 u0020"
+
+
+def test_optimizer_state_moves_between_flat_adam_and_torch_adam():
+    """The 'optimizer' entry of a snapshot (src/train_cnn_lstm.py:429 stores torch.optim.Adam's state_dict): FlatClampAdam writes and
+    reads that format, so its moments load into a torch.optim.Adam over the same model and the other way round."""
+    import vistaocr_amd as va
+    kw = dict(alphabet=va.english_alphabet(), gpu=False, verbose=False, input_line_height=30, rds_line_height=30, lstm_input_dim=16,
+              num_lstm_layers=1, num_lstm_hidden_units=16, p_lstm_dropout=0.0)
+    torch.manual_seed(0)
+    ma, mb = va.CnnOcrModel(**kw), va.CnnOcrModel(**kw)
+    flat = va.FlatClampAdam(ma.parameters(), lr=3e-4, weight_decay=1e-5)
+    flat.step_count = 7
+    flat.exp_avg.copy_(torch.arange(flat.exp_avg.numel(), dtype=torch.float32) * 1e-3)
+    flat.exp_avg_sq.copy_(torch.arange(flat.exp_avg_sq.numel(), dtype=torch.float32) * 1e-6 + 1.0)
+    sd = flat.state_dict()
+    assert set(sd) == {"state", "param_groups"} and sd["param_groups"][0]["params"] == list(range(len(list(ma.parameters()))))
+    adam = torch.optim.Adam(mb.parameters(), lr=1e-3)
+    adam.load_state_dict(sd)                                            # torch's own loader accepts it
+    assert adam.param_groups[0]["lr"] == 3e-4 and adam.param_groups[0]["weight_decay"] == 1e-5
+    off = 0
+    for p in mb.parameters():
+        st = adam.state[p]
+        assert float(st["step"]) == 7.0
+        assert torch.equal(st["exp_avg"].reshape(-1), flat.exp_avg[off:off + p.numel()])
+        assert torch.equal(st["exp_avg_sq"].reshape(-1), flat.exp_avg_sq[off:off + p.numel()])
+        off += p.numel()
+    # and back: a torch.optim.Adam state into a fresh FlatClampAdam
+    mc = va.CnnOcrModel(**kw)
+    flat2 = va.FlatClampAdam(mc.parameters(), lr=1e-3)
+    flat2.load_state_dict(adam.state_dict())
+    assert flat2.step_count == 7 and flat2.param_groups[0]["lr"] == 3e-4
+    assert torch.equal(flat2.exp_avg, flat.exp_avg) and torch.equal(flat2.exp_avg_sq, flat.exp_avg_sq)
+    # round-1 snapshots (flat moments) still load
+    flat2.load_state_dict(dict(step=3, exp_avg=flat.exp_avg * 2, exp_avg_sq=flat.exp_avg_sq, param_groups=[dict(lr=5e-4)]))
+    assert flat2.step_count == 3 and flat2.param_groups[0]["lr"] == 5e-4

@@ -123,13 +123,44 @@ class FlatClampAdam(object):
         ops.check_health(ops.health(self.flat_g.device).cpu().tolist())
 
     def state_dict(self):
-        return dict(step=self.step_count, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, param_groups=self.param_groups)
+        """In torch.optim.Adam's own format ({'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [...]}, the
+        parameters numbered in model.parameters() order), so the 'optimizer' entry of a snapshot (src/train_cnn_lstm.py:429)
+        loads into a torch.optim.Adam over the same model and vice versa.  The moments are views of the flat buffers."""
+        g = self.param_groups[0]
+        state, off = {}, 0
+        for i, p in enumerate(self.params):
+            k = p.numel()
+            state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": self.exp_avg[off:off + k].view_as(p),
+                        "exp_avg_sq": self.exp_avg_sq[off:off + k].view_as(p)}
+            off += k
+        group = {"lr": g["lr"], "betas": tuple(g["betas"]), "eps": g["eps"], "weight_decay": g["weight_decay"], "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "decoupled_weight_decay": False, "clamp": g["clamp"], "params": list(range(len(self.params)))}
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
-        self.step_count = int(sd["step"])
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
-        self.param_groups[0].update({k: v for k, v in sd["param_groups"][0].items()})
+        if "state" not in sd:                                         # round-1 snapshots: flat moments
+            self.step_count = int(sd["step"])
+            self.exp_avg.copy_(sd["exp_avg"])
+            self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+            self.param_groups[0].update({k: v for k, v in sd["param_groups"][0].items()})
+            return
+        if sd["state"] and len(sd["state"]) != len(self.params):
+            raise ValueError("optimizer state has %d parameters, the model %d" % (len(sd["state"]), len(self.params)))
+        off = 0
+        with torch.no_grad():
+            for i, p in enumerate(self.params):
+                k = p.numel()
+                st = sd["state"].get(i)
+                if st is not None:
+                    self.exp_avg[off:off + k].copy_(st["exp_avg"].reshape(-1))
+                    self.exp_avg_sq[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
+                    self.step_count = int(float(st["step"]))
+                off += k
+        g = sd["param_groups"][0]
+        for key in ("lr", "betas", "eps", "weight_decay", "clamp"):
+            if key in g:
+                self.param_groups[0][key] = g[key]
 
 
 def make_optimizer(model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clamp=5.0):
