@@ -260,13 +260,13 @@ def run_rank(args):
     # on the stream they are launched on, in every 10th timed step (an event pair costs the queue a few microseconds of
     # overlap; 26 pairs per step slowed the step by 3-5 %); the full per-entry-point breakdown comes from a separate
     # un-timed pass below
-    CONV_FWD_ONLY = {"vocr_conv3x3_fwd": lambda a: a[2] is not None}
+    CONV_FWD_ONLY = {"vocr_conv3x3_fwd": lambda a: a[2] is not None, "vocr_conv3x3_wino_fwd": lambda a: a[2] is not None}
     _lib.enable_timing(CONV_FWD_ONLY)
     dt, final_loss = timed(batch_dev, args.steps, event_every=args.event_every)
-    conv_recs = _lib.timing_records().get("vocr_conv3x3_fwd", [])
+    conv_recs = _lib.timing_records().get("vocr_conv3x3_fwd", []) + _lib.timing_records().get("vocr_conv3x3_wino_fwd", [])
     _lib.enable_timing(None)
     dt_h2d, _ = timed(batch_host, args.steps)
-    names = ["vocr_conv3x3_fwd", "vocr_conv3x3_wgrad", "vocr_lstm_fwd", "vocr_lstm_fwd_range", "vocr_lstm_bwd_bias", "vocr_gemm",
+    names = ["vocr_conv3x3_fwd", "vocr_conv3x3_wino_fwd", "vocr_conv3x3_wgrad", "vocr_lstm_fwd", "vocr_lstm_fwd_range", "vocr_lstm_bwd_bias", "vocr_gemm",
              "vocr_bn_train_stats", "vocr_bn_relu_apply", "vocr_bn_relu_fracpool2x2_fwd", "vocr_bn_relu_bwd", "vocr_fracpool2x2_bwd",
              "vocr_ctc_loss_grad", "vocr_clamp_adam"]
     _lib.enable_timing(names)
@@ -291,7 +291,7 @@ def run_rank(args):
         cf_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in fwd_recs)
         n_launch = max(1, len(fwd_recs))
         achieved = cf_flops / (cf_ms * 1e-3) / 1e12 if cf_ms > 0 else 0.0
-        prof_conv = prof.get("vocr_conv3x3_fwd", [])
+        prof_conv = prof.get("vocr_conv3x3_fwd", []) + prof.get("vocr_conv3x3_wino_fwd", [])
         all_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in prof_conv)
         all_tf = sum(conv_flops(a) for a, _, _ in prof_conv) / (all_ms * 1e-3) / 1e12 if all_ms > 0 else 0.0
         per_step = len(prof_conv) // PROFILE_STEPS
@@ -317,7 +317,7 @@ def run_rank(args):
                        "final_loss": round(float(final_loss), 3)},
             "h2d_inclusive": {"value": round(B * world * args.steps / dt_h2d, 2), "ms_per_step": round(1000.0 * dt_h2d / args.steps, 3),
                               "what": "same K steps with the image batch in pinned host memory (H2D inside train())"},
-            "roofline": {"bound": "mfma", "kernel": "conv3x3_dma_kernel / conv3x3_kernel behind vocr_conv3x3_fwd (implicit GEMM, f32 MFMA 32x32x2), forward-pass launches",
+            "roofline": {"bound": "mfma", "kernel": "conv3x3_wino_kernel (F(2,3) along the row: 2/3 of the multiplications; first layer: conv3x3_kernel) behind vocr_conv3x3_wino_fwd / vocr_conv3x3_fwd, implicit GEMM on f32 MFMA 32x32x2, forward-pass launches; achieved = ALGORITHMIC direct-convolution FLOPs / time",
                          "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "avg_launch_ms": round(cf_ms / n_launch, 4), "launches_per_step": n_conv, "launches_timed": n_launch,

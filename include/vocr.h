@@ -49,6 +49,16 @@ int vocr_conv3x3_fwd(const float* x, const float* wpack, const float* bias, floa
 size_t vocr_conv3x3_wgrad_workspace_bytes(int n, int cin, int h, int w, int cout);
 int vocr_conv3x3_wgrad(const float* x, const float* dy, float* dw, void* workspace,
                        int n, int cin, int h, int w, int cout, void* stream);
+/* Same op with the minimal-filtering transform F(2,3) along the row (conv_wino.hip): fp32 operands and accumulation, 2/3 of the
+ * multiplications.  Weight packs hold the transformed filter rows: fwd [(ci*12 + kh*4 + x)][co], dgrad [(co*12 + kh*4 + x)][ci]
+ * (taps flipped), each followed by the direct pack's 9 rows per channel (used for the last partial round of tiles): cout*cin*21
+ * floats per pack (vocr_conv3x3_wino_pack_floats), 16-byte aligned.  Needs cin >= 4 and cout % 4 == 0
+ * (vocr_conv3x3_wino_supported).  dgrad = vocr_conv3x3_wino_fwd(dy, wpack_dgrad, NULL, dx, n, cout, h, w, cin). */
+int vocr_conv3x3_wino_supported(int cin, int cout);
+size_t vocr_conv3x3_wino_pack_floats(int cout, int cin);
+int vocr_conv3x3_wino_pack_weights(const float* w, float* wpack_fwd, float* wpack_dgrad, int cout, int cin, void* stream);
+int vocr_conv3x3_wino_fwd(const float* x, const float* wpack, const float* bias, float* y,
+                          int n, int cin, int h, int w, int cout, void* stream);
 /* fp16-operand variant (BASELINE config 5: "fp16 conv MFMA", fp32 accumulate): tensors stay fp32 in HBM, operands are
  * rounded to fp16 on the way into the matrix cores (v_mfma_f32_32x32x16_f16).  Weight packs are fp16:
  * fwd  [ceil(cin/16)][9][2][cout][8],  dgrad [ceil(cout/16)][9][2][cin][8] (taps flipped); sizes from *_pack_bytes.

@@ -1,9 +1,7 @@
 cd $GRAFT_REPO_ROOT
-python bench.py --no-cpu-baseline --hidden 256 2>/dev/null | python -c "
+python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|FAILED|Error" | tail -5
+SWEEP=0 python scripts/conv_bench.py | tail -7
+for i in 1 2; do python bench.py 2>/dev/null | python -c "
 import sys, json
-j = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('H=256:', j['value'], j['ms_per_step'])"
-python bench.py --no-cpu-baseline --conv-dtype fp16 2>/dev/null | python -c "
-import sys, json
-j = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('fp16 conv:', j['value'], j['ms_per_step'])"
-python scripts/decode_bench.py 2>&1 | tail -3
-python scripts/sync_step_bench.py 2>&1 | tail -3
+j = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print(j['value'], j['ms_per_step'], 'h2d', j['h2d_inclusive']['ms_per_step'], 'conv', j['roofline']['achieved'], j['roofline']['frac'], j['parity']['loss_rel_err'], j['parity']['label_mismatches'])"; done

@@ -12,6 +12,7 @@
 //   the pixel range is split over workgroups into slabs that a second kernel sums in a fixed order
 //   (bitwise reproducible, no float atomics).
 #include "vocr_common.h"
+#include "conv_tail.h"
 
 namespace {
 
@@ -41,7 +42,6 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
 // loaders' per-lane offsets and the store masks do.  (A remainder used to cost a whole segment per row: 8 % of the MFMA
 // work at W = 294, 6 % at W = 420.)
 struct SegGeom { int FS, RW, RR, per_img, nseg; };
-struct SegInfo { long base; int n; int h; int w0; int valid; int rows; int pw; int ow; };
 
 __host__ __device__ inline SegGeom seg_geom(int N, int H, int W) {
     SegGeom g;
@@ -349,75 +349,11 @@ __device__ __forceinline__ void conv3x3_tail_piece(float* __restrict__ red_, int
                                                    const float* __restrict__ wpack, const float* __restrict__ bias, float* __restrict__ out,
                                                    const float* __restrict__ zero_page, int Cin, int H, int W, int Cout,
                                                    const SegGeom& geo, int co_tiles, int co_t, int nseg_wg, int first_tile) {
-    float (*red)[16][64] = (float (*)[16][64])red_;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31, lk = lane >> 5;
     const int cosub = co_t / 32, ppw = cosub * nseg_wg;
     const int v = first_tile + piece / ppw, sub = piece % ppw;
     const int co_base = (v % co_tiles) * co_t + (sub % cosub) * 32;
     const SegInfo sg = seg_decode((v / co_tiles) * nseg_wg + sub / cosub, geo, H, 0);
-    if (!sg.valid || co_base >= Cout) return;                           // whole workgroup: no barrier is skipped by part of it
-    const long HW = (long)H * W;
-    const int rr = li / sg.pw, cc = li - rr * sg.pw;
-    const bool pix_ok = rr < sg.rows && cc < sg.ow;                     // lane position li is an output pixel
-    // the nine taps of this lane's pixel: offsets inside a channel plane (clamped) and 0/1 masks
-    int toff[9];
-    float tm[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int hh = sg.h + rr + t / 3 - 1, ww = sg.w0 + cc + t % 3 - 1;
-        tm[t] = (rr < sg.rows && cc < sg.pw && hh >= 0 && hh < H && ww >= 0 && ww < W) ? 1.f : 0.f;
-        toff[t] = min(max(hh, 0), H - 1) * W + min(max(ww, 0), W - 1);
-    }
-    const float* xin = in + (long)sg.n * Cin * HW;
-    const int co = co_base + li;
-    const bool co_ok = co < Cout;
-    const int nsteps = (Cin + 2 * TAIL_WAVES - 1) / (2 * TAIL_WAVES);
-    constexpr int DEPTH = 3;
-    float a[DEPTH][9], b[DEPTH][9];
-    auto loads = [&](int s, float (&av)[9], float (&bv)[9]) {
-        const int ci = 2 * (TAIL_WAVES * s + wave) + lk;
-        const bool ok = ci < Cin && s < nsteps;
-        const float* wrow = (ok && co_ok) ? wpack + (long)ci * 9 * Cout + co : zero_page;
-        const long wstride = (ok && co_ok) ? Cout : 0;
-        const float* xc = xin + (long)min(ci, Cin - 1) * HW;
-        const float cm = ok ? 1.f : 0.f;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            av[t] = wrow[t * wstride];
-            bv[t] = xc[toff[t]] * (tm[t] * cm);
-        }
-    };
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) loads(d, a[d], b[d]);
-    for (int s0 = 0; s0 < nsteps; s0 += DEPTH) {
-#pragma unroll
-        for (int d = 0; d < DEPTH; ++d) {
-            if (s0 + d < nsteps) {                                                       // wave-uniform
-#pragma unroll
-                for (int t = 0; t < 9; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[d][t], b[d][t], acc, 0, 0, 0);
-                loads(s0 + d + DEPTH, a[d], b[d]);
-            }
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
-    __syncthreads();
-    // thread (wave, lane) finishes 16 / TAIL_WAVES registers of lane's column
-#pragma unroll
-    for (int q = 0; q < 16 / TAIL_WAVES; ++q) {
-        const int r = (16 / TAIL_WAVES) * wave + q;
-        float sum = 0.f;
-#pragma unroll
-        for (int w8 = 0; w8 < TAIL_WAVES; ++w8) sum += red[w8][r][lane];
-        const int oc = co_base + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (pix_ok && oc < Cout)
-            out[(long)sg.n * Cout * HW + (long)oc * HW + (long)(sg.h + rr) * W + sg.w0 + cc] = sum + (bias ? bias[oc] : 0.f);
-    }
+    conv3x3_tail_piece_at<TAIL_WAVES>(red_, sg, co_base, in, wpack, bias, out, zero_page, Cin, H, W, Cout);
 }
 
 __global__ __launch_bounds__(512) void conv3x3_tail_kernel(const float* __restrict__ in, const float* __restrict__ wpack,

@@ -190,11 +190,27 @@ def forward_prep(conv_weights, lstm_layers, with_transposes):
 
 
 # ------------------------------------------------------------------------------------------------ conv + BN + ReLU
+_WINO = _os.environ.get("VOCR_CONV_WINO", "1") == "1"
+
+
+def _wino_ok(cin, cout):
+    """The F(2,3)-along-the-row kernel (conv_wino.hip) takes the layers with Cin >= 4 and Cout % 4 == 0."""
+    return _WINO and cin >= 4 and cout % 4 == 0
+
+
 def conv3x3_pack(weight):
+    """(pack_fwd, pack_dgrad) for conv3x3_forward.  Each pack is either the direct kernel's [(ci,kh,kw)][co] or the
+    transformed-filter pack of the F(2,3) kernel (12 rows per input channel, followed by the direct pack for its tail pieces);
+    conv3x3_forward tells them apart by shape."""
     cout, cin = weight.shape[0], weight.shape[1]
-    pf = torch.empty(cin * 9, cout, dtype=torch.float32, device=weight.device)
-    pd = torch.empty(cout * 9, cin, dtype=torch.float32, device=weight.device)
-    call("vocr_conv3x3_pack_weights", _p(weight), _p(pf), _p(pd), cout, cin, _stream())
+    dev = weight.device
+    wf, wd = _wino_ok(cin, cout), _wino_ok(cout, cin)
+    pf = torch.empty(cin * (21 if wf else 9), cout, dtype=torch.float32, device=dev)
+    pd = torch.empty(cout * (21 if wd else 9), cin, dtype=torch.float32, device=dev)
+    if wf or wd:
+        call("vocr_conv3x3_wino_pack_weights", _p(weight), _p(pf) if wf else None, _p(pd) if wd else None, cout, cin, _stream())
+    if not (wf and wd):
+        call("vocr_conv3x3_pack_weights", _p(weight), None if wf else _p(pf), None if wd else _p(pd), cout, cin, _stream())
     return pf, pd
 
 
@@ -218,7 +234,12 @@ def conv3x3_forward_f16(x, wpack16, bias, cout):
 def conv3x3_forward(x, wpack, bias, cout):
     n, cin, h, w = x.shape
     y = torch.empty(n, cout, h, w, dtype=torch.float32, device=x.device)
-    call("vocr_conv3x3_fwd", _p(x), _p(wpack), _p(bias), _p(y), n, cin, h, w, cout, _stream())
+    # the pack says which kernel it is for: 12 transformed + 9 direct rows per input channel (conv_wino.hip) or 9 taps (conv.hip);
+    # the shape survives save_for_backward, a Python attribute on the tensor would not
+    if wpack.dim() != 2 or wpack.shape[0] not in (9 * cin, 21 * cin) or wpack.shape[1] != cout:
+        raise ValueError("conv3x3_forward: weight pack %s does not fit cin=%d cout=%d" % (tuple(wpack.shape), cin, cout))
+    fn = "vocr_conv3x3_wino_fwd" if wpack.shape[0] == 21 * cin else "vocr_conv3x3_fwd"
+    call(fn, _p(x), _p(wpack), _p(bias), _p(y), n, cin, h, w, cout, _stream())
     return y
 
 
