@@ -59,6 +59,11 @@ size_t vocr_conv3x3_wino_pack_floats(int cout, int cin);
 int vocr_conv3x3_wino_pack_weights(const float* w, float* wpack_fwd, float* wpack_dgrad, int cout, int cin, void* stream);
 int vocr_conv3x3_wino_fwd(const float* x, const float* wpack, const float* bias, float* y,
                           int n, int cin, int h, int w, int cout, void* stream);
+/* Weight gradient with the transposed transform F(3,2) along the row (4 multiplications per column pair instead of 6): same
+ * contract as vocr_conv3x3_wgrad (own workspace size), needs cin >= 4. */
+size_t vocr_conv3x3_wgrad_wino_workspace_bytes(int n, int cin, int h, int w, int cout);
+int vocr_conv3x3_wgrad_wino(const float* x, const float* dy, float* dw, void* workspace,
+                            int n, int cin, int h, int w, int cout, void* stream);
 /* fp16-operand variant (BASELINE config 5: "fp16 conv MFMA", fp32 accumulate): tensors stay fp32 in HBM, operands are
  * rounded to fp16 on the way into the matrix cores (v_mfma_f32_32x32x16_f16).  Weight packs are fp16:
  * fwd  [ceil(cin/16)][9][2][cout][8],  dgrad [ceil(cout/16)][9][2][cin][8] (taps flipped); sizes from *_pack_bytes.

@@ -24,6 +24,8 @@ SIGNATURES = {
     "vocr_conv3x3_wino_pack_floats": (Z, [I, I]),
     "vocr_conv3x3_wino_pack_weights": (I, [P, P, P, I, I, P]),
     "vocr_conv3x3_wino_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "vocr_conv3x3_wgrad_wino_workspace_bytes": (Z, [I, I, I, I, I]),
+    "vocr_conv3x3_wgrad_wino": (I, [P, P, P, P, I, I, I, I, I, P]),
     "vocr_conv3x3_f16_pack_bytes": (Z, [I, I, I]),
     "vocr_conv3x3_f16_pack_weights": (I, [P, P, P, I, I, P]),
     "vocr_conv3x3_f16_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),

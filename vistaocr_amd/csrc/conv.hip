@@ -1284,6 +1284,12 @@ int wgrad_splits(int n, int cin, int h, int w, int cout, int* segs_per_split, bo
 
 }  // namespace
 
+// used by conv_wino.hip (same slab layout [split][tap][co][ci])
+void vocr_internal_wgrad_reduce(const float* slab, float* dw, int cout, int cin, int splits, hipStream_t s) {
+    launch_wgrad_reduce(slab, dw, cout, cin, splits, s);
+}
+
+
 extern "C" int vocr_conv3x3_pack_weights(const float* w, float* wpack_fwd, float* wpack_dgrad, int cout, int cin, void* stream) {
     VOCR_CHECK_ARG(w && (wpack_fwd || wpack_dgrad) && cout > 0 && cin > 0, "vocr_conv3x3_pack_weights: bad argument");
     const int total = cout * cin * 9;

@@ -271,6 +271,156 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const float* __res
         }
 }
 
+// ---------------------------------------------------------------- weight gradient, F(3,2) along the row
+// dw[co][ci][kh][kw] = sum over pixels of dy[co][h][w] * x[ci][h+kh-1][w+kw-1].  For a column PAIR (2p, 2p+1) the three taps kw
+// are the outputs of a 2-tap filter g = (dy[2p], dy[2p+1]) over d0..d3 = x columns 2p-1 .. 2p+2 - the transposed form of the
+// forward transform: 4 multiplications per pair, channel pair and kh instead of 6:
+//   a0 = g0   a1 = (g0+g1)/2   a2 = (g0-g1)/2   a3 = g1          b0 = d0 - d2   b1 = d1 + d2   b2 = d2 - d1   b3 = d3 - d1
+//   M_x += a_x * b_x  over all pairs                              dw(kw=0) = M0+M1+M2   dw(1) = M1-M2   dw(2) = M1+M2+M3
+// The output transform is linear, so it is applied once to the accumulators at the end.  A workgroup (4 waves) owns 64 output x 64
+// input channels and a range of 64-pixel row segments; a wave holds 3 kh x 4 accumulator tiles (192 registers: one wave per SIMD).
+// Per segment: barrier, one burst of loads (dy 64x64, x 64 channels x 3 rows x 66 columns split into even / odd columns), LDS
+// stores, barrier, 16 k-steps of 12 MFMAs.  (Loads beside running MFMAs are throttled on this chip - see conv.hip's weight-gradient
+// kernel - so the burst sits between the k-loops on purpose.)
+constexpr int GW_DYP = 65;                 // dy row pitch (odd: conflict-free across channels)
+constexpr int GW_XCI = 3 * PRW + 1;        // 205: x pitch per channel (odd)
+
+__global__ __launch_bounds__(256) void conv3x3_wgrad_wino_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                 float* __restrict__ slab, int N, int Cin, int H, int W, int Cout,
+                                                                 WGeom geo, int segs_per_split) {
+    __shared__ float lds[64 * GW_DYP + 64 * GW_XCI + 64];
+    float* const dyS = lds;
+    float* const xS = lds + 64 * GW_DYP;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lk = lane >> 5;
+    // the 16 (ci, co) tiles of a split on one XCD (see conv3x3_wgrad_kernel)
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if ((gridDim.z & 7) == 0) {
+        const int nxy = gridDim.x * gridDim.y;
+        const int b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int k = b & 7, slot = b >> 3;
+        bz = k + 8 * (slot / nxy);
+        const int xy = slot - (slot / nxy) * nxy;
+        bx = xy % gridDim.x;
+        by = xy / gridDim.x;
+    }
+    const int ci0 = bx * 64, co0 = by * 64, split = bz;
+    const int wco = (wave >> 1) * 32, wci = (wave & 1) * 32;
+    const long HW = (long)H * W;
+
+    f32x16 acc[3][4];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[kh][q][r] = 0.f;
+
+    const int sbeg = split * segs_per_split;
+    const int send = min(geo.nseg, sbeg + segs_per_split);
+    // loader maps: dy - thread = (pixel lane, channel tid>>6 + 4e); x - wave w stages channels 16w .. 16w+15, a row = lanes 0..63
+    // (columns w0-1 .. w0+62) and the last two columns of 32 rows per extra load
+    float rdy[16], rx[48], rxh[2];
+    const int m_lds = (lane & 1) * POFF + (lane >> 1);
+    for (int g = sbeg; g < send; ++g) {
+        const int n = g / geo.per_img, loc = g - n * geo.per_img, h = loc / geo.nsr, w0 = (loc - h * geo.nsr) * 2 * TS;
+        __syncthreads();                                             // every wave is done with the previous segment's tiles
+        {
+            const int px = w0 + lane;
+            const float pm = px < W ? 1.f : 0.f;
+            const long base = (long)n * Cout * HW + (long)h * W + min(px, W - 1);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = co0 + wave + 4 * e;
+                rdy[e] = dy[base + (long)min(co, Cout - 1) * HW] * (co < Cout ? pm : 0.f);
+            }
+            const int mcol = w0 - 1 + lane;
+            const float cm = (mcol >= 0 && mcol < W) ? 1.f : 0.f;
+            const int moff = min(max(mcol, 0), W - 1);
+            const long xb = (long)n * Cin * HW;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const int ci = ci0 + wave * 16 + c;
+                const float chm = ci < Cin ? cm : 0.f;
+                const float* cb = x + xb + (long)min(ci, Cin - 1) * HW;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const int hh = h + kh - 1;
+                    rx[c * 3 + kh] = cb[(long)min(max(hh, 0), H - 1) * W + moff] * ((hh >= 0 && hh < H) ? chm : 0.f);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {                               // halo items: t -> (row t>>1 of the wave's 48, column 64 + (t&1))
+                const int t = lane + 64 * j, row = min(t >> 1, 47), c = row / 3, kh = row - 3 * c, hcol = w0 + 63 + (t & 1);
+                const int ci = ci0 + wave * 16 + c, hh = h + kh - 1;
+                const float m = (t < 96 && ci < Cin && hcol < W && hh >= 0 && hh < H) ? 1.f : 0.f;
+                rxh[j] = x[xb + (long)min(ci, Cin - 1) * HW + (long)min(max(hh, 0), H - 1) * W + min(hcol, W - 1)] * m;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dyS[(wave + 4 * e) * GW_DYP + lane] = rdy[e];
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) xS[(wave * 16 + c) * GW_XCI + kh * PRW + m_lds] = rx[c * 3 + kh];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int t = lane + 64 * j, row = min(t >> 1, 47), c = row / 3, kh = row - 3 * c;
+                xS[t < 96 ? (wave * 16 + c) * GW_XCI + kh * PRW + (t & 1) * POFF + 32 : 64 * GW_XCI + (lane & 31)] = rxh[j];
+            }
+        }
+        __syncthreads();
+        // k-step s multiplies pairs 2s (lanes 0-31) and 2s+1 (lanes 32-63)
+        const float* ap = dyS + (wco + li) * GW_DYP + 2 * lk;
+        const float* bp = xS + (wci + li) * GW_XCI + lk;
+        float g0 = ap[0], g1 = ap[1], e0[3], e1[3], o0[3], o1[3];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) { e0[kh] = bp[kh * PRW]; e1[kh] = bp[kh * PRW + 1]; o0[kh] = bp[kh * PRW + POFF]; o1[kh] = bp[kh * PRW + POFF + 1]; }
+#pragma unroll
+        for (int s = 0; s < TS / 2; ++s) {
+            float ng0 = 0.f, ng1 = 0.f, ne0[3], ne1[3], no0[3], no1[3];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) ne0[kh] = ne1[kh] = no0[kh] = no1[kh] = 0.f;
+            if (s + 1 < TS / 2) {
+                ng0 = ap[4 * (s + 1)]; ng1 = ap[4 * (s + 1) + 1];
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const float* q = bp + kh * PRW + 2 * (s + 1);
+                    ne0[kh] = q[0]; ne1[kh] = q[1]; no0[kh] = q[POFF]; no1[kh] = q[POFF + 1];
+                }
+            }
+            const float a[4] = {g0, 0.5f * (g0 + g1), 0.5f * (g0 - g1), g1};
+            float b[3][4];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) { b[kh][0] = e0[kh] - e1[kh]; b[kh][1] = o0[kh] + e1[kh]; b[kh][2] = e1[kh] - o0[kh]; b[kh][3] = o1[kh] - o0[kh]; }
+            __builtin_amdgcn_sched_barrier(0);      // next step's ds_reads stay above this step's MFMAs
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[kh][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[kh][q], acc[kh][q], 0, 0, 0);
+            g0 = ng0; g1 = ng1;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) { e0[kh] = ne0[kh]; e1[kh] = ne1[kh]; o0[kh] = no0[kh]; o1[kh] = no1[kh]; }
+        }
+    }
+    // slab[split][tap][co][ci]  (ci contiguous -> coalesced stores); output transform per (co, ci)
+    const long plane = (long)Cout * Cin;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wco + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            const int ci = ci0 + wci + li;
+            if (co < Cout && ci < Cin) {
+                const float m0 = acc[kh][0][r], m1 = acc[kh][1][r], m2 = acc[kh][2][r], m3 = acc[kh][3][r];
+                float* o = slab + ((long)split * 9 + kh * 3) * plane + (long)co * Cin + ci;
+                o[0] = (m0 + m1) + m2;
+                o[plane] = m1 - m2;
+                o[2 * plane] = (m1 + m2) + m3;
+            }
+        }
+}
+
 const float* wino_zero_page_ptr() {
     static const float* zp[64] = {nullptr};
     int dev = 0;
@@ -336,5 +486,47 @@ extern "C" int vocr_conv3x3_wino_fwd(const float* x, const float* wpack, const f
     else VOCR_WINO_LAUNCH(64, 4, 1);
 #undef VOCR_WINO_LAUNCH
     VOCR_CHECK_LAUNCH("vocr_conv3x3_wino_fwd");
+    return VOCR_OK;
+}
+
+void vocr_internal_wgrad_reduce(const float* slab, float* dw, int cout, int cin, int splits, hipStream_t s);     // conv.hip
+
+namespace {
+int wgrad_wino_splits(int n, int cin, int h, int w, int cout, int* segs_per_split) {
+    const int nsr = vocr_cdiv(vocr_cdiv(w, 2), TS);
+    const long nseg = (long)n * h * nsr;
+    const int tiles = vocr_cdiv(cin, 64) * vocr_cdiv(cout, 64);
+    long s = (256 + tiles - 1) / tiles;                      // one workgroup per CU (192 accumulator registers per lane)
+    if (s > nseg) s = nseg;
+    if (s < 1) s = 1;
+    const int sps = (int)((nseg + s - 1) / s);
+    *segs_per_split = sps;
+    return (int)((nseg + sps - 1) / sps);
+}
+}  // namespace
+
+extern "C" size_t vocr_conv3x3_wgrad_wino_workspace_bytes(int n, int cin, int h, int w, int cout) {
+    if (n <= 0 || cin <= 0 || h <= 0 || w <= 0 || cout <= 0) return 0;
+    int sps;
+    return (size_t)wgrad_wino_splits(n, cin, h, w, cout, &sps) * 9 * cout * cin * sizeof(float);
+}
+
+extern "C" int vocr_conv3x3_wgrad_wino(const float* x, const float* dy, float* dw, void* workspace, int n, int cin, int h, int w,
+                                       int cout, void* stream) {
+    VOCR_CHECK_ARG(x && dy && dw && workspace, "vocr_conv3x3_wgrad_wino: null pointer");
+    VOCR_CHECK_ARG(n > 0 && cin >= 4 && h > 0 && w > 0 && cout > 0, "vocr_conv3x3_wgrad_wino: bad shape (needs cin >= 4)");
+    VOCR_CHECK_ARG((long)n * (cin > cout ? cin : cout) * h * w < (1l << 31), "vocr_conv3x3_wgrad_wino: tensor exceeds 2^31 elements");
+    WGeom geo;
+    geo.nsr = vocr_cdiv(vocr_cdiv(w, 2), TS);
+    geo.per_img = h * geo.nsr;
+    geo.nseg = n * geo.per_img;
+    int sps;
+    const int splits = wgrad_wino_splits(n, cin, h, w, cout, &sps);
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(vocr_cdiv(cin, 64), vocr_cdiv(cout, 64), splits);
+    conv3x3_wgrad_wino_kernel<<<grid, 256, 0, s>>>(x, dy, (float*)workspace, n, cin, h, w, cout, geo, sps);
+    VOCR_CHECK_LAUNCH("vocr_conv3x3_wgrad_wino");
+    vocr_internal_wgrad_reduce((const float*)workspace, dw, cout, cin, splits, s);
+    VOCR_CHECK_LAUNCH("vocr_conv3x3_wgrad_wino(reduce)");
     return VOCR_OK;
 }

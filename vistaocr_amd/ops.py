@@ -191,6 +191,7 @@ def forward_prep(conv_weights, lstm_layers, with_transposes):
 
 # ------------------------------------------------------------------------------------------------ conv + BN + ReLU
 _WINO = _os.environ.get("VOCR_CONV_WINO", "1") == "1"
+_WINO_WGRAD = _os.environ.get("VOCR_WGRAD_WINO", "1") == "1"
 
 
 def _wino_ok(cin, cout):
@@ -247,8 +248,12 @@ def conv3x3_wgrad(x, dy, out=None, f16=False):
     n, cin, h, w = x.shape
     cout = dy.shape[1]
     lib = _lib.load()
-    ws = _ws(lib.vocr_conv3x3_wgrad_workspace_bytes(n, cin, h, w, cout), x.device)
     dw = out if out is not None else torch.empty(cout, cin, 3, 3, dtype=torch.float32, device=x.device)
+    if not f16 and _WINO_WGRAD and cin >= 4:
+        ws = _ws(lib.vocr_conv3x3_wgrad_wino_workspace_bytes(n, cin, h, w, cout), x.device)
+        call("vocr_conv3x3_wgrad_wino", _p(x), _p(dy), _p(dw), _p(ws), n, cin, h, w, cout, _stream())
+        return dw
+    ws = _ws(lib.vocr_conv3x3_wgrad_workspace_bytes(n, cin, h, w, cout), x.device)
     call("vocr_conv3x3_wgrad_f16" if f16 else "vocr_conv3x3_wgrad", _p(x), _p(dy), _p(dw), _p(ws), n, cin, h, w, cout, _stream())
     return dw
 
