@@ -59,7 +59,8 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
     }
 }
 
-struct WGeom { int nsr, per_img, nseg; };       // segments per image row, per image, in all
+struct WGeom { int nsr, per_img, nseg; };
+typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));       // segments per image row, per image, in all
 
 template <int CO_T>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const float* __restrict__ in, const float* __restrict__ wpack,
@@ -319,54 +320,81 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_wino_kernel(const float* __
 
     const int sbeg = split * segs_per_split;
     const int send = min(geo.nseg, sbeg + segs_per_split);
-    // loader maps: dy - thread = (pixel lane, channel tid>>6 + 4e); x - wave w stages channels 16w .. 16w+15, a row = lanes 0..63
-    // (columns w0-1 .. w0+62) and the last two columns of 32 rows per extra load
-    float rdy[16], rx[48], rxh[2];
-    const int m_lds = (lane & 1) * POFF + (lane >> 1);
+    // Loader: 16-byte buffer loads (a load outside the tensor returns 0, so nothing needs an address clamp at the tensor's ends).
+    //   dy: lane = (row slot lane>>4, piece lane&15 = pixels 4*piece .. +3); load e covers channels 16*wave + 4*e + slot: 4 loads
+    //   x : a staged row is raw index j = 0..65 <-> column w0-1+j; pieces q = 1..16 cover j = 4q-3 .. 4q (columns w0-4+4q .. +3), item
+    //       t = lane + 64*i <-> (row 4*i + (lane>>4) of the wave's 48 (c, kh) rows, q = (lane&15) + 1): 12 loads; j = 0 and j = 65 of
+    //       all 48 rows take two dword loads.  A piece's elements go to O[2q-2], E[2q-1], O[2q-1], E[2q]: two ds_write2.
+    // (66 dword loads and ~380 vector instructions per segment took 8000 cycles beside the 12300 of the MFMAs; this form ~4000.)
+    const __amdgpu_buffer_rsrc_t dyrs = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)((long)N * Cout * HW * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((long)N * Cin * HW * 4), 0x00020000);
+    const int slot = lane >> 4, piece = lane & 15;
+    int d_off[4], d_lds[4];
+    float d_m[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int col = wave * 16 + 4 * e + slot, co = co0 + col;
+        d_off[e] = min(co, Cout - 1) * (int)HW + 4 * piece;
+        d_m[e] = co < Cout ? 1.f : 0.f;
+        d_lds[e] = col * GW_DYP + 4 * piece;
+    }
+    int x_ch[12], x_kh[12], x_lds[12];
+    float x_m[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const int row = 4 * i + slot, c = row / 3, kh = row - 3 * c, ci = ci0 + wave * 16 + c;
+        x_ch[i] = min(ci, Cin - 1) * (int)HW + 4 * piece;            // + column w0 of the segment: first element = column w0 + 4*piece
+        x_kh[i] = kh;
+        x_m[i] = ci < Cin ? 1.f : 0.f;
+        x_lds[i] = (wave * 16 + c) * GW_XCI + kh * PRW + 2 * piece;   // q = piece + 1: E[2q-1] = E[2*piece + 1], O[2q-2] = O[2*piece]
+    }
     for (int g = sbeg; g < send; ++g) {
         const int n = g / geo.per_img, loc = g - n * geo.per_img, h = loc / geo.nsr, w0 = (loc - h * geo.nsr) * 2 * TS;
         __syncthreads();                                             // every wave is done with the previous segment's tiles
         {
-            const int px = w0 + lane;
-            const float pm = px < W ? 1.f : 0.f;
-            const long base = (long)n * Cout * HW + (long)h * W + min(px, W - 1);
+            u32x4w rd[4], rx4[12];
+            float rxh[2];
+            // the whole offset goes through the range-checked vector operand: a piece that runs past the end of the tensor reads zeros
+            const int dbase = n * Cout * (int)HW + h * W + w0;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int co = co0 + wave + 4 * e;
-                rdy[e] = dy[base + (long)min(co, Cout - 1) * HW] * (co < Cout ? pm : 0.f);
+            for (int e = 0; e < 4; ++e) rd[e] = __builtin_amdgcn_raw_buffer_load_b128(dyrs, (d_off[e] + dbase) * 4, 0, 0);
+            const int xbase = n * Cin * (int)HW + w0;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                const int hh = min(max(h + x_kh[i] - 1, 0), H - 1);
+                rx4[i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (x_ch[i] + hh * W + xbase) * 4, 0, 0);
             }
-            const int mcol = w0 - 1 + lane;
-            const float cm = (mcol >= 0 && mcol < W) ? 1.f : 0.f;
-            const int moff = min(max(mcol, 0), W - 1);
             const long xb = (long)n * Cin * HW;
 #pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                const int ci = ci0 + wave * 16 + c;
-                const float chm = ci < Cin ? cm : 0.f;
-                const float* cb = x + xb + (long)min(ci, Cin - 1) * HW;
-#pragma unroll
-                for (int kh = 0; kh < 3; ++kh) {
-                    const int hh = h + kh - 1;
-                    rx[c * 3 + kh] = cb[(long)min(max(hh, 0), H - 1) * W + moff] * ((hh >= 0 && hh < H) ? chm : 0.f);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {                               // halo items: t -> (row t>>1 of the wave's 48, column 64 + (t&1))
-                const int t = lane + 64 * j, row = min(t >> 1, 47), c = row / 3, kh = row - 3 * c, hcol = w0 + 63 + (t & 1);
+            for (int j = 0; j < 2; ++j) {                               // raw index 0 (column w0-1, item parity 0) and 65 (column w0+64)
+                const int t = lane + 64 * j, row = min(t >> 1, 47), c = row / 3, kh = row - 3 * c, hcol = (t & 1) ? w0 + 64 : w0 - 1;
                 const int ci = ci0 + wave * 16 + c, hh = h + kh - 1;
-                const float m = (t < 96 && ci < Cin && hcol < W && hh >= 0 && hh < H) ? 1.f : 0.f;
-                rxh[j] = x[xb + (long)min(ci, Cin - 1) * HW + (long)min(max(hh, 0), H - 1) * W + min(hcol, W - 1)] * m;
+                const float m = (t < 96 && ci < Cin && hcol >= 0 && hcol < W && hh >= 0 && hh < H) ? 1.f : 0.f;
+                rxh[j] = x[xb + (long)min(ci, Cin - 1) * HW + (long)min(max(hh, 0), H - 1) * W + min(max(hcol, 0), W - 1)] * m;
             }
+            // dy: elements at pixels 4*piece + k
+            float pm[4];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) dyS[(wave + 4 * e) * GW_DYP + lane] = rdy[e];
+            for (int k = 0; k < 4; ++k) pm[k] = (w0 + 4 * piece + k) < W ? 1.f : 0.f;
 #pragma unroll
-            for (int c = 0; c < 16; ++c)
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int kh = 0; kh < 3; ++kh) xS[(wave * 16 + c) * GW_XCI + kh * PRW + m_lds] = rx[c * 3 + kh];
+                for (int k = 0; k < 4; ++k) dyS[d_lds[e] + k] = __uint_as_float(rd[e][k]) * (pm[k] * d_m[e]);
+            // x: element k of piece q is column w0 + 4*piece + k, raw index j = 4*piece + k + 1
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                const int hh = h + x_kh[i] - 1;
+                const float rm = (hh >= 0 && hh < H) ? x_m[i] : 0.f;
+                float* o = xS + x_lds[i];
+                o[POFF] = __uint_as_float(rx4[i][0]) * (pm[0] * rm);          // j = 4p+1 -> O[2p]
+                o[1] = __uint_as_float(rx4[i][1]) * (pm[1] * rm);             // j = 4p+2 -> E[2p+1]
+                o[POFF + 1] = __uint_as_float(rx4[i][2]) * (pm[2] * rm);      // j = 4p+3 -> O[2p+1]
+                o[2] = __uint_as_float(rx4[i][3]) * (pm[3] * rm);             // j = 4p+4 -> E[2p+2]
+            }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int t = lane + 64 * j, row = min(t >> 1, 47), c = row / 3, kh = row - 3 * c;
-                xS[t < 96 ? (wave * 16 + c) * GW_XCI + kh * PRW + (t & 1) * POFF + 32 : 64 * GW_XCI + (lane & 31)] = rxh[j];
+                xS[t < 96 ? (wave * 16 + c) * GW_XCI + kh * PRW + ((t & 1) ? POFF + 32 : 0) : 64 * GW_XCI + (lane & 31)] = rxh[j];
             }
         }
         __syncthreads();
@@ -515,7 +543,7 @@ extern "C" int vocr_conv3x3_wgrad_wino(const float* x, const float* dy, float* d
                                        int cout, void* stream) {
     VOCR_CHECK_ARG(x && dy && dw && workspace, "vocr_conv3x3_wgrad_wino: null pointer");
     VOCR_CHECK_ARG(n > 0 && cin >= 4 && h > 0 && w > 0 && cout > 0, "vocr_conv3x3_wgrad_wino: bad shape (needs cin >= 4)");
-    VOCR_CHECK_ARG((long)n * (cin > cout ? cin : cout) * h * w < (1l << 31), "vocr_conv3x3_wgrad_wino: tensor exceeds 2^31 elements");
+    VOCR_CHECK_ARG((long)n * (cin > cout ? cin : cout) * h * w < (1l << 29), "vocr_conv3x3_wgrad_wino: tensor exceeds 2^29 elements (32-bit byte offsets)");
     WGeom geo;
     geo.nsr = vocr_cdiv(vocr_cdiv(w, 2), TS);
     geo.per_img = h * geo.nsr;

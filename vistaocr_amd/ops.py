@@ -249,7 +249,7 @@ def conv3x3_wgrad(x, dy, out=None, f16=False):
     cout = dy.shape[1]
     lib = _lib.load()
     dw = out if out is not None else torch.empty(cout, cin, 3, 3, dtype=torch.float32, device=x.device)
-    if not f16 and _WINO_WGRAD and cin >= 4:
+    if not f16 and _WINO_WGRAD and cin >= 4 and n * max(cin, cout) * h * w < (1 << 29):
         ws = _ws(lib.vocr_conv3x3_wgrad_wino_workspace_bytes(n, cin, h, w, cout), x.device)
         call("vocr_conv3x3_wgrad_wino", _p(x), _p(dy), _p(dw), _p(ws), n, cin, h, w, cout, _stream())
         return dw
