@@ -10,29 +10,29 @@ namespace {
 // one MFMA N-tile of 32 lane positions: `rows` sub-rows of `pw` patch columns (ow outputs each) starting at image row h, column w0
 struct SegInfo { long base; int n; int h; int w0; int valid; int rows; int pw; int ow; };
 
+// Lane position li (both lane halves) computes output pixel (pn, ph, pwc) if pix_ok; `live` is wave-uniform (false: nothing to do).
 template <int TAIL_WAVES>
-__device__ __forceinline__ void conv3x3_tail_piece_at(float* __restrict__ red_, const SegInfo& sg, int co_base, const float* __restrict__ in,
-                                                      const float* __restrict__ wpack, const float* __restrict__ bias, float* __restrict__ out,
-                                                      const float* __restrict__ zero_page, int Cin, int H, int W, int Cout) {
+__device__ __forceinline__ void conv3x3_tail_piece_px(float* __restrict__ red_, int pn, int ph, int pwc, bool pix_ok, bool live, int co_base,
+                                                      const float* __restrict__ in, const float* __restrict__ wpack, const float* __restrict__ bias,
+                                                      float* __restrict__ out, const float* __restrict__ zero_page, int Cin, int H, int W, int Cout) {
     float (*red)[16][64] = (float (*)[16][64])red_;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lk = lane >> 5;
-    if (!sg.valid || co_base >= Cout) return;                           // whole workgroup: no barrier is skipped by part of it
+    (void)li;
+    if (!live || co_base >= Cout) return;                               // whole workgroup: no barrier is skipped by part of it
     const long HW = (long)H * W;
-    const int rr = li / sg.pw, cc = li - rr * sg.pw;
-    const bool pix_ok = rr < sg.rows && cc < sg.ow;                     // lane position li is an output pixel
     // the nine taps of this lane's pixel: offsets inside a channel plane (clamped) and 0/1 masks
     int toff[9];
     float tm[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-        const int hh = sg.h + rr + t / 3 - 1, ww = sg.w0 + cc + t % 3 - 1;
-        tm[t] = (rr < sg.rows && cc < sg.pw && hh >= 0 && hh < H && ww >= 0 && ww < W) ? 1.f : 0.f;
+        const int hh = ph + t / 3 - 1, ww = pwc + t % 3 - 1;
+        tm[t] = (pix_ok && hh >= 0 && hh < H && ww >= 0 && ww < W) ? 1.f : 0.f;
         toff[t] = min(max(hh, 0), H - 1) * W + min(max(ww, 0), W - 1);
     }
-    const float* xin = in + (long)sg.n * Cin * HW;
-    const int co = co_base + li;
+    const float* xin = in + (long)pn * Cin * HW;
+    const int co = co_base + (lane & 31);
     const bool co_ok = co < Cout;
     const int nsteps = (Cin + 2 * TAIL_WAVES - 1) / (2 * TAIL_WAVES);
     constexpr int DEPTH = 3;
@@ -77,8 +77,19 @@ __device__ __forceinline__ void conv3x3_tail_piece_at(float* __restrict__ red_, 
         for (int w8 = 0; w8 < TAIL_WAVES; ++w8) sum += red[w8][r][lane];
         const int oc = co_base + (r & 3) + 8 * (r >> 2) + 4 * lk;
         if (pix_ok && oc < Cout)
-            out[(long)sg.n * Cout * HW + (long)oc * HW + (long)(sg.h + rr) * W + sg.w0 + cc] = sum + (bias ? bias[oc] : 0.f);
+            out[(long)pn * Cout * HW + (long)oc * HW + (long)ph * W + pwc] = sum + (bias ? bias[oc] : 0.f);
     }
+}
+
+// the same for one segment of conv.hip's geometry: lane position li = sub-row li / pw, column li % pw
+template <int TAIL_WAVES>
+__device__ __forceinline__ void conv3x3_tail_piece_at(float* __restrict__ red_, const SegInfo& sg, int co_base, const float* __restrict__ in,
+                                                      const float* __restrict__ wpack, const float* __restrict__ bias, float* __restrict__ out,
+                                                      const float* __restrict__ zero_page, int Cin, int H, int W, int Cout) {
+    const int li = threadIdx.x & 31;
+    const int rr = li / sg.pw, cc = li - rr * sg.pw;
+    conv3x3_tail_piece_px<TAIL_WAVES>(red_, sg.n, sg.h + rr, sg.w0 + cc, rr < sg.rows && cc < sg.ow, sg.valid != 0, co_base, in, wpack, bias, out,
+                                      zero_page, Cin, H, W, Cout);
 }
 
 }  // namespace

@@ -59,8 +59,23 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
     }
 }
 
-struct WGeom { int nsr, per_img, nseg; };
-typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));       // segments per image row, per image, in all
+typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
+// Forward / data-gradient geometry: the column pairs of all image rows form ONE stream - a row contributes its T = ceil(W/2) pairs and
+// one gap slot (the pair after the last one of a row must not see the next row's first columns) - and a segment is any 32 consecutive
+// slots, so only 1 of T+1 lane positions is idle (whole 32-pair segments per row idled 8 % of them at W = 294, 6 % at 420 / 600).
+// Slot q -> image n, row h, pair k (k == T: the gap).  The weight-gradient kernel keeps whole segments per row (nsr, per_img, nseg).
+struct WGeom { int nsr, per_img, nseg; int T, S, slots_img, nslot; };
+struct WSlot { int n, h, k, valid; };
+__device__ __forceinline__ WSlot wslot(int q, const WGeom& g) {
+    WSlot s;
+    s.valid = q < g.nslot;
+    const int qq = s.valid ? q : 0;
+    s.n = qq / g.slots_img;
+    const int r = qq - s.n * g.slots_img;
+    s.h = r / g.S;
+    s.k = r - s.h * g.S;
+    return s;
+}
 
 template <int CO_T>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const float* __restrict__ in, const float* __restrict__ wpack,
@@ -90,17 +105,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const float* __res
         // from global memory (conv_tail.h; conv.hip explains why): a tile is (CO_T/32) channel blocks x 2*NSEG pixel blocks
         constexpr int COSUB = CO_T / 32, PPW = COSUB * 2 * NSEG;
         const int piece = blockIdx.x, vt = first_tail_tile + piece / PPW, sub = piece % PPW;
-        const int g = (vt / co_tiles) * NSEG + (sub / COSUB) / 2;
-        SegInfo sgi;
-        sgi.valid = g < geo.nseg;
-        const int gg = sgi.valid ? g : 0;
-        sgi.n = gg / geo.per_img;
-        const int loc = gg - sgi.n * geo.per_img;
-        sgi.h = loc / geo.nsr;
-        sgi.w0 = (loc - sgi.h * geo.nsr) * 2 * TS + ((sub / COSUB) & 1) * 32;
-        sgi.rows = 1; sgi.pw = 34; sgi.ow = min(32, W - sgi.w0); sgi.base = 0;
-        if (sgi.ow <= 0) sgi.valid = 0;
-        conv3x3_tail_piece_at<4>(lds, sgi, (vt % co_tiles) * CO_T + (sub % COSUB) * 32, in, wdirect, bias, out, zero_page, Cin, H, W, Cout);
+        // piece pixel block pb: 16 slots = 32 lane positions (lane position li = slot li >> 1, pixel parity li & 1)
+        const int pb = sub / COSUB, q0 = ((vt / co_tiles) * NSEG + pb / 2) * TS + (pb & 1) * 16;
+        const int pli = threadIdx.x & 31;
+        const WSlot ps = wslot(q0 + (pli >> 1), geo);
+        const int pcol = 2 * ps.k + (pli & 1);
+        conv3x3_tail_piece_px<4>(lds, ps.n, ps.h, pcol, ps.valid && ps.k < geo.T && pcol < W, q0 < geo.nslot,
+                                 (vt % co_tiles) * CO_T + (sub % COSUB) * 32, in, wdirect, bias, out, zero_page, Cin, H, W, Cout);
         return;
     }
     const int tid = threadIdx.x, lane = tid & 63;
@@ -110,15 +121,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const float* __res
     const int co0 = (v % co_tiles) * CO_T;
     const int seg0 = (v / co_tiles) * NSEG;
     const long HW = (long)H * W;
-    if (tid < NSEG) {
-        const int g = seg0 + tid;
-        const int valid = g < geo.nseg;
-        const int gg = valid ? g : 0;
-        const int n = gg / geo.per_img, loc = gg - n * geo.per_img, h = loc / geo.nsr, w0 = (loc - h * geo.nsr) * 2 * TS;
-        int* o = segw + tid * 8;
-        o[0] = n; o[1] = h; o[2] = w0; o[3] = valid;
-    }
-    __syncthreads();
 
     const int wco = (wave / NSEG) * 64;
     const int wsg = wave % NSEG;
@@ -141,45 +143,46 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const float* __res
     }
     // (with ROWS_W = 6 or 12 a wave's rows belong to ONE segment when NSEG*3 divides 12, i.e. always here)
     const int st_seg = (wave * ROWS_W) / RPS;
-    const int* sgs = segw + st_seg * 8;
-    const int s_n = sgs[0], s_h = sgs[1], s_w0 = sgs[2], s_ok = sgs[3];
-    const float* p_base = in + (long)s_n * Cin * HW;
-    const int mcol = s_w0 - 1 + lane;                                          // main lanes: column of lane
-    const float m_ok = (s_ok && mcol >= 0 && mcol < W) ? 1.f : 0.f;
-    const int m_off = min(max(mcol, 0), W - 1);
-    const int m_lds = (lane & 1) * POFF + (lane >> 1);                         // even columns -> E, odd -> O
-    // halo items: lane -> (row j = lane >> 1, column 64 + (lane & 1))
-    const int hj = min(lane >> 1, ROWS_W - 1), hcol = s_w0 + 63 + (lane & 1);
+    // main lanes: entry e = lane >> 1 of the segment's 33 (entry e serves pair e as d0/d1 and pair e-1 as d2/d3), E or O by lane & 1
+    const WSlot ms = wslot((seg0 + st_seg) * TS + (lane >> 1), geo);
+    const int mcol = 2 * ms.k - 1 + (lane & 1);
+    const float m_ok = (ms.valid && mcol >= 0 && mcol < W) ? 1.f : 0.f;
+    const int m_base = ms.n * Cin * (int)HW + min(max(mcol, 0), W - 1);
+    int m_row[3];
+    float m_rok[3];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int hh = ms.h + kh - 1;
+        m_row[kh] = min(max(hh, 0), H - 1) * W;
+        m_rok[kh] = (hh >= 0 && hh < H) ? m_ok : 0.f;
+    }
+    const int m_lds = (lane & 1) * POFF + (lane >> 1);                         // even raw index -> E, odd -> O
+    // halo items: lane -> (row j = lane >> 1 of this wave's rows, E or O of entry 32 = the first slot of the next segment)
+    const int hj = min(lane >> 1, ROWS_W - 1);
     const bool h_lane = lane < 2 * ROWS_W;
-    const float h_okc = (s_ok && h_lane && hcol < W) ? 1.f : 0.f;
-    const int h_off = min(hcol, W - 1);
+    const WSlot hs = wslot((seg0 + st_seg) * TS + 32, geo);
+    const int hcol = 2 * hs.k - 1 + (lane & 1);
     const int h_c = ((wave * ROWS_W + hj) % RPS) / 3, h_kh = (wave * ROWS_W + hj) % 3;
+    const int h_hh = hs.h + h_kh - 1;
+    const float h_okc = (hs.valid && h_lane && hcol >= 0 && hcol < W && h_hh >= 0 && h_hh < H) ? 1.f : 0.f;
+    const int h_off = hs.n * Cin * (int)HW + min(max(h_hh, 0), H - 1) * W + min(max(hcol, 0), W - 1);
     const int h_lds = h_lane ? (st_seg * PSEG + h_c * 3 * PRW + h_kh * PRW + (lane & 1) * POFF + 32) : -1;
     float rp[ROWS_W + 1];
     auto load_patch = [&](int ci0) {
 #pragma unroll
         for (int j = 0; j < ROWS_W; ++j) {
-            const int hh = min(max(s_h + r_kh[j] - 1, 0), H - 1);
-            const float* cb = p_base + (long)min(ci0 + r_c[j], Cin - 1) * HW + (long)hh * W;      // wave-uniform
-            rp[j] = cb[m_off];
+            const float* cb = in + (long)min(ci0 + r_c[j], Cin - 1) * HW;                          // wave-uniform
+            rp[j] = cb[m_base + m_row[r_kh[j]]];
         }
-        {
-            const int hh = min(max(s_h + h_kh - 1, 0), H - 1);
-            rp[ROWS_W] = p_base[(long)min(ci0 + h_c, Cin - 1) * HW + (long)hh * W + h_off];
-        }
+        rp[ROWS_W] = in[(long)min(ci0 + h_c, Cin - 1) * HW + h_off];
     };
     auto store_patch = [&](int ci0, int buf) {
 #pragma unroll
         for (int j = 0; j < ROWS_W; ++j) {
-            const int hh = s_h + r_kh[j] - 1;
-            const float rm = ((ci0 + r_c[j]) < Cin && hh >= 0 && hh < H) ? 1.f : 0.f;               // wave-uniform
-            P[buf * PBUF + r_seg[j] * PSEG + r_c[j] * 3 * PRW + r_kh[j] * PRW + m_lds] = rp[j] * (m_ok * rm);
+            const float rm = (ci0 + r_c[j]) < Cin ? 1.f : 0.f;                                       // wave-uniform
+            P[buf * PBUF + r_seg[j] * PSEG + r_c[j] * 3 * PRW + r_kh[j] * PRW + m_lds] = rp[j] * (m_rok[r_kh[j]] * rm);
         }
-        {
-            const int hh = s_h + h_kh - 1;
-            const float rm = ((ci0 + h_c) < Cin && hh >= 0 && hh < H) ? 1.f : 0.f;
-            P[h_lane ? buf * PBUF + h_lds : DUMMY + lane] = rp[ROWS_W] * (h_okc * rm);
-        }
+        P[h_lane ? buf * PBUF + h_lds : DUMMY + lane] = rp[ROWS_W] * ((ci0 + h_c) < Cin ? h_okc : 0.f);
     };
     // ---- weight DMA: instruction q of a half-chunk moves rows [q*RPI, (q+1)*RPI) x CO_T floats = 1 KiB
     const int Ktot = Cin * 12;
@@ -251,12 +254,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const float* __res
     }
 
     // ---- output transform and stores: lane li = column pair, y(2t) = m0 + m1 + m2, y(2t+1) = m1 - m2 - m3
-    const int* sg = segw + wsg * 8;
-    if (!sg[3]) return;
-    const int px = sg[2] + 2 * li;
-    if (px >= W) return;
+    const WSlot os = wslot((seg0 + wsg) * TS + li, geo);
+    const int px = 2 * os.k;
+    if (!os.valid || os.k >= geo.T || px >= W) return;
     const bool two = px + 1 < W;
-    float* obase = out + (long)sg[0] * Cout * HW + (long)sg[1] * W + px;
+    float* obase = out + (long)os.n * Cout * HW + (long)os.h * W + px;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -486,9 +488,12 @@ extern "C" int vocr_conv3x3_wino_fwd(const float* x, const float* wpack, const f
     VOCR_CHECK_ARG(cout % 4 == 0 && ((((uintptr_t)wpack) & 15) == 0), "vocr_conv3x3_wino_fwd: needs Cout %% 4 == 0 and a 16-byte aligned pack");
     VOCR_CHECK_ARG((long)n * (cin > cout ? cin : cout) * h * w < (1l << 31), "vocr_conv3x3_wino_fwd: tensor exceeds 2^31 elements");
     WGeom geo;
-    geo.nsr = vocr_cdiv(vocr_cdiv(w, 2), TS);
-    geo.per_img = h * geo.nsr;
-    geo.nseg = n * geo.per_img;
+    geo.T = vocr_cdiv(w, 2);
+    geo.S = geo.T + 1;
+    geo.slots_img = h * geo.S;
+    geo.nslot = n * geo.slots_img;
+    geo.nseg = vocr_cdiv(geo.nslot, TS);
+    geo.nsr = 0; geo.per_img = 0;
     const float* zp = wino_zero_page_ptr();
     VOCR_CHECK_ARG(zp != nullptr, "vocr_conv3x3_wino_fwd: no device zero page");
     hipStream_t s = (hipStream_t)stream;
@@ -548,6 +553,7 @@ extern "C" int vocr_conv3x3_wgrad_wino(const float* x, const float* dy, float* d
     geo.nsr = vocr_cdiv(vocr_cdiv(w, 2), TS);
     geo.per_img = h * geo.nsr;
     geo.nseg = n * geo.per_img;
+    geo.T = geo.S = geo.slots_img = geo.nslot = 0;
     int sps;
     const int splits = wgrad_wino_splits(n, cin, h, w, cout, &sps);
     hipStream_t s = (hipStream_t)stream;
