@@ -31,7 +31,7 @@ def traffic(paths):
         for r in sorted(rows, key=lambda r: int(r["Dispatch_Id"])):
             k = short(r["Kernel_Name"])
             per.setdefault(k, []).append(float(r["Counter_Value"]))
-            if k.startswith("conv3x3_dma_kernel<") or k.startswith("conv3x3_kernel<"):
+            if k.startswith("conv3x3_wino_kernel<") or k.startswith("conv3x3_dma_kernel<") or k.startswith("conv3x3_kernel<"):
                 conv.append(float(r["Counter_Value"]))
         print(cname)
         for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1]))[:14]:
@@ -52,7 +52,8 @@ def busy(paths):
         rows, dur = load(path)
         for r in rows:
             k = short(r["Kernel_Name"])
-            key = "conv forward (conv3x3_dma_kernel)" if k.startswith("conv3x3_dma_kernel") else "conv weight gradient (conv3x3_wgrad_kernel)" if k.startswith("conv3x3_wgrad_kernel") \
+            key = "conv forward (%s)" % k.split("<")[0] if (k.startswith("conv3x3_dma_kernel") or k.startswith("conv3x3_wino_kernel")) \
+                else "conv weight gradient (%s)" % k.split("<")[0] if (k.startswith("conv3x3_wgrad_kernel") or k.startswith("conv3x3_wgrad_wino_kernel")) \
                 else "x-projection GEMM (gemm_f32_kernel NT)" if k.startswith("gemm_f32_kernel") else None
             if key is None:
                 continue
