@@ -44,8 +44,13 @@ def _close(a, b, rtol, atol, what="", max_bad_frac=0.0):
                                             # more than 256 workgroup tiles with a short last round: conv3x3_tail_kernel computes it
                                             # (326 tiles of 128co x 2 segments, the last one half empty; 297 of 64co x 4; 293 with Cout = 72)
                                             (5, 20, 7, 294, 256), (6, 12, 15, 420, 64), (9, 8, 7, 294, 72)])
-def test_conv3x3_fwd_dgrad_wgrad(dev, n, cin, h, w, cout):
+@pytest.mark.parametrize("form", ["transform", "direct"])
+def test_conv3x3_fwd_dgrad_wgrad(dev, n, cin, h, w, cout, form, monkeypatch):
+    """Both forms of the three conv kernels against F.conv2d: "transform" = F(2,3) / F(3,2) along the row (conv_wino.hip, the default
+    for Cin >= 4), "direct" = conv.hip (VOCR_CONV_WINO=0 / VOCR_WGRAD_WINO=0, and what Cin < 4 always uses)."""
     from vistaocr_amd import ops
+    monkeypatch.setattr(ops, "_WINO", form == "transform")
+    monkeypatch.setattr(ops, "_WINO_WGRAD", form == "transform")
     x = _rand((n, cin, h, w), 1)
     wt = _rand((cout, cin, 3, 3), 2, 0.2)
     bias = _rand((cout,), 3)
