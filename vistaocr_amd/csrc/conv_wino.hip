@@ -451,6 +451,207 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_wino_kernel(const float* __
         }
 }
 
+// ---------------------------------------------------------------- weight gradient F(3,2), operands staged by LDS-DMA
+// The same contraction as conv3x3_wgrad_wino_kernel; what changes is how a segment's operands reach LDS.  There the four waves
+// load them through registers between two k-loops (a burst of 66 KB per workgroup that runs at the memory system's rate with the
+// matrix pipe idle: 37 % of the kernel).  Loads that return into VGPRs beside running MFMAs are throttled on this chip and 192
+// accumulator registers leave no room for loader waves, but an LDS-DMA (buffer_load ... lds, 16 bytes per lane) returns nothing to
+// a register: each wave issues the 18 DMAs of the NEXT segment in front of its k-loop into the other LDS buffer and only waits for
+// them behind it.  A DMA writes 64 consecutive 16-byte pieces, so the LDS layouts are piece-linear and bank conflicts are handled
+// by XOR-swizzling the piece position with the channel (source addresses are per lane, so the swizzle costs nothing to write):
+//   dy  [co 64][16 pieces]            piece p of channel co at position p ^ (co & 15)
+//   x   [ci 64][56 pieces]            logical piece L = kh*18 + q (q = 0..17: columns w0-4+4q .. +3; 54, 55 unused) at L ^ (ci & 7)
+// Padding (rows above / below the image, columns left of it, channels past the end, whole pieces right of the row) = a load outside
+// the buffer's range, which delivers zeros; a piece that straddles the END of an image row (W % 4 != 0) is patched with zeros after
+// it has landed.
+constexpr int GD_DYB = 64 * 64;            // floats of dy per buffer
+constexpr int GD_XCI = 56 * 4;             // floats of x per input channel (224 = 0 mod 32 banks)
+constexpr int GD_XB = 64 * GD_XCI;         // floats of x per buffer
+
+__global__ __launch_bounds__(256) void conv3x3_wgrad_wino_dma_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                     float* __restrict__ slab, int N, int Cin, int H, int W, int Cout,
+                                                                     WGeom geo, int segs_per_split) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * (GD_DYB + GD_XB)];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lk = lane >> 5;
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if ((gridDim.z & 7) == 0) {             // the (ci, co) tiles of a split on one XCD (see conv3x3_wgrad_kernel)
+        const int nxy = gridDim.x * gridDim.y;
+        const int b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int k = b & 7, slot = b >> 3;
+        bz = k + 8 * (slot / nxy);
+        const int xy = slot - (slot / nxy) * nxy;
+        bx = xy % gridDim.x;
+        by = xy / gridDim.x;
+    }
+    const int ci0 = bx * 64, co0 = by * 64, split = bz;
+    const int wco = (wave >> 1) * 32, wci = (wave & 1) * 32;
+    const long HW = (long)H * W;
+    const int iHW = (int)HW;
+
+    f32x16 acc[3][4];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[kh][q][r] = 0.f;
+
+    const int sbeg = split * segs_per_split;
+    const int send = min(geo.nseg, sbeg + segs_per_split);
+    const __amdgpu_buffer_rsrc_t dyrs = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)((long)N * Cout * HW * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((long)N * Cin * HW * 4), 0x00020000);
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+
+    // ---- DMA maps (kernel constants per lane): instruction m of a wave covers pieces [64m, 64m+64) of the buffer
+    int d_off[4], d_px[4];             // dy: element offset co*HW + 4p, first pixel 4p; d_off < 0: channel past the end
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int id = 64 * (wave + 4 * e) + lane, co = id >> 4, p = (id & 15) ^ (co & 15);
+        d_px[e] = 4 * p;
+        d_off[e] = co0 + co < Cout ? (co0 + co) * iHW + 4 * p : -1;
+    }
+    int x_off[14], x_meta[14];         // x: element offset ci*HW + 4q; meta = kh | q << 2, or -1: unused piece / channel past the end
+#pragma unroll
+    for (int i = 0; i < 14; ++i) {
+        const int id = 64 * (wave + 4 * i) + lane, ci = id / 56, L = (id - 56 * ci) ^ (ci & 7), kh = L / 18, q = L - 18 * kh;
+        const bool ok = L < 54 && ci0 + ci < Cin;
+        x_off[i] = (ci0 + ci) * iHW + 4 * q;
+        x_meta[i] = ok ? (kh | (q << 2)) : -1;
+    }
+    auto seg_of = [&](int g, int& n, int& h, int& w0) {
+        n = g / geo.per_img;
+        const int loc = g - n * geo.per_img;
+        h = loc / geo.nsr;
+        w0 = (loc - h * geo.nsr) * 2 * TS;
+    };
+    auto issue = [&](int g, int buf) {
+        int n, h, w0;
+        seg_of(g, n, h, w0);
+        float* const dyb = lds + buf * (GD_DYB + GD_XB);
+        float* const xb = dyb + GD_DYB;
+        const int dbase = n * Cout * iHW + h * W + w0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned vo = (d_off[e] >= 0 && w0 + d_px[e] < W) ? (unsigned)(dbase + d_off[e]) * 4u : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(dyrs, (__attribute__((address_space(3))) void*)(dyb + (wave + 4 * e) * 256), 16, vo, 0, 0, 0);
+        }
+        const int xbase = n * Cin * iHW + w0 - 4;
+#pragma unroll
+        for (int i = 0; i < 14; ++i) {
+            const int kh = x_meta[i] & 3, q = x_meta[i] >> 2, row = h + kh - 1, col0 = w0 - 4 + 4 * q;
+            const bool ok = x_meta[i] >= 0 && row >= 0 && row < H && col0 >= 0 && col0 < W;
+            const unsigned vo = ok ? (unsigned)(xbase + x_off[i] + row * W) * 4u : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(xb + (wave + 4 * i) * 256), 16, vo, 0, 0, 0);
+        }
+    };
+    // a piece that straddles the end of its image row carries the next row's first columns: zero them (after the DMA has landed)
+    auto patch = [&](int g, int buf) {
+        int n, h, w0;
+        seg_of(g, n, h, w0);
+        if ((W & 3) == 0 || w0 + 68 <= W) return;                       // wave-uniform
+        float* const dyb = lds + buf * (GD_DYB + GD_XB);
+        float* const xb = dyb + GD_DYB;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c0 = w0 + d_px[e];
+            if (d_off[e] >= 0 && c0 < W && c0 + 4 > W) {
+                float* o = dyb + (wave + 4 * e) * 256 + lane * 4;
+#pragma unroll
+                for (int k = 1; k < 4; ++k)
+                    if (c0 + k >= W) o[k] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 14; ++i) {
+            const int q = x_meta[i] >> 2, c0 = w0 - 4 + 4 * q;
+            if (x_meta[i] >= 0 && c0 >= 0 && c0 < W && c0 + 4 > W) {
+                float* o = xb + (wave + 4 * i) * 256 + lane * 4;
+#pragma unroll
+                for (int k = 1; k < 4; ++k)
+                    if (c0 + k >= W) o[k] = 0.f;
+            }
+        }
+    };
+
+    // ---- fragment addressing (kernel constants per lane)
+    const int cA = wco + li, sA = cA & 15, baseA = cA * 64 + 2 * lk;
+    const int cB = wci + li, s7 = cB & 7, baseB = cB * GD_XCI;
+    int dpi[4], doi[4];                 // element i of pair p = 2s + lk sits in piece s + dpi[i] at offset doi[i] (raw index 3 + 2p + i)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { dpi[i] = (3 + 2 * lk + i) >> 2; doi[i] = (3 + 2 * lk + i) & 3; }
+
+    if (sbeg < send) {
+        issue(sbeg, 0);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        patch(sbeg, 0);
+    }
+    __syncthreads();
+    for (int g = sbeg; g < send; ++g) {
+        const int cur = (g - sbeg) & 1;
+        if (g + 1 < send) issue(g + 1, cur ^ 1);
+        const float* dyb = lds + cur * (GD_DYB + GD_XB);
+        const float* xb = dyb + GD_DYB;
+        auto readA = [&](int s, float& g0, float& g1) {
+            const float* a = dyb + baseA + 4 * (s ^ sA);
+            g0 = a[0]; g1 = a[1];
+        };
+        auto readB = [&](int s, float (&d)[3][4]) {
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d[kh][i] = xb[baseB + 4 * ((kh * 18 + s + dpi[i]) ^ s7) + doi[i]];
+        };
+        float g0, g1, d[3][4];
+        readA(0, g0, g1);
+        readB(0, d);
+#pragma unroll
+        for (int s = 0; s < TS / 2; ++s) {
+            float ng0 = 0.f, ng1 = 0.f, nd[3][4];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) nd[kh][i] = 0.f;
+            if (s + 1 < TS / 2) { readA(s + 1, ng0, ng1); readB(s + 1, nd); }
+            const float a[4] = {g0, 0.5f * (g0 + g1), 0.5f * (g0 - g1), g1};
+            float b[3][4];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) { b[kh][0] = d[kh][0] - d[kh][2]; b[kh][1] = d[kh][1] + d[kh][2]; b[kh][2] = d[kh][2] - d[kh][1]; b[kh][3] = d[kh][3] - d[kh][1]; }
+            __builtin_amdgcn_sched_barrier(0);      // next step's ds_reads stay above this step's MFMAs
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[kh][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[kh][q], acc[kh][q], 0, 0, 0);
+            g0 = ng0; g1 = ng1;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d[kh][i] = nd[kh][i];
+        }
+        if (g + 1 < send) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);     // the next segment's DMAs have landed
+            patch(g + 1, cur ^ 1);
+        }
+        __syncthreads();                            // next buffer complete, this one free
+    }
+    const long plane = (long)Cout * Cin;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wco + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            const int ci = ci0 + wci + li;
+            if (co < Cout && ci < Cin) {
+                const float m0 = acc[kh][0][r], m1 = acc[kh][1][r], m2 = acc[kh][2][r], m3 = acc[kh][3][r];
+                float* o = slab + ((long)split * 9 + kh * 3) * plane + (long)co * Cin + ci;
+                o[0] = (m0 + m1) + m2;
+                o[plane] = m1 - m2;
+                o[2 * plane] = (m1 + m2) + m3;
+            }
+        }
+}
+
 const float* wino_zero_page_ptr() {
     static const float* zp[64] = {nullptr};
     int dev = 0;
@@ -558,7 +759,9 @@ extern "C" int vocr_conv3x3_wgrad_wino(const float* x, const float* dy, float* d
     const int splits = wgrad_wino_splits(n, cin, h, w, cout, &sps);
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(vocr_cdiv(cin, 64), vocr_cdiv(cout, 64), splits);
-    conv3x3_wgrad_wino_kernel<<<grid, 256, 0, s>>>(x, dy, (float*)workspace, n, cin, h, w, cout, geo, sps);
+    static const int dma = getenv("VOCR_WGRAD_WINO_DMA") ? atoi(getenv("VOCR_WGRAD_WINO_DMA")) : 1;
+    if (dma) conv3x3_wgrad_wino_dma_kernel<<<grid, 256, 0, s>>>(x, dy, (float*)workspace, n, cin, h, w, cout, geo, sps);
+    else conv3x3_wgrad_wino_kernel<<<grid, 256, 0, s>>>(x, dy, (float*)workspace, n, cin, h, w, cout, geo, sps);
     VOCR_CHECK_LAUNCH("vocr_conv3x3_wgrad_wino");
     vocr_internal_wgrad_reduce((const float*)workspace, dw, cout, cin, splits, s);
     VOCR_CHECK_LAUNCH("vocr_conv3x3_wgrad_wino(reduce)");
