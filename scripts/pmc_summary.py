@@ -53,7 +53,7 @@ def busy(paths):
         for r in rows:
             k = short(r["Kernel_Name"])
             key = "conv forward (%s)" % k.split("<")[0] if (k.startswith("conv3x3_dma_kernel") or k.startswith("conv3x3_wino_kernel")) \
-                else "conv weight gradient (%s)" % k.split("<")[0] if (k.startswith("conv3x3_wgrad_kernel") or k.startswith("conv3x3_wgrad_wino_kernel")) \
+                else "conv weight gradient (%s)" % k.split("<")[0] if (k.startswith("conv3x3_wgrad_kernel") or k.startswith("conv3x3_wgrad_wino")) \
                 else "x-projection GEMM (gemm_f32_kernel NT)" if k.startswith("gemm_f32_kernel") else None
             if key is None:
                 continue
