@@ -317,7 +317,7 @@ def run_rank(args):
                        "final_loss": round(float(final_loss), 3)},
             "h2d_inclusive": {"value": round(B * world * args.steps / dt_h2d, 2), "ms_per_step": round(1000.0 * dt_h2d / args.steps, 3),
                               "what": "same K steps with the image batch in pinned host memory (H2D inside train())"},
-            "roofline": {"bound": "mfma", "kernel": "conv3x3_wino_kernel (F(2,3) along the row: 2/3 of the multiplications; first layer: conv3x3_kernel) behind vocr_conv3x3_wino_fwd / vocr_conv3x3_fwd, implicit GEMM on f32 MFMA 32x32x2, forward-pass launches; achieved = ALGORITHMIC direct-convolution FLOPs / time",
+            "roofline": {"bound": "mfma", "kernel": "conv3x3_wino_kernel (F(2,3) along the row: 2/3 of the multiplications) behind vocr_conv3x3_wino_fwd (vocr_conv3x3_fwd with VOCR_CONV_WINO=0), implicit GEMM on f32 MFMA 32x32x2, forward-pass launches; achieved = ALGORITHMIC direct-convolution FLOPs / time",
                          "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "avg_launch_ms": round(cf_ms / n_launch, 4), "launches_per_step": n_conv, "launches_timed": n_launch,

@@ -52,7 +52,7 @@ int vocr_conv3x3_wgrad(const float* x, const float* dy, float* dw, void* workspa
 /* Same op with the minimal-filtering transform F(2,3) along the row (conv_wino.hip): fp32 operands and accumulation, 2/3 of the
  * multiplications.  Weight packs hold the transformed filter rows: fwd [(ci*12 + kh*4 + x)][co], dgrad [(co*12 + kh*4 + x)][ci]
  * (taps flipped), each followed by the direct pack's 9 rows per channel (used for the last partial round of tiles): cout*cin*21
- * floats per pack (vocr_conv3x3_wino_pack_floats), 16-byte aligned.  Needs cin >= 4 and cout % 4 == 0
+ * floats per pack (vocr_conv3x3_wino_pack_floats), 16-byte aligned.  Needs cout % 4 == 0 (input channels are padded to 4 inside)
  * (vocr_conv3x3_wino_supported).  dgrad = vocr_conv3x3_wino_fwd(dy, wpack_dgrad, NULL, dx, n, cout, h, w, cin). */
 int vocr_conv3x3_wino_supported(int cin, int cout);
 size_t vocr_conv3x3_wino_pack_floats(int cout, int cin);

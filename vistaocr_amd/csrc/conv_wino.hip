@@ -666,7 +666,7 @@ const float* wino_zero_page_ptr() {
 
 }  // namespace
 
-extern "C" int vocr_conv3x3_wino_supported(int cin, int cout) { return cin >= 4 && cout % 4 == 0 ? 1 : 0; }
+extern "C" int vocr_conv3x3_wino_supported(int cin, int cout) { return cin >= 1 && cout % 4 == 0 ? 1 : 0; }
 
 // a pack = 12 transformed rows per contraction channel, followed by the direct pack's 9 rows per channel (for the tail pieces)
 extern "C" size_t vocr_conv3x3_wino_pack_floats(int cout, int cin) { return (size_t)cout * cin * 21; }

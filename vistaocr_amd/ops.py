@@ -194,9 +194,12 @@ _WINO = _os.environ.get("VOCR_CONV_WINO", "1") == "1"
 _WINO_WGRAD = _os.environ.get("VOCR_WGRAD_WINO", "1") == "1"
 
 
+_WINO_MIN_CIN = int(_os.environ.get("VOCR_CONV_WINO_MIN_CIN", "1"))
+
+
 def _wino_ok(cin, cout):
-    """The F(2,3)-along-the-row kernel (conv_wino.hip) takes the layers with Cin >= 4 and Cout % 4 == 0."""
-    return _WINO and cin >= 4 and cout % 4 == 0
+    """The F(2,3)-along-the-row kernel (conv_wino.hip) needs Cout % 4 == 0; input channels are padded to 4 inside the kernel."""
+    return _WINO and cin >= _WINO_MIN_CIN and cout % 4 == 0
 
 
 def conv3x3_pack(weight):
