@@ -266,7 +266,7 @@ def run_rank(args):
     conv_recs = _lib.timing_records().get("vocr_conv3x3_fwd", []) + _lib.timing_records().get("vocr_conv3x3_wino_fwd", [])
     _lib.enable_timing(None)
     dt_h2d, _ = timed(batch_host, args.steps)
-    names = ["vocr_conv3x3_fwd", "vocr_conv3x3_wino_fwd", "vocr_conv3x3_wgrad", "vocr_lstm_fwd", "vocr_lstm_fwd_range", "vocr_lstm_bwd_bias", "vocr_gemm",
+    names = ["vocr_conv3x3_fwd", "vocr_conv3x3_wino_fwd", "vocr_conv3x3_wgrad", "vocr_conv3x3_wgrad_wino", "vocr_lstm_fwd", "vocr_lstm_fwd_range", "vocr_lstm_bwd_bias", "vocr_gemm",
              "vocr_bn_train_stats", "vocr_bn_relu_apply", "vocr_bn_relu_fracpool2x2_fwd", "vocr_bn_relu_bwd", "vocr_fracpool2x2_bwd",
              "vocr_ctc_loss_grad", "vocr_clamp_adam"]
     _lib.enable_timing(names)

@@ -1,4 +1,6 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|FAILED|Error" | tail -5
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-python bench.py 2>/dev/null | tail -1 | cut -c1-900
+for v in 1 0 1 0; do VOCR_WGRAD_WINO_DMA=$v python bench.py --no-cpu-baseline 2>/dev/null | python -c "
+import sys, json
+j = json.loads(sys.stdin.read().strip().splitlines()[-1])
+b = j['ms_per_step_by_entry_point']
+print('dma=$v', j['value'], j['ms_per_step'], 'h2d', j['h2d_inclusive']['ms_per_step'], 'poolbwd', b.get('vocr_fracpool2x2_bwd'), 'bnbwd', b.get('vocr_bn_relu_bwd'), 'wgrad', b.get('vocr_conv3x3_wgrad_wino'))"; done
