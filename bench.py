@@ -16,6 +16,8 @@ Prints ONE JSON line on rank 0."""
 import argparse
 import json
 import os
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before the first HIP call: see vistaocr_amd/__init__.py
 import subprocess
 import sys
 import tempfile

@@ -1,6 +1,10 @@
 cd $GRAFT_REPO_ROOT
-for v in 1 0 1 0; do VOCR_WGRAD_WINO_DMA=$v python bench.py --no-cpu-baseline 2>/dev/null | python -c "
+VOCR_FORCE_DIST=1 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29531 python bench.py --no-cpu-baseline 2>/dev/null | python -c "
 import sys, json
 j = json.loads(sys.stdin.read().strip().splitlines()[-1])
-b = j['ms_per_step_by_entry_point']
-print('dma=$v', j['value'], j['ms_per_step'], 'h2d', j['h2d_inclusive']['ms_per_step'], 'poolbwd', b.get('vocr_fracpool2x2_bwd'), 'bnbwd', b.get('vocr_bn_relu_bwd'), 'wgrad', b.get('vocr_conv3x3_wgrad_wino'))"; done
+print('default env, nccl world 1:', j['value'], j['ms_per_step'], 'gemm', j['ms_per_step_by_entry_point']['vocr_gemm'])"
+python bench.py --no-cpu-baseline 2>/dev/null | python -c "
+import sys, json
+j = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('no dist:', j['value'], j['ms_per_step'])"
+python -m pytest tests/test_round2_gpu.py -q -m gpu -k "rccl or allreduce or bench_launches or fit" 2>&1 | grep -E "passed|failed|Error" | tail -3

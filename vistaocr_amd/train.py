@@ -60,6 +60,7 @@ class FlatClampAdam(object):
         # exchange over xGMI is launched there and hides under the CNN backward (make_optimizer registers the hook).
         self._split = int(named_split) if named_split is not None else 0
         self._tail_work = None
+        self._comm_stream = None
 
     # ---- direct-gradient bookkeeping (ops._sinks)
     def owns_grads(self, params):
@@ -95,8 +96,18 @@ class FlatClampAdam(object):
         """Backward hook: bridge/LSTM/prob gradients are final -> start their all-reduce asynchronously."""
         if self._split > 0 and self._tail_work is None and _dp_active():
             if self.flat_g.is_cuda:
-                ops.join_side_stream(self.flat_g.device)
-            self._tail_work = dist.all_reduce(self.flat_g[self._split:], op=dist.ReduceOp.SUM, async_op=True)
+                # The exchange must see the weight-gradient kernels still queued on the side stream (LSTM layer 0's), but the
+                # MAIN stream must not wait for them: it goes straight on into the CNN backward, which those kernels overlap.
+                # So the collective is enqueued from a stream of its own that waits for both.
+                dev = self.flat_g.device
+                if self._comm_stream is None:
+                    self._comm_stream = torch.cuda.Stream(device=dev)
+                self._comm_stream.wait_stream(torch.cuda.current_stream(dev))
+                self._comm_stream.wait_stream(ops.side_stream(dev))
+                with torch.cuda.stream(self._comm_stream):
+                    self._tail_work = dist.all_reduce(self.flat_g[self._split:], op=dist.ReduceOp.SUM, async_op=True)
+            else:
+                self._tail_work = dist.all_reduce(self.flat_g[self._split:], op=dist.ReduceOp.SUM, async_op=True)
 
     def all_reduce_grads(self, group=None):
         """Sum gradients over data-parallel ranks (RCCL over xGMI when the backend is 'nccl')."""
