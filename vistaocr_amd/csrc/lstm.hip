@@ -1028,8 +1028,10 @@ __global__ __launch_bounds__(512) void lstm_bwd_kowner8(const float* __restrict_
     bool timed_out = false;
     const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc((void*)partials, 0, 2 * 8 * 32 * 32 * 128 * 4, 0x00020000);
 
+    LSTM_STAMP_DECL;
     for (int step = 0; step < T; ++step) {
         const int t = dir == 0 ? T - 1 - step : step;
+        LSTM_STAMP(7);
         const bool act = ev && t < len;
         float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, c = 0.f, cprev = 0.f, dyv = 0.f;
         if (act) {
@@ -1060,7 +1062,9 @@ __global__ __launch_bounds__(512) void lstm_bwd_kowner8(const float* __restrict_
                     }
                 }
             }
+            LSTM_STAMP(0);          // gate/cell loads issued + poll (wave 7)
             __syncthreads();
+            LSTM_STAMP(1);
             if (cellw) {
                 // this workgroup's block of every member's partials of the previous step: [member m][row][unit]
                 const int pbase = (((((step - 1) & 1) * 8 + chain) * 32 + member) * 32 * 128 + tid) * 4;
@@ -1071,6 +1075,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_kowner8(const float* __restrict_
                 for (int m = 0; m < members; ++m) rs += pv[m];
             }
         }
+        LSTM_STAMP(2);              // 32 partial loads + sum (waves 0, 1)
         if (cellw) {
             float dg[4] = {0.f, 0.f, 0.f, 0.f};
             if (act) dcar = lstm_cell_grad(dyv + rs, dcar, ig, fg, gg, og, c, cprev, dg);
@@ -1090,8 +1095,10 @@ __global__ __launch_bounds__(512) void lstm_bwd_kowner8(const float* __restrict_
                 for (int g = 0; g < 4; ++g) dgl[(tid >> 4) * DP + g * 16 + ej] = dg[g];
             }
         }
+        LSTM_STAMP(3);              // cell gradient + dgates stores + LDS (waves 0, 1)
         if (step + 1 < T) {
             __syncthreads();
+            LSTM_STAMP(4);
             // B operand: own dgates of row 4*rg + li, all 64 (gate, unit) values
             f32x4 bv[4][4];
 #pragma unroll
@@ -1121,7 +1128,9 @@ __global__ __launch_bounds__(512) void lstm_bwd_kowner8(const float* __restrict_
                 if (local) __builtin_amdgcn_raw_buffer_store_b128(raw, prsrc, soff, 0, 1);        // sc0: stays in this XCD's L2
                 else __builtin_amdgcn_raw_buffer_store_b128(raw, prsrc, soff, 0, 16);            // write-through (sc1), 16 B
             }
+            LSTM_STAMP(5);          // MFMA + partial stores issued
             __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): every storing wave drains before the flag
+            LSTM_STAMP(6);
         }
         __syncthreads();                                     // also: dgl is free for the next step
         if (tid == 0) {
@@ -1129,6 +1138,12 @@ __global__ __launch_bounds__(512) void lstm_bwd_kowner8(const float* __restrict_
             else __hip_atomic_store(cflags + member, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+#ifdef VOCR_LSTM_STAMPS
+    if (lane == 0 && (wave == 0 || wave == 7) && g_lstm_stamp_out) {
+        unsigned long long* o = g_lstm_stamp_out + ((size_t)(256 + blockIdx.x) * 2 + (wave == 7)) * 8;
+        for (int k = 0; k < 8; ++k) o[k] = st_acc[k];
+    }
+#endif
     // bias gradient of this chain's rows: sum the 8 rows in a fixed order -> bias_part[chain][gate*H + unit]
     if (bias_part) {
         if (cellw) {
