@@ -28,10 +28,13 @@ extern "C" {
 #define VOCR_ENODEVICE  -3   /* no gfx950 device visible */
 #define VOCR_ECOMM      -4   /* RCCL missing or a collective failed */
 
-/* "health" words: an optional caller-owned int32[2] in device memory, zeroed once by the caller and then sticky.
- *   health[0] != 0: a hand-off inside a persistent LSTM sweep timed out (that sweep's output is NaN-poisoned);
+/* "health" words: an optional caller-owned int32[2] in device memory.  The library only ever SETS them (report-only: no
+ * kernel's result depends on their value), the caller zeroes them — once, and again after it has handled a report.
+ *   health[0] != 0: a hand-off inside a persistent LSTM sweep timed out (THAT sweep's output is NaN-poisoned: the sweep
+ *                   decides on a per-call word in its workspace, so later sweeps are unaffected);
  *   health[1] != 0: a NaN gradient reached vocr_clamp_adam / vocr_clamp (the reference's clamp_ propagates NaN too).
- * The host reads it whenever it synchronises anyway (vistaocr_amd.train() copies it next to the loss). */
+ * The host reads it whenever it synchronises anyway (vistaocr_amd.train() copies it next to the loss and clears it
+ * before raising; vistaocr_amd.ops.reset_health() clears it explicitly). */
 
 const char* vocr_last_error(void);
 int  vocr_abi_version(void);
@@ -167,7 +170,7 @@ int vocr_dropout_fwd(const float* x, float* out, float* mask, size_t count, floa
  * hand h_t (forward) / partial sums (backward) to each other through memory: it needs its grid (<= one workgroup per CU)
  * co-resident, so do not run two sweeps concurrently on one device; a hand-off that times out (seconds) poisons the
  * output with NaN instead of hanging.  VOCR_LSTM_PERSISTENT=0 selects one launch per time step instead.
- * `health` (may be NULL): see the note on health words at the top; with NULL the timeout flag lives in the workspace. */
+ * `health` (may be NULL): see the note on health words at the top; the timeout flag the sweep itself tests lives in the workspace. */
 size_t vocr_lstm_workspace_bytes(int t, int b, int h);
 int vocr_lstm_fwd(const float* xproj, const float* whh_fwd, const float* whh_rev, const int32_t* lens, float* y,
                   float* gates, float* cell, void* workspace, int t, int b, int h, int32_t* health, void* stream);

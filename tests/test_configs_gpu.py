@@ -1,7 +1,8 @@
 """GPU: the remaining BASELINE.json configs against the on-box oracle (same seeded inputs, sizes the CPU oracle
 finishes in seconds): config 4 — MADCAT-style Arabic alphabet (V=166), wide lines up to 1200 px, variable widths in
 SortByWidthCollater layout; config 5 — 60-px lines through rapid_ds (60 -> 30) with the 512-hidden BiLSTM.
-Integer outputs (lens, labels on frames whose oracle top-2 margin exceeds fp32 noise) bit-exact; CTC loss 1e-3."""
+Integer outputs (lens, greedy label sequences) bit-exact - the batch seed is chosen on the oracle side so that no frame's decision is
+within the decode margin of flipping - CTC loss 1e-3, every gradient tensor element-wise 1e-2."""
 import numpy as np
 import pytest
 import torch
@@ -12,108 +13,177 @@ from oracle import vista_oracle as vo
 pytestmark = pytest.mark.gpu
 
 
-def _run_pair(hp, chars, B, widths, labels_per_line, seed, ltr=True, loss_rtol=1e-3, logit_rtol=5e-4, grad_rtol=1e-2,
-              min_label_agreement=1.0, state_kw=None):
-    import vistaocr_amd as va
-    V = len(chars)
-    sd_np = cf.closed_form_state(hp, V, **(state_kw or {}))
-    x, w, tgt, tl = cf.closed_form_batch(B, hp.get("num_in_channels", 1), hp["input_line_height"], widths, V, labels_per_line, seed=seed)
+def _masks(T, B, H, n, seed):
+    r = np.random.RandomState(seed)
+    return [torch.from_numpy((r.uniform(size=(T, B, 2 * H)) >= 0.5).astype(np.float32) * 2.0) for _ in range(n)]
+
+
+def _hp(h_img=30, rds=30, din=32, layers=1, hidden=32, drop=0.0, cin=1, **kw):
+    return dict(input_line_height=h_img, rds_line_height=rds, lstm_input_dim=din, num_lstm_layers=layers, num_lstm_hidden_units=hidden,
+                p_lstm_dropout=drop, num_in_channels=cin, **kw)
+
+
+# name -> arguments of _run_pair.  `seed` is the first batch seed tried; scripts/margin_search.py cases runs the oracle-side search of
+# every case on the CPU and prints the seed it settles on, so the seeds below make the first try succeed.
+CASES = {
+    "config4_arabic": dict(hp=_hp(din=64, layers=2, hidden=64, drop=0.5), alphabet="arabic", B=6, widths=[1200, 1113, 907, 640, 333, 15],
+                           labels_per_line=[40, 33, 25, 17, 9, 1], seed=7, ltr=False),
+    # config 4 on the DEFAULT sweep kernels: H = 512, 3 layers, B = 8 (one 8-row chain per direction), ragged T = 588 ... 7, dropout masks
+    "config4_h512": dict(hp=_hp(din=128, layers=3, hidden=512, drop=0.5), alphabet="arabic", B=8,
+                         widths=[1200, 1113, 907, 640, 333, 150, 64, 15], labels_per_line=[40, 33, 25, 17, 9, 4, 2, 1], seed=1, ltr=False,
+                         state_kw=dict(lstm_scale=0.08, prob_scale=2.0), masks=(588, 8, 512, 2, 44)),
+    # the 0.3-scaled closed form saturates the 512-unit gates (|logit| ~ 20, logit error ~ 3e-3): ask for a wider margin
+    "config5_rds": dict(hp=_hp(h_img=60, din=128, layers=3, hidden=512, drop=0.5), alphabet="english", B=3, widths=[400, 322, 128],
+                        labels_per_line=[12, 9, 3], seed=11, want_margin=1e-2, tries=200),
+    "config5_fp16": dict(hp=_hp(h_img=60, din=128, layers=3, hidden=512, drop=0.5, conv_dtype="fp16"), alphabet="english", B=3,
+                         widths=[400, 322, 128], labels_per_line=[12, 9, 3], seed=11, loss_rtol=1e-2, logit_rtol=2e-2, grad_rtol=0.1,
+                         min_label_agreement=0.97, state_kw=dict(lstm_scale=0.08, prob_scale=0.5)),
+    "rgb": dict(hp=_hp(cin=3), alphabet="english", B=2, widths=[150, 90], labels_per_line=[5, 3], seed=3),
+    "batch40": dict(hp=_hp(hidden=64), alphabet="english", B=40, widths=[100] * 30 + [64] * 10, labels_per_line=[3] * 40, seed=5),
+}
+
+
+def _inputs(case, seed):
+    from tests import golden_util as gu
+    chars = gu.alphabet_chars(case["alphabet"])
+    hp, B = case["hp"], case["B"]
+    x, w, tgt, tl = cf.closed_form_batch(B, hp.get("num_in_channels", 1), hp["input_line_height"], case["widths"], len(chars),
+                                         case["labels_per_line"], seed=seed)
     r = np.random.RandomState(seed + 100)
-    s1 = r.uniform(0, 0.999, size=(B, 64, 2)).astype(np.float32)
-    s2 = r.uniform(0, 0.999, size=(B, 128, 2)).astype(np.float32)
-    al = va.Alphabet(chars, left_to_right=ltr)
+    s1 = torch.from_numpy(r.uniform(0, 0.999, size=(B, 64, 2)).astype(np.float32))
+    s2 = torch.from_numpy(r.uniform(0, 0.999, size=(B, 128, 2)).astype(np.float32))
+    return chars, x, w, tgt, tl, s1, s2
+
+
+def _oracle_kw(masks):
+    return dict(training=True, dropout_masks=masks) if masks is not None else dict(training=True, lstm_training=False)
+
+
+def pick_case_seed(case, sd_np=None, masks=None):
+    """Oracle side only (no GPU): the first batch seed >= case['seed'] whose greedy decode is `want_margin` away from flipping."""
+    from tests import golden_util as gu
+    from tests import parity_util as pu
+    V = len(gu.alphabet_chars(case["alphabet"]))
+    if sd_np is None:
+        sd_np = cf.closed_form_state(case["hp"], V, **(case.get("state_kw") or {}))
+    if masks is None and case.get("masks"):
+        masks = _masks(*case["masks"])
+
+    def oracle_logits(seed):
+        _, x, w, _, _, s1, s2 = _inputs(case, seed)
+        with torch.no_grad():
+            lo, ln = vo.forward(vo.state_from_numpy(sd_np, requires_grad=False), case["hp"], torch.from_numpy(x), w, (s1, s2), **_oracle_kw(masks))
+        return lo, ln, V
+
+    seed, margin, _ = pu.pick_seed(oracle_logits, case["seed"], want=case.get("want_margin", 1e-3), tries=case.get("tries", 40))
+    return seed, margin
+
+
+def _run_pair(name):
+    """One train-mode forward + backward on the HIP path and on the oracle.  For the fp32 path (min_label_agreement == 1) the batch
+    seed is advanced on the ORACLE side until its greedy decode is at least `want_margin` away from flipping on every valid frame;
+    the label sequences are then compared bit for bit, unconditionally.  Gradients: every tensor element-wise."""
+    import os
+    import vistaocr_amd as va
+    from tests import parity_util as pu
+    case = CASES[name]
+    hp = case["hp"]
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    masks = _masks(*case["masks"]) if case.get("masks") else None
+    exact = case.get("min_label_agreement", 1.0) >= 1.0
+    seed, margin = case["seed"], None
+    chars = _inputs(case, seed)[0]
+    V = len(chars)
+    sd_np = cf.closed_form_state(hp, V, **(case.get("state_kw") or {}))
+    if exact:
+        seed, margin = pick_case_seed(case, sd_np, masks)
+    chars, x, w, tgt, tl, s1, s2 = _inputs(case, seed)
+    al = va.Alphabet(chars, left_to_right=case.get("ltr", True))
     model = va.CnnOcrModel(alphabet=al, verbose=False, **hp)
     sd = model.state_dict()
     for k, v in sd_np.items():
         sd[k] = torch.from_numpy(v)
     model.load_state_dict(sd)
     model.train()
-    model.lstm.eval()
-    model.pool_samples = [torch.from_numpy(s1), torch.from_numpy(s2)]
+    if masks is not None:
+        model.dropout_masks = masks
+    else:
+        model.lstm.eval()
+    model.pool_samples = [s1, s2]
     logits, lens = model(torch.from_numpy(x), torch.from_numpy(w))
     loss = va.CTCLoss()(logits, torch.from_numpy(tgt), lens, torch.from_numpy(tl))
     loss.backward()
     osd = vo.state_from_numpy(sd_np)
-    lo, ln = vo.forward(osd, hp, torch.from_numpy(x), w, (torch.from_numpy(s1), torch.from_numpy(s2)), training=True, lstm_training=False)
+    lo, ln = vo.forward(osd, hp, torch.from_numpy(x), w, (s1, s2), **_oracle_kw(masks))
     lo_loss = vo.ctc_criterion(lo, torch.from_numpy(tgt), ln, torch.from_numpy(tl))
     lo_loss.backward()
     assert lens.tolist() == ln.tolist()
-    assert abs(float(loss) - float(lo_loss)) <= loss_rtol * abs(float(lo_loss)), (float(loss), float(lo_loss))
+    rel = abs(float(loss) - float(lo_loss)) / abs(float(lo_loss))
+    assert rel <= case.get("loss_rtol", 1e-3), (float(loss), float(lo_loss))
     lg = logits.detach().cpu()
     T = lg.shape[0]
     valid = torch.arange(T).unsqueeze(1) < ln.unsqueeze(0)
     # fp32 logits with a different summation order: tolerance relative to the logit scale (the 512-hidden, 3-layer
     # closed-form model saturates its gates and reaches |logit| ~ 20, measured error 3e-3 there, 2e-5 at H=48)
     scale = max(1.0, float(lo.detach().abs()[valid].max()))
-    assert float((lg - lo.detach()).abs()[valid].max()) < logit_rtol * scale, (float((lg - lo.detach()).abs()[valid].max()), scale)
-    top2 = torch.sort(lo.detach(), dim=2, descending=True)[0]
-    margin = top2[:, :, 0] - top2[:, :, 1]
-    safe = valid & (margin > 1e-3)
-    agree = float((lg.argmax(2)[safe] == lo.detach().argmax(2)[safe]).float().mean())
-    assert agree >= min_label_agreement, "per-frame argmax agreement %.4f on well-separated frames" % agree
-    if min_label_agreement >= 1.0 and float(margin[valid].min()) > 1e-3:
-        assert model.decode_labels(logits, lens) == vo.greedy_decode(lo.detach(), ln, al.idx_to_char, uxxxx=True)[1]
-    for k, p in model.named_parameters():
-        if k.startswith("cnn.") and k.endswith(".bias") and int(k.split(".")[1]) in (0, 3, 7, 10, 14, 17, 20):
-            continue
-        rn = float(osd[k].grad.double().norm())
-        assert abs(float(p.grad.double().norm()) - rn) <= grad_rtol * rn + 1e-5, k
+    err = float((lg - lo.detach()).abs()[valid].max())
+    assert err < case.get("logit_rtol", 5e-4) * scale, (err, scale)
+    emitted = -1
+    if exact:
+        olabels = vo.greedy_decode(lo.detach(), ln, al.idx_to_char, uxxxx=True)[1]
+        emitted = sum(len(l) for l in olabels)
+        assert err <= margin / 2, "logit error %.2e against an oracle decode margin of %.2e" % (err, margin)
+        assert emitted >= 1, "no label emitted: the comparison would be vacuous"
+        assert model.decode_labels(logits, lens) == olabels, "greedy label sequences differ"
+    else:       # fp16 conv operands (config 5): agreement rate on well-separated frames, SURVEY.md §7
+        top2 = torch.sort(lo.detach(), dim=2, descending=True)[0]
+        safe = valid & ((top2[:, :, 0] - top2[:, :, 1]) > 1e-3)
+        agree = float((lg.argmax(2)[safe] == lo.detach().argmax(2)[safe]).float().mean())
+        assert agree >= case["min_label_agreement"], "per-frame argmax agreement %.4f on well-separated frames" % agree
+    worst = pu.assert_grads_close(model, osd, rtol=case.get("grad_rtol", 1e-2))
+    print("%s (batch seed %d): loss rel %.2e, max |dlogit| %.2e at scale %.1f, oracle decode margin %s, labels emitted %d, worst "
+          "element-wise gradient error %.2e (%s)" % (name, seed, rel, err, scale, "%.2e" % margin if margin else "-", emitted, worst[1], worst[0]))
     return model, logits, lens
 
 
 def test_config4_arabic_wide_variable_width():
-    from tests import golden_util as gu
-    chars = gu.alphabet_chars("arabic")
-    hp = dict(input_line_height=30, rds_line_height=30, lstm_input_dim=64, num_lstm_layers=2, num_lstm_hidden_units=64,
-              p_lstm_dropout=0.5, num_in_channels=1)
-    widths = [1200, 1113, 907, 640, 333, 15]                  # MADCAT-like spread, sorted descending, min width 15
-    model, logits, lens = _run_pair(hp, chars, 6, widths, [40, 33, 25, 17, 9, 1], seed=7, ltr=False)
+    model, logits, lens = _run_pair("config4_arabic")
     assert lens.tolist() == [588, 545, 443, 313, 163, 7]
     assert logits.shape[2] == 166
 
 
+def test_config4_wide_ragged_hidden512_on_the_8row_sweeps():
+    """Config 4 on the DEFAULT sweep kernels: H = 512, 3 layers, B = 8 (one 8-row chain per direction), widths 1200 ... 15, i.e. ragged
+    T = 588 ... 7 through lstm_fwd_chain8 / lstm_bwd_kowner8 with explicit inter-layer dropout masks, Arabic alphabet (V = 166)."""
+    model, logits, lens = _run_pair("config4_h512")
+    assert lens.tolist() == [588, 545, 443, 313, 163, 73, 30, 7]
+    assert logits.shape[2] == 166
+
+
 def test_config5_rds_60px_hidden512():
-    from tests import golden_util as gu
-    chars = gu.alphabet_chars("english")
-    hp = dict(input_line_height=60, rds_line_height=30, lstm_input_dim=128, num_lstm_layers=3, num_lstm_hidden_units=512,
-              p_lstm_dropout=0.5, num_in_channels=1)
-    model, logits, lens = _run_pair(hp, chars, 3, [400, 322, 128], [12, 9, 3], seed=11)
+    model, logits, lens = _run_pair("config5_rds")
     assert lens.tolist() == [98, 78, 30]
 
 
 def test_config5_fp16_conv_mfma():
     """Config 5 as BASELINE.json words it: 60-px lines, rapid_ds, 512-hidden BiLSTM, fp16 conv MFMA with fp32 accumulate
     (CTC in fp32).  The oracle applies the same operand rounding (oracle/vista_oracle.py _ConvF16Operands)."""
-    from tests import golden_util as gu
-    chars = gu.alphabet_chars("english")
-    hp = dict(input_line_height=60, rds_line_height=30, lstm_input_dim=128, num_lstm_layers=3, num_lstm_hidden_units=512,
-              p_lstm_dropout=0.5, num_in_channels=1, conv_dtype="fp16")
     # fp16 operand rounding is a discontinuity: a 1e-7 difference in an activation (summation order) can flip its
     # rounding at the next layer, which acts as 2^-11-sized noise that the saturated 512-hidden closed-form LSTM
     # amplifies.  Per SURVEY.md §7, fp16 results get a looser loss tolerance and a label-agreement rate; the
     # 1e-3 / bit-exact contract applies to the fp32 path only.
     # (recurrent weights drawn from the reference's own init range +-0.08 so the 512-hidden LSTM is not saturated)
-    model, logits, lens = _run_pair(hp, chars, 3, [400, 322, 128], [12, 9, 3], seed=11, loss_rtol=1e-2, logit_rtol=2e-2,
-                                    grad_rtol=0.1, min_label_agreement=0.97, state_kw=dict(lstm_scale=0.08, prob_scale=0.5))
+    model, logits, lens = _run_pair("config5_fp16")
     assert lens.tolist() == [98, 78, 30] and model.conv_dtype == "fp16"
 
 
 def test_rgb_input_three_channels():
-    from tests import golden_util as gu
-    chars = gu.alphabet_chars("english")
-    hp = dict(input_line_height=30, rds_line_height=30, lstm_input_dim=32, num_lstm_layers=1, num_lstm_hidden_units=32,
-              p_lstm_dropout=0.0, num_in_channels=3)
-    _run_pair(hp, chars, 2, [150, 90], [5, 3], seed=3)
+    _run_pair("rgb")
 
 
 def test_batch_64_speed_test_shape():
     """The reference's own speed_test.py shape: batch 64 (src/speed_test.py:16): 4 MFMA row tiles in the sweeps."""
-    import vistaocr_amd as va
-    al = va.english_alphabet()
-    hp = dict(input_line_height=30, rds_line_height=30, lstm_input_dim=32, num_lstm_layers=1, num_lstm_hidden_units=64,
-              p_lstm_dropout=0.0, num_in_channels=1)
-    from tests import golden_util as gu
-    _run_pair(hp, gu.alphabet_chars("english"), 40, [100] * 30 + [64] * 10, [3] * 40, seed=5)
+    _run_pair("batch40")
 
 
 def test_validation_pass_and_snapshot_roundtrip(tmp_path):

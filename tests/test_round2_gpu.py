@@ -1,7 +1,8 @@
 """GPU: round-2 parity and drop-in cases.
 
   * BASELINE configs[1] at FULL size (B=32, 30x600, 3xBiLSTM-512, V=96) against the on-box oracle, explicit pool samples and
-    explicit inter-layer dropout masks: lens, CTC loss 1e-3, greedy labels bit-exact, per-tensor gradient norms 1e-2;
+    explicit inter-layer dropout masks, batch seed chosen on the oracle side for a decode margin >= 1e-3: lens, CTC loss 1e-3, greedy
+    labels bit-exact (unconditional), every gradient tensor element-wise to 1e-2;
   * the reference's decode edge-case fixture through every decode entry point of the HIP path;
   * config 5 at its full line size 60x1200 (fp16 conv operands) with the measured agreement printed;
   * CTC on an infeasible alignment; determinism of the weight gradients; train() with torch.optim.Adam;
@@ -32,23 +33,41 @@ def _load_state(model, sd_np):
     model.load_state_dict(sd)
 
 
+FULL_SIZE_SEED = 73          # scripts/margin_search.py 2.0 1.0 1 140: oracle decode margin 1.17e-3 with this batch
+
+
 def test_config1_full_size_vs_oracle():
-    """B=32 x 1x30x600, V=96, lstm_input_dim 128, 3xBiLSTM-512 with dropout masks: the bench workload, pinned to the oracle."""
+    """B=32 x 1x30x600, V=96, lstm_input_dim 128, 3xBiLSTM-512 with dropout masks: the bench workload, pinned to the oracle.
+    The batch seed is chosen on the ORACLE side so that no valid frame's greedy decision is closer than 1e-3 to flipping (the way
+    oracle/gen_golden.py picks its batches); with that, the label sequences are compared bit for bit UNCONDITIONALLY, and every
+    gradient tensor element-wise."""
     import vistaocr_amd as va
+    from tests import parity_util as pu
     chars = gu.alphabet_chars("english")
     V = len(chars)
     hp = dict(input_line_height=30, rds_line_height=30, lstm_input_dim=128, num_lstm_layers=3, num_lstm_hidden_units=512,
               p_lstm_dropout=0.5, num_in_channels=1)
     # recurrent weights from the reference's own init range (+-0.08, cnnlstm.py:158-159): the 0.3-scaled closed form
     # saturates a 512-unit LSTM, which turns fp32 summation-order noise into O(1e-3) logit differences
-    sd_np = cf.closed_form_state(hp, V, lstm_scale=0.08, prob_scale=0.5)
+    sd_np = cf.closed_form_state(hp, V, lstm_scale=0.08, prob_scale=2.0)
     B, T, H = 32, 294, 512
-    x, w, tgt, tl = cf.closed_form_batch(B, 1, 30, [600] * B, V, [20] * B, seed=21)
     r = np.random.RandomState(121)
     s1 = torch.from_numpy(r.uniform(0, 0.999, size=(B, 64, 2)).astype(np.float32))
     s2 = torch.from_numpy(r.uniform(0, 0.999, size=(B, 128, 2)).astype(np.float32))
     masks = [torch.from_numpy((r.uniform(size=(T, B, 2 * H)) >= 0.5).astype(np.float32) * 2.0) for _ in range(2)]
     al = va.Alphabet(chars, left_to_right=True)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+
+    def oracle_logits(seed):
+        xs, ws, _, _ = cf.closed_form_batch(B, 1, 30, [600] * B, V, [20] * B, seed=seed)
+        with torch.no_grad():
+            lo_, ln_ = vo.forward(vo.state_from_numpy(sd_np, requires_grad=False), hp, torch.from_numpy(xs), ws, (s1, s2),
+                                  training=True, dropout_masks=masks)
+        return lo_, ln_, V
+
+    seed, margin, _ = pu.pick_seed(oracle_logits, FULL_SIZE_SEED, want=1e-3)
+    x, w, tgt, tl = cf.closed_form_batch(B, 1, 30, [600] * B, V, [20] * B, seed=seed)
+
     model = va.CnnOcrModel(alphabet=al, verbose=False, **hp)
     _load_state(model, sd_np)
     model.train()
@@ -59,7 +78,6 @@ def test_config1_full_size_vs_oracle():
     loss.backward()
     labels = model.decode_labels(logits, lens)
 
-    torch.set_num_threads(min(32, os.cpu_count() or 1))
     osd = vo.state_from_numpy(sd_np)
     lo, ln = vo.forward(osd, hp, torch.from_numpy(x), w, (s1, s2), training=True, dropout_masks=masks)
     lo_loss = vo.ctc_criterion(lo, torch.from_numpy(tgt), ln, torch.from_numpy(tl))
@@ -68,29 +86,19 @@ def test_config1_full_size_vs_oracle():
     rel = abs(float(loss) - float(lo_loss)) / abs(float(lo_loss))
     lg = logits.detach().cpu()
     err = float((lg - lo.detach()).abs().max())
-    top2 = torch.sort(lo.detach(), dim=2, descending=True)[0]
-    margin = top2[:, :, 0] - top2[:, :, 1]
-    safe = margin > 1e-3
-    agree = float((lg.argmax(2)[safe] == lo.detach().argmax(2)[safe]).float().mean())
     olabels = vo.greedy_decode(lo.detach(), ln, al.idx_to_char, uxxxx=True)[1]
     mism = sum(int(a != b) for a, b in zip(labels, olabels))
-    print("full-size configs[1]: loss %.4f vs oracle %.4f (rel %.2e); max |dlogit| %.2e at scale %.1f; min top-2 margin %.2e, "
-          "%.2f%% of frames above 1e-3; label sequences differing: %d of %d"
-          % (float(loss), float(lo_loss), rel, err, float(lo.detach().abs().max()), float(margin.min()), 100 * float(safe.float().mean()), mism, B))
+    emitted = sum(len(l) for l in olabels)
+    print("full-size configs[1] (batch seed %d): loss %.4f vs oracle %.4f (rel %.2e); max |dlogit| %.2e at scale %.1f; oracle decode "
+          "margin %.2e; labels emitted %d; label sequences differing: %d of %d"
+          % (seed, float(loss), float(lo_loss), rel, err, float(lo.detach().abs().max()), margin, emitted, mism, B))
     assert rel <= 1e-3
-    assert agree == 1.0, "per-frame argmax differs on a frame whose oracle margin exceeds 1e-3"
-    if float(margin.min()) > 1e-4:
-        assert mism == 0, "greedy label sequences differ"
-    worst = ("", 0.0)
-    for k, p in model.named_parameters():
-        if k.startswith("cnn.") and k.endswith(".bias") and int(k.split(".")[1]) in (0, 3, 7, 10, 14, 17, 20):
-            continue          # exactly zero in exact arithmetic (bias in front of a batch-stat BN): rounding noise on both sides
-        rn = float(osd[k].grad.double().norm())
-        d = abs(float(p.grad.double().norm()) - rn) / (rn + 1e-12)
-        if d > worst[1]:
-            worst = (k, d)
-        assert d <= 1e-2 + 1e-5 / (rn + 1e-12), (k, d)
-    print("full-size configs[1]: worst per-tensor gradient-norm deviation %.2e (%s)" % (worst[1], worst[0]))
+    assert emitted >= 10 * B, "the label comparison would be vacuous"
+    assert err <= margin / 4, "logit error %.2e is not small against the decode margin %.2e" % (err, margin)
+    assert mism == 0, "greedy label sequences differ"
+    assert labels == olabels
+    worst = pu.assert_grads_close(model, osd, rtol=1e-2)
+    print("full-size configs[1]: worst per-tensor element-wise gradient error %.2e (%s)" % (worst[1], worst[0]))
 
 
 def test_reference_decode_edge_cases_on_the_hip_decoder():

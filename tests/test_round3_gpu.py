@@ -1,0 +1,142 @@
+"""GPU: round-3 cases.
+
+  * data-parallel replicas with per-rank randomness: two real ranks (gloo on one GPU always; RCCL on two GPUs when the box has them)
+    run the identical init, va.seed_rank, one forward of the SAME batch (logits must differ: the ranks' FractionalMaxPool samples
+    differ) and two train steps on per-rank batches (weights must stay bit-identical across ranks);
+  * the health words are report-only: a raised word does not poison later sweeps, and a report is cleared when it is raised;
+  * FlatClampAdam refuses step() while a bucket of the exchange is in flight and nobody collected it."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_ranks(n, backend, share_gpu, out, limit_s=900):
+    """Fresh child process per rank (nothing is exec'ed from a GPU-initialised process); the first failing rank ends the others."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = {k: v for k, v in os.environ.items()}
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if share_gpu:
+            env["VOCR_LSTM_PERSISTENT"] = "0"          # two processes' persistent sweeps must not compete for one GPU's CUs
+        cmd = [sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), "--backend", backend, "--out", out] + (["--share-gpu"] if share_gpu else [])
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    t0 = time.time()
+    while True:
+        rcs = [p.poll() for p in procs]
+        if all(rc == 0 for rc in rcs):
+            break
+        if any(rc not in (None, 0) for rc in rcs) or time.time() - t0 > limit_s:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            raise AssertionError("ranks failed: %s\n%s" % (rcs, "\n----\n".join((p.communicate()[0] or "")[-1500:] for p in procs)))
+        time.sleep(0.2)
+    return json.load(open(out))
+
+
+def _check_replicas(recs, n):
+    assert len(recs) == n and sorted(r["rank"] for r in recs) == list(range(n)) and all(r["world"] == n for r in recs)
+    assert len({r["init_hash"] for r in recs}) == 1, "replicas must start from the identical init"
+    assert len({r["dropout_seed"] for r in recs}) == n, "every rank needs its own dropout stream"
+    assert len({r["logit_sum"] for r in recs}) == n, "the same batch must give different logits on different ranks (own pool samples)"
+    assert len({r["weights_hash"] for r in recs}) == 1, "after summed-gradient steps every rank must hold bit-identical weights"
+    assert all(np.isfinite(l) for r in recs for l in r["losses"])
+    assert len({tuple(r["losses"]) for r in recs}) == n, "per-rank batches: the ranks' losses differ"
+
+
+def test_two_ranks_on_one_gpu_rank_rng_and_identical_weights(tmp_path):
+    recs = _run_ranks(2, "gloo", True, os.path.join(tmp_path, "dp.json"))
+    _check_replicas(recs, 2)
+
+
+def test_two_ranks_on_two_gpus_over_rccl(tmp_path):
+    """The real thing: one process per GPU, RCCL all-reduce in two buckets inside the backward, persistent sweeps on.  Skipped on the
+    1-GPU boxes of this pool; the driver's multi-GPU bench is the first place it can run."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (this box has %d)" % torch.cuda.device_count())
+    recs = _run_ranks(2, "nccl", False, os.path.join(tmp_path, "dp.json"))
+    _check_replicas(recs, 2)
+    assert {r["device"] for r in recs} == {0, 1}
+
+
+def test_health_word_reports_but_never_poisons_later_sweeps():
+    """the sweeps used to test the caller's sticky health word, so one transient hand-off timeout NaN-poisoned every later
+    sweep of the process.  Now a raised word changes no result, check_health() raises once and clears the report."""
+    import vistaocr_amd as va
+    from vistaocr_amd import ops
+    dev = torch.device("cuda", 0)
+    al = va.english_alphabet()
+    torch.manual_seed(0)
+    model = va.CnnOcrModel(alphabet=al, verbose=False, input_line_height=30, rds_line_height=30, lstm_input_dim=32, num_lstm_layers=1,
+                           num_lstm_hidden_units=256, p_lstm_dropout=0.0, num_in_channels=1)
+    model.eval()
+    x = torch.rand(3, 1, 30, 120)
+    widths = torch.tensor([120, 100, 60], dtype=torch.int32)
+    model.pool_samples = [torch.rand(3, 64, 2), torch.rand(3, 128, 2)]
+    with torch.no_grad():
+        ref, _ = model(x, widths)
+    ops.health(dev)[0] = 1                           # as if an earlier sweep had timed out
+    with torch.no_grad():
+        again, _ = model(x, widths)
+    assert torch.isfinite(again).all() and torch.equal(again, ref), "a stale report must not change a later sweep's result"
+    with pytest.raises(RuntimeError, match="timed out"):
+        ops.check_health_sync(dev)
+    ops.check_health_sync(dev)                       # the report was cleared when it was raised
+    assert ops.health(dev).cpu().tolist() == [0, 0]
+    ops.health(dev)[1] = 1
+    with pytest.raises(RuntimeError, match="NaN gradient"):
+        ops.check_health_sync(dev)
+    ops.check_health_sync(dev)
+
+
+def test_step_refuses_an_uncollected_exchange():
+    """backward() starts the sequence-side all-reduce when a process group is active; step() without all_reduce_grads() used
+    to race it.  It now refuses (and zero_grad() waits for the collective before clearing the buffer)."""
+    import torch.distributed as dist
+    import vistaocr_amd as va
+    if dist.is_initialized():
+        pytest.skip("a process group is already initialised in this interpreter")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + os.getpid() % 2000), VOCR_FORCE_DIST="1")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        torch.manual_seed(0)
+        model = va.CnnOcrModel(alphabet=va.english_alphabet(), verbose=False, input_line_height=30, rds_line_height=30, lstm_input_dim=16,
+                               num_lstm_layers=1, num_lstm_hidden_units=64, p_lstm_dropout=0.0)
+        opt = va.make_optimizer(model)
+        crit = va.CTCLoss()
+        model.train()
+        x = torch.rand(2, 1, 30, 100)
+        widths = torch.tensor([100, 100], dtype=torch.int32)
+        tgt = torch.tensor([3, 4, 5, 6], dtype=torch.int32)
+        tl = torch.tensor([2, 2], dtype=torch.int32)
+        opt.zero_grad()
+        lg, lens = model(x, widths)
+        crit(lg, tgt, lens, tl).backward()
+        assert opt._tail_work is not None
+        with pytest.raises(RuntimeError, match="all_reduce_grads"):
+            opt.step()
+        assert opt._tail_work is None
+        opt.zero_grad()
+        lg, lens = model(x, widths)
+        crit(lg, tgt, lens, tl).backward()
+        opt.all_reduce_grads()
+        opt.step()
+        opt.check_health()
+    finally:
+        os.environ.pop("VOCR_FORCE_DIST", None)
+        dist.destroy_process_group()

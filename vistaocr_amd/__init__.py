@@ -13,8 +13,8 @@ from .alphabet import Alphabet, arabic_alphabet, english_alphabet, french_alphab
 from .ctc import CTCLoss                                                                # noqa: F401,E402
 from .decoder import ArgmaxDecoder                                                      # noqa: F401,E402
 from .model import CnnOcrModel                                                          # noqa: F401,E402
-from .train import FlatClampAdam, make_optimizer, train, train_async                                    # noqa: F401,E402
+from .train import FlatClampAdam, make_optimizer, seed_rank, train, train_async                                    # noqa: F401,E402
 from .dataset import OcrDataset                                                         # noqa: F401,E402
 
 __all__ = ["Alphabet", "english_alphabet", "arabic_alphabet", "french_alphabet", "CTCLoss", "ArgmaxDecoder",
-           "CnnOcrModel", "FlatClampAdam", "make_optimizer", "train", "train_async", "OcrDataset"]
+           "CnnOcrModel", "FlatClampAdam", "make_optimizer", "seed_rank", "train", "train_async", "OcrDataset"]

@@ -1344,9 +1344,11 @@ extern "C" int vocr_conv3x3_fwd(const float* x, const float* wpack, const float*
     // half-chunk instead of hiding behind the issuing wave's own MFMAs; a third buffer does not fit three workgroups per CU.)
     static const int use_dma = getenv("VOCR_CONV_DMA") ? atoi(getenv("VOCR_CONV_DMA")) : 1;
     // VOCR_CONV_TAIL: 1 (default) the last partial round of tiles is cut into pieces that lead the same launch, 3 the pieces
-    // run as conv3x3_tail_kernel behind the launch, 0 one launch of whole tiles as before,
-    // 2 EXPERIMENT (wrong results): the partial round is dropped - the upper bound of what the pieces can buy
-    static const int tail_mode = getenv("VOCR_CONV_TAIL") ? atoi(getenv("VOCR_CONV_TAIL")) : 1;
+    // run as conv3x3_tail_kernel behind the launch, 0 one launch of whole tiles as before; any other value = 1.  (The
+    // upper-bound experiment that dropped the partial round - wrong results, -8.7 % on the forward stack - is no longer in
+    // the shipped library.)
+    static const int tail_env = getenv("VOCR_CONV_TAIL") ? atoi(getenv("VOCR_CONV_TAIL")) : 1;
+    static const int tail_mode = (tail_env == 0 || tail_env == 3) ? tail_env : 1;
     const int ncu = conv_cu_count();
     if (use_dma && vec && !tiny) {
         // LDS-DMA form (weights by global_load_lds into ping-pong half-chunk buffers)

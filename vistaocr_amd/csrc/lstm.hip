@@ -336,9 +336,17 @@ __device__ __forceinline__ unsigned xcc_id() {
     return x;
 }
 
+// A hand-off timed out: the poison decision of THIS sweep reads the per-call status word (workspace, zeroed by the host's
+// memset in front of every launch); the caller's health word only collects the event for reporting.  (The sweeps used to
+// test the caller's sticky word itself: one transient timeout then NaN-poisoned every later sweep of the process.)
+__device__ __forceinline__ void raise_timeout(unsigned* status, unsigned* health) {
+    __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (health) __hip_atomic_store(health, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Returns true iff all `members` workgroups of this chain report the same XCC id.  ids: one word per member, zeroed
 // by the host.  Called by every thread of the workgroup; scratch is one LDS word.
-__device__ __forceinline__ bool chain_is_xcd_local(unsigned* ids, int members, int member, unsigned* status, unsigned* scratch) {
+__device__ __forceinline__ bool chain_is_xcd_local(unsigned* ids, int members, int member, unsigned* status, unsigned* health, unsigned* scratch) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned mine = xcc_id() + 1u;
     if (tid == 0) __hip_atomic_store(ids + member, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -351,7 +359,7 @@ __device__ __forceinline__ bool chain_is_xcd_local(unsigned* ids, int members, i
             if (__all(v != 0u)) { same = __all(v == mine); break; }
             __builtin_amdgcn_s_sleep(2);
             if (++spins > (1u << 22)) {
-                if (lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) raise_timeout(status, health);
                 break;
             }
         }
@@ -370,7 +378,7 @@ template <int KQ4>
 __global__ __launch_bounds__(256) void lstm_fwd_chain(const float* __restrict__ xproj, const float* __restrict__ whh_f,
                                                       const float* __restrict__ whh_r, const int32_t* __restrict__ lens,
                                                       float* y, float* __restrict__ gates, float* __restrict__ cell,
-                                                      unsigned* flags, unsigned* ids, unsigned* status, int T, int B, int nbt, int force_wt,
+                                                      unsigned* flags, unsigned* ids, unsigned* status, unsigned* health, int T, int B, int nbt, int force_wt,
                                                       int s0, int s1) {
     constexpr int H = 64 * KQ4;
     constexpr int members = H >> 4;
@@ -387,7 +395,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_chain(const float* __restrict__ 
     const int kbase = wave * (H >> 2) + q * 4;
     const float* whh = dir ? whh_r : whh_f;
     unsigned* cflags = flags + chain * 32;
-    const bool local = chain_is_xcd_local(ids + chain * 32, members, member, status, (unsigned*)(lds + 4 * 16 * 65)) && !force_wt;
+    const bool local = chain_is_xcd_local(ids + chain * 32, members, member, status, health, (unsigned*)(lds + 4 * 16 * 65)) && !force_wt;
 
     // resident W_hh fragments: tile j holds units unit0+4j..+3; B-operand lane lr = gate (lr>>2), unit 4j + (lr&3)
     f32x4 wv[4][KQ4];
@@ -445,7 +453,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_chain(const float* __restrict__ 
                     if (__all(f0 >= (unsigned)step)) break;
                     __builtin_amdgcn_s_sleep(1);
                     if (++spins > (1u << 22)) {
-                        if (lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (lane == 0) raise_timeout(status, health);
                         timed_out = true;
                         break;
                     }
@@ -531,7 +539,7 @@ template <int KQ4>
 __global__ __launch_bounds__(512) void lstm_fwd_chain8(const float* __restrict__ xproj, const float* __restrict__ whh_f,
                                                        const float* __restrict__ whh_r, const int32_t* __restrict__ lens,
                                                        float* y, float* __restrict__ gates, float* __restrict__ cell,
-                                                       unsigned* flags, unsigned* ids, unsigned* status, int T, int B, int NT8, int force_wt,
+                                                       unsigned* flags, unsigned* ids, unsigned* status, unsigned* health, int T, int B, int NT8, int force_wt,
                                                        int s0, int s1) {
     constexpr int H = 64 * KQ4;
     constexpr int members = H >> 4;
@@ -552,7 +560,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_chain8(const float* __restrict__
     const int kbase = wave * KW;
     const float* whh = dir ? whh_r : whh_f;
     unsigned* cflags = flags + chain * 32;
-    const bool local = chain_is_xcd_local(ids + chain * 32, members, member, status, (unsigned*)(lds + 8 * 8 * 65)) && !force_wt;
+    const bool local = chain_is_xcd_local(ids + chain * 32, members, member, status, health, (unsigned*)(lds + 8 * 8 * 65)) && !force_wt;
 
     // resident B operand: column 32*I + 4*cg + li = (gate, local unit) = (col >> 4, col & 15)
     f32x4 wv[2][NL];
@@ -620,7 +628,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_chain8(const float* __restrict__
                     if (__all(f0 >= (unsigned)step)) break;
                     __builtin_amdgcn_s_sleep(1);
                     if (++spins > (1u << 22)) {
-                        if (lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (lane == 0) raise_timeout(status, health);
                         timed_out = true;
                         break;
                     }
@@ -848,7 +856,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kowner(const float* __restrict__
                                                        const float* __restrict__ whht_r, const int32_t* __restrict__ lens,
                                                        const float* __restrict__ gates, const float* __restrict__ cell,
                                                        float* __restrict__ dgates, float* partials, unsigned* flags, unsigned* ids,
-                                                       unsigned* status, int T, int B, int RT, int force_wt) {
+                                                       unsigned* status, unsigned* health, int T, int B, int RT, int force_wt) {
     constexpr int H = 128 * NCH;
     constexpr int members = H / 16;
     constexpr int TPW = members / 4;                  // 16-unit output tiles per wave
@@ -863,7 +871,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kowner(const float* __restrict__
     unsigned* cflags = flags + chain * 32;
     // chain on one XCD: partials and flags stay in its L2 (sc0 stores); the loads stay sc1 (L1 bypassed) because a
     // partial block is rewritten every other step, so an L1 copy of it would be stale
-    const bool local = chain_is_xcd_local(ids + chain * 32, members, member, status, (unsigned*)(dgl + 16 * DP)) && !force_wt;
+    const bool local = chain_is_xcd_local(ids + chain * 32, members, member, status, health, (unsigned*)(dgl + 16 * DP)) && !force_wt;
 
     // resident A fragments: aw[j][i][e] = W_hh[q*H + unit0 + 4i + e][n0 + lr] = whht[n0 + lr][q*H + unit0 + 4i + e]
     f32x4 aw[TPW][4];
@@ -912,7 +920,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kowner(const float* __restrict__
                     if (__all(f0 >= (unsigned)step)) break;
                     __builtin_amdgcn_s_sleep(1);
                     if (++spins > (1u << 22)) {
-                        if (lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (lane == 0) raise_timeout(status, health);
                         timed_out = true;
                         break;
                     }
@@ -987,7 +995,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_kowner8(const float* __restrict_
                                                         const float* __restrict__ whht_r, const int32_t* __restrict__ lens,
                                                         const float* __restrict__ gates, const float* __restrict__ cell,
                                                         float* __restrict__ dgates, float* partials, unsigned* flags, unsigned* ids,
-                                                        unsigned* status, float* bias_part, int T, int B, int NT8, int force_wt) {
+                                                        unsigned* status, unsigned* health, float* bias_part, int T, int B, int NT8, int force_wt) {
     constexpr int H = 128 * NCH;
     constexpr int members = H / 16;
     constexpr int NG = H / 32 / 8;                    // 32-unit output groups per wave (2 at H = 512)
@@ -999,7 +1007,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_kowner8(const float* __restrict_
     const int dir = chain / NT8, bt = chain % NT8, unit0 = member * 16;
     const int blk = lane >> 2, li = lane & 3, ug = blk >> 1, rg = blk & 1;
     unsigned* cflags = flags + chain * 32;
-    const bool local = chain_is_xcd_local(ids + chain * 32, members, member, status, (unsigned*)(dgl + 8 * DP)) && !force_wt;
+    const bool local = chain_is_xcd_local(ids + chain * 32, members, member, status, health, (unsigned*)(dgl + 8 * DP)) && !force_wt;
 
     // resident A operand: aw[g][gate][i][e] = W_hh[gate*H + unit0 + 4i + e][n] = whht[n][gate*H + unit0 + 4i + e],
     // n = 32*(wave*NG + g) + 4*ug + li
@@ -1056,7 +1064,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_kowner8(const float* __restrict_
                     if (__all(f0 >= (unsigned)step)) break;
                     __builtin_amdgcn_s_sleep(1);
                     if (++spins > (1u << 22)) {
-                        if (lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (lane == 0) raise_timeout(status, health);
                         timed_out = true;
                         break;
                     }
@@ -1230,8 +1238,9 @@ extern "C" int vocr_lstm_fwd_range(const float* xproj, const float* whh_fwd, con
     if (fast && fits32 && (persistent_mode & 1) && 8 * (h / 16) <= resident_workgroup_capacity()) {
         // chain sweep.  arrival flags: [chain <= 8][32 workgroups] at [0..255], XCC ids at [256..511]; status words at [512..]
         unsigned* flags = (unsigned*)workspace;
-        // a hand-off timeout is recorded in the caller's sticky health word (health[0]) when one is given
-        unsigned* status = health ? (unsigned*)health : flags + 512;
+        // the sweep's own status word is per call (zeroed here); a timeout is also reported in the caller's health word
+        unsigned* status = flags + 512;
+        unsigned* hword = (unsigned*)health;
         if (hipMemsetAsync(flags, 0, 520 * sizeof(unsigned), s) != hipSuccess) {
             vocr_set_error("vocr_lstm_fwd: memset failed");
             return VOCR_ELAUNCH;
@@ -1241,15 +1250,15 @@ extern "C" int vocr_lstm_fwd_range(const float* xproj, const float* whh_fwd, con
         const int nt8 = (b + 7) / 8;
         if (2 * nt8 <= 8 && !(persistent_mode & 32) && (h == 512 || h == 256)) {      // 8-row chains on all 8 XCDs, 4x4x1 MFMA
             if (h == 512)
-                lstm_fwd_chain8<8><<<cg, 512, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, flags, flags + 256, status, t, b, nt8, fwt,
+                lstm_fwd_chain8<8><<<cg, 512, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, flags, flags + 256, status, hword, t, b, nt8, fwt,
                                                       step_begin, step_end);
             else
-                lstm_fwd_chain8<4><<<cg, 512, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, flags, flags + 256, status, t, b, nt8, fwt,
+                lstm_fwd_chain8<4><<<cg, 512, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, flags, flags + 256, status, hword, t, b, nt8, fwt,
                                                       step_begin, step_end);
             VOCR_CHECK_LAUNCH("vocr_lstm_fwd(chain, 8-row)");
             return VOCR_OK;
         }
-#define VOCR_CHAIN(KQ4) lstm_fwd_chain<KQ4><<<cg, 256, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, flags, flags + 256, status, t, b, rt, fwt, step_begin, step_end)
+#define VOCR_CHAIN(KQ4) lstm_fwd_chain<KQ4><<<cg, 256, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, flags, flags + 256, status, hword, t, b, rt, fwt, step_begin, step_end)
         if (h == 64) VOCR_CHAIN(1); else if (h == 128) VOCR_CHAIN(2); else if (h == 256) VOCR_CHAIN(4); else VOCR_CHAIN(8);
 #undef VOCR_CHAIN
         VOCR_CHECK_LAUNCH("vocr_lstm_fwd(chain)");
@@ -1311,7 +1320,8 @@ extern "C" int vocr_lstm_bwd_bias(const float* dy, const float* whht_fwd, const 
     if (fast && (persistent_mode & 2) && 8 * (h / 16) <= resident_workgroup_capacity() && aligned16(gates)) {
         // arrival flags: [chain <= 8][32 workgroups] at [0..255]; status words at [512..]
         unsigned* flags = (unsigned*)workspace;
-        unsigned* status = health ? (unsigned*)health : flags + 512;
+        unsigned* status = flags + 512;
+        unsigned* hword = (unsigned*)health;
         if (hipMemsetAsync(flags, 0, 520 * sizeof(unsigned), s) != hipSuccess) {
             vocr_set_error("vocr_lstm_bwd: memset failed");
             return VOCR_ELAUNCH;
@@ -1324,9 +1334,9 @@ extern "C" int vocr_lstm_bwd_bias(const float* dy, const float* whht_fwd, const 
             const int fwt8 = (persistent_mode & 8) ? 1 : 0;
             float* bpart = dbias ? (float*)((char*)workspace + 4096 + ((size_t)16 << 20)) : nullptr;     // [chain][4H]
             if (h == 512)
-                lstm_bwd_kowner8<4><<<g, 512, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, bpart, t, b, nt8, fwt8);
+                lstm_bwd_kowner8<4><<<g, 512, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, hword, bpart, t, b, nt8, fwt8);
             else
-                lstm_bwd_kowner8<2><<<g, 512, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, bpart, t, b, nt8, fwt8);
+                lstm_bwd_kowner8<2><<<g, 512, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, hword, bpart, t, b, nt8, fwt8);
             VOCR_CHECK_LAUNCH("vocr_lstm_bwd(k-owner, 8-row chains)");
             if (dbias) {
                 lstm_bias_combine_kernel<<<dim3(vocr_cdiv(4 * h, 256), 2), 256, 0, s>>>(bpart, dbias, 4 * h, nt8);
@@ -1335,9 +1345,9 @@ extern "C" int vocr_lstm_bwd_bias(const float* dy, const float* whht_fwd, const 
             return VOCR_OK;
         }
         const int fwt = (persistent_mode & 8) ? 1 : 0;       // experiments: write-through hand-off even on one XCD
-        if (h == 128) lstm_bwd_kowner<1><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, t, b, rt, fwt);
-        else if (h == 256) lstm_bwd_kowner<2><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, t, b, rt, fwt);
-        else lstm_bwd_kowner<4><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, t, b, rt, fwt);
+        if (h == 128) lstm_bwd_kowner<1><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, hword, t, b, rt, fwt);
+        else if (h == 256) lstm_bwd_kowner<2><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, hword, t, b, rt, fwt);
+        else lstm_bwd_kowner<4><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, hword, t, b, rt, fwt);
         VOCR_CHECK_LAUNCH("vocr_lstm_bwd(k-owner)");
         return lstm_bias_by_colsum(dgates, dbias, workspace, t, b, h, stream);
     }

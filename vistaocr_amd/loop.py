@@ -145,6 +145,13 @@ def SortByWidthCollater(batch):
     return x, targets, widths, target_lens, meta
 
 
+def _check_device_health(model):
+    from . import ops
+    dev = next(model.parameters()).device
+    if dev.type == "cuda":
+        ops.check_health_sync(dev)
+
+
 def test_on_val(val_dataloader, model, criterion):
     """src/train_cnn_lstm.py:32-100 — running means of loss/batch, CER and WER over the validation loader."""
     cer_avg = wer_avg = loss_avg = 0.0
@@ -171,6 +178,7 @@ def test_on_val(val_dataloader, model, criterion):
             cer_avg += (bc / bsz - cer_avg) / n
             wer_avg += (bw / bsz - wer_avg) / n
     model.train()
+    _check_device_health(model)          # a timed-out LSTM sweep poisons its logits with NaN: never report them as a score
     return loss_avg, cer_avg, wer_avg
 
 
@@ -255,4 +263,5 @@ def decode_dataset(model, dataloader, outdir, visual_to_logical=None, seed=7):
                 fh.write("%s (%s)\n" % (utf8_to_uxxxx(hyp_utf8), uttid))
                 fh8.write("%s (%s)\n" % (hyp_utf8, uttid[:uttid.rfind("_")]))
                 n += 1
+    _check_device_health(model)
     return n

@@ -74,8 +74,11 @@ def join_side_stream(device=None):
         st["pending"] = False
 
 
-# ---- health words (include/vocr.h): one sticky int32[2] per device.  [0]: a persistent LSTM sweep's hand-off timed out,
-# [1]: a NaN gradient reached the optimiser.  The kernels set them; train() reads them next to the loss (no extra sync).
+# ---- health words (include/vocr.h): one int32[2] per device, report-only.  [0]: a persistent LSTM sweep's hand-off timed
+# out (that sweep's output is NaN-poisoned; the sweep tests a per-call word of its own, so later sweeps are unaffected),
+# [1]: a NaN gradient reached the optimiser.  The kernels set them; train() reads them next to the loss (no extra sync),
+# test_on_val / decode_dataset read them once per pass.  A report is cleared when it is raised, so a loop that handles the
+# exception (reload the best snapshot, skip the batch) can go on.
 _HEALTH = {}
 
 
@@ -89,13 +92,28 @@ def health(device):
     return h
 
 
-def check_health(values):
-    """Raise if the two health words (any int sequence) report a failure."""
-    if int(values[0]) != 0:
+def reset_health(device=None):
+    """Clear the device's health words (stream-ordered memset)."""
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    health(device).zero_()
+
+
+def check_health(values, device=None):
+    """Raise if the two health words (any int sequence, read from `device`) report a failure; the report is cleared first."""
+    bad0, bad1 = int(values[0]) != 0, int(values[1]) != 0
+    if (bad0 or bad1) and device is not None:
+        reset_health(device)
+    if bad0:
         raise RuntimeError("vistaocr_amd: a hand-off inside a persistent LSTM sweep timed out (its output is NaN-poisoned); "
                            "is another persistent sweep running on this GPU?  VOCR_LSTM_PERSISTENT=0 selects per-step launches")
-    if int(values[1]) != 0:
+    if bad1:
         raise RuntimeError("vistaocr_amd: a NaN gradient reached the optimiser (the reference's clamp_ would propagate it too)")
+
+
+def check_health_sync(device):
+    """Synchronising form: copy the words to the host and check them (eval / decode passes call this once per pass)."""
+    check_health(health(device).cpu().tolist(), device)
 
 
 # ---- direct gradient sinks: an optimiser that owns a persistent gradient buffer per parameter (FlatClampAdam's flat

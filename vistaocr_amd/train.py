@@ -61,6 +61,9 @@ class FlatClampAdam(object):
         self._split = int(named_split) if named_split is not None else 0
         self._tail_work = None
         self._comm_stream = None
+        self._group = None               # process group of BOTH buckets (None = the default group); see set_group()
+        self._time_comm = False          # bench.py: HIP events around both buckets of the exchange
+        self._comm_events = []           # (bucket name, start event, end event)
 
     # ---- direct-gradient bookkeeping (ops._sinks)
     def owns_grads(self, params):
@@ -80,7 +83,39 @@ class FlatClampAdam(object):
                                    "gradient accumulation.")
             self._written.add(id(p))
 
+    def set_group(self, group):
+        """Data-parallel process group for the gradient exchange (both buckets); None = the default group."""
+        self._finish_tail()
+        self._group = group
+
+    def time_comm(self, on):
+        """Record HIP events around the two all-reduce buckets of the following steps (bench.py's allreduce_ms_per_step)."""
+        self._time_comm = bool(on) and self.flat_g.is_cuda
+
+    def comm_times_ms(self):
+        """{"sequence_bucket": ms, "cnn_bucket": ms, "steps": n}: mean duration of each bucket's all-reduce over the steps recorded
+        since the last call, from 'inputs ready' to 'reduced' on the stream that carries it (None if nothing was recorded)."""
+        if not self._comm_events:
+            return None
+        torch.cuda.synchronize(self.flat_g.device)
+        acc, cnt = {}, {}
+        for name, e0, e1 in self._comm_events:
+            acc[name] = acc.get(name, 0.0) + e0.elapsed_time(e1)
+            cnt[name] = cnt.get(name, 0) + 1
+        self._comm_events = []
+        out = {k: round(acc[k] / cnt[k], 4) for k in acc}
+        out["steps"] = max(cnt.values())
+        out["bytes"] = {"sequence_bucket": 4 * (self.flat_g.numel() - self._split), "cnn_bucket": 4 * self._split}
+        return out
+
+    def _finish_tail(self):
+        """Wait for a sequence-side all-reduce that a backward pass started and nobody has collected yet."""
+        if self._tail_work is not None:
+            self._tail_work.wait()
+            self._tail_work = None
+
     def zero_grad(self, set_to_none=False):
+        self._finish_tail()              # never clear a buffer a collective is still reducing
         self.flat_g.zero_()
         self._written.clear()
         off = 0
@@ -94,7 +129,7 @@ class FlatClampAdam(object):
 
     def _start_tail_allreduce(self):
         """Backward hook: bridge/LSTM/prob gradients are final -> start their all-reduce asynchronously."""
-        if self._split > 0 and self._tail_work is None and _dp_active():
+        if self._split > 0 and self._tail_work is None and _dp_active(self._group):
             if self.flat_g.is_cuda:
                 # The exchange must see the weight-gradient kernels still queued on the side stream (LSTM layer 0's), but the
                 # MAIN stream must not wait for them: it goes straight on into the CNN backward, which those kernels overlap.
@@ -105,25 +140,56 @@ class FlatClampAdam(object):
                 self._comm_stream.wait_stream(torch.cuda.current_stream(dev))
                 self._comm_stream.wait_stream(ops.side_stream(dev))
                 with torch.cuda.stream(self._comm_stream):
-                    self._tail_work = dist.all_reduce(self.flat_g[self._split:], op=dist.ReduceOp.SUM, async_op=True)
+                    if self._time_comm:
+                        e0 = torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                    self._tail_work = dist.all_reduce(self.flat_g[self._split:], op=dist.ReduceOp.SUM, group=self._group, async_op=True)
+                    if self._time_comm:
+                        self._tail_work.wait()          # orders the (dedicated) comm stream behind the collective, not the host
+                        e1 = torch.cuda.Event(enable_timing=True)
+                        e1.record()
+                        self._comm_events.append(("sequence_bucket", e0, e1))
             else:
-                self._tail_work = dist.all_reduce(self.flat_g[self._split:], op=dist.ReduceOp.SUM, async_op=True)
+                self._tail_work = dist.all_reduce(self.flat_g[self._split:], op=dist.ReduceOp.SUM, group=self._group, async_op=True)
 
     def all_reduce_grads(self, group=None):
-        """Sum gradients over data-parallel ranks (RCCL over xGMI when the backend is 'nccl')."""
+        """Sum gradients over data-parallel ranks (RCCL over xGMI when the backend is 'nccl').  `group`: a process group
+        other than the one set with set_group() is only accepted while no bucket is in flight on the latter."""
         if self.flat_g.is_cuda:
             ops.join_side_stream(self.flat_g.device)
+        if group is None:
+            group = self._group
+        elif group is not self._group:
+            if self._tail_work is not None:
+                raise RuntimeError("vistaocr_amd.FlatClampAdam: the sequence-side bucket is already being reduced on the group "
+                                   "given to set_group(); pass the same group here (or call set_group(group) before backward)")
         if not _dp_active(group):
+            self._finish_tail()
             return
+        e0 = None
+        if self._time_comm:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         if self._tail_work is not None:                 # tail bucket already in flight since mid-backward
             dist.all_reduce(self.flat_g[:self._split], op=dist.ReduceOp.SUM, group=group)
-            self._tail_work.wait()
-            self._tail_work = None
+            name = "cnn_bucket"
         else:
             dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=group)
+            name = "whole_gradient"
+        if e0 is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self._comm_events.append((name, e0, e1))
+        self._finish_tail()
 
     def step(self, grad_scale=1.0):
         g = self.param_groups[0]
+        if self._tail_work is not None:
+            # a backward pass started the sequence-side bucket's exchange but all_reduce_grads() never ran: the CNN bucket is
+            # unreduced and the collective may still be writing flat_g - refuse instead of racing it
+            self._finish_tail()
+            raise RuntimeError("vistaocr_amd.FlatClampAdam.step(): a data-parallel process group is active and backward() has "
+                               "started the gradient exchange; call optimizer.all_reduce_grads() between backward() and step()")
         ops.join_side_stream(self.flat_g.device)
         self.step_count += 1
         ops.clamp_adam(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, g["lr"], g["betas"][0], g["betas"][1],
@@ -131,7 +197,7 @@ class FlatClampAdam(object):
 
     def check_health(self):
         """Synchronising check of the device health words (LSTM hand-off timeout, NaN gradient)."""
-        ops.check_health(ops.health(self.flat_g.device).cpu().tolist())
+        ops.check_health_sync(self.flat_g.device)
 
     def state_dict(self):
         """In torch.optim.Adam's own format ({'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [...]}, the
@@ -185,6 +251,19 @@ def make_optimizer(model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.
     return opt
 
 
+def seed_rank(model, rank, base=0):
+    """Per-rank randomness of a data-parallel replica: call AFTER the identical initialisation.  Re-seeds torch's
+    CPU and device generators (FractionalMaxPool2d samples are torch.rand draws per forward, src/models/cnnlstm.py:127,130) with
+    base + 1000*rank and offsets the model's counter-based dropout stream (nn.LSTM's inter-layer dropout,
+    src/train_cnn_lstm.py:331), so ranks draw different samples and masks while their weights stay identical."""
+    torch.manual_seed(int(base) + 1000 * int(rank))
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed(int(base) + 1000 * int(rank))
+    if hasattr(model, "dropout_seed"):
+        model.dropout_seed = 0x5EED + 1000003 * int(rank)
+        model._dropout_calls = 0
+
+
 GRAD_CLAMP = 5.0          # src/train_cnn_lstm.py:143-145
 
 
@@ -233,7 +312,7 @@ def _step(batch, model, criterion, optimizer, want_float):
     if ev is None:
         return loss.data[0].item()
     ev.synchronize()
-    ops.check_health(host_health.tolist())
+    ops.check_health(host_health.tolist(), loss.device)
     return float(host[0])
 
 
