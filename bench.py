@@ -58,9 +58,9 @@ def parity_samples():
 # Parity leg: random-init weights emit almost no labels (the blank wins every frame), so the label comparison would be vacuous.
 # The leg therefore loads the tests' closed-form weights (recurrent weights in the reference's own +-0.08 init range, output layer
 # widened so that ~6000 labels come out of the 32 lines) and a closed-form batch whose seed was chosen on the ORACLE side for a
-# greedy-decode margin >= 1e-3 (scripts/margin_search.py 2.0 1.0 1 200 nomask); the oracle re-checks the margin on the box.
+# greedy-decode margin >= 1e-3 (scripts/margin_search.py bench 1 300); the oracle re-computes and reports the margin on the box.
 PARITY_STATE_KW = dict(lstm_scale=0.08, prob_scale=2.0)
-PARITY_BATCH_SEED = 1
+PARITY_BATCH_SEED = 56          # scripts/margin_search.py bench 1 300: oracle decode margin 1.02e-3 (the best of 299 seeds)
 
 
 def parity_inputs(hidden, vocab):
@@ -83,6 +83,11 @@ def gemm_flops(args):
     return 2.0 * m * n * k
 
 
+def gemm_pair_flops(args):
+    m, n, k = args[3:6]
+    return 2 * 2.0 * m * n * k                   # two products (mode 0) or one product with two K segments (mode 1)
+
+
 def lstm_flops(args, first_dim_arg):
     t, b, h = args[first_dim_arg:first_dim_arg + 3]
     return 2.0 * 2 * t * b * h * 4 * h           # both directions: [B, H] x [H, 4H] per time step
@@ -91,14 +96,15 @@ def lstm_flops(args, first_dim_arg):
 # MFMA FLOPs a launch EXECUTES per algorithmic FLOP: the F(2,3) / F(3,2) kernels issue 4 multiplications where the direct form needs 6
 EXECUTED_SHARE = {"vocr_conv3x3_wino_fwd": 2.0 / 3.0, "vocr_conv3x3_wgrad_wino": 2.0 / 3.0}
 FLOPS_OF = {"vocr_conv3x3_fwd": conv_flops, "vocr_conv3x3_wino_fwd": conv_flops, "vocr_conv3x3_wgrad": conv_flops,
-            "vocr_conv3x3_wgrad_wino": conv_flops, "vocr_gemm": gemm_flops,
+            "vocr_conv3x3_wgrad_wino": conv_flops, "vocr_gemm": gemm_flops, "vocr_gemm_pair": gemm_pair_flops,
             "vocr_lstm_fwd": lambda a: lstm_flops(a, 8), "vocr_lstm_fwd_range": lambda a: lstm_flops(a, 8),
             "vocr_lstm_bwd_bias": lambda a: lstm_flops(a, 9)}
 FAMILY = {"vocr_conv3x3_fwd": "conv3x3 forward + data gradient (conv3x3_wino_kernel / conv3x3_dma_kernel)",
           "vocr_conv3x3_wino_fwd": "conv3x3 forward + data gradient (conv3x3_wino_kernel / conv3x3_dma_kernel)",
           "vocr_conv3x3_wgrad": "conv3x3 weight gradient (conv3x3_wgrad_wino_dma_kernel)",
           "vocr_conv3x3_wgrad_wino": "conv3x3 weight gradient (conv3x3_wgrad_wino_dma_kernel)",
-          "vocr_gemm": "dense GEMMs (gemm kernels behind vocr_gemm: bridge, LSTM projections, prob and their dX / dW)",
+          "vocr_gemm": "dense GEMMs (gemm_dma_kernel / gemm_f32_kernel behind vocr_gemm and vocr_gemm_pair: bridge, LSTM projections, prob, their dX / dW)",
+          "vocr_gemm_pair": "dense GEMMs (gemm_dma_kernel / gemm_f32_kernel behind vocr_gemm and vocr_gemm_pair: bridge, LSTM projections, prob, their dX / dW)",
           "vocr_lstm_fwd": "LSTM sweeps (lstm_fwd_chain8 / lstm_bwd_kowner8)", "vocr_lstm_fwd_range": "LSTM sweeps (lstm_fwd_chain8 / lstm_bwd_kowner8)",
           "vocr_lstm_bwd_bias": "LSTM sweeps (lstm_fwd_chain8 / lstm_bwd_kowner8)"}
 
@@ -320,7 +326,7 @@ def run_rank(args):
             dist.barrier()
         torch.cuda.synchronize()
 
-    MFMA_NAMES = ["vocr_conv3x3_fwd", "vocr_conv3x3_wino_fwd", "vocr_conv3x3_wgrad", "vocr_conv3x3_wgrad_wino", "vocr_gemm",
+    MFMA_NAMES = ["vocr_conv3x3_fwd", "vocr_conv3x3_wino_fwd", "vocr_conv3x3_wgrad", "vocr_conv3x3_wgrad_wino", "vocr_gemm", "vocr_gemm_pair",
                   "vocr_lstm_fwd", "vocr_lstm_fwd_range", "vocr_lstm_bwd_bias"]
 
     def timed(batch, steps, event_every=None):

@@ -143,6 +143,18 @@ size_t vocr_gemm_workspace_bytes(int m, int n, int k, int has_bias_or_relu);
 int vocr_gemm(int transa, int transb, int m, int n, int k,
               const float* a, int lda, const float* b, int ldb, float* c, int ldc,
               const float* bias, int relu, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* Two products of ONE shape in one launch — the two directions of a bidirectional nn.LSTM layer (cnnlstm.py:148-149,288-290):
+ *   mode 0: c0 = op(a0) op(b0) (+bias0)(relu),  c1 = op(a1) op(b1) (+bias1)(relu)      (x W_ih^T of both directions: a0 == a1;
+ *           the weight gradients dgates_dir^T x and dgates_dir^T h of both directions)
+ *   mode 1: c0 = op(a0) op(b0) + op(a1) op(b1) (+bias0)(relu), c1 = bias1 = NULL        (dx = dgates_fwd W_ih_fwd + dgates_rev W_ih_rev:
+ *           one product with the K dimension running through both operands pairs instead of a product and an accumulating one)
+ * Same operand conventions as vocr_gemm; all leading dimensions are shared by the two products.  Large 16-byte aligned shapes run
+ * as ONE launch of the panel kernel whose workgroups cover both products (no partial last round); anything else is two vocr_gemm
+ * calls.  workspace: vocr_gemm_pair_workspace_bytes (K slabs, fixed-order sum: reproducible). */
+size_t vocr_gemm_pair_workspace_bytes(int m, int n, int k, int mode);
+int vocr_gemm_pair(int mode, int transa, int transb, int m, int n, int k, const float* a0, const float* a1, int lda,
+                   const float* b0, const float* b1, int ldb, float* c0, float* c1, int ldc, const float* bias0, const float* bias1,
+                   int relu, void* workspace, size_t workspace_bytes, void* stream);
 /* out[N] = sum over M rows of x[M,N] (bias gradients); partial rows in `workspace` (vocr_colsum_workspace_bytes, may be
  * NULL = one workgroup per 64 columns), added in a fixed order */
 size_t vocr_colsum_workspace_bytes(int m, int n);

@@ -54,7 +54,8 @@ def busy(paths):
             k = short(r["Kernel_Name"])
             key = "conv forward (%s)" % k.split("<")[0] if (k.startswith("conv3x3_dma_kernel") or k.startswith("conv3x3_wino_kernel")) \
                 else "conv weight gradient (%s)" % k.split("<")[0] if (k.startswith("conv3x3_wgrad_kernel") or k.startswith("conv3x3_wgrad_wino")) \
-                else "x-projection GEMM (gemm_f32_kernel NT)" if k.startswith("gemm_f32_kernel") else None
+                else "GEMM tile kernel (%s)" % k[:60] if k.startswith("gemm_f32_kernel") \
+                else "GEMM panel kernel (%s)" % k[:60] if k.startswith("gemm_dma_kernel") else None
             if key is None:
                 continue
             acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))

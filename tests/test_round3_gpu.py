@@ -140,3 +140,83 @@ def test_step_refuses_an_uncollected_exchange():
     finally:
         os.environ.pop("VOCR_FORCE_DIST", None)
         dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------------------- panel GEMM (gemm_dma.hip)
+def _r(shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(shape, generator=g) * 2 - 1
+
+
+def _check(c, ref, k, what):
+    err = (c.detach().cpu().double() - ref).abs()
+    tol = 3e-6 * k + 1e-5 * ref.abs()
+    assert bool((err <= tol).all()), "%s: max abs err %.3e (scale %.2e)" % (what, float(err.max()), float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("m,n,k", [(9408, 2048, 1024), (9408, 1024, 2048), (2048, 1024, 9408), (4200, 1000, 1000), (2052, 512, 4096),
+                                   (9408, 2048, 128), (2560, 384, 8192), (8200, 260, 72)])
+def test_panel_gemm_all_layouts(m, n, k):
+    """The DMA-staged panel kernel on the step's large products and on edge shapes (M, N, K not multiples of the tile sizes, K cut into
+    slabs for the long-K / few-tile ones), all four operand layouts, bias + ReLU, accumulate; bitwise reproducible."""
+    from vistaocr_amd import ops
+    dev = torch.device("cuda", 0)
+    a, b, bias = _r((m, k), 1), _r((k, n), 2), _r((n,), 3)
+    ref = a.double() @ b.double()
+    ad, bd, at, bt = a.to(dev), b.to(dev), a.t().contiguous().to(dev), b.t().contiguous().to(dev)
+    c = torch.empty(m, n, device=dev)
+    ops.gemm(0, 1, m, n, k, ad, k, bt, k, c, n, bias=bias.to(dev), relu=True)
+    _check(c, torch.relu(ref + bias.double()), k, "NT bias relu")
+    c1 = torch.empty(m, n, device=dev)
+    ops.gemm(0, 1, m, n, k, ad, k, bt, k, c1, n, bias=bias.to(dev), relu=True)
+    assert torch.equal(c, c1), "two runs must agree bit for bit"
+    ops.gemm(0, 0, m, n, k, ad, k, bd, n, c, n)
+    _check(c, ref, k, "NN")
+    ops.gemm(1, 0, m, n, k, at, m, bd, n, c, n)
+    _check(c, ref, k, "TN")
+    c2 = torch.empty(m, n, device=dev)
+    ops.gemm(1, 0, m, n, k, at, m, bd, n, c2, n)
+    assert torch.equal(c, c2), "two runs (K slabs) must agree bit for bit"
+    ops.gemm(1, 1, m, n, k, at, m, bt, k, c, n, bias=bias.to(dev))
+    _check(c, ref + bias.double(), k, "TT bias")
+    c0 = _r((m, n), 4)
+    c = c0.clone().to(dev)
+    ops.gemm(1, 0, m, n, k, at, m, bd, n, c, n, accumulate=True)
+    _check(c, ref + c0.double(), k, "TN accumulate")
+    # output and operands embedded in wider matrices (leading dimensions > extents), like the LSTM's y[:, H:] / xproj[d] views
+    wide = torch.zeros(m, n + 64, device=dev)
+    awide = torch.zeros(m, k + 32, device=dev)
+    awide[:, 16:16 + k] = ad
+    ops.gemm(0, 0, m, n, k, awide[:, 16:], k + 32, bd, n, wide[:, 32:], n + 64)
+    _check(wide[:, 32:32 + n], ref, k, "NN with leading dimensions")
+    assert float(wide[:, :32].abs().max()) == 0.0 and float(wide[:, 32 + n:].abs().max()) == 0.0, "wrote outside the output view"
+
+
+@pytest.mark.parametrize("m,n,k", [(9408, 2048, 1024), (9408, 2048, 128), (2048, 1024, 9408), (2048, 512, 9376), (9408, 1024, 2048),
+                                   (9408, 128, 2048), (1000, 300, 520)])
+def test_gemm_pair_modes(m, n, k):
+    """vocr_gemm_pair: two products of one shape in one launch (mode 0) and one product whose K runs through two operand pairs (mode 1)
+    against fp64; shapes the panel kernel does not take fall back to two vocr_gemm calls with the same results contract."""
+    from vistaocr_amd import ops
+    dev = torch.device("cuda", 0)
+    a0, a1, b0, b1 = _r((m, k), 1), _r((m, k), 2), _r((k, n), 3), _r((k, n), 4)
+    bias0, bias1 = _r((n,), 5), _r((n,), 6)
+    r0, r1 = a0.double() @ b0.double(), a1.double() @ b1.double()
+    d = lambda t: t.to(dev)
+    c0, c1 = torch.empty(m, n, device=dev), torch.empty(m, n, device=dev)
+    # mode 0, NT with biases (the x-projections: one A, two weight matrices)
+    ops.gemm_pair(0, 0, 1, m, n, k, d(a0), d(a0), k, d(b0.t().contiguous()), d(b1.t().contiguous()), k, c0, c1, n, bias0=d(bias0), bias1=d(bias1))
+    _check(c0, r0 + bias0.double(), k, "pair mode 0 NT / product 0")
+    _check(c1, a0.double() @ b1.double() + bias1.double(), k, "pair mode 0 NT / product 1")
+    # mode 0, TN (the weight gradients: two A, one B)
+    ops.gemm_pair(0, 1, 0, m, n, k, d(a0.t().contiguous()), d(a1.t().contiguous()), m, d(b0), d(b0), n, c0, c1, n)
+    _check(c0, r0, k, "pair mode 0 TN / product 0")
+    _check(c1, a1.double() @ b0.double(), k, "pair mode 0 TN / product 1")
+    e0, e1 = torch.empty(m, n, device=dev), torch.empty(m, n, device=dev)
+    ops.gemm_pair(0, 1, 0, m, n, k, d(a0.t().contiguous()), d(a1.t().contiguous()), m, d(b0), d(b0), n, e0, e1, n)
+    assert torch.equal(c0, e0) and torch.equal(c1, e1), "two runs must agree bit for bit"
+    # mode 1, NN (the data gradient: K through both pairs)
+    ops.gemm_pair(1, 0, 0, m, n, k, d(a0), d(a1), k, d(b0), d(b1), n, c0, None, n)
+    _check(c0, r0 + r1, 2 * k, "pair mode 1 NN")
+    ops.gemm_pair(1, 0, 0, m, n, k, d(a0), d(a1), k, d(b0), d(b1), n, e0, None, n, bias0=d(bias0), relu=True)
+    _check(e0, torch.relu(r0 + r1 + bias0.double()), 2 * k, "pair mode 1 NN bias relu")

@@ -46,6 +46,8 @@ SIGNATURES = {
     "vocr_relu_maxpool2_bwd": (I, [P, P, P, P, I, I, I, I, P]),
     "vocr_gemm_workspace_bytes": (Z, [I, I, I, I]),
     "vocr_gemm": (I, [I, I, I, I, I, P, I, P, I, P, I, P, I, I, P, Z, P]),
+    "vocr_gemm_pair_workspace_bytes": (Z, [I, I, I, I]),
+    "vocr_gemm_pair": (I, [I, I, I, I, I, I, P, P, I, P, P, I, P, P, I, P, P, I, P, Z, P]),
     "vocr_colsum_workspace_bytes": (Z, [I, I]),
     "vocr_colsum": (I, [P, P, I, I, P, P]),
     "vocr_relu_bwd": (I, [P, P, P, Z, P]),

@@ -7,7 +7,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-SOURCES = ["gemm.hip", "conv.hip", "conv_wino.hip", "conv_f16.hip", "bn_pool.hip", "lstm.hip", "ctc.hip", "misc.cpp", "comm.cpp"]
+SOURCES = ["gemm.hip", "gemm_dma.hip", "conv.hip", "conv_wino.hip", "conv_f16.hip", "bn_pool.hip", "lstm.hip", "ctc.hip", "misc.cpp", "comm.cpp"]
 LIB = os.path.join(CSRC, "libvocr.so")
 ARCH = "gfx950"
 
@@ -23,7 +23,7 @@ def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "vocr_common.h"), os.path.join(CSRC, "conv_tail.h"),
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "vocr_common.h"), os.path.join(CSRC, "conv_tail.h"), os.path.join(CSRC, "gemm_dma.h"),
                                                       os.path.join(CSRC, "..", "..", "include", "vocr.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 

@@ -6,6 +6,7 @@
 // is 32 consecutive dwords per lane-half (conflict-free ds_read_b32); global->LDS goes through registers
 // and is issued one K-tile ahead of the MFMAs that consume it.
 #include "vocr_common.h"
+#include "gemm_dma.h"
 
 namespace {
 
@@ -480,7 +481,24 @@ bool gemm_tail_fill_enabled() {
 extern "C" size_t vocr_gemm_workspace_bytes(int m, int n, int k, int has_bias_or_relu) {
     if (m <= 0 || n <= 0 || k <= 0) return 0;
     const GemmPlan p = gemm_plan(m, n, k, has_bias_or_relu != 0, 1l << 40, gemm_tail_fill_enabled());
-    return (size_t)p.pieces * p.bm * p.bn * sizeof(float);
+    size_t bytes = (size_t)p.pieces * p.bm * p.bn * sizeof(float);
+    // the DMA-staged kernel's K slabs (whatever the transposition flags and leading dimensions turn out to be: densest case)
+    for (int ta = 0; ta < 2; ++ta) {
+        const vocr_dma_gemm::Plan d = vocr_dma_gemm::plan(ta, 0, m, n, k, ta ? m : k, n, n, 1, 1, false);
+        if (d.ok && d.slab_bytes > bytes) bytes = d.slab_bytes;
+    }
+    return bytes;
+}
+
+// Two products of one shape in one launch: slabs for both
+extern "C" size_t vocr_gemm_pair_workspace_bytes(int m, int n, int k, int mode) {
+    if (m <= 0 || n <= 0 || k <= 0) return 0;
+    size_t bytes = vocr_gemm_workspace_bytes(m, n, k, 0);
+    for (int ta = 0; ta < 2; ++ta) {
+        const vocr_dma_gemm::Plan d = vocr_dma_gemm::plan(ta, 0, m, n, k, ta ? m : k, n, n, mode ? 1 : 2, mode ? 2 : 1, false);
+        if (d.ok && d.slab_bytes > bytes) bytes = d.slab_bytes;
+    }
+    return bytes;
 }
 
 extern "C" int vocr_gemm(int transa, int transb, int m, int n, int k, const float* a, int lda, const float* b, int ldb,
@@ -490,6 +508,25 @@ extern "C" int vocr_gemm(int transa, int transb, int m, int n, int k, const floa
     VOCR_CHECK_ARG(a && b && c, "vocr_gemm: null pointer");
     VOCR_CHECK_ARG(lda >= (transa ? m : k) && ldb >= (transb ? k : n) && ldc >= n, "vocr_gemm: bad leading dimension");
     hipStream_t s = (hipStream_t)stream;
+    // large, aligned products: the DMA-staged panel kernel (gemm_dma.hip); `accumulate` only through its slab reduce
+    if (((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)bias)) & 15) == 0) {
+        const vocr_dma_gemm::Plan d = vocr_dma_gemm::plan(transa, transb, m, n, k, lda, ldb, ldc, 1, 1, false);
+        const bool ws_ok = d.ok && (d.ksplit == 1 || (workspace && (((uintptr_t)workspace) & 15) == 0 && workspace_bytes >= d.slab_bytes));
+        if (ws_ok && (!accumulate || d.ksplit > 1)) {
+            const float* aa[2] = {a, nullptr};
+            const float* bb[2] = {b, nullptr};
+            float* cc[2] = {c, nullptr};
+            const float* bs[2] = {d.ksplit > 1 ? nullptr : bias, nullptr};
+            vocr_dma_gemm::launch(d, transa, transb, m, n, k, aa, lda, bb, ldb, cc, ldc, bs, d.ksplit > 1 ? 0 : relu, 1, 1, (float*)workspace, s);
+            VOCR_CHECK_LAUNCH("vocr_gemm(dma)");
+            if (d.ksplit > 1) {
+                const int tiles = d.groups * d.panels;
+                splitk_reduce_kernel<<<tiles * 32, 256, 0, s>>>((const float*)workspace, c, m, n, ldc, 256, 128, 0, d.ksplit, d.panels, bias, relu, accumulate);
+                VOCR_CHECK_LAUNCH("vocr_gemm(dma, split-K reduce)");
+            }
+            return VOCR_OK;
+        }
+    }
     const long sam = transa ? 1 : lda, sak = transa ? lda : 1;
     const long sbk = transb ? 1 : ldb, sbn = transb ? ldb : 1;
     // K cuts need room for one tile-sized slab per piece; with less workspace there are fewer pieces, with none K is never cut
@@ -522,6 +559,50 @@ extern "C" int vocr_gemm(int transa, int transb, int m, int n, int k, const floa
         VOCR_CHECK_LAUNCH("vocr_gemm(split-K reduce)");
     }
     return VOCR_OK;
+}
+
+extern "C" int vocr_gemm_pair(int mode, int transa, int transb, int m, int n, int k, const float* a0, const float* a1, int lda,
+                              const float* b0, const float* b1, int ldb, float* c0, float* c1, int ldc, const float* bias0,
+                              const float* bias1, int relu, void* workspace, size_t workspace_bytes, void* stream) {
+    VOCR_CHECK_ARG(mode == 0 || mode == 1, "vocr_gemm_pair: mode must be 0 (two products) or 1 (two K segments summed)");
+    VOCR_CHECK_ARG(m > 0 && n > 0 && k > 0, "vocr_gemm_pair: bad shape m=%d n=%d k=%d", m, n, k);
+    VOCR_CHECK_ARG(a0 && a1 && b0 && b1 && c0 && (mode == 1 || c1), "vocr_gemm_pair: null pointer");
+    VOCR_CHECK_ARG(mode == 0 || (c1 == nullptr && bias1 == nullptr), "vocr_gemm_pair: mode 1 has one output and one bias");
+    hipStream_t s = (hipStream_t)stream;
+    const uintptr_t al = ((uintptr_t)a0) | ((uintptr_t)a1) | ((uintptr_t)b0) | ((uintptr_t)b1) | ((uintptr_t)c0) | ((uintptr_t)c1) |
+                         ((uintptr_t)bias0) | ((uintptr_t)bias1);
+    if ((al & 15) == 0) {
+        const int nprob = mode ? 1 : 2, nseg = mode ? 2 : 1;
+        const vocr_dma_gemm::Plan d = vocr_dma_gemm::plan(transa, transb, m, n, k, lda, ldb, ldc, nprob, nseg, false);
+        const bool ws_ok = d.ok && (d.ksplit == 1 || (workspace && (((uintptr_t)workspace) & 15) == 0 && workspace_bytes >= d.slab_bytes));
+        if (ws_ok) {
+            const float* aa[2] = {a0, a1};
+            const float* bb[2] = {b0, b1};
+            float* cc[2] = {c0, c1};
+            const bool split = d.ksplit > 1;
+            const float* bs[2] = {split ? nullptr : bias0, split ? nullptr : bias1};
+            vocr_dma_gemm::launch(d, transa, transb, m, n, k, aa, lda, bb, ldb, cc, ldc, bs, split ? 0 : relu, nprob, nseg, (float*)workspace, s);
+            VOCR_CHECK_LAUNCH("vocr_gemm_pair(dma)");
+            if (split) {
+                const int tiles = d.groups * d.panels;
+                for (int p = 0; p < nprob; ++p) {
+                    const float* sl = (const float*)workspace + (size_t)p * tiles * d.ksplit * 256 * 128;
+                    splitk_reduce_kernel<<<tiles * 32, 256, 0, s>>>(sl, p ? c1 : c0, m, n, ldc, 256, 128, 0, d.ksplit, d.panels, p ? bias1 : bias0, relu, 0);
+                    VOCR_CHECK_LAUNCH("vocr_gemm_pair(dma, split-K reduce)");
+                }
+            }
+            return VOCR_OK;
+        }
+    }
+    // shapes the panel kernel does not take: two calls of the tile kernel (mode 1: the second one accumulates, the ReLU comes last)
+    if (mode == 0) {
+        int rc = vocr_gemm(transa, transb, m, n, k, a0, lda, b0, ldb, c0, ldc, bias0, relu, 0, workspace, workspace_bytes, stream);
+        if (rc != VOCR_OK) return rc;
+        return vocr_gemm(transa, transb, m, n, k, a1, lda, b1, ldb, c1, ldc, bias1, relu, 0, workspace, workspace_bytes, stream);
+    }
+    int rc = vocr_gemm(transa, transb, m, n, k, a0, lda, b0, ldb, c0, ldc, bias0, 0, 0, workspace, workspace_bytes, stream);
+    if (rc != VOCR_OK) return rc;
+    return vocr_gemm(transa, transb, m, n, k, a1, lda, b1, ldb, c0, ldc, nullptr, relu, 1, workspace, workspace_bytes, stream);
 }
 
 namespace {

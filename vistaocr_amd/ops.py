@@ -486,6 +486,15 @@ def gemm(ta, tb, m, n, k, a, lda, b, ldb, c, ldc, bias=None, relu=False, accumul
          _p(ws), nb, _stream())
 
 
+def gemm_pair(mode, ta, tb, m, n, k, a0, a1, lda, b0, b1, ldb, c0, c1, ldc, bias0=None, bias1=None, relu=False):
+    """Two products of one shape in one launch (include/vocr.h: vocr_gemm_pair): mode 0 = two independent products, mode 1 =
+    c0 = a0 b0 + a1 b1.  The two directions of a BiLSTM layer."""
+    nb = _lib.load().vocr_gemm_pair_workspace_bytes(m, n, k, int(mode))
+    ws = _ws(nb, c0.device) if nb else None
+    call("vocr_gemm_pair", int(mode), int(ta), int(tb), m, n, k, _p(a0), _p(a1), lda, _p(b0), _p(b1), ldb, _p(c0), _p(c1), ldc,
+         _p(bias0), _p(bias1), int(relu), _p(ws), nb, _stream())
+
+
 def colsum(x2d, out=None):
     m, n = x2d.shape
     out = out if out is not None else torch.empty(n, dtype=torch.float32, device=x2d.device)
@@ -665,8 +674,8 @@ class BiLstmLayerFn(torch.autograd.Function):
             torch.cuda.current_stream().wait_stream(side)
             call("vocr_lstm_fwd_range", *args, Th, T, _p(health(dev)), _stream())
         else:
-            xgemm(0, 0, T * B)
-            xgemm(1, 0, T * B)
+            # both directions' x-projections in one launch: 2 x (columns / 128) panels x row groups == the CU count
+            gemm_pair(0, 0, 1, T * B, G, din, x, x, din, w_ih_f, w_ih_r, din, xproj[0], xproj[1], G, bias0=bsum[0], bias1=bsum[1])
             call("vocr_lstm_fwd", _p(xproj), _p(w_hh_f), _p(w_hh_r), _p(lens_dev), _p(y), _p(gates), _p(cell), _p(ws), T, B, H,
                  _p(health(dev)), _stream())
         ctx.dims = (T, B, H, din)
@@ -695,8 +704,8 @@ class BiLstmLayerFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            gemm(0, 0, T * B, din, G, dg[0], G, w_ih_f, din, dx, din)
-            gemm(0, 0, T * B, din, G, dg[1], G, w_ih_r, din, dx, din, accumulate=True)
+            # dx = dg_fwd W_ih_fwd + dg_rev W_ih_rev as ONE product whose K runs through both pairs (no accumulating second pass)
+            gemm_pair(1, 0, 0, T * B, din, G, dg[0], dg[1], G, w_ih_f, w_ih_r, din, dx, None, din)
 
         # weight gradients: if every parameter already owns a gradient buffer (FlatClampAdam aliases them into one
         # flat buffer), write them there from the side stream so they overlap the next layer's sweep; otherwise
@@ -707,13 +716,11 @@ class BiLstmLayerFn(torch.autograd.Function):
 
         def weight_grads(outs):
             dwi_f, dwh_f, dbi_f, dbh_f, dwi_r, dwh_r, dbi_r, dbh_r = outs
-            gemm(1, 0, G, din, T * B, dg[0], G, x, din, dwi_f, din)
-            gemm(1, 0, G, din, T * B, dg[1], G, x, din, dwi_r, din)
+            gemm_pair(0, 1, 0, G, din, T * B, dg[0], dg[1], G, x, x, din, dwi_f, dwi_r, din)
             if T > 1:
                 # forward dir: h_{t-1} = y[t-1, :, :H];   reverse dir: h_{t+1} = y[t+1, :, H:]  (zero past the length)
                 m = (T - 1) * B
-                gemm(1, 0, G, H, m, dg[0][B:], G, y, 2 * H, dwh_f, H)
-                gemm(1, 0, G, H, m, dg[1], G, y[B:, H:], 2 * H, dwh_r, H)
+                gemm_pair(0, 1, 0, G, H, m, dg[0][B:], dg[1], G, y, y[B:, H:], 2 * H, dwh_f, dwh_r, H)
             else:
                 dwh_f.zero_()
                 dwh_r.zero_()
