@@ -348,6 +348,11 @@ def run_rank(args):
 
     for _ in range(args.warmup):
         va.train(batch_host, model, crit, opt)
+    # Two timed loops of exactly K steps each, both bracketed by barrier + synchronize.  The side number (batch resident in HBM) runs
+    # FIRST: on every box the first timed loop of a process measured 2-4 % slower than the second whichever of the two it was (20.09 vs
+    # 19.18 ms in round 2's driver run with the loops the other way round), so the headline loop would otherwise report the warm-up of
+    # the clocks and of the caching allocator rather than the step.
+    dt_res, _ = timed(batch_dev, args.steps)
     # timed region (headline): the batch comes from pinned host memory inside train().  HIP events, on the stream each kernel is
     # launched on, around every launch of the MFMA kernel families in every `event_every`-th step only (an event pair costs the queue
     # a few microseconds of overlap: ~70 pairs slow that step by a few percent); the full per-entry-point breakdown comes from a
@@ -359,7 +364,6 @@ def run_rank(args):
     sampled_steps = max(1, len(range(0, args.steps, args.event_every)) if args.event_every else 0)
     _lib.enable_timing(None)
     opt.time_comm(False)
-    dt_res, _ = timed(batch_dev, args.steps)
     names = MFMA_NAMES + ["vocr_bn_train_stats", "vocr_bn_relu_apply", "vocr_bn_relu_fracpool2x2_fwd", "vocr_bn_relu_bwd",
                           "vocr_fracpool2x2_bwd", "vocr_bn_relu_fracpool2x2_bwd", "vocr_ctc_loss_grad", "vocr_clamp_adam", "vocr_bchw_to_wbch", "vocr_wbch_to_bchw"]
     _lib.enable_timing(names)
@@ -443,7 +447,8 @@ def run_rank(args):
                        "backend": (args.backend + ("/RCCL" if args.backend == "nccl" else "")) if use_dist else "none",
                        "final_loss": round(float(final_loss), 3), "per_rank_rng": "seed 1234 + 1000*rank after an identical init"},
             "resident_input": {"value": round(B * world * args.steps / dt_res, 2), "ms_per_step": round(1000.0 * dt_res / args.steps, 3),
-                               "what": "same K steps with the image batch already in HBM (no H2D inside train())"},
+                               "what": "same K steps with the image batch already in HBM (no H2D inside train()); this loop runs before the "
+                                       "headline loop (the first timed loop of a process is 2-4 % slower than the second on every box)"},
             "allreduce_ms_per_step": comm_ms,
             "roofline": {"bound": "mfma",
                          "kernel": dom[0] + " - the kernel family with the most device time in the step (HIP events around every launch of the "

@@ -27,19 +27,24 @@ def _hp(h_img=30, rds=30, din=32, layers=1, hidden=32, drop=0.0, cin=1, **kw):
 # every case on the CPU and prints the seed it settles on, so the seeds below make the first try succeed.
 CASES = {
     "config4_arabic": dict(hp=_hp(din=64, layers=2, hidden=64, drop=0.5), alphabet="arabic", B=6, widths=[1200, 1113, 907, 640, 333, 15],
-                           labels_per_line=[40, 33, 25, 17, 9, 1], seed=7, ltr=False),
+                           labels_per_line=[40, 33, 25, 17, 9, 1], seed=8, ltr=False),
     # config 4 on the DEFAULT sweep kernels: H = 512, 3 layers, B = 8 (one 8-row chain per direction), ragged T = 588 ... 7, dropout masks
     "config4_h512": dict(hp=_hp(din=128, layers=3, hidden=512, drop=0.5), alphabet="arabic", B=8,
-                         widths=[1200, 1113, 907, 640, 333, 150, 64, 15], labels_per_line=[40, 33, 25, 17, 9, 4, 2, 1], seed=1, ltr=False,
+                         widths=[1200, 1113, 907, 640, 333, 150, 64, 15], labels_per_line=[40, 33, 25, 17, 9, 4, 2, 1], seed=6, ltr=False,
                          state_kw=dict(lstm_scale=0.08, prob_scale=2.0), masks=(588, 8, 512, 2, 44)),
     # the 0.3-scaled closed form saturates the 512-unit gates (|logit| ~ 20, logit error ~ 3e-3): ask for a wider margin
     "config5_rds": dict(hp=_hp(h_img=60, din=128, layers=3, hidden=512, drop=0.5), alphabet="english", B=3, widths=[400, 322, 128],
-                        labels_per_line=[12, 9, 3], seed=11, want_margin=1e-2, tries=200),
+                        labels_per_line=[12, 9, 3], seed=15, want_margin=1e-2, tries=200),
     "config5_fp16": dict(hp=_hp(h_img=60, din=128, layers=3, hidden=512, drop=0.5, conv_dtype="fp16"), alphabet="english", B=3,
                          widths=[400, 322, 128], labels_per_line=[12, 9, 3], seed=11, loss_rtol=1e-2, logit_rtol=2e-2, grad_rtol=0.1,
                          min_label_agreement=0.97, state_kw=dict(lstm_scale=0.08, prob_scale=0.5)),
     "rgb": dict(hp=_hp(cin=3), alphabet="english", B=2, widths=[150, 90], labels_per_line=[5, 3], seed=3),
     "batch40": dict(hp=_hp(hidden=64), alphabet="english", B=40, widths=[100] * 30 + [64] * 10, labels_per_line=[3] * 40, seed=5),
+    # more than 64 lines per batch (the reference's --batch-size is free, src/train_cnn_lstm.py:155): the LSTM runs as two batch tiles, the
+    # second one over its own shorter T; 2 layers so that a tiled layer feeds a tiled layer; H = 256 = the 8-row chain kernels (B tile 48 > 32:
+    # 16-row chains) - and dropout masks
+    "batch96": dict(hp=_hp(din=64, layers=2, hidden=256, drop=0.5), alphabet="english", B=96, widths=[120] * 40 + [90] * 30 + [64] * 26,
+                    labels_per_line=[3] * 96, seed=5, state_kw=dict(lstm_scale=0.08, prob_scale=2.0), masks=(58, 96, 256, 1, 45)),
 }
 
 
@@ -181,6 +186,12 @@ def test_rgb_input_three_channels():
     _run_pair("rgb")
 
 
+def test_batch_96_runs_as_lstm_batch_tiles():
+    """B = 96 > 64: CnnOcrModel splits every BiLSTM layer into batch tiles of <= 64 rows (model._bilstm_layer)."""
+    model, logits, lens = _run_pair("batch96")
+    assert logits.shape[1] == 96 and lens.tolist() == [58] * 40 + [43] * 30 + [30] * 26
+
+
 def test_batch_64_speed_test_shape():
     """The reference's own speed_test.py shape: batch 64 (src/speed_test.py:16): 4 MFMA row tiles in the sweeps."""
     _run_pair("batch40")
@@ -214,7 +225,9 @@ def test_validation_pass_and_snapshot_roundtrip(tmp_path):
 
 
 def test_decode_dataset_writes_reference_hyp_files(tmp_path):
-    """decode_testset.py's loop + file format on the HIP path; the strings equal the oracle's greedy decode of the same logits."""
+    """decode_testset.py's loop + file format on the HIP path: line count, "<uxxxx ...> (<utt-id>)" / "<utf8> (<utt-id minus the last
+    _part>)" framing, the two files agreeing through uxxxx_to_utf8.  (What the strings must BE is pinned elsewhere: the decode edge-case
+    fixture and the golden label sequences.)"""
     import os
     import vistaocr_amd as va
     from vistaocr_amd.loop import SortByWidthCollater, decode_dataset

@@ -85,6 +85,36 @@ def test_scale_sizes_and_bicubic_properties():
     assert np.array_equal(ds.InvertBlackWhite()(np.array([[0, 1, 255]], dtype=np.uint8)), np.array([[255, 254, 0]], dtype=np.uint8))
 
 
+def test_fixed_point_bilinear_known_answers():
+    """The no-OpenCV uint8 rescale restates OpenCV's INTER_LINEAR fixed-point path (11-bit weights; src/imagetransforms.py:492 ends up
+    there because the reference passes its interpolation flag into `dst`).  Known answers worked out by hand from the published
+    arithmetic, a case where it differs from float bilinear + round-half-even, the 2x2 box average of an exact halving, and the bound
+    against the float64 bilinear: at most one grey level."""
+    f = ds._resize_linear_u8_cv
+    # [0, 100] -> 4 wide: taps 2048/0, 1536/512, 512/1536, 0/2048 -> D = 0, 51200, 153600, 204800 -> ((2048 * (D >> 4)) >> 16) + 2 >> 2
+    assert f(np.array([[0, 100]], dtype=np.uint8), 4, 1).tolist() == [[0, 25, 75, 100]]
+    # [10, 20, 40] -> 2 wide: f = 0.25 -> D = 10*1536 + 20*512 = 25600 -> (50 + 2) >> 2 = 13 (float bilinear: 12.5 -> 12); f = 0.75 -> 35
+    assert f(np.array([[10, 20, 40]], dtype=np.uint8), 2, 1).tolist() == [[13, 35]]
+    assert ds._resize_bilinear(np.array([[10, 20, 40]], dtype=np.uint8), 2, 1).tolist() == [[12, 35]]
+    # exact halving in both directions -> INTER_AREA's 2x2 mean with rounding: (1 + 2 + 3 + 5 + 2) >> 2
+    assert f(np.array([[1, 2], [3, 5]], dtype=np.uint8), 1, 1).tolist() == [[3]]
+    r = np.random.RandomState(0)
+    for (h, w, nh, nw) in ((45, 133, 30, 88), (64, 301, 30, 141), (22, 50, 30, 68), (60, 200, 30, 100), (31, 77, 30, 74)):
+        img = r.randint(0, 256, size=(h, w)).astype(np.uint8)
+        a = f(img, nw, nh).astype(np.int64)
+        if (h, w) == (2 * nh, 2 * nw):
+            ref = img.astype(np.float64).reshape(nh, 2, nw, 2).mean(axis=(1, 3))
+        else:
+            ref = ds._resize_bilinear(img.astype(np.float64), nw, nh)
+        assert a.shape == (nh, nw) and float(np.abs(a - ref).max()) <= 1.0, (h, w, nh, nw)
+    rgb = r.randint(0, 256, size=(40, 90, 3)).astype(np.uint8)
+    out = f(rgb, 67, 30)
+    assert out.shape == (30, 67, 3)
+    for c in range(3):
+        assert np.array_equal(out[:, :, c], f(rgb[:, :, c], 67, 30))              # channels are independent
+    assert np.array_equal(ds.Scale(new_h=30)(rgb), f(rgb, 67, 30))                  # int(90 * 30 / 40) = 67: the Scale transform uses it
+
+
 def test_decode_pipeline_follows_the_models_channel_count():
     """src/decode_testset.py:48-65: InvertBlackWhite only for single-channel models; ConvertGray only with --cvtGray;
     grey conversion = OpenCV's integer BGR2GRAY formula."""

@@ -2,7 +2,8 @@
 (src/english.py:16-33, src/arabic.py:23-53, src/french.py:26).  Index 0 is always '<ctc-blank>'.
 
 The tables are data: they are stored as runs of hexadecimal code points and expanded to the reference's
-'uXXXX' spelling; tests/test_alphabet.py checks them entry by entry against tests/golden/alphabets.npz."""
+'uXXXX' spelling; tests/test_host_cpu.py::test_alphabets_match_reference_tables checks them entry by entry against
+tests/golden/alphabets.npz."""
 
 BLANK = "<ctc-blank>"
 

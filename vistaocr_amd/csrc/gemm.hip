@@ -501,6 +501,8 @@ extern "C" size_t vocr_gemm_pair_workspace_bytes(int m, int n, int k, int mode) 
     return bytes;
 }
 
+static thread_local bool g_gemm_tiles_only = false;      // set by vocr_gemm_pair's co-scheduling hint around its two vocr_gemm calls
+
 extern "C" int vocr_gemm(int transa, int transb, int m, int n, int k, const float* a, int lda, const float* b, int ldb,
                          float* c, int ldc, const float* bias, int relu, int accumulate, void* workspace,
                          size_t workspace_bytes, void* stream) {
@@ -509,7 +511,7 @@ extern "C" int vocr_gemm(int transa, int transb, int m, int n, int k, const floa
     VOCR_CHECK_ARG(lda >= (transa ? m : k) && ldb >= (transb ? k : n) && ldc >= n, "vocr_gemm: bad leading dimension");
     hipStream_t s = (hipStream_t)stream;
     // large, aligned products: the DMA-staged panel kernel (gemm_dma.hip); `accumulate` only through its slab reduce
-    if (((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)bias)) & 15) == 0) {
+    if (!g_gemm_tiles_only && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)bias)) & 15) == 0) {
         const vocr_dma_gemm::Plan d = vocr_dma_gemm::plan(transa, transb, m, n, k, lda, ldb, ldc, 1, 1, false);
         const bool ws_ok = d.ok && (d.ksplit == 1 || (workspace && (((uintptr_t)workspace) & 15) == 0 && workspace_bytes >= d.slab_bytes));
         if (ws_ok && (!accumulate || d.ksplit > 1)) {
@@ -564,14 +566,16 @@ extern "C" int vocr_gemm(int transa, int transb, int m, int n, int k, const floa
 extern "C" int vocr_gemm_pair(int mode, int transa, int transb, int m, int n, int k, const float* a0, const float* a1, int lda,
                               const float* b0, const float* b1, int ldb, float* c0, float* c1, int ldc, const float* bias0,
                               const float* bias1, int relu, void* workspace, size_t workspace_bytes, void* stream) {
-    VOCR_CHECK_ARG(mode == 0 || mode == 1, "vocr_gemm_pair: mode must be 0 (two products) or 1 (two K segments summed)");
+    const bool co_sched = (mode & 4) != 0;           // hint: prefer the tile kernel, whose workgroups can share a CU with a persistent LSTM sweep
+    mode &= ~4;
+    VOCR_CHECK_ARG(mode == 0 || mode == 1, "vocr_gemm_pair: mode must be 0 (two products) or 1 (two K segments summed), optionally | 4");
     VOCR_CHECK_ARG(m > 0 && n > 0 && k > 0, "vocr_gemm_pair: bad shape m=%d n=%d k=%d", m, n, k);
     VOCR_CHECK_ARG(a0 && a1 && b0 && b1 && c0 && (mode == 1 || c1), "vocr_gemm_pair: null pointer");
     VOCR_CHECK_ARG(mode == 0 || (c1 == nullptr && bias1 == nullptr), "vocr_gemm_pair: mode 1 has one output and one bias");
     hipStream_t s = (hipStream_t)stream;
     const uintptr_t al = ((uintptr_t)a0) | ((uintptr_t)a1) | ((uintptr_t)b0) | ((uintptr_t)b1) | ((uintptr_t)c0) | ((uintptr_t)c1) |
                          ((uintptr_t)bias0) | ((uintptr_t)bias1);
-    if ((al & 15) == 0) {
+    if ((al & 15) == 0 && !co_sched) {
         const int nprob = mode ? 1 : 2, nseg = mode ? 2 : 1;
         const vocr_dma_gemm::Plan d = vocr_dma_gemm::plan(transa, transb, m, n, k, lda, ldb, ldc, nprob, nseg, false);
         const bool ws_ok = d.ok && (d.ksplit == 1 || (workspace && (((uintptr_t)workspace) & 15) == 0 && workspace_bytes >= d.slab_bytes));
@@ -594,7 +598,9 @@ extern "C" int vocr_gemm_pair(int mode, int transa, int transb, int m, int n, in
             return VOCR_OK;
         }
     }
-    // shapes the panel kernel does not take: two calls of the tile kernel (mode 1: the second one accumulates, the ReLU comes last)
+    // shapes the panel kernel does not take (or the co-scheduling hint): two calls of the tile kernel (mode 1: the second one
+    // accumulates, the ReLU comes last)
+    struct TileOnly { TileOnly(bool on) { g_gemm_tiles_only = on; } ~TileOnly() { g_gemm_tiles_only = false; } } tile_only(co_sched);
     if (mode == 0) {
         int rc = vocr_gemm(transa, transb, m, n, k, a0, lda, b0, ldb, c0, ldc, bias0, relu, 0, workspace, workspace_bytes, stream);
         if (rc != VOCR_OK) return rc;

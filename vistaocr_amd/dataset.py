@@ -6,13 +6,17 @@ reference's drivers compose for this path, `Scale(new_h=...)` -> `InvertBlackWhi
 src/train_cnn_lstm.py:215-243).  Host code only: it produces the `(image[C,H,W] float, label indices, metadata)`
 items that `loop.SortByWidthCollater` batches for `CnnOcrModel`.
 
-What is NOT pinned here: the reference decodes the LMDB payload with `cv2.imdecode` and rescales with `cv2.resize`
-(INTER_CUBIC); neither `cv2` nor `lmdb` exists in the build image, so
+What is NOT pinned here: the reference decodes the LMDB payload with `cv2.imdecode` and rescales with `cv2.resize`; neither
+`cv2` nor `lmdb` exists in the build image, so
   * `LmdbImageStore` imports both lazily and fails loudly without them;
   * `NpyDirImageStore` (one decoded `<id>.npy` array per line) is the store the tests use;
-  * `Scale` calls `cv2.resize` when OpenCV is importable and otherwise a numpy bicubic with OpenCV's conventions
-    (a = -0.75, half-pixel centres, replicated border) whose rounding has not been compared with OpenCV's:
-    "parity unpinned" for the rescale.  Images already at the model's line height never touch that code.
+  * `Scale` calls `cv2.resize` when OpenCV is importable.  The reference passes its `interpolation=cv2.INTER_CUBIC` POSITIONALLY
+    (src/imagetransforms.py:492), i.e. into cv2.resize's third parameter `dst`, so OpenCV resamples with its default,
+    INTER_LINEAR - bilinear, not cubic.  Without OpenCV, uint8 images go through `_resize_linear_u8_cv`, a restatement of OpenCV's
+    published uint8 bilinear path (11-bit fixed-point tap weights, INTER_RESIZE_COEF_BITS; 2x2 box average for an exact halving);
+    it is pinned by hand-computed known answers and stays within 1 grey level of the float64 bilinear (tests/test_dataset_cpu.py),
+    but could not be compared with a cv2 binary here: "parity unpinned" against OpenCV itself.  Images already at the model's
+    line height never touch that code.
 """
 import json
 import os
@@ -123,9 +127,50 @@ class Scale:
             # POSITIONALLY, i.e. into cv2.resize's third parameter `dst`, so OpenCV resamples with its default, INTER_LINEAR
             return cv2.resize(img, (nw, nh), cv2.INTER_CUBIC)          # pragma: no cover - cv2 absent in the build image
         except ImportError:
-            # without OpenCV: bilinear with OpenCV's half-pixel sample positions (what the call above effectively does);
-            # "parity unpinned" - cv2's uint8 path uses 11-bit fixed-point weights, this one float64 + round-to-nearest
-            return _resize_bilinear(img, nw, max(nh, 1)) if self.interpolation == "linear" else _resize_bicubic(img, nw, max(nh, 1))
+            # without OpenCV: what the call above effectively does (INTER_LINEAR).  uint8: OpenCV's fixed-point arithmetic restated;
+            # other dtypes: float64 bilinear with OpenCV's half-pixel sample positions
+            if self.interpolation != "linear":
+                return _resize_bicubic(img, nw, max(nh, 1))
+            if img.dtype == np.uint8:
+                return _resize_linear_u8_cv(img, nw, max(nh, 1))
+            return _resize_bilinear(img, nw, max(nh, 1))
+
+
+def _resize_linear_u8_cv(img, new_w, new_h):
+    """cv2.resize(img, (new_w, new_h)) for uint8 with the default INTER_LINEAR, restated from OpenCV's resize.cpp (3.x / 4.x, the plain
+    C++ path):
+      * an exact halving in both directions is rerouted to INTER_AREA, whose 2x2 case is (a + b + c + d + 2) >> 2;
+      * otherwise, per destination column dx: fx = float((dx + 0.5) * (src_w / new_w) - 0.5), sx = floor(fx), fx -= sx; sx < 0 ->
+        (sx, fx) = (0, 0); sx >= src_w - 1 -> (sx, fx) = (src_w - 1, 0); tap weights cvRound((1 - fx) * 2048) and cvRound(fx * 2048)
+        as int16 (INTER_RESIZE_COEF_BITS = 11; cvRound rounds half to even); rows likewise;
+      * horizontal pass in int32: D = S[sx] * a0 + S[sx + 1] * a1; vertical pass and cast:
+        dst = (((b0 * (D0 >> 4)) >> 16) + ((b1 * (D1 >> 4)) >> 16) + 2) >> 2."""
+    src = np.ascontiguousarray(img)
+    h, w = src.shape[:2]
+    if h == 2 * new_h and w == 2 * new_w:
+        v = src.astype(np.int32)
+        return ((v[0::2, 0::2] + v[0::2, 1::2] + v[1::2, 0::2] + v[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+
+    def taps(n_out, n_in):
+        scale = float(n_in) / float(n_out)
+        f = ((np.arange(n_out, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+        s0 = np.floor(f).astype(np.int64)
+        f = (f - s0.astype(np.float32)).astype(np.float32)
+        lo, hi = s0 < 0, s0 >= n_in - 1
+        s0 = np.where(lo, 0, np.where(hi, n_in - 1, s0))
+        f = np.where(lo | hi, np.float32(0), f).astype(np.float32)
+        w1 = np.rint(f * np.float32(2048)).astype(np.int64)              # np.rint = round half to even = cvRound
+        w0 = np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int64)
+        return s0, np.minimum(s0 + 1, n_in - 1), w0, w1
+
+    x0, x1, a0, a1 = taps(new_w, w)
+    y0, y1, b0, b1 = taps(new_h, h)
+    v = src.astype(np.int64)
+    shape_a = (1, -1) + (1,) * (src.ndim - 2)
+    rows = v[:, x0] * a0.reshape(shape_a) + v[:, x1] * a1.reshape(shape_a)          # [h, new_w, ...] scaled by 2^11
+    shape_b = (-1, 1) + (1,) * (src.ndim - 2)
+    out = (((b0.reshape(shape_b) * (rows[y0] >> 4)) >> 16) + ((b1.reshape(shape_b) * (rows[y1] >> 4)) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)
 
 
 def _resize_bilinear(img, new_w, new_h):

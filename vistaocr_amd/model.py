@@ -282,7 +282,7 @@ class CnnOcrModel(nn.Module):
         for l in range(self.num_lstm_layers):
             f = self.lstm.layer(l, "")
             r = self.lstm.layer(l, "_reverse")
-            hseq = ops.BiLstmLayerFn.apply(hseq, lens_dev, T, b, f[0], f[1], f[2], f[3], r[0], r[1], r[2], r[3], prep)
+            hseq = self._bilstm_layer(hseq, lens_dev, out_w, T, b, f, r, prep)
             if l < self.num_lstm_layers - 1:
                 if self.dropout_masks is not None:
                     hseq = ops.MulMaskFn.apply(hseq, self.dropout_masks[l].to(dev).reshape(T * b, -1))
@@ -292,6 +292,28 @@ class CnnOcrModel(nn.Module):
         pr = getattr(self.prob_layer, "0")
         prob_output = ops.LinearFn.apply(hseq, pr.weight, pr.bias, False).view(T, b, -1)
         return prob_output, lens_cpu
+
+    def _bilstm_layer(self, hseq, lens_dev, out_w, T, b, f, r, prep):
+        """One bidirectional layer.  The sweep kernels take up to 64 batch rows per call (include/vocr.h); the reference's --batch-size is
+        free (src/train_cnn_lstm.py:155), so a larger batch runs as tiles of <= 64 rows: the recurrence never couples batch rows, the
+        widths are sorted, so a tile is itself a valid packed batch and only sweeps its own longest sequence.  A tile's weight
+        gradients go through autograd (which adds the tiles' contributions) instead of the direct sinks."""
+        if b <= 64:
+            return ops.BiLstmLayerFn.apply(hseq, lens_dev, T, b, f[0], f[1], f[2], f[3], r[0], r[1], r[2], r[3], prep)
+        ntile = (b + 63) // 64
+        rows = (b + ntile - 1) // ntile
+        h3 = hseq.view(T, b, -1)
+        outs = []
+        for b0 in range(0, b, rows):
+            b1 = min(b, b0 + rows)
+            tt = int(out_w[b0])
+            xt = h3[:tt, b0:b1].reshape(tt * (b1 - b0), h3.shape[2])
+            yt = ops.BiLstmLayerFn.apply(xt, lens_dev[b0:b1], tt, b1 - b0, f[0], f[1], f[2], f[3], r[0], r[1], r[2], r[3], prep, False)
+            yt = yt.view(tt, b1 - b0, -1)
+            if tt < T:
+                yt = torch.cat([yt, yt.new_zeros(T - tt, b1 - b0, yt.shape[2])], dim=0)
+            outs.append(yt)
+        return torch.cat(outs, dim=1).reshape(T * b, -1)
 
     # ------------------------------------------------------------------ decode (cnnlstm.py:479-541)
     def decode_without_lm(self, model_output, batch_actual_timesteps, uxxxx=False):

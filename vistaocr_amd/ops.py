@@ -353,11 +353,11 @@ class ConvBnReluFn(torch.autograd.Function):
         fused_pool_bwd = False
         if ctx.pool is not None:
             oh, ow = ctx.pool
-            # Opt-in (VOCR_POOL_BWD_FUSED=1): pooling gradient + ReLU + BatchNorm backward in one gather pass.  Alone on the
-            # chip it beats the three passes (139 vs 167 us per layer), but beside the weight-gradient kernel on the side
-            # stream its address/VALU work gets starved (370-420 us) and the step is unchanged (21.34 vs 21.42 ms): the CNN
-            # backward is bound by the dgrad + wgrad MFMA work, not by these passes.
-            fused_pool_bwd = bool(lib.vocr_bn_relu_fracpool2x2_bwd_supported(h, w, oh, ow)) and _os.environ.get("VOCR_POOL_BWD_FUSED", "0") == "1"
+            # Pooling gradient + ReLU + BatchNorm backward in one gather pass over the plane (VOCR_POOL_BWD_FUSED=0: the pooling
+            # gradient as a pass of its own that materialises the full plane).  Alone on the chip it always beat the three passes
+            # (139 vs 167 us per layer); in the step it was neutral in round 2 (starved beside the weight-gradient kernel) and is
+            # worth -0.15 ms since the round-3 GEMMs (same-box A/B 18.96 -> 18.81 ms).  Bit-identical results either way.
+            fused_pool_bwd = bool(lib.vocr_bn_relu_fracpool2x2_bwd_supported(h, w, oh, ow)) and _os.environ.get("VOCR_POOL_BWD_FUSED", "1") == "1"
             if not fused_pool_bwd:          # gradient of the fused pooling first: back to the full plane
                 dfull = torch.empty(n, cout, h, w, dtype=torch.float32, device=da.device)
                 call("vocr_fracpool2x2_bwd", _p(da), _p(idx), _p(dfull), n, cout, h, w, oh, ow, _stream())
@@ -626,7 +626,7 @@ class BiLstmLayerFn(torch.autograd.Function):
     x: [T*B, Din] time-major; returns y: [T*B, 2H] with zeros past each sequence's length."""
 
     @staticmethod
-    def forward(ctx, x, lens_dev, T, B, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r, prep=None):
+    def forward(ctx, x, lens_dev, T, B, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r, prep=None, direct_grads=True):
         _need_gpu(x, lens_dev, w_ih_f, w_hh_f, w_ih_r, w_hh_r)
         x = _f32c(x)
         lib = _lib.load()
@@ -679,6 +679,7 @@ class BiLstmLayerFn(torch.autograd.Function):
             call("vocr_lstm_fwd", _p(xproj), _p(w_hh_f), _p(w_hh_r), _p(lens_dev), _p(y), _p(gates), _p(cell), _p(ws), T, B, H,
                  _p(health(dev)), _stream())
         ctx.dims = (T, B, H, din)
+        ctx.direct_grads = bool(direct_grads)       # False: the layer runs as several batch tiles, autograd adds their weight gradients
         ctx.b_refs = (b_ih_f, b_hh_f, b_ih_r, b_hh_r)
         ctx.save_for_backward(x, lens_dev, y, gates, cell, w_ih_f, w_hh_f, w_ih_r, w_hh_r)
         return y
@@ -711,16 +712,16 @@ class BiLstmLayerFn(torch.autograd.Function):
         # flat buffer), write them there from the side stream so they overlap the next layer's sweep; otherwise
         # return them to autograd on the current stream.
         params = (w_ih_f, w_hh_f, ctx.b_refs[0], ctx.b_refs[1], w_ih_r, w_hh_r, ctx.b_refs[2], ctx.b_refs[3])
-        sinks = _sinks(params)
+        sinks = _sinks(params) if ctx.direct_grads else None
         direct = sinks is not None
 
-        def weight_grads(outs):
+        def weight_grads(outs, co=0):
             dwi_f, dwh_f, dbi_f, dbh_f, dwi_r, dwh_r, dbi_r, dbh_r = outs
-            gemm_pair(0, 1, 0, G, din, T * B, dg[0], dg[1], G, x, x, din, dwi_f, dwi_r, din)
+            gemm_pair(co, 1, 0, G, din, T * B, dg[0], dg[1], G, x, x, din, dwi_f, dwi_r, din)
             if T > 1:
                 # forward dir: h_{t-1} = y[t-1, :, :H];   reverse dir: h_{t+1} = y[t+1, :, H:]  (zero past the length)
                 m = (T - 1) * B
-                gemm_pair(0, 1, 0, G, H, m, dg[0][B:], dg[1], G, y, y[B:, H:], 2 * H, dwh_f, dwh_r, H)
+                gemm_pair(co, 1, 0, G, H, m, dg[0][B:], dg[1], G, y, y[B:, H:], 2 * H, dwh_f, dwh_r, H)
             else:
                 dwh_f.zero_()
                 dwh_r.zero_()
@@ -735,15 +736,17 @@ class BiLstmLayerFn(torch.autograd.Function):
             for t_ in (dg, x, y, dbias):
                 t_.record_stream(side)
             with torch.cuda.stream(side):
-                weight_grads(sinks)
+                # under the next layer's persistent sweep: VOCR_DW_TILES=1 asks for the tile kernel, whose workgroups fit on a CU beside a
+                # sweep workgroup (the panel kernel's do not: 144 KB of LDS and 340 registers per lane)
+                weight_grads(sinks, co=4 if _os.environ.get("VOCR_DW_TILES", "0") == "1" else 0)
             mark_side_pending()
-            return (dx, None, None, None) + (None,) * 9
+            return (dx, None, None, None) + (None,) * 10
         if direct:
             weight_grads(sinks)
-            return (dx, None, None, None) + (None,) * 9
+            return (dx, None, None, None) + (None,) * 10
         outs = [torch.empty_like(p) for p in params]
         weight_grads(outs)
-        return (dx, None, None, None) + tuple(outs) + (None,)
+        return (dx, None, None, None) + tuple(outs) + (None, None)
 
 
 # ------------------------------------------------------------------------------------------------ CTC
