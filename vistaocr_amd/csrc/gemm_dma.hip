@@ -56,10 +56,11 @@ struct DmaGemmArgs {
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
 template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256) void gemm_dma_kernel(const DmaGemmArgs g) {
+__global__ __launch_bounds__(512) void gemm_dma_kernel(const DmaGemmArgs g) {
     __shared__ __attribute__((aligned(16))) float lds[NSTAGE * STAGE_FL];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // 0 .. 7: two waves per SIMD
+    const int cw = wave & 3, kh = wave >> 2;                            // column group (32 columns) and which half of a chunk's row tiles
     const int m = lane & 31, h = lane >> 5;
 
     // ---- which panel: XCD-sliced order (consecutive work items = the column panels of one row group = one L2 shares the A rows)
@@ -77,13 +78,13 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const DmaGemmArgs g) {
     const int prob = t_ / g.ksplit;
     const int n0 = panel * DN;
 
-    // rows of this group: the 32-row tiles are dealt evenly, chunks of <= 8 tiles
+    // rows of this group: the 32-row tiles are dealt evenly over the groups; a group walks them in chunks of 8 tiles (the last chunk
+    // takes what is left), and inside a chunk the first ceil(n/2) tiles belong to waves 0-3, the rest to waves 4-7
     const int mt = (g.M + 31) >> 5;
     const int tb_ = mt / g.groups, te_ = mt % g.groups;
     const int gtiles = tb_ + (group < te_ ? 1 : 0);
     const int gstart = group * tb_ + min(group, te_);
     const int nch = (gtiles + 7) >> 3;
-    const int cb = nch ? gtiles / nch : 0, ce = nch ? gtiles % nch : 0;
     const int kbeg = split * g.kps, kend = min(g.K, kbeg + g.kps);
     const int kts = (kend - kbeg + DK - 1) / DK;          // K-tiles of one segment
     const int KT = kts * g.nseg;
@@ -95,9 +96,9 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const DmaGemmArgs g) {
     const __amdgpu_buffer_rsrc_t rb0 = __builtin_amdgcn_make_buffer_rsrc((void*)g.b[g.nseg > 1 ? 0 : prob], 0, (int)g.b_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb1 = __builtin_amdgcn_make_buffer_rsrc((void*)g.b[1], 0, (int)g.b_bytes, 0x00020000);
 
-    // ---- DMA maps (per-lane constants).  K-contiguous operand: instruction e of wave w covers rows 32e + 8w + lane/8, piece
-    // position lane%8 holds k-piece kb = pos ^ ((row >> 1) & 7).  M/N-contiguous: one instruction = 256 consecutive rows of one k
-    // (A: k = w + 4e) or 128 rows of two k (B: k = 2(w + 4e) + lane/32).
+    // ---- DMA maps (per-lane constants): 48 instructions of 1 KB per K-tile, six per wave (four of A, two of B).  K-contiguous
+    // operand: instruction e of wave w covers rows 64e + 8w + lane/8, piece position lane%8 holds k-piece kb = pos ^ ((row >> 1) & 7).
+    // M/N-contiguous: one instruction = 256 consecutive rows of one k (A: k = w + 8e) or 128 rows of two k (B: k = 2(w + 8e) + lane/32).
     const int kc_row = 8 * wave + (lane >> 3);
     const int kc_k4 = 4 * ((lane & 7) ^ ((4 * wave + (lane >> 4)) & 7));
 
@@ -111,59 +112,58 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const DmaGemmArgs g) {
         Step st;
         st.seg = cu.kt >= kts ? 1 : 0;
         st.k0 = kbeg + (cu.kt - st.seg * kts) * DK;
-        st.ntile = cb + (cu.c < ce ? 1 : 0);
-        st.row0 = 32 * (gstart + cu.c * cb + min(cu.c, ce));
+        st.ntile = min(8, gtiles - 8 * cu.c);
+        st.row0 = 32 * (gstart + 8 * cu.c);
         st.slot = cu.slot;
         return st;
     };
-    // The 12 DMA byte offsets of a step (0 .. 7: A, 8 .. 11: B; OOB = out of range = zeros) are computed one at a time BETWEEN the
-    // MFMAs of the first K-block of the step that issues them (each is ~6 vector instructions and fits behind one MFMA); the issue
-    // itself is then `s_mov m0` + `buffer_load ... lds`.  (Computed next to each load, the dependent v_cmp -> s_and -> v_cndmask -> load
-    // chain held the in-order wave ~100 cycles per DMA; computed in one batch at the head of the step, the matrix pipe drained.)
-    // per-step head: byte offset of instruction 0 and the range limit of the instruction index for A and for B (limit <= 0: nothing in range)
+    // The six DMA byte offsets of a step (0 .. 3: A, 4, 5: B; OOB = out of range = zeros) are computed one at a time BETWEEN the MFMAs
+    // of the first K-block of the step that issues them (each is ~3 vector instructions and fits behind one MFMA); the issue itself
+    // is then `s_mov m0` + `buffer_load ... lds`.  (Computed next to each load, the dependent v_cmp -> s_and -> v_cndmask -> load chain
+    // held the in-order wave ~100 cycles per DMA; computed in one batch at the head of the step, the matrix pipe drained.)
     struct Prep { unsigned a_off, b_off; int a_lim, b_lim; unsigned a_step, b_step; };
     auto prep_head = [&](const Step& st, bool live) {
         Prep pr;
         const int dead = live ? 0 : (1 << 30);
         if (A_KC) {
             pr.a_off = (unsigned)((st.row0 + kc_row) * g.lda + st.k0 + kc_k4) * 4u;
-            pr.a_lim = (st.k0 + kc_k4 < kend ? min(g.M - st.row0, 32 * st.ntile) - kc_row : 0) - dead;       // instruction e in range iff 32 e < lim
-            pr.a_step = (unsigned)(32 * g.lda) * 4u;
+            pr.a_lim = (st.k0 + kc_k4 < kend ? min(g.M - st.row0, 32 * st.ntile) - kc_row : 0) - dead;       // instruction e in range iff 64 e < lim
+            pr.a_step = (unsigned)(64 * g.lda) * 4u;
         } else {
             pr.a_off = (unsigned)((st.k0 + wave) * g.lda + st.row0 + 4 * lane) * 4u;
-            pr.a_lim = (4 * lane < min(g.M - st.row0, 32 * st.ntile) ? kend - st.k0 - wave : 0) - dead;       // iff 4 e < lim
-            pr.a_step = (unsigned)(4 * g.lda) * 4u;
+            pr.a_lim = (4 * lane < min(g.M - st.row0, 32 * st.ntile) ? kend - st.k0 - wave : 0) - dead;       // iff 8 e < lim
+            pr.a_step = (unsigned)(8 * g.lda) * 4u;
         }
         if (B_KC) {
             pr.b_off = (unsigned)((n0 + kc_row) * g.ldb + st.k0 + kc_k4) * 4u;
-            pr.b_lim = (st.k0 + kc_k4 < kend ? g.N - n0 - kc_row : 0) - dead;                                  // iff 32 e < lim
-            pr.b_step = (unsigned)(32 * g.ldb) * 4u;
+            pr.b_lim = (st.k0 + kc_k4 < kend ? g.N - n0 - kc_row : 0) - dead;                                  // iff 64 e < lim
+            pr.b_step = (unsigned)(64 * g.ldb) * 4u;
         } else {
             pr.b_off = (unsigned)((st.k0 + 2 * wave + (lane >> 5)) * g.ldb + n0 + 4 * (lane & 31)) * 4u;
-            pr.b_lim = (n0 + 4 * (lane & 31) < g.N ? kend - st.k0 - 2 * wave - (lane >> 5) : 0) - dead;        // iff 8 e < lim
-            pr.b_step = (unsigned)(8 * g.ldb) * 4u;
+            pr.b_lim = (n0 + 4 * (lane & 31) < g.N ? kend - st.k0 - 2 * wave - (lane >> 5) : 0) - dead;        // iff 16 e < lim
+            pr.b_step = (unsigned)(16 * g.ldb) * 4u;
         }
         return pr;
     };
-    auto prep_one = [&](const Prep& pr, unsigned (&vo)[12], int d) {       // three vector instructions
-        if (d < 8) vo[d] = ((A_KC ? 32 : 4) * d < pr.a_lim) ? pr.a_off + (unsigned)d * pr.a_step : OOB;
-        else vo[d] = ((B_KC ? 32 : 8) * (d - 8) < pr.b_lim) ? pr.b_off + (unsigned)(d - 8) * pr.b_step : OOB;
+    auto prep_one = [&](const Prep& pr, unsigned (&vo)[6], int d) {       // three vector instructions
+        if (d < 4) vo[d] = ((A_KC ? 64 : 8) * d < pr.a_lim) ? pr.a_off + (unsigned)d * pr.a_step : OOB;
+        else vo[d] = ((B_KC ? 64 : 16) * (d - 4) < pr.b_lim) ? pr.b_off + (unsigned)(d - 4) * pr.b_step : OOB;
     };
-    auto issue = [&](const __amdgpu_buffer_rsrc_t& ra, const __amdgpu_buffer_rsrc_t& rb, float* slot, const unsigned (&vo)[12], int d) {
-        if (d < 8) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(slot + (wave + 4 * d) * 256), 16, vo[d], 0, 0, 0);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(slot + A_FL + (wave + 4 * (d - 8)) * 256), 16, vo[d], 0, 0, 0);
+    auto issue = [&](const __amdgpu_buffer_rsrc_t& ra, const __amdgpu_buffer_rsrc_t& rb, float* slot, const unsigned (&vo)[6], int d) {
+        if (d < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(slot + (wave + 8 * d) * 256), 16, vo[d], 0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(slot + A_FL + (wave + 8 * (d - 4)) * 256), 16, vo[d], 0, 0, 0);
     };
 
     // ---- fragment addressing
     const int sw = (m >> 1) & 7;
     const int a_kc_base = m * 32;                          // floats: row m, + tile * 1024 + ((2j + h) ^ sw) * 4
-    const int b_kc_base = (32 * wave + m) * 32;
+    const int b_kc_base = (32 * cw + m) * 32;
     const int a_mc_base = 4 * h * 256 + m;                 // floats: k = 8j + 4h + s -> + (8j + s) * 256 + tile * 32
-    const int b_nc_base = 4 * h * 128 + 32 * wave + m;
+    const int b_nc_base = 4 * h * 128 + 32 * cw + m;
 
     // epilogue constants: this lane stores columns col4 .. +3 of rows srow + 8 * pass of every 32 x 32 tile
     const int col4 = 4 * (lane & 7), srow = lane >> 3;
-    const int gcol = n0 + 32 * wave + col4;
+    const int gcol = n0 + 32 * cw + col4;
     const bool slabbed = g.slab != nullptr;
     f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (!slabbed && g.bias[prob] && gcol < g.N) bv = *(const f32x4*)(g.bias[prob] + gcol);      // before any DMA: nothing else returns to a register
@@ -171,57 +171,60 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const DmaGemmArgs g) {
     const int ld_out = slabbed ? DN : g.ldc;
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, (int)(slabbed ? (unsigned)(DM * DN * 4) : g.c_bytes), 0x00020000);
     const int ncols = slabbed ? DN : g.N;
-    const int ocol = slabbed ? 32 * wave + col4 : gcol;
+    const int ocol = slabbed ? 32 * cw + col4 : gcol;
 
     // prologue: two K-tiles in flight
     Cursor cnext = {0, 0, 0};                              // the step whose DMAs are issued next
     for (int i = 0; i < 2; ++i) {
         const Step s0 = step_at(cnext);
-        unsigned vo[12];
+        unsigned vo[6];
         const Prep pr = prep_head(s0, i < total);
 #pragma unroll
-        for (int d = 0; d < 12; ++d) prep_one(pr, vo, d);
+        for (int d = 0; d < 6; ++d) prep_one(pr, vo, d);
 #pragma unroll
-        for (int d = 0; d < 12; ++d) issue(s0.seg ? ra1 : ra0, s0.seg ? rb1 : rb0, lds + s0.slot * STAGE_FL, vo, d);
+        for (int d = 0; d < 6; ++d) issue(s0.seg ? ra1 : ra0, s0.seg ? rb1 : rb0, lds + s0.slot * STAGE_FL, vo, d);
         if (i < total) advance(cnext);
     }
     int issued = total > 1 ? 2 : 1;                        // steps whose (real) DMAs have been issued
     Cursor ccur = {0, 0, 0};
-    int since_store = 1;                                   // 0: the previous chunk's 32 stores are the youngest outstanding operations
-    // cold start: the first K-tile has landed (all but the 12 DMAs of the second are done), for every wave
-    __builtin_amdgcn_s_waitcnt(0x0F70 | 12);
+    int since_store = 1;                                   // 0: the previous chunk's 16 stores are the youngest outstanding operations
+    // cold start: the first K-tile has landed (all but the 6 DMAs of the second are done), for every wave
+    __builtin_amdgcn_s_waitcnt(0x0F70 | 6);
     asm volatile("s_barrier" ::: "memory");
 
-    // One chunk = NT row tiles (compile-time: the accumulators live in AGPRs for the whole K loop and no branch sits between the
-    // MFMAs) x all K-tiles.  The DMA ring runs on across chunk boundaries.  A step (one K-tile) is four blocks of 8 k:
-    //   blocks 0 .. 2   MFMAs; the fragments of the next block are read while a block's MFMAs run; the offsets of the 12 DMAs this step
+    // One chunk = NT of its row tiles for this wave (compile-time: the accumulators live in AGPRs for the whole K loop and no branch sits
+    // between the MFMAs; 0 = this wave only moves data and keeps the barriers) x all K-tiles.  The DMA ring runs on across chunk
+    // boundaries.  A step (one K-tile) is four blocks of 8 k:
+    //   blocks 0 .. 2   MFMAs; the fragments of the next block are read while a block's MFMAs run; the offsets of the 6 DMAs this wave
     //                   will issue are computed between the MFMAs of block 0
     //   after block 2   this wave's DMAs of step +1 have landed (vmcnt), then the step's ONE barrier: every wave's DMAs of step +1 have
     //                   landed and every wave is past step -1 entirely, so its ring slot may be refilled
-    //   block 3         MFMAs; the 12 DMAs of step +2 (into the slot of step -1), three per MFMA group; the fragments of step +1's
-    //                   first block are read here, so no barrier and no LDS latency sits between two steps
-    // (A barrier at the head of every step, with the fragment reads behind it, cost ~2000 of a step's 8192 MFMA cycles.)
-    auto run_chunk = [&](auto nt_c) {
+    //   block 3         MFMAs; the DMAs of step +2 (into the slot of step -1); the fragments of step +1's first block are read here, so
+    //                   no barrier and no LDS latency sits between two steps
+    // Two waves share a SIMD: while one waits (barrier, DMA issue, LDS latency, epilogue) the other one's MFMAs keep the pipe busy.
+    // (One wave per SIMD with all 8 tiles: 0.79 MFMA-busy; a barrier at the head of every step with the fragment reads behind it cost
+    // another ~2000 of a step's 8192 MFMA cycles.)
+    auto run_chunk = [&](auto nt_c, int toff) {
         constexpr int NT = decltype(nt_c)::value;
-        f32x16 acc[NT];
+        constexpr int NA = NT > 0 ? NT : 1;
+        f32x16 acc[NA];
 #pragma unroll
-        for (int i = 0; i < NT; ++i)
+        for (int i = 0; i < NA; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
         Step st = step_at(ccur);
-        f32x4 af[2][NT], bf[2];
-        // (Measured and not kept: the fragment reads of the next block cut into single LDS instructions spread behind this block's MFMAs
-        // instead of one burst in front of them - 627 vs 611 us on the pair of x-projections, 657 vs 642 on the weight gradients.)
+        f32x4 af[2][NA], bf[2];
         auto read_frags = [&](const float* As, int j, int buf) {
+            if (NT == 0) return;
             const float* const Bs = As + A_FL;
             if (A_KC) {
 #pragma unroll
-                for (int tm = 0; tm < NT; ++tm) af[buf][tm] = *(const f32x4*)(As + a_kc_base + tm * 1024 + (((2 * j + h) ^ sw) << 2));
+                for (int tm = 0; tm < NT; ++tm) af[buf][tm] = *(const f32x4*)(As + a_kc_base + (toff + tm) * 1024 + (((2 * j + h) ^ sw) << 2));
             } else {
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
-                    for (int tm = 0; tm < NT; ++tm) af[buf][tm][s] = As[a_mc_base + (8 * j + s) * 256 + tm * 32];
+                    for (int tm = 0; tm < NT; ++tm) af[buf][tm][s] = As[a_mc_base + (8 * j + s) * 256 + (toff + tm) * 32];
             }
             if (B_KC) {
                 bf[buf] = *(const f32x4*)(Bs + b_kc_base + (((2 * j + h) ^ sw) << 2));
@@ -234,19 +237,24 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const DmaGemmArgs g) {
         for (int kt = 0; kt < KT; ++kt) {
             const bool more = issued < total;
             const Step nx = step_at(cnext);
-            unsigned vo[12];
+            unsigned vo[6];
             Prep pr;
             const __amdgpu_buffer_rsrc_t rxa = nx.seg ? ra1 : ra0, rxb = nx.seg ? rb1 : rb0;
             float* const nslot = lds + nx.slot * STAGE_FL;
             const float* const As = lds + st.slot * STAGE_FL;
             const int s_next = st.slot == NSTAGE - 1 ? 0 : st.slot + 1;
+            if (NT < 2) {                                   // too few MFMAs in block 0 to hide the offsets behind
+                pr = prep_head(nx, more && !(g.dbg & 1));
+#pragma unroll
+                for (int d = 0; d < 6; ++d) prep_one(pr, vo, d);
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int cur = j & 1;
                 if (j == 3) {
                     // This wave's DMAs of the next step have landed: nothing younger is outstanding except, in the first step after an
-                    // epilogue, that chunk's 32 stores (issued behind those DMAs).
-                    if (since_store == 0) __builtin_amdgcn_s_waitcnt(0x0F70 | (32 & 15) | ((32 >> 4) << 14));       // vmcnt(32)
+                    // epilogue, that chunk's 16 stores (issued behind those DMAs).
+                    if (since_store == 0) __builtin_amdgcn_s_waitcnt(0x0F70 | (16 & 15) | ((16 >> 4) << 14));       // vmcnt(16)
                     else __builtin_amdgcn_s_waitcnt(0x0F70);                                                        // vmcnt(0)
                     // Bare barrier: __syncthreads() carries a workgroup-scope release, which the compiler implements by draining EVERY
                     // outstanding LDS-DMA.  The asm is opaque (no LDS access moves across it); what it orders is spelled out above.
@@ -254,25 +262,29 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const DmaGemmArgs g) {
                     since_store = 1;
                 }
                 const float* const nAs = j == 3 ? lds + s_next * STAGE_FL : As;      // where the next block's fragments come from
-                const int nj = j == 3 ? 0 : j + 1;
-                if (j < 3 || kt + 1 < KT) read_frags(nAs, nj, cur ^ 1);
+                if (j < 3 || kt + 1 < KT) read_frags(nAs, j == 3 ? 0 : j + 1, cur ^ 1);
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    if (j == 3) {
+                    if (j == 3) {                           // 2, 2, 1, 1 DMAs in front of the block's four MFMA groups
+                        const int d0 = s < 2 ? 2 * s : 2 + s, d1 = s < 2 ? d0 + 2 : d0 + 1;
 #pragma unroll
-                        for (int d = 3 * s; d < 3 * s + 3; ++d) issue(rxa, rxb, nslot, vo, d);
+                        for (int d = d0; d < d1; ++d) issue(rxa, rxb, nslot, vo, d);
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int tm = 0; tm < NT; ++tm) {
                         acc[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][tm][s], bf[cur][s], acc[tm], 0, 0, 0);
-                        const int idx = s * NT + tm;                            // position of this MFMA in the block
-                        if (j == 0) {           // the offsets' common part behind the first MFMA, one DMA offset behind each of the next 12
-                            if (idx == 0) pr = prep_head(nx, more && !(g.dbg & 1));             // (NT < 4: what is left goes behind the block's last one)
-                            if (idx >= 1 && idx <= 12) prep_one(pr, vo, idx - 1);
-                            if (s == 3 && tm == NT - 1) {
-#pragma unroll
-                                for (int d = 4 * NT - 1; d < 12; ++d) prep_one(pr, vo, d);
+                        if (j == 0 && NT >= 2) {            // the offsets' common part behind the first MFMA, one DMA offset behind each of the next 6
+                            const int idx = s * NT + tm;
+                            // (the empty asm pins each value HERE: LLVM's sink pass otherwise moves the whole computation down to its
+                            // use, in front of block 3's MFMAs - sched_barrier only binds the machine scheduler)
+                            if (idx == 0) {
+                                pr = prep_head(nx, more && !(g.dbg & 1));
+                                asm volatile("" : "+v"(pr.a_off), "+v"(pr.b_off), "+v"(pr.a_lim), "+v"(pr.b_lim));
+                            }
+                            if (idx >= 1 && idx <= 6) {
+                                prep_one(pr, vo, idx - 1);
+                                asm volatile("" : "+v"(vo[idx - 1]));
                             }
                         }
                         __builtin_amdgcn_sched_barrier(0);
@@ -285,12 +297,12 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const DmaGemmArgs g) {
                 st = step_at(t);
             }
         }
-        // ---- epilogue through the slot just consumed (wave-private 32 x 36 scratch): 16-byte row-contiguous stores, ALWAYS 32 per wave
+        // ---- epilogue through the slot just consumed (wave-private 32 x 36 scratch): 16-byte row-contiguous stores, ALWAYS 16 per wave
         // (out-of-range ones are dropped by the range check) because the wait count of the next step relies on the number.
         asm volatile("s_barrier" ::: "memory");            // every wave is past its fragment reads of the last step: the slot becomes scratch
         float* const sc = lds + st.slot * STAGE_FL + wave * (32 * EP);
 #pragma unroll
-        for (int tm = 0; tm < 8; ++tm) {
+        for (int tm = 0; tm < 4; ++tm) {
             if (tm < NT) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sc[((r & 3) + 8 * (r >> 2) + 4 * h) * EP + m] = acc[tm < NT ? tm : 0][r];
@@ -310,7 +322,8 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const DmaGemmArgs g) {
                     }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) raw[k] = __float_as_uint(v[k]);
-                    const int orow = slabbed ? 32 * tm + lrow : st.row0 + 32 * tm + lrow;
+                    const int trow = 32 * (toff + tm) + lrow;
+                    const int orow = slabbed ? trow : st.row0 + trow;
                     const bool ok = ocol < ncols && (slabbed || orow < g.M);
                     vo = ok ? (unsigned)(orow * ld_out + ocol) * 4u : OOB;
                 }
@@ -324,15 +337,14 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const DmaGemmArgs g) {
     };
 
     for (int c = 0; c < nch; ++c) {
-        switch (cb + (c < ce ? 1 : 0)) {
-            case 1: run_chunk(std::integral_constant<int, 1>{}); break;
-            case 2: run_chunk(std::integral_constant<int, 2>{}); break;
-            case 3: run_chunk(std::integral_constant<int, 3>{}); break;
-            case 4: run_chunk(std::integral_constant<int, 4>{}); break;
-            case 5: run_chunk(std::integral_constant<int, 5>{}); break;
-            case 6: run_chunk(std::integral_constant<int, 6>{}); break;
-            case 7: run_chunk(std::integral_constant<int, 7>{}); break;
-            default: run_chunk(std::integral_constant<int, 8>{}); break;
+        const int nt = min(8, gtiles - 8 * c), na = (nt + 1) >> 1;
+        const int mine = kh ? nt - na : na, toff = kh ? na : 0;
+        switch (mine) {
+            case 0: run_chunk(std::integral_constant<int, 0>{}, toff); break;
+            case 1: run_chunk(std::integral_constant<int, 1>{}, toff); break;
+            case 2: run_chunk(std::integral_constant<int, 2>{}, toff); break;
+            case 3: run_chunk(std::integral_constant<int, 3>{}, toff); break;
+            default: run_chunk(std::integral_constant<int, 4>{}, toff); break;
         }
     }
 }
@@ -414,10 +426,10 @@ int launch(const Plan& p, int transa, int transb, int m, int n, int k, const flo
     g.dbg = dbg;
     g.slab = p.ksplit > 1 ? slab : nullptr;
     const dim3 grid(nprob * p.panels * p.groups * p.ksplit);
-    if (!transa && transb) gemm_dma_kernel<true, true><<<grid, 256, 0, s>>>(g);
-    else if (!transa && !transb) gemm_dma_kernel<true, false><<<grid, 256, 0, s>>>(g);
-    else if (transa && !transb) gemm_dma_kernel<false, false><<<grid, 256, 0, s>>>(g);
-    else gemm_dma_kernel<false, true><<<grid, 256, 0, s>>>(g);
+    if (!transa && transb) gemm_dma_kernel<true, true><<<grid, 512, 0, s>>>(g);
+    else if (!transa && !transb) gemm_dma_kernel<true, false><<<grid, 512, 0, s>>>(g);
+    else if (transa && !transb) gemm_dma_kernel<false, false><<<grid, 512, 0, s>>>(g);
+    else gemm_dma_kernel<false, true><<<grid, 512, 0, s>>>(g);
     return 0;
 }
 
