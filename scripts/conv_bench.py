@@ -5,8 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from vistaocr_amd import ops
 dev = torch.device("cuda:0")
-def timeit(fn, n=20):
-    for _ in range(5): fn()
+def timeit(fn, n=30):
+    for _ in range(40): fn()           # the first launches of a process run at another clock
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n
