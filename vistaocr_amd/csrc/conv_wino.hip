@@ -36,7 +36,9 @@ __device__ __forceinline__ int xcd_slice_order(int b, int nwg) {
 }
 
 // pf[(ci*12 + kh*4 + x)][co], pd[(co*12 + kh*4 + x)][ci] (data gradient: taps flipped, channels transposed)
-__global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ pf, float* __restrict__ pd, int cout, int cin) {
+// x4 != 0: the four transform points of a (channel, filter row) are CONTIGUOUS per output channel - pf[(ci*3 + kh)][co][x] - so that a
+// lane's four A operands of a k-step are one 16-byte LDS read (conv3x3_wino8_kernel<.., true>)
+__global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ pf, float* __restrict__ pd, int cout, int cin, int x4) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int total = cout * cin * 3;
     if (i >= total) return;
@@ -44,19 +46,26 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
     const float* g = w + ((long)(co * cin + ci) * 3 + kh) * 3;
     const float g0 = g[0], g1 = g[1], g2 = g[2];
     if (pf) {
-        float* o = pf + (long)(ci * 12 + kh * 4) * cout + co;
+        float* o = x4 ? pf + ((long)(ci * 3 + kh) * cout + co) * 4 : pf + (long)(ci * 12 + kh * 4) * cout + co;
+        const long st = x4 ? 1 : cout;
         o[0] = g0;
-        o[cout] = 0.5f * ((g0 + g2) + g1);
-        o[2 * cout] = 0.5f * ((g0 + g2) - g1);
-        o[3 * cout] = g2;
+        o[st] = 0.5f * ((g0 + g2) + g1);
+        o[2 * st] = 0.5f * ((g0 + g2) - g1);
+        o[3 * st] = g2;
     }
     if (pd) {       // flipped filter: row 2-kh, taps (g2, g1, g0)
-        float* o = pd + (long)(co * 12 + (2 - kh) * 4) * cin + ci;
+        float* o = x4 ? pd + ((long)(co * 3 + (2 - kh)) * cin + ci) * 4 : pd + (long)(co * 12 + (2 - kh) * 4) * cin + ci;
+        const long st = x4 ? 1 : cin;
         o[0] = g2;
-        o[cin] = 0.5f * ((g2 + g0) + g1);
-        o[2 * cin] = 0.5f * ((g2 + g0) - g1);
-        o[3 * cin] = g0;
+        o[st] = 0.5f * ((g2 + g0) + g1);
+        o[2 * st] = 0.5f * ((g2 + g0) - g1);
+        o[3 * st] = g0;
     }
+}
+
+static int wino_pack_x4() {
+    static const int v = getenv("VOCR_CONV_PACK4") ? atoi(getenv("VOCR_CONV_PACK4")) : 0;      // experiments: needs VOCR_CONV_WINO8=1
+    return v;
 }
 
 typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
@@ -292,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const float* __res
 // the barriers it removes were already covered by the second workgroup of the CU) and slower on the 64-channel ones (eight
 // segments per workgroup: 397 vs 297 us), so it is NOT the default; kept as the A/B that shows the k-loop itself - 12 LDS reads
 // per 8 MFMAs - is what bounds these kernels.
-template <int CO_T>
+template <int CO_T, bool PK4>
 __global__ __launch_bounds__(512) void conv3x3_wino8_kernel(const float* __restrict__ in, const float* __restrict__ wpack,
                                                             const float* __restrict__ bias, float* __restrict__ out,
                                                             const float* __restrict__ zero_page, int N, int Cin, int H, int W,
@@ -407,8 +416,17 @@ __global__ __launch_bounds__(512) void conv3x3_wino8_kernel(const float* __restr
         for (int d = 0; d < DPW; ++d) {
             const int q = wave + 8 * d;                                               // wave-uniform
             const bool real = q < NDMA;
-            const int gk = ci0 * 12 + q * RPI + drow;
-            const float* src = (real && gk < Ktot && dcol_ok) ? wpack + (long)gk * Cout + co0 + dcol : zero_page;
+            const float* src;
+            if (PK4) {
+                // pack [(ci*3 + kh)][co][4]: a stage row is CO_T x 4 floats = CO_T / 64 instructions, lane = one output channel
+                constexpr int IPR = CO_T / 64;
+                const int row = q / IPR, co = co0 + (q % IPR) * 64 + lane;
+                const int grow = ci0 * 3 + row;
+                src = (real && grow < Cin * 3 && co < Cout) ? wpack + ((long)grow * Cout + co) * 4 : zero_page;
+            } else {
+                const int gk = ci0 * 12 + q * RPI + drow;
+                src = (real && gk < Ktot && dcol_ok) ? wpack + (long)gk * Cout + co0 + dcol : zero_page;
+            }
             float* const dst = real ? lds + slot * SBUF + q * 256 : lds + DMA_DUMMY;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -418,16 +436,26 @@ __global__ __launch_bounds__(512) void conv3x3_wino8_kernel(const float* __restr
     // each 4 transform points x TM row blocks = 8 MFMAs
     auto kloop = [&](int slot) {
         const float* wa = lds + slot * SBUF + wco + li + lk * (2 * 12) * CO_T;
+        const float* wa4 = lds + slot * SBUF + (wco + li) * 4 + lk * (2 * 3) * CO_T * 4;       // PK4: [(c*3 + kh)][co][4]
         const float* pb = lds + slot * SBUF + WBUF + wsg * PSEG + li + lk * 2 * 3 * PRW;
         float a[4][TM], e0, e1, o0, o1;
         auto reads = [&](int s, float (&aa)[4][TM], float& E0, float& E1, float& O0, float& O1) {
             const int cp = s / 3, kh = s % 3;                                            // compile-time after unrolling
             const float* pr = pb + (cp * 3 + kh) * PRW;
             E0 = pr[0]; E1 = pr[1]; O0 = pr[POFF]; O1 = pr[POFF + 1];
+            if (PK4) {
 #pragma unroll
-            for (int x = 0; x < 4; ++x)
+                for (int i = 0; i < TM; ++i) {
+                    const f32x4 q4 = *(const f32x4*)(wa4 + ((cp * 3 + kh) * CO_T + 32 * i) * 4);
 #pragma unroll
-                for (int i = 0; i < TM; ++i) aa[x][i] = wa[((cp * 3 + kh) * 4 + x) * CO_T + 32 * i];
+                    for (int x = 0; x < 4; ++x) aa[x][i] = q4[x];
+                }
+            } else {
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) aa[x][i] = wa[((cp * 3 + kh) * 4 + x) * CO_T + 32 * i];
+            }
         };
         reads(0, a, e0, e1, o0, o1);
 #pragma unroll
@@ -909,7 +937,7 @@ extern "C" int vocr_conv3x3_wino_pack_weights(const float* w, float* wpack_fwd, 
     VOCR_CHECK_ARG(w && (wpack_fwd || wpack_dgrad), "vocr_conv3x3_wino_pack_weights: null pointer");
     VOCR_CHECK_ARG(cout > 0 && cin > 0, "vocr_conv3x3_wino_pack_weights: bad shape");
     const int total = cout * cin * 3;
-    wino_pack_kernel<<<vocr_cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(w, wpack_fwd, wpack_dgrad, cout, cin);
+    wino_pack_kernel<<<vocr_cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(w, wpack_fwd, wpack_dgrad, cout, cin, wino_pack_x4());
     VOCR_CHECK_LAUNCH("vocr_conv3x3_wino_pack_weights");
     // the direct pack behind the transformed rows
     return vocr_conv3x3_pack_weights(w, wpack_fwd ? wpack_fwd + (size_t)cout * cin * 12 : nullptr,
@@ -948,17 +976,20 @@ extern "C" int vocr_conv3x3_wino_fwd(const float* x, const float* wpack, const f
         /* measured worth it up to a quarter round of tiles, up to half a round from 128 input channels on               */  \
         const bool cut = tail_mode == 1 && tiles > ncu && rem > 0 && (rem <= ncu / 4 || (rem <= ncu / 2 && cin >= 128));   \
         const int n_main = cut ? tiles - rem : tiles, n_tail = cut ? rem * (CO_T / 32) * 2 * NSEG : 0;                      \
-        KERNEL<CO_T><<<dim3(n_tail + n_main), THREADS, 0, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, geo, (CO_TILES), wdirect, n_tail, n_main); \
+        KERNEL<<<dim3(n_tail + n_main), THREADS, 0, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, geo, (CO_TILES), wdirect, n_tail, n_main); \
     } while (0)
     // VOCR_CONV_WINO8=1: one 8-wave workgroup per CU with a three-stage ring (measured no faster, see the kernel); default: the
     // two-stage 4-wave kernel, two workgroups per CU
     static const int wino8 = getenv("VOCR_CONV_WINO8") ? atoi(getenv("VOCR_CONV_WINO8")) : 0;
-    if (wino8) {
-        if (cout > 64) VOCR_WINO_LAUNCH(conv3x3_wino8_kernel, 512, 128, 4, vocr_cdiv(cout, 128));
-        else VOCR_WINO_LAUNCH(conv3x3_wino8_kernel, 512, 64, 8, 1);
+    if (wino8 && wino_pack_x4()) {
+        if (cout > 64) VOCR_WINO_LAUNCH((conv3x3_wino8_kernel<128, true>), 512, 128, 4, vocr_cdiv(cout, 128));
+        else VOCR_WINO_LAUNCH((conv3x3_wino8_kernel<64, true>), 512, 64, 8, 1);
+    } else if (wino8) {
+        if (cout > 64) VOCR_WINO_LAUNCH((conv3x3_wino8_kernel<128, false>), 512, 128, 4, vocr_cdiv(cout, 128));
+        else VOCR_WINO_LAUNCH((conv3x3_wino8_kernel<64, false>), 512, 64, 8, 1);
     } else {
-        if (cout > 64) VOCR_WINO_LAUNCH(conv3x3_wino_kernel, 256, 128, 2, vocr_cdiv(cout, 128));
-        else VOCR_WINO_LAUNCH(conv3x3_wino_kernel, 256, 64, 4, 1);
+        if (cout > 64) VOCR_WINO_LAUNCH(conv3x3_wino_kernel<128>, 256, 128, 2, vocr_cdiv(cout, 128));
+        else VOCR_WINO_LAUNCH(conv3x3_wino_kernel<64>, 256, 64, 4, 1);
     }
 #undef VOCR_WINO_LAUNCH
     VOCR_CHECK_LAUNCH("vocr_conv3x3_wino_fwd");
