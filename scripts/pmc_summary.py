@@ -82,8 +82,44 @@ def busy(paths):
         print()
 
 
+FAMILIES = (      # bench.py's FAMILY names -> kernel-name prefixes
+    ("conv3x3 forward + data gradient (conv3x3_wino_kernel / conv3x3_dma_kernel)", ("conv3x3_wino_kernel", "conv3x3_wino8_kernel", "conv3x3_dma_kernel", "conv3x3_kernel", "conv3x3_tail")),
+    ("conv3x3 weight gradient (conv3x3_wgrad_wino_dma_kernel)", ("conv3x3_wgrad",)),
+    ("dense GEMMs (gemm_dma_kernel / gemm_f32_kernel behind vocr_gemm and vocr_gemm_pair: bridge, LSTM projections, prob, their dX / dW)", ("gemm_dma_kernel", "gemm_f32_kernel")),
+    ("LSTM sweeps (lstm_fwd_chain8 / lstm_bwd_kowner8)", ("lstm_fwd_", "lstm_bwd_")),
+)
+
+
+def traffic_json(fetch_csv, write_csv, out_path):
+    """profiles/kernel_traffic.json: HBM-side KB per launch of every MFMA kernel family (FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950
+    correction, WRITE_SIZE as reported), averaged over the launches of the profiled steps."""
+    import json
+    res = {}
+    for cname, path in (("fetch", fetch_csv), ("write", write_csv)):
+        rows, _ = load(path)
+        for fam, prefixes in FAMILIES:
+            vals = [float(r["Counter_Value"]) for r in rows if short(r["Kernel_Name"]).startswith(prefixes)]
+            if vals:
+                e = res.setdefault(fam, {})
+                e[cname + "_KB_per_launch_reported"] = round(sum(vals) / len(vals), 1)
+                e["launches_profiled"] = len(vals)
+    for fam, e in res.items():
+        e["fetch_KB_per_launch"] = round(2.0 * e.get("fetch_KB_per_launch_reported", 0.0), 1)
+        e["write_KB_per_launch"] = e.get("write_KB_per_launch_reported", 0.0)
+    res["_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py --steps 2 --warmup 1; fetch_KB_per_launch = 2 x FETCH_SIZE "
+                    "(gfx950 reports 1/2 of streamed read bytes: MI355X_MICROARCH.md, calibrated here with scripts/fetch_calib.hip), WRITE_SIZE exact; "
+                    "per launch, averaged over all launches of the family in the profiled steps")
+    json.dump(res, open(out_path, "w"), indent=1)
+    for fam, e in res.items():
+        if fam != "_note":
+            print("%-60s fetch %9.1f KB (2 x %9.1f)  write %9.1f KB  per launch, n=%d" % (fam[:60], e["fetch_KB_per_launch"], e.get("fetch_KB_per_launch_reported", 0),
+                                                                                          e["write_KB_per_launch"], e["launches_profiled"]))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "traffic":
         traffic(sys.argv[2:])
+    elif sys.argv[1] == "traffic_json":
+        traffic_json(sys.argv[2], sys.argv[3], sys.argv[4])
     else:
         busy(sys.argv[2:])
