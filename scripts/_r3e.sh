@@ -3,9 +3,9 @@ export TMPDIR=/tmp
 T=${1:-r3e}
 mkdir -p gpurun_out/$T
 python bench.py --no-cpu-baseline > gpurun_out/$T/bench_default.json 2> gpurun_out/$T/bench_default.err
-${2:-VOCR_DW_TILES=1} python bench.py --no-cpu-baseline > gpurun_out/$T/bench_b.json 2> /dev/null
+env ${2:-VOCR_DW_TILES=1} python bench.py --no-cpu-baseline > gpurun_out/$T/bench_b.json 2> /dev/null
 python bench.py --no-cpu-baseline > gpurun_out/$T/bench_default2.json 2> /dev/null
-${2:-VOCR_DW_TILES=1} python bench.py --no-cpu-baseline > gpurun_out/$T/bench_b2.json 2> /dev/null
+env ${2:-VOCR_DW_TILES=1} python bench.py --no-cpu-baseline > gpurun_out/$T/bench_b2.json 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$T/trace -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/$T/bench_profiled.json 2> gpurun_out/$T/bench_profiled.err
 for f in default b default2 b2; do python - <<PY
 import json

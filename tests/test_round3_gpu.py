@@ -155,7 +155,7 @@ def _check(c, ref, k, what):
 
 
 @pytest.mark.parametrize("m,n,k", [(9408, 2048, 1024), (9408, 1024, 2048), (2048, 1024, 9408), (4200, 1000, 1000), (2052, 512, 4096),
-                                   (9408, 2048, 128), (2560, 384, 8192), (8200, 260, 72)])
+                                   (9408, 2048, 128), (2560, 384, 8192), (8200, 260, 72), (2080, 128, 4096)])
 def test_panel_gemm_all_layouts(m, n, k):
     """The DMA-staged panel kernel on the step's large products and on edge shapes (M, N, K not multiples of the tile sizes, K cut into
     slabs for the long-K / few-tile ones), all four operand layouts, bias + ReLU, accumulate; bitwise reproducible."""
@@ -193,7 +193,7 @@ def test_panel_gemm_all_layouts(m, n, k):
 
 
 @pytest.mark.parametrize("m,n,k", [(9408, 2048, 1024), (9408, 2048, 128), (2048, 1024, 9408), (2048, 512, 9376), (9408, 1024, 2048),
-                                   (9408, 128, 2048), (1000, 300, 520)])
+                                   (9408, 128, 2048), (2048, 128, 9408), (1000, 300, 520)])
 def test_gemm_pair_modes(m, n, k):
     """vocr_gemm_pair: two products of one shape in one launch (mode 0) and one product whose K runs through two operand pairs (mode 1)
     against fp64; shapes the panel kernel does not take fall back to two vocr_gemm calls with the same results contract."""

@@ -82,8 +82,9 @@ __global__ __launch_bounds__(512) void gemm_dma_kernel(const DmaGemmArgs g) {
     // takes what is left), and inside a chunk the first ceil(n/2) tiles belong to waves 0-3, the rest to waves 4-7
     const int mt = (g.M + 31) >> 5;
     const int tb_ = mt / g.groups, te_ = mt % g.groups;
-    const int gtiles = tb_ + (group < te_ ? 1 : 0);
-    const int gstart = group * tb_ + min(group, te_);
+    // (K split into slabs: whole 8-tile groups, because the slab reduce maps slab tile (group, panel) to rows group * 256)
+    const int gtiles = g.ksplit > 1 ? min(8, mt - 8 * group) : tb_ + (group < te_ ? 1 : 0);
+    const int gstart = g.ksplit > 1 ? 8 * group : group * tb_ + min(group, te_);
     const int nch = (gtiles + 7) >> 3;
     const int kbeg = split * g.kps, kend = min(g.K, kbeg + g.kps);
     const int kts = (kend - kbeg + DK - 1) / DK;          // K-tiles of one segment
@@ -371,7 +372,7 @@ Plan plan(int transa, int transb, int m, int n, int k, int lda, int ldb, int ldc
     Plan p = {false, 0, 0, 1, 0, 0};
     static const int on = getenv("VOCR_GEMM_DMA") ? atoi(getenv("VOCR_GEMM_DMA")) : 1;
     if (!on) return p;
-    if (m < 256 || n < 256 || k < 64) return p;
+    if (m < 256 || n < 128 || k < 64) return p;
     if ((lda | ldb | ldc | k | n) & 3) return p;
     if (transa && (m & 3)) return p;
     const long a_ext = transa ? (long)k * lda : (long)m * lda, b_ext = transb ? (long)n * ldb : (long)k * ldb, c_ext = (long)m * ldc;
@@ -385,19 +386,18 @@ Plan plan(int transa, int transb, int m, int n, int k, int lda, int ldb, int ldc
     if (groups > mt) groups = mt;
     p.ksplit = 1;
     p.kps = vocr_cdiv(k, DK) * DK;
-    if (mt / groups < 8 && k >= 2048 && nseg == 1 && !no_split) {
-        // few rows per workgroup but a long K (weight gradients): whole 256-row groups, K cut into slabs
+    if (mt / groups < 8 && (long)k * nseg >= 2048 && !no_split) {
+        // few rows per workgroup but a long K (weight gradients; the data gradient of a narrow layer): whole 256-row groups, K cut into
+        // slabs.  With two K segments every slab covers the same k range of BOTH segments.
         groups = vocr_cdiv(mt, 8);
         int ks = ncu / (units * groups);
-        if (ks > k / 512) ks = k / 512;
+        if (ks > k / 256) ks = k / 256;
         if (ks < 1) ks = 1;
         p.kps = vocr_cdiv(vocr_cdiv(k, ks), DK) * DK;
         p.ksplit = vocr_cdiv(k, p.kps);
-        if (mt % 8 != 0 && groups * 8 != mt) {
-            // uniform 8-tile groups are what the slab reduce assumes: the even dealing above gives them only when mt is a multiple of 8
-            if (p.ksplit > 1) return Plan{false, 0, 0, 1, 0, 0};
-        }
+        if (p.ksplit == 1) { groups = ncu / units < 1 ? 1 : (ncu / units > mt ? mt : ncu / units); }      // K too short to cut after all
     }
+    if (n < 256 && p.ksplit == 1) return p;            // a single column panel only pays when K is cut (else gemm.hip's tiles do better)
     if (mt / groups < 2) return p;                     // too few rows per workgroup: gemm.hip's tiles do better
     p.groups = groups;
     p.slab_bytes = p.ksplit > 1 ? (size_t)nprob * p.groups * p.panels * p.ksplit * DM * DN * sizeof(float) : 0;

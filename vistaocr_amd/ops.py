@@ -64,14 +64,72 @@ def mark_side_pending(device=None):
 
 
 def join_side_stream(device=None):
-    """Make the current stream wait for every weight-gradient kernel issued on this device's side stream."""
+    """Make the current stream wait for every weight-gradient kernel issued on this device's side streams (deferred work is launched
+    first)."""
     if not torch.cuda.is_available():
         return
     idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    flush_deferred(idx)
     st = _SIDE.get(idx)
     if st is not None and st["pending"]:
         torch.cuda.current_stream(idx).wait_stream(st["stream"])
         st["pending"] = False
+    d = _DEFER.get(idx)
+    if d is not None and d["pending"]:
+        torch.cuda.current_stream(idx).wait_stream(d["stream"])
+        d["pending"] = False
+
+
+# ---- deferred weight gradients (opt-in, VOCR_LSTM_DW_DEFER=1; MEASURED SLOWER: 18.82 vs 18.50 ms per step).  The idea: the LSTM
+# layers' dW GEMMs (2.3 ms of MFMA work per step, off the critical path) are not launched during the LSTM backward - the persistent
+# sweeps and the panel GEMM cannot share a CU (registers, LDS), so there they only take turns with the sweeps and the data-gradient
+# GEMMs - but when the backward reaches the CNN, on a third low-priority stream, to fill the matrix pipe while the HBM-bound
+# BatchNorm / pooling passes stream.  What happened: the sweeps do run alone then (3 x 0.83 instead of 3 x 1.23 ms), but the CNN
+# backward's own MFMA kernels (data + weight gradient on two streams) already cover its HBM passes, so the deferred GEMMs just
+# lengthen that window by more than the LSTM window shrinks.  Each entry: (event where the operands became ready, closure).
+_DEFER = {}
+_DEFER_ON = _os.environ.get("VOCR_LSTM_DW_DEFER", "0") == "1"
+
+
+def _defer(device=None):
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    d = _DEFER.get(idx)
+    if d is None:
+        lo, _hi = torch.cuda.Stream.priority_range()
+        with torch.cuda.device(idx):
+            d = _DEFER[idx] = {"stream": torch.cuda.Stream(priority=lo), "pending": False, "work": []}
+    return d
+
+
+def defer_stream(device=None):
+    return _defer(device)["stream"]
+
+
+def defer_work(fn, device=None):
+    """Queue `fn` (a closure that issues kernels on the CURRENT stream) for flush_deferred(); its operands are ready at this point of the
+    current stream."""
+    d = _defer(device)
+    ev = torch.cuda.Event()
+    ev.record()
+    d["work"].append((ev, fn))
+
+
+def flush_deferred(device=None):
+    """Launch everything queued by defer_work() on the deferred stream (called when the backward reaches the CNN, and by every join)."""
+    idx = torch.cuda.current_device() if device is None else (device if isinstance(device, int) else torch.device(device).index)
+    d = _DEFER.get(idx)
+    if d is None or not d["work"]:
+        return
+    work, d["work"] = d["work"], []
+    # Behind the CURRENT point of the main stream, not merely behind the operands' events: the host runs milliseconds ahead of the
+    # device, so kernels that only waited for their operands would start in the middle of the LSTM backward after all.
+    d["stream"].wait_stream(torch.cuda.current_stream(idx))
+    with torch.cuda.stream(d["stream"]):
+        for ev, fn in work:
+            fn()
+    d["pending"] = True
 
 
 # ---- health words (include/vocr.h): one int32[2] per device, report-only.  [0]: a persistent LSTM sweep's hand-off timed
@@ -530,7 +588,9 @@ class PermuteBchwToWbchFn(torch.autograd.Function):
     def backward(ctx, dout):
         b, c, h, w = ctx.shape
         dout = _f32c(dout)
-        # everything above the CNN (bridge, LSTM, prob) has produced its gradients by now
+        # everything above the CNN (bridge, LSTM, prob) has produced its gradients by now - or is about to: the deferred LSTM weight
+        # gradients start here, beside the CNN backward
+        flush_deferred()
         _fire(ctx.hooks, "sequence_grads_ready")
         dx = torch.empty(b, c, h, w, dtype=torch.float32, device=dout.device)
         call("vocr_wbch_to_bchw", _p(dout), _p(dx), b, c, h, w, _stream())
@@ -730,6 +790,11 @@ class BiLstmLayerFn(torch.autograd.Function):
             dbh_f.copy_(dbias[0])
             dbh_r.copy_(dbias[1])
 
+        if direct and _SIDE_ENABLED and _DEFER_ON:
+            for t_ in (dg, x, y, dbias):
+                t_.record_stream(defer_stream())
+            defer_work(lambda: weight_grads(sinks))
+            return (dx, None, None, None) + (None,) * 10
         if direct and _SIDE_ENABLED and _os.environ.get("VOCR_LSTM_DW_OVERLAP", "1") == "1":
             side = side_stream()
             side.wait_stream(torch.cuda.current_stream())

@@ -139,6 +139,7 @@ class FlatClampAdam(object):
                     self._comm_stream = torch.cuda.Stream(device=dev)
                 self._comm_stream.wait_stream(torch.cuda.current_stream(dev))
                 self._comm_stream.wait_stream(ops.side_stream(dev))
+                self._comm_stream.wait_stream(ops.defer_stream(dev))      # the deferred LSTM weight gradients (launched just before this hook)
                 with torch.cuda.stream(self._comm_stream):
                     if self._time_comm:
                         e0 = torch.cuda.Event(enable_timing=True)
