@@ -109,6 +109,39 @@ FAMILY = {"vocr_conv3x3_fwd": "conv3x3 forward + data gradient (conv3x3_wino_ker
           "vocr_lstm_bwd_bias": "LSTM sweeps (lstm_fwd_chain8 / lstm_bwd_kowner8)"}
 
 
+def gemm_alone(hidden, din=128):
+    """The step's large GEMM launches ALONE on the chip (both directions of a BiLSTM layer per launch, random operands): inside the
+    step the side-stream launches also wait for CUs that the persistent sweeps hold, so their in-step durations say little about the
+    kernel.  ~0.1 s."""
+    import torch
+    from vistaocr_amd import ops
+    dev = torch.device("cuda", torch.cuda.current_device())
+    M, G, H = 294 * B, 4 * hidden, hidden
+    out = []
+    for what, mode, ta, tb, m, n, k in (("x-projection, layers 1-2", 0, 0, 1, M, G, 2 * H), ("data gradient, layers 1-2", 1, 0, 0, M, 2 * H, G),
+                                        ("weight gradient W_ih, layers 1-2", 0, 1, 0, G, 2 * H, M), ("weight gradient W_hh", 0, 1, 0, G, H, M - B)):
+        a0 = torch.randn((k, m) if ta else (m, k), device=dev)
+        a1 = torch.randn_like(a0)
+        b0 = torch.randn((n, k) if tb else (k, n), device=dev)
+        b1 = torch.randn_like(b0)
+        c0 = torch.empty(m, n, device=dev)
+        c1 = torch.empty(m, n, device=dev) if mode == 0 else None
+        fn = lambda: ops.gemm_pair(mode, ta, tb, m, n, k, a0, a1, a0.shape[1], b0, b1, b0.shape[1], c0, c1, n)
+        for _ in range(15):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        tf = 2 * 2.0 * m * n * k / (ms * 1e-3) / 1e12
+        out.append({"what": what, "m_n_k": [m, n, k], "products_per_launch": 2, "ms": round(ms, 4), "achieved": round(tf, 1), "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4)})
+        del a0, a1, b0, b1, c0, c1
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ CPU leg (child process)
 def cpu_baseline_worker(parity_file):
     """The oracle (CPU restatement of the same step on PyTorch-CPU).  (1) parity: ONE forward of the parity batch with the closed-form
@@ -348,10 +381,15 @@ def run_rank(args):
 
     for _ in range(args.warmup):
         va.train(batch_host, model, crit, opt)
-    # Two timed loops of exactly K steps each, both bracketed by barrier + synchronize.  The side number (batch resident in HBM) runs
-    # FIRST: on every box the first timed loop of a process measured 2-4 % slower than the second whichever of the two it was (20.09 vs
-    # 19.18 ms in round 2's driver run with the loops the other way round), so the headline loop would otherwise report the warm-up of
-    # the clocks and of the caching allocator rather than the step.
+    # Python's cyclic garbage collector, not the GPU, made "the first timed loop of a process 2-4 % slower than the second" in rounds
+    # 1-2 (20.09 vs 19.18 ms in round 2's driver run): about 20 steps after start-up its first full collection walks every object of
+    # the process for 55-75 ms - one step's worth of 4 (scripts/warmup_curve.py: per-step times are flat at 18.45 ms from step 1 with
+    # the collector off, with it on step 21 takes 76 ms).  Everything alive now (modules, parameters, the optimiser) is moved out of
+    # the collector's sight; garbage created by the steps themselves is still collected.
+    import gc
+    gc.collect()
+    gc.freeze()
+    # Two timed loops of exactly K steps each, both bracketed by barrier + synchronize; the side number (batch resident in HBM) first.
     dt_res, _ = timed(batch_dev, args.steps)
     # timed region (headline): the batch comes from pinned host memory inside train().  HIP events, on the stream each kernel is
     # launched on, around every launch of the MFMA kernel families in every `event_every`-th step only (an event pair costs the queue
@@ -374,6 +412,7 @@ def run_rank(args):
     _lib.enable_timing(None)
     opt.check_health()
     ranks_seen = dist.get_world_size() if use_dist else 1
+    alone = gemm_alone(args.hidden) if rank == 0 and args.hidden == 512 else None
 
     out = None
     parity_failed = None
@@ -447,18 +486,19 @@ def run_rank(args):
                        "backend": (args.backend + ("/RCCL" if args.backend == "nccl" else "")) if use_dist else "none",
                        "final_loss": round(float(final_loss), 3), "per_rank_rng": "seed 1234 + 1000*rank after an identical init"},
             "resident_input": {"value": round(B * world * args.steps / dt_res, 2), "ms_per_step": round(1000.0 * dt_res / args.steps, 3),
-                               "what": "same K steps with the image batch already in HBM (no H2D inside train()); this loop runs before the "
-                                       "headline loop (the first timed loop of a process is 2-4 % slower than the second on every box)"},
+                               "what": "same K steps with the image batch already in HBM (no H2D inside train()); runs before the headline loop"},
             "allreduce_ms_per_step": comm_ms,
             "roofline": {"bound": "mfma",
                          "kernel": dom[0] + " - the kernel family with the most device time in the step (HIP events around every launch of the "
                                             "MFMA families in every %d-th timed step; families overlap on two streams, so their times add up to more "
-                                            "than the step)" % max(1, args.event_every),
+                                            "than the step, and a side-stream launch's duration includes waiting for CUs that a persistent LSTM sweep holds: "
+                                            "gemm_launches_alone has the same launches alone on the chip)" % max(1, args.event_every),
                          "achieved": dom[1]["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": dom[1]["frac"],
                          "executed_frac": dom[1]["executed_frac"], "traffic": traffic,
                          "avg_launch_ms": dom[1]["avg_launch_ms"], "launches_per_step": dom[1]["launches_per_step"],
                          "launches_timed": dom[1]["launches_timed"],
                          "dominant_by_time": dom[0], "families_in_step": fams, "conv_forward_alone": conv_fwd,
+                         "gemm_launches_alone": alone,
                          "whole_step": {"flop": round(step_flop), "executed_flop": round(step_exe),
                                         "achieved": round(step_flop / (ms * 1e-3) / 1e12, 2), "frac": round(step_flop / (ms * 1e-3) / 1e12 / peak, 4),
                                         "executed_frac": round(step_exe / (ms * 1e-3) / 1e12 / peak, 4),
