@@ -107,6 +107,14 @@ def defer_stream(device=None):
     return _defer(device)["stream"]
 
 
+def deferred_stream_if_used(device=None):
+    """The deferred stream if work has been launched on it since the last join, else None (never creates the stream: every extra
+    stream competes for the GPU's hardware queues, see vistaocr_amd/__init__.py)."""
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    d = _DEFER.get(idx)
+    return d["stream"] if d is not None and d["pending"] else None
+
+
 def defer_work(fn, device=None):
     """Queue `fn` (a closure that issues kernels on the CURRENT stream) for flush_deferred(); its operands are ready at this point of the
     current stream."""
