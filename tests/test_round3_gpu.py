@@ -220,3 +220,24 @@ def test_gemm_pair_modes(m, n, k):
     _check(c0, r0 + r1, 2 * k, "pair mode 1 NN")
     ops.gemm_pair(1, 0, 0, m, n, k, d(a0), d(a1), k, d(b0), d(b1), n, e0, None, n, bias0=d(bias0), relu=True)
     _check(e0, torch.relu(r0 + r1 + bias0.double()), 2 * k, "pair mode 1 NN bias relu")
+
+
+def test_a_process_group_does_not_cost_the_step_its_overlap():
+    """Regression guard for the hardware-queue trap: with a process group initialised (RCCL, one rank) the step must take
+    what it takes without one.  An extra stream created on the data-parallel path once cost 3.4 of 18.5 ms; the bound is generous."""
+    def run(extra_env):
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+        env.update(extra_env)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline"],
+                           capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-1500:]
+        return json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    plain = run({})
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist = run({"VOCR_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": "0", "WORLD_SIZE": "1"})
+    assert dist["config"]["backend"].startswith("nccl") and dist["allreduce_ms_per_step"] is not None
+    print("ms per step: %.2f without a process group, %.2f with one (RCCL, one rank)" % (plain["ms_per_step"], dist["ms_per_step"]))
+    assert dist["ms_per_step"] <= 1.06 * plain["ms_per_step"], (plain["ms_per_step"], dist["ms_per_step"])
