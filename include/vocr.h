@@ -38,6 +38,12 @@ extern "C" {
 
 const char* vocr_last_error(void);
 int  vocr_abi_version(void);
+/* Named ranges on the profiler's timeline (rocprofv3 --marker-trace), nested push / pop on the calling thread.  roctx is dlopen'ed on
+ * first use; returns 0 when the range was recorded, 1 when roctx is not available (not an error), negative on a bad argument.  The
+ * reference's only instrumentation is wall-clock prints around the step (src/train_cnn_lstm.py:382-393): the Python mirror marks the
+ * same phases (forward / loss / backward / exchange / optimizer, and the model's stages) when VOCR_ROCTX=1. */
+int  vocr_profile_range_push(const char* name);
+int  vocr_profile_range_pop(void);
 /* number of visible HIP devices (>=0) or VOCR_ENODEVICE */
 int  vocr_device_count(void);
 

@@ -14,6 +14,19 @@ python scripts/pmc_summary.py traffic_json $F $W gpurun_out/$T/kernel_traffic.js
 python scripts/pmc_summary.py busy $(find gpurun_out/$T/sq -name "*counter_collection.csv") $(find gpurun_out/$T/sq2 -name "*counter_collection.csv") > gpurun_out/$T/mfma_busy.txt 2>&1
 python scripts/timeline.py $(find gpurun_out/$T/trace -name "*kernel_trace.csv" | head -1) 3 > gpurun_out/$T/timeline.txt 2>&1
 cp $(find gpurun_out/$T/trace -name "*kernel_stats.csv" | head -1) gpurun_out/$T/kernel_stats.csv
+VOCR_ROCTX=1 rocprofv3 --kernel-trace --marker-trace --output-format csv -d gpurun_out/$T/marker -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+python - > gpurun_out/$T/marker_ranges.txt 2>&1 <<PY
+import csv, glob, collections
+f = glob.glob("gpurun_out/$T/marker/*/*marker_api_trace.csv")[0]
+acc = collections.OrderedDict()
+for r in csv.DictReader(open(f)):
+    a = acc.setdefault(r["Function"], [0, 0.0])
+    a[0] += 1
+    a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+print("VOCR_ROCTX=1 rocprofv3 --kernel-trace --marker-trace -- python3 bench.py --steps 4 --warmup 2: roctx ranges (host-side spans: the host enqueues ahead of the device)")
+for k, (n, us) in acc.items():
+    print("  %-24s calls %4d   mean host span %9.1f us" % (k, n, us / n))
+PY
 python bench.py > gpurun_out/$T/bench.json 2> gpurun_out/$T/bench.err; echo "bench rc $?"
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/$T/smoke.txt 2>&1; tail -2 gpurun_out/$T/smoke.txt
 /tmp/clock_calib >> gpurun_out/$T/clock_calib.txt 2>&1

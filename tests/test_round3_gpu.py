@@ -241,3 +241,17 @@ def test_a_process_group_does_not_cost_the_step_its_overlap():
     assert dist["config"]["backend"].startswith("nccl") and dist["allreduce_ms_per_step"] is not None
     print("ms per step: %.2f without a process group, %.2f with one (RCCL, one rank)" % (plain["ms_per_step"], dist["ms_per_step"]))
     assert dist["ms_per_step"] <= 1.06 * plain["ms_per_step"], (plain["ms_per_step"], dist["ms_per_step"])
+
+
+def test_profile_ranges_are_harmless_and_balanced():
+    """vocr_profile_range_push / pop (roctx, dlopen'ed lazily): 0 = recorded, 1 = roctx not on this machine; the Python mirror's ranges
+    (VOCR_ROCTX=1) must not change a result."""
+    from vistaocr_amd import _lib
+    lib = _lib.load()
+    rc = lib.vocr_profile_range_push(b"test.range")
+    assert rc in (0, 1)
+    assert lib.vocr_profile_range_pop() == rc
+    assert lib.vocr_profile_range_push(None) < 0
+    env = dict(os.environ, VOCR_ROCTX="1")
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "smoke ok" in r.stdout, r.stderr[-1500:]

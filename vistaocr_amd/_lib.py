@@ -16,6 +16,8 @@ SIGNATURES = {
     "vocr_last_error": (c_char_p, []),
     "vocr_abi_version": (I, []),
     "vocr_device_count": (I, []),
+    "vocr_profile_range_push": (I, [c_char_p]),
+    "vocr_profile_range_pop": (I, []),
     "vocr_conv3x3_pack_weights": (I, [P, P, P, I, I, P]),
     "vocr_conv3x3_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
     "vocr_conv3x3_wgrad_workspace_bytes": (Z, [I, I, I, I, I]),
@@ -136,3 +138,22 @@ def call(name, *args):
         rc = getattr(load(), name)(*args)
     if rc != 0:
         check(rc, name)
+
+
+# ---- named ranges for rocprofv3 --marker-trace (VOCR_ROCTX=1): `with prof_range("lstm.l1"): ...`
+import contextlib as _contextlib
+
+ROCTX = os.environ.get("VOCR_ROCTX", "0") == "1"
+
+
+@_contextlib.contextmanager
+def prof_range(name):
+    if not ROCTX:
+        yield
+        return
+    lib = load()
+    lib.vocr_profile_range_push(name.encode())
+    try:
+        yield
+    finally:
+        lib.vocr_profile_range_pop()

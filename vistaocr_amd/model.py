@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from ._lib import prof_range
 from .decoder import decode_greedy, greedy_label_sequences
 
 logger = logging.getLogger("root")
@@ -230,39 +231,41 @@ class CnnOcrModel(nn.Module):
             a = ops.ConvReluPoolFn.apply(a, conv.weight, conv.bias, self.conv_dtype == "fp16")
         pool_i = 0
         fused_pool = False
-        for si, step in enumerate(self._plan):
-            if step == "pool":
-                if fused_pool:                      # already applied inside the conv layer before it
-                    fused_pool = False
+        with prof_range("model.cnn"):
+            for si, step in enumerate(self._plan):
+                if step == "pool":
+                    if fused_pool:                      # already applied inside the conv layer before it
+                        fused_pool = False
+                        continue
+                    n, c, h, w = a.shape
+                    oh, ow = math.floor(h * 0.5), math.floor(w * 0.7)
+                    if self.pool_samples is not None:
+                        u = self.pool_samples[pool_i].to(dev)
+                    else:
+                        u = torch.rand(n, c, 2, dtype=torch.float32, device=dev)
+                    a = ops.FracPoolFn.apply(a, u, oh, ow)
+                    pool_i += 1
                     continue
-                n, c, h, w = a.shape
-                oh, ow = math.floor(h * 0.5), math.floor(w * 0.7)
-                if self.pool_samples is not None:
-                    u = self.pool_samples[pool_i].to(dev)
-                else:
-                    u = torch.rand(n, c, 2, dtype=torch.float32, device=dev)
-                a = ops.FracPoolFn.apply(a, u, oh, ow)
-                pool_i += 1
-                continue
-            conv, bn = step
-            u, oh, ow = None, 0, 0
-            if si + 1 < len(self._plan) and self._plan[si + 1] == "pool":
-                # the pooling layer that follows is fused into this layer's BatchNorm + ReLU pass
-                n, h, w = a.shape[0], a.shape[2], a.shape[3]
-                oh, ow = math.floor(h * 0.5), math.floor(w * 0.7)
-                if self.pool_samples is not None:
-                    u = self.pool_samples[pool_i].to(dev)
-                else:
-                    u = torch.rand(n, conv.weight.shape[0], 2, dtype=torch.float32, device=dev)
-                pool_i += 1
-                fused_pool = True
-            a = ops.ConvBnReluFn.apply(a, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                       self.training, bn.eps, bn.momentum, self.conv_dtype == "fp16", u, oh, ow,
-                                       bn.num_batches_tracked if self.training else None, prep)
+                conv, bn = step
+                u, oh, ow = None, 0, 0
+                if si + 1 < len(self._plan) and self._plan[si + 1] == "pool":
+                    # the pooling layer that follows is fused into this layer's BatchNorm + ReLU pass
+                    n, h, w = a.shape[0], a.shape[2], a.shape[3]
+                    oh, ow = math.floor(h * 0.5), math.floor(w * 0.7)
+                    if self.pool_samples is not None:
+                        u = self.pool_samples[pool_i].to(dev)
+                    else:
+                        u = torch.rand(n, conv.weight.shape[0], 2, dtype=torch.float32, device=dev)
+                    pool_i += 1
+                    fused_pool = True
+                a = ops.ConvBnReluFn.apply(a, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                           self.training, bn.eps, bn.momentum, self.conv_dtype == "fp16", u, oh, ow,
+                                           bn.num_batches_tracked if self.training else None, prep)
         b, c, h, w = a.shape
-        feat = ops.PermuteBchwToWbchFn.apply(a, self._vocr_hooks)                                   # [w*b, c*h]
-        br = getattr(self.bridge_layer, "0")
-        lstm_in = ops.LinearFn.apply(feat, br.weight, br.bias, True)              # [w*b, D]
+        with prof_range("model.bridge"):
+            feat = ops.PermuteBchwToWbchFn.apply(a, self._vocr_hooks)                                   # [w*b, c*h]
+            br = getattr(self.bridge_layer, "0")
+            lstm_in = ops.LinearFn.apply(feat, br.weight, br.bias, True)              # [w*b, D]
 
         widths = actual_minibatch_widths.data if torch.is_tensor(actual_minibatch_widths) else actual_minibatch_widths
         out_w = [self.cnn_input_size_to_output_size((self.input_line_height, int(wd)))[1] for wd in widths]
@@ -282,7 +285,8 @@ class CnnOcrModel(nn.Module):
         for l in range(self.num_lstm_layers):
             f = self.lstm.layer(l, "")
             r = self.lstm.layer(l, "_reverse")
-            hseq = self._bilstm_layer(hseq, lens_dev, out_w, T, b, f, r, prep)
+            with prof_range("model.lstm.l%d" % l):
+                hseq = self._bilstm_layer(hseq, lens_dev, out_w, T, b, f, r, prep)
             if l < self.num_lstm_layers - 1:
                 if self.dropout_masks is not None:
                     hseq = ops.MulMaskFn.apply(hseq, self.dropout_masks[l].to(dev).reshape(T * b, -1))
@@ -290,7 +294,8 @@ class CnnOcrModel(nn.Module):
                     self._dropout_calls += 1
                     hseq = ops.DropoutFn.apply(hseq, self.p_lstm_dropout, self.dropout_seed + self._dropout_calls)
         pr = getattr(self.prob_layer, "0")
-        prob_output = ops.LinearFn.apply(hseq, pr.weight, pr.bias, False).view(T, b, -1)
+        with prof_range("model.prob"):
+            prob_output = ops.LinearFn.apply(hseq, pr.weight, pr.bias, False).view(T, b, -1)
         return prob_output, lens_cpu
 
     def _bilstm_layer(self, hseq, lens_dev, out_w, T, b, f, r, prep):

@@ -7,11 +7,26 @@ import math
 import torch
 
 from . import _lib
-from ._lib import call
+from ._lib import call, prof_range
 
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
+
+
+def _ranged(name):
+    """Decorator: run a backward staticmethod inside a profiling range (VOCR_ROCTX=1; a no-op otherwise)."""
+    def deco(fn):
+        if not _lib.ROCTX:
+            return fn
+
+        def wrapped(*a, **k):
+            with prof_range(name):
+                return fn(*a, **k)
+        wrapped.__name__ = fn.__name__
+        wrapped.__doc__ = fn.__doc__
+        return wrapped
+    return deco
 
 
 def _p(t):
@@ -408,6 +423,7 @@ class ConvBnReluFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_ranged("bwd.conv_bn_relu")
     def backward(ctx, da):
         if not ctx.training:
             raise RuntimeError("vistaocr_amd: backward through eval-mode BatchNorm is not part of the reference path")
@@ -494,6 +510,7 @@ class ConvReluPoolFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_ranged("bwd.rapid_ds")
     def backward(ctx, dout):
         x, out, idx, pd = ctx.saved_tensors
         dout = _f32c(dout)
@@ -593,6 +610,7 @@ class PermuteBchwToWbchFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_ranged("bwd.permute")
     def backward(ctx, dout):
         b, c, h, w = ctx.shape
         dout = _f32c(dout)
@@ -622,6 +640,7 @@ class LinearFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_ranged("bwd.linear")
     def backward(ctx, dout):
         x, weight, out = ctx.saved_tensors
         dout = _f32c(dout)
@@ -753,6 +772,7 @@ class BiLstmLayerFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_ranged("bwd.bilstm")
     def backward(ctx, dy):
         x, lens_dev, y, gates, cell, w_ih_f, w_hh_f, w_ih_r, w_hh_r = ctx.saved_tensors
         T, B, H, din = ctx.dims
@@ -843,6 +863,7 @@ class CtcFn(torch.autograd.Function):
         return loss
 
     @staticmethod
+    @_ranged("bwd.ctc")
     def backward(ctx, dloss):
         (dlogits,) = ctx.saved_tensors
         dloss = _f32c(dloss)

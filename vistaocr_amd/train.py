@@ -15,6 +15,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops
+from ._lib import prof_range
 
 
 def _dp_active(group=None):
@@ -290,8 +291,10 @@ def _step(batch, model, criterion, optimizer, want_float):
     input_tensor, target, input_widths, target_widths, metadata = batch
     input_tensor = input_tensor.cuda(non_blocking=True)
     optimizer.zero_grad()
-    model_output, model_output_actual_lengths = model(input_tensor, input_widths)
-    loss = criterion(model_output, target, model_output_actual_lengths, target_widths)
+    with prof_range("train.forward"):
+        model_output, model_output_actual_lengths = model(input_tensor, input_widths)
+    with prof_range("train.ctc"):
+        loss = criterion(model_output, target, model_output_actual_lengths, target_widths)
     # The float the reference returns is known as soon as the forward pass is done: its copy to pinned host memory is
     # queued HERE, ahead of the backward kernels, and only that copy is waited for at the end.  The host then gets the
     # value while the device is still busy with this step's backward + Adam and starts queueing the next step at once
@@ -304,12 +307,16 @@ def _step(batch, model, criterion, optimizer, want_float):
         host_health.copy_(ops.health(loss.device), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-    loss.backward()
+    with prof_range("train.backward"):
+        loss.backward()
     if hasattr(optimizer, "all_reduce_grads"):
-        optimizer.all_reduce_grads()
-        optimizer.step()
+        with prof_range("train.exchange"):
+            optimizer.all_reduce_grads()
+        with prof_range("train.clamp_adam"):
+            optimizer.step()
     else:
-        _generic_update(model, optimizer)
+        with prof_range("train.exchange_clamp_step"):
+            _generic_update(model, optimizer)
     if not want_float:
         return loss.detach()
     if ev is None:
