@@ -412,7 +412,7 @@ def run_rank(args):
     _lib.enable_timing(None)
     opt.check_health()
     ranks_seen = dist.get_world_size() if use_dist else 1
-    alone = gemm_alone(args.hidden) if rank == 0 and args.hidden == 512 else None
+    alone = gemm_alone(args.hidden) if rank == 0 and args.hidden == 512 and not args.no_gemm_alone else None
 
     out = None
     parity_failed = None
@@ -541,6 +541,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gemm-alone", action="store_true", help="skip the alone-on-the-chip GEMM launches (profiling passes that average per launch)")
     ap.add_argument("--event-every", type=int, default=10, help="HIP events around the dominant kernel in every n-th timed step (0: none)")
     ap.add_argument("--hidden", type=int, default=512)
     ap.add_argument("--conv-dtype", default="fp32", choices=["fp32", "fp16"],
