@@ -183,10 +183,11 @@ int vocr_dropout_fwd(const float* x, float* out, float* mask, size_t count, floa
  * whh_fwd / whh_rev [4H][H] (the two directions' weight_hh), lens[B] int32 (device, descending).  Outputs y[T][B][2H] (zeros past lens),
  * gates[dir][T][B][H][4] (post-activation i,f,g,o interleaved per unit, 16-byte aligned) and cell[dir][T][B][H]
  * for backward.  h_{t-1}/c_{t-1} are read back from y/cell, so the sweep keeps no separate state.
- * workspace: vocr_lstm_workspace_bytes (256-byte aligned device memory; contents need not be preserved between calls).
+ * workspace: vocr_lstm_workspace_bytes (256-byte aligned device memory; contents need not be preserved between calls, except
+ * between the vocr_lstm_fwd_range calls of ONE sweep: the forward sweep's hand-off buffer lives there).
  * Supports B <= 64 per call, H % 16 == 0 (a larger batch is several calls on batch tiles: the recurrence never couples batch rows and
  * a tile of a length-sorted batch is itself a valid packed batch - vistaocr_amd.CnnOcrModel does that).  For H in {64,128,256,512} a whole sweep is ONE persistent launch whose workgroups
- * hand h_t (forward) / partial sums (backward) to each other through memory: it needs its grid (<= one workgroup per CU)
+ * hand h_t (forward) / partial sums (backward) to each other through memory: it needs its grid (<= two workgroups per CU)
  * co-resident, so do not run two sweeps concurrently on one device; a hand-off that times out (seconds) poisons the
  * output with NaN instead of hanging.  VOCR_LSTM_PERSISTENT=0 selects one launch per time step instead.
  * `health` (may be NULL): see the note on health words at the top; the timeout flag the sweep itself tests lives in the workspace. */

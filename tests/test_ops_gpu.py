@@ -304,8 +304,9 @@ def test_bilstm_layer(dev, T, B, D, H, lens):
 @pytest.mark.parametrize("T,B,H", [(40, 20, 128), (25, 5, 64), (33, 32, 512), (12, 40, 256), (9, 64, 128), (21, 27, 256), (15, 7, 512),
                                    (1, 1, 256), (2, 3, 512), (3, 64, 512)])
 def test_persistent_sweeps_match_per_step_launches(dev, T, B, H):
-    """Persistent sweeps (weights in registers, flag hand-off with sc1 payload): bit-identical to one launch per step,
-    forward (y, gates, cell) and backward (dgates)."""
+    """Persistent sweeps (weights in registers; forward hand-off by self-validating payload on 4-row chains, or - VOCR_LSTM_SELFVAL=0 -
+    by arrival flags on 8/16-row chains; backward by flags) against one launch per step: forward (y, gates, cell) and backward
+    (dgates), bit-identical where the summation order is the same, to rounding where it is another fixed order."""
     import os
     import subprocess
     import sys
@@ -334,16 +335,20 @@ def test_persistent_sweeps_match_per_step_launches(dev, T, B, H):
     outs = []
     # per-step | default sweeps (8-row 4x4x1 chains where they apply, else as 35) | 16-row chains | forced write-through
     # hand-off, 8-row and 16-row
-    modes = ("0", "3", "35", "11", "43")
-    for mode in modes:
+    # "/f" = flag hand-off in the forward sweep too
+    modes = ("0", "3", "3/f", "35", "11", "11/f", "43")
+    for mode_ in modes:
+        mode = mode_.split("/")[0]
         f = tempfile.mktemp(suffix=".pt")
-        r = subprocess.run([sys.executable, "-c", code, f, mode], env=dict(os.environ, VOCR_LSTM_PERSISTENT=mode), capture_output=True, text=True, timeout=120)
+        r = subprocess.run([sys.executable, "-c", code, f, mode], env=dict(os.environ, VOCR_LSTM_PERSISTENT=mode, VOCR_LSTM_SELFVAL="0" if "/f" in mode_ else "1"),
+                           capture_output=True, text=True, timeout=120)
         assert r.returncode == 0, r.stderr[-500:]
         assert "STATUS 0" in r.stdout, r.stdout
         outs.append(torch.load(f))
         os.unlink(f)
     eight_row = H in (256, 512) and B <= 32          # mode 3 then runs the 4x4x1 kernels: another (fixed) summation order
-    for mode, other in zip(modes[1:], outs[1:]):
+    for mode_, other in zip(modes[1:], outs[1:]):
+        mode = mode_.split("/")[0]
         for nm, a, b in zip(("y", "gates", "cell", "dgates"), outs[0], other):
             if H < 128 and nm == "dgates":
                 continue                      # no backward fast path below H = 128: dgates untouched in both runs
@@ -351,9 +356,9 @@ def test_persistent_sweeps_match_per_step_launches(dev, T, B, H):
             if reordered:
                 # same arithmetic, different fp32 summation order: rounding differences only
                 tol = 3e-5 * float(a.abs().max())
-                assert float((a - b).abs().max()) <= tol, "%s (mode %s): max |diff| %.3e > %.3e" % (nm, mode, float((a - b).abs().max()), tol)
+                assert float((a - b).abs().max()) <= tol, "%s (mode %s): max |diff| %.3e > %.3e" % (nm, mode_, float((a - b).abs().max()), tol)
                 continue
-            assert torch.equal(a, b), "%s (mode %s) differs: max |diff| %.3e at %d of %d" % (nm, mode, float((a - b).abs().max()), int((a != b).sum()), a.numel())
+            assert torch.equal(a, b), "%s (mode %s) differs: max |diff| %.3e at %d of %d" % (nm, mode_, float((a - b).abs().max()), int((a != b).sum()), a.numel())
 
 
 @pytest.mark.parametrize("n,cin,cout,h,w", [(3, 5, 8, 30, 75), (2, 64, 64, 15, 42)])

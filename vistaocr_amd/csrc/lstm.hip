@@ -12,6 +12,7 @@
 // h / dh ping-pong between two small global buffers (the only cross-workgroup traffic, L2 resident).
 #include "vocr_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -720,6 +721,205 @@ __global__ __launch_bounds__(512) void lstm_fwd_chain8(const float* __restrict__
 #endif
 }
 
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(f);
+    }
+}
+
+// Self-validating hand-off: the host fills the hand-off buffer with this bit pattern before a sweep (a NaN no arithmetic here
+// produces: h is stored canonicalised); a consumer wave re-issues ITS OWN loads until no dword holds the pattern, a producer only
+// stores.  Against the flag protocol of lstm_fwd_chain8 (flag poll and h loads = two L2 round trips in series, plus a store drain
+// + barrier + flag store on the producing side): no flags, no drain, two barriers per step instead of four, and a wave starts its
+// MFMAs as soon as its own k-slice has arrived.
+constexpr unsigned kHandoffSentinel = 0xFFFFFFFFu;
+
+// Forward chain sweep on 4-row chains ("chain4v"): 2*ceil(B/4) <= 16 chains of H/16 workgroups with 4 waves; up to 8 chains
+// one workgroup per CU, above that two (chains c and c + 8 share an XCD), each with its own barriers and its own copy of its
+// W_hh slice (128 VGPRs per lane at H = 512, K = H split over the 4 waves).  One v_mfma_f32_4x4x1_16b_f32 = 4 rows x 64 gate
+// columns x one k (all 16 blocks take the same A rows through the instruction's A broadcast), so no operand is duplicated and
+// h never passes through LDS.  Measured at T = 294, H = 512 (scripts/lstm_ab.py, lstm_stamp4.hip): B = 32 2.25-2.3 us per step
+// (8-row flag chains 2.53), B = 16 1.55 (2.17).  What a step is made of at B = 16 (s_memtime ticks of 0.46 ns, wave 0): hand-off
+// 930 (own stores -> every member's slice readable; a poll round trip is ~450 when the line is valid in L2 but ~900-1200 on the
+// first read of a freshly written line) | 128 MFMAs 1170 (two accumulators: a single dependent chain took 1740) | barriers 350 |
+// reduction + activation 260 | cell update 620.  With two workgroups per CU the MFMA phases of one hide behind the waits of the
+// other only partly (random relative phase on every CU, and a chain moves at the pace of its slowest member).
+template <int KQ4>
+__global__ __launch_bounds__(256) void lstm_fwd_chain4v(const float* __restrict__ xproj, const float* __restrict__ whh_f,
+                                                        const float* __restrict__ whh_r, const int32_t* __restrict__ lens,
+                                                        float* y, float* __restrict__ gates, float* __restrict__ cell,
+                                                        float* hx, unsigned* ids, unsigned* status, unsigned* health, int T, int B, int NT4,
+                                                        int force_wt, int s0, int s1) {
+    constexpr int H = 64 * KQ4;
+    constexpr int members = H >> 4;
+    constexpr int KW = H / 4;                         // k per wave
+    constexpr int NL = KW / 4;                        // 16-byte pieces of a row's k-slice
+    __shared__ float lds[4 * 4 * 65 + 4 + 4 * 64];
+    float (*red)[4][65] = (float (*)[4][65])lds;
+    float (*actb)[64] = (float (*)[64])(lds + 4 * 4 * 65 + 4);
+    const int nch = 2 * NT4;
+    const int chain = nch > 8 ? (int)(blockIdx.x & 7) + 8 * (int)((blockIdx.x >> 3) & 1) : (int)(blockIdx.x & 7);
+    const int member = nch > 8 ? blockIdx.x >> 4 : blockIdx.x >> 3;
+    if (chain >= nch) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int dir = chain / NT4, bt = chain % NT4;
+    const int unit0 = member * 16, b0 = bt * 4;
+    const int nrows = min(B - b0, 4);
+    const int kbase = wave * KW;
+    const float* whh = dir ? whh_r : whh_f;
+    const bool local = chain_is_xcd_local(ids + chain * 32, members, member, status, health, (unsigned*)(lds + 4 * 4 * 65)) && !force_wt;
+
+    // resident B operand: lane = gate column (gate, local unit) = (lane >> 4, lane & 15), the wave's KW k
+    f32x4 wv[NL];
+    {
+        const f32x4* wp = (const f32x4*)(whh + ((long)(lane >> 4) * H + unit0 + (lane & 15)) * H + kbase);
+#pragma unroll
+        for (int i = 0; i < NL; ++i) wv[i] = wp[i];
+    }
+    // epilogue: (A) thread (wave = gate, lane = row*16 + unit) reduces the four partial tiles and activates ONE pre-activation,
+    // (B) wave 0 (lane = row*16 + unit) combines the four gates of its cell
+    const int egate = __builtin_amdgcn_readfirstlane(wave);
+    const int erow = lane >> 4, ecol = egate * 16 + (lane & 15);
+    const bool erowok = erow < nrows;
+    const int bl = lane >> 4, cu = lane & 15, cb_ = b0 + bl, unit = unit0 + cu;
+    const bool cellthr = tid < 64 && bl < nrows;
+    const int len_b = cellthr ? lens[cb_] : 0;
+    float cstate = 0.f;
+    if (s0 > 0 && cellthr) {
+        const int tp0 = dir == 0 ? s0 - 1 : T - s0;
+        cstate = cell[(((long)dir * T + tp0) * B + cb_) * H + unit];
+    }
+    bool timed_out = false;
+    // hand-off buffer hx[t][chain][member][4 rows][16 units]: a member's block of a step is 256 contiguous bytes = two whole
+    // 128-byte lines written by ONE store instruction (in y a line is shared by two members: a half-written line is a partial
+    // line in L2 and a read of it goes to memory to merge), and a consumer wave's 8 members are 2 KB contiguous
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)hx, 0, T * nch * 4 * H * 4, 0x00020000);
+    // A operand without LDS: the instruction's A-broadcast (cbsz = 4: all 16 blocks take block `abid`'s A lanes) lets one
+    // VGPR carry 16 different k: load j of lane 4b + r is the 16-byte piece k = kbase + 64j + 4b .. +3 of row r (an
+    // instruction covers 256 contiguous bytes of each row), and the MFMA for k = 64j + 4b + e names register (j, e) with
+    // abid = b (probe: scripts/mfma_cbsz_probe.hip)
+    constexpr int KB = KW / 16;
+    constexpr int NP = KB / 4;                        // 16-byte loads per lane
+    int poff[NP];
+    {
+        const int prow = (lane & 3) < nrows ? (lane & 3) : 0;             // rows clamped, never masked: A row r only reaches output row r
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int kk = kbase + 64 * j + 4 * (lane >> 2);
+            poff[j] = (((kk >> 4) * 4 + prow) * 16 + (kk & 15)) * 4;
+        }
+    }
+
+    const int xb = erowok ? b0 + erow : b0;
+    auto x_load = [&](int st) {
+        const int tt = dir == 0 ? st : T - 1 - st;
+        return xproj[(((long)dir * T + tt) * B + xb) * 4 * H + (long)egate * H + unit0 + (lane & 15)];
+    };
+    float xn = x_load(s0);
+    // the resident operand is complete before the loop (otherwise every iteration carries the first one's vmcnt waits, which
+    // then also wait for whatever else is in flight)
+#pragma unroll
+    for (int i = 0; i < NL; ++i) asm volatile("" : "+v"(wv[i]));
+
+    LSTM_STAMP_DECL;
+    for (int step = s0; step < s1; ++step) {
+        const int t = dir == 0 ? step : T - 1 - step;
+        LSTM_STAMP(7);
+        const int tprev = dir == 0 ? t - 1 : t + 1;
+        const float xp = xn;
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};      // even / odd 4-k pieces: two independent MFMA chains
+        u32x4_t pv[NP];
+        if (step > 0) {
+            const int toff = (tprev * nch + chain) * 4 * H * 4;
+            unsigned spins = 0;
+            for (;;) {
+                unsigned mx = 0u;
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    // first try: plain load (this CU has not touched these lines yet; served by the XCD's L2); a retry must not be
+                    // served from the CU's L1, which now holds the stale line: sc1
+                    if (spins == 0) pv[j] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, toff + poff[j], 0, 0);
+                    else pv[j] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, toff + poff[j], 0, 16);
+                    mx = max(max(mx, pv[j][0]), max(max(pv[j][1], pv[j][2]), pv[j][3]));
+                }
+                if (__all(mx != kHandoffSentinel) || timed_out) break;
+                if (++spins > (1u << 22)) {
+                    if (lane == 0) raise_timeout(status, health);
+                    timed_out = true;
+                    break;
+                }
+            }
+        }
+        LSTM_STAMP(0);              // own slice of h_{t-1} arrived (polls)
+        xn = x_load(step + 1 < T ? step + 1 : step);           // behind the polls: loads return in order
+        if (step > 0) {
+            {
+#pragma unroll
+                for (int j = 0; j < NP; ++j)
+                    static_for<16>([&](auto bc) {
+                        constexpr int b = decltype(bc)::value;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if constexpr (b % 2 == 0) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(__uint_as_float(pv[j][e]), wv[16 * j + b][e], acc, 4, b, 0);
+                            else acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(__uint_as_float(pv[j][e]), wv[16 * j + b][e], acc1, 4, b, 0);
+                        }
+                    });
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] += acc1[r];
+        }
+        // acc[r] = partial of (row r, column lane)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][r][lane] = acc[r];
+        LSTM_STAMP(1);              // MFMA + partial tile to LDS
+        __syncthreads();
+        LSTM_STAMP(2);
+        {
+            const float pre = ((red[0][erow][ecol] + red[1][erow][ecol]) + (red[2][erow][ecol] + red[3][erow][ecol])) + xp;
+            actb[erow][ecol] = egate == 2 ? tanhf(pre) : sigmoidf_(pre);           // wave-uniform choice
+            // the next step's x-projection value has long arrived: take it HERE, so that no load is pending at the loop's
+            // back edge (the compiler otherwise closes every iteration with vmcnt(0) = wave 0 waiting for its stores' acks)
+            asm volatile("" : "+v"(xn));
+        }
+        LSTM_STAMP(3);              // reduce + activation
+        __syncthreads();
+        LSTM_STAMP(4);
+        if (cellthr) {
+            const bool active = t < len_b;
+            const long sidx = (((long)dir * T + t) * B + cb_) * H + unit;
+            float* yo = y + ((long)t * B + cb_) * 2 * H + dir * H + unit;
+            f32x4* go = (f32x4*)(gates + sidx * 4);
+            float h = 0.f, c = 0.f;
+            f32x4 gv = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (active) {
+                const float ig = actb[bl][cu], fg = actb[bl][16 + cu], gg = actb[bl][32 + cu], og = actb[bl][48 + cu];
+                c = fg * cstate + ig * gg;
+                h = og * tanhf(c);
+                gv = (f32x4){ig, fg, gg, og};
+            }
+            cstate = c;
+            if (h != h) h = __uint_as_float(0x7FC00000u);                                // never the hand-off pattern
+            if (step == s1 - 1 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+                h = __uint_as_float(0x7FC00000u);                                        // a hand-off timed out: fail loudly
+            float* xo = hx + ((long)(t * nch + chain) * 4 * H + (member * 4 + bl) * 16 + cu);
+            if (local) __hip_atomic_store(xo, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // stays in this XCD's L2
+            else __hip_atomic_store(xo, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                // write-through (sc1)
+            *yo = h;
+            *go = gv;
+            cell[sidx] = c;
+        }
+        LSTM_STAMP(5);              // cell update + stores issued (wave 0)
+    }
+#ifdef VOCR_LSTM_STAMPS
+    if (lane == 0 && (wave == 0 || wave == 3) && g_lstm_stamp_out) {
+        unsigned long long* o = g_lstm_stamp_out + ((size_t)blockIdx.x * 2 + (wave == 3)) * 8;
+        for (int k = 0; k < 8; ++k) o[k] = st_acc[k];
+    }
+#endif
+}
+
 // Gradient of one LSTM cell; shared by the per-step and the persistent backward kernels so both contract the same
 // expressions (the two sweeps are compared bit for bit).  Returns the dc carried to the previous step.
 __device__ __forceinline__ float lstm_cell_grad(float dh, float dcar, float ig, float fg, float gg, float og, float c, float cprev,
@@ -1209,14 +1409,21 @@ int resident_workgroup_capacity() {
 
 }  // namespace
 
+static size_t lstm_ws_handoff_offset(int b, int h) {
+    const size_t o = (size_t)6 * 2 * b * h * sizeof(float) + 4096 + ((size_t)16 << 20) + (size_t)8 * 4 * h * sizeof(float) +
+                     (size_t)64 * 4 * h * sizeof(float);
+    return (o + 255) / 256 * 256;
+}
+
 extern "C" size_t vocr_lstm_workspace_bytes(int t, int b, int h) {
     if (t <= 0 || b <= 0 || h <= 0) return 0;
     // dc carry [2][B][H] (+ spare); 4 KiB of arrival flags / status; 16 MiB of partial-sum blocks for the backward chain
     // sweep (2 parities x 8 chains x 32 consumers x 32 producers x 1 KiB)
     // + per-chain bias-gradient rows [8][4H]
     // + 64 partial rows [4H] for the fixed-order column sums of the bias gradient (paths without in-sweep accumulation)
-    return (size_t)6 * 2 * b * h * sizeof(float) + 4096 + ((size_t)16 << 20) + (size_t)8 * 4 * h * sizeof(float) +
-           (size_t)64 * 4 * h * sizeof(float);
+    // + the forward chain sweeps' hand-off buffer hx[t][2 directions][rows padded to 8][H] (must survive from one
+    //   vocr_lstm_fwd_range call of a sweep to the next)
+    return lstm_ws_handoff_offset(b, h) + (size_t)t * 2 * ((b + 7) / 8 * 8) * h * sizeof(float);
 }
 
 extern "C" int vocr_lstm_fwd_range(const float* xproj, const float* whh_fwd, const float* whh_rev, const int32_t* lens, float* y,
@@ -1248,6 +1455,22 @@ extern "C" int vocr_lstm_fwd_range(const float* xproj, const float* whh_fwd, con
         const dim3 cg(8 * (h / 16));
         const int fwt = (persistent_mode & 8) ? 1 : 0;       // experiments: write-through hand-off even on one XCD
         const int nt8 = (b + 7) / 8;
+        static const int selfval = getenv("VOCR_LSTM_SELFVAL") ? atoi(getenv("VOCR_LSTM_SELFVAL")) : 1;     // 0: flag hand-off (lstm_fwd_chain8 / lstm_fwd_chain)
+        const int nt4 = (b + 3) / 4;
+        if (selfval && 2 * nt4 <= 16 && !(persistent_mode & 32) && (h == 512 || h == 256) &&
+            (2 * nt4 > 8 ? 16 : 8) * (h / 16) <= 2 * resident_workgroup_capacity() && (long)t * 2 * nt4 * 4 * h * 4 < (1l << 31)) {
+            // 4-row chains; the hand-off buffer starts as the "not written yet" pattern (first range of a sweep only)
+            float* hx = (float*)((char*)workspace + lstm_ws_handoff_offset(b, h));
+            if (step_begin == 0 && hipMemsetAsync(hx, 0xFF, (size_t)t * 2 * nt4 * 4 * h * sizeof(float), s) != hipSuccess) {
+                vocr_set_error("vocr_lstm_fwd: memset failed");
+                return VOCR_ELAUNCH;
+            }
+            const dim3 cg4((2 * nt4 > 8 ? 16 : 8) * (h / 16));
+            if (h == 512) lstm_fwd_chain4v<8><<<cg4, 256, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, hx, flags, status, hword, t, b, nt4, fwt, step_begin, step_end);
+            else lstm_fwd_chain4v<4><<<cg4, 256, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, hx, flags, status, hword, t, b, nt4, fwt, step_begin, step_end);
+            VOCR_CHECK_LAUNCH("vocr_lstm_fwd(chain, 4-row, self-validating)");
+            return VOCR_OK;
+        }
         if (2 * nt8 <= 8 && !(persistent_mode & 32) && (h == 512 || h == 256)) {      // 8-row chains on all 8 XCDs, 4x4x1 MFMA
             if (h == 512)
                 lstm_fwd_chain8<8><<<cg, 512, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, flags, flags + 256, status, hword, t, b, nt8, fwt,
