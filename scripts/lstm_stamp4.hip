@@ -1,4 +1,4 @@
-// Diagnostic build (never shipped): the 4-row forward chain sweep (lstm_fwd_chain4v; VOCR_LSTM_SELFVAL=1: the 8-row lstm_fwd_chain8v) with s_memtime stamps around the phases
+// Diagnostic build (never shipped): the 4-row forward chain sweep (lstm_fwd_chain4v) with s_memtime stamps around the phases
 // of a time step.  usage: lstm_stamp4 [B]
 #define VOCR_LSTM_STAMPS 1
 #include "../vistaocr_amd/csrc/lstm.hip"
@@ -25,8 +25,8 @@ int main(int argc, char** argv) {
         hipEventRecord(e1, nullptr); hipDeviceSynchronize(); hipEventElapsedTime(&ms, e0, e1);
         if (rc) { printf("rc %d\n", rc); return 1; }
     }
-    const bool eight = getenv("VOCR_LSTM_SELFVAL") && atoi(getenv("VOCR_LSTM_SELFVAL")) == 1;      // lstm_fwd_chain8v: waves 0 and 7
-    const int nwg = eight ? 256 : B > 16 ? 512 : 256;
+    const bool eight = false;
+    const int nwg = B > 16 ? 512 : 256;
     std::vector<unsigned long long> h(512 * 2 * 8);
     hipMemcpy(h.data(), dbg, 512 * 2 * 8 * 8, hipMemcpyDeviceToHost);
     const char* names[8] = {"h slice arrived (poll loop)", "MFMA + partial tile to LDS", "barrier A", "reduce + activation", "barrier B", "cell update + stores issued",
@@ -38,6 +38,16 @@ int main(int argc, char** argv) {
         for (int k = 0; k < 8; ++k) if (k != 6) tot += s[k];
         printf("wave %d, s_memtime ticks per step (total %.1f => one tick = %.2f ns):\n", w ? (eight ? 7 : 3) : 0, tot, ms * 1e6 / T / tot);
         for (int k = 0; k < 8; ++k) printf("   %-38s %8.1f  %5.1f %%\n", names[k], s[k], 100 * s[k] / tot);
+    }
+    if (nwg == 512) {      // two workgroups per CU: do the two chains of an XCD (slot = bit 3 of the block index) progress alike?
+        for (int slot = 0; slot < 2; ++slot) {
+            double tot = 0, poll = 0; int n = 0;
+            for (int b = 0; b < nwg; ++b) if (((b >> 3) & 1) == slot) {
+                for (int k = 0; k < 8; ++k) if (k != 6) tot += (double)h[(b * 2) * 8 + k];
+                poll += (double)h[(b * 2) * 8 + 0]; ++n;
+            }
+            printf("slot %d workgroups: wave 0 total %.0f ticks per sweep (%.1f per step), of which polling %.1f per step\n", slot, tot / n, tot / n / T, poll / n / T);
+        }
     }
     return 0;
 }

@@ -735,6 +735,12 @@ __device__ __forceinline__ void static_for(F&& f) {
 // + barrier + flag store on the producing side): no flags, no drain, two barriers per step instead of four, and a wave starts its
 // MFMAs as soon as its own k-slice has arrived.
 constexpr unsigned kHandoffSentinel = 0xFFFFFFFFu;
+// cache policy of a polling load: sc1 (never served from the CU's vector L1, which may hold the line from an earlier look or
+// from the slot's previous use).  Every polling loop opens with POLL_FENCE: to the compiler the load is loop-invariant, and
+// without a memory clobber in the loop it hoists the load and a poll that fails once spins on the same registers until it
+// times out (seen in a variant of these kernels; the intrinsic's volatile bit does not stop the hoist and turns the load system-scope).
+constexpr int kPollAux = 16;
+#define POLL_FENCE() asm volatile("" ::: "memory")
 
 // Forward chain sweep on 4-row chains ("chain4v"): 2*ceil(B/4) <= 16 chains of H/16 workgroups with 4 waves; up to 8 chains
 // one workgroup per CU, above that two (chains c and c + 8 share an XCD), each with its own barriers and its own copy of its
@@ -746,6 +752,10 @@ constexpr unsigned kHandoffSentinel = 0xFFFFFFFFu;
 // first read of a freshly written line) | 128 MFMAs 1170 (two accumulators: a single dependent chain took 1740) | barriers 350 |
 // reduction + activation 260 | cell update 620.  With two workgroups per CU the MFMA phases of one hide behind the waits of the
 // other only partly (random relative phase on every CU, and a chain moves at the pace of its slowest member).
+// Measured and dropped for 16 < B <= 32: ONE 8-wave workgroup per CU running its two 4-row halves as alternating sub-chains with a
+// shared W_hh slice (64 VGPRs), so that one half's hand-off travels while the other half computes: 2.73 us per step against 2.36
+// here - inside one workgroup the barriers serialise poll round trip, MFMAs, reduction and cell update of each half (the MFMAs are
+// a quarter of a sub-step), which is exactly what two independent workgroups let the hardware overlap.
 template <int KQ4>
 __global__ __launch_bounds__(256) void lstm_fwd_chain4v(const float* __restrict__ xproj, const float* __restrict__ whh_f,
                                                         const float* __restrict__ whh_r, const int32_t* __restrict__ lens,
@@ -792,10 +802,15 @@ __global__ __launch_bounds__(256) void lstm_fwd_chain4v(const float* __restrict_
         cstate = cell[(((long)dir * T + tp0) * B + cb_) * H + unit];
     }
     bool timed_out = false;
-    // hand-off buffer hx[t][chain][member][4 rows][16 units]: a member's block of a step is 256 contiguous bytes = two whole
+    // hand-off ring hx[step & 3][chain][member][4 rows][16 units]: a member's block of a step is 256 contiguous bytes = two whole
     // 128-byte lines written by ONE store instruction (in y a line is shared by two members: a half-written line is a partial
-    // line in L2 and a read of it goes to memory to merge), and a consumer wave's 8 members are 2 KB contiguous
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)hx, 0, T * nch * 4 * H * 4, 0x00020000);
+    // line in L2 and a read of it goes to memory to merge), a consumer wave's 8 members are 2 KB contiguous, and the ring stays
+    // in L2 (a poll that comes too early costs an L2 round trip, ~450 ticks, not a fetch of a never-touched line, ~1000).  A
+    // block goes back to "not written yet" two steps after it was written, by the lane that wrote it: by then this workgroup has
+    // read every member's h of the step after (all four waves are past their polls), and a member stores that only after ITS
+    // four waves have read the block.  Ordered before anybody's poll of the slot's next use: the resetting wave's next poll
+    // waits for all its outstanding stores, and its next h store - which every consumer needs to get that far - comes after.
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)hx, 0, 4 * nch * 4 * H * 4, 0x00020000);
     // A operand without LDS: the instruction's A-broadcast (cbsz = 4: all 16 blocks take block `abid`'s A lanes) lets one
     // VGPR carry 16 different k: load j of lane 4b + r is the 16-byte piece k = kbase + 64j + 4b .. +3 of row r (an
     // instruction covers 256 contiguous bytes of each row), and the MFMA for k = 64j + 4b + e names register (j, e) with
@@ -832,16 +847,14 @@ __global__ __launch_bounds__(256) void lstm_fwd_chain4v(const float* __restrict_
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};      // even / odd 4-k pieces: two independent MFMA chains
         u32x4_t pv[NP];
         if (step > 0) {
-            const int toff = (tprev * nch + chain) * 4 * H * 4;
+            const int toff = (((step - 1) & 3) * nch + chain) * 4 * H * 4;
             unsigned spins = 0;
             for (;;) {
+                POLL_FENCE();
                 unsigned mx = 0u;
 #pragma unroll
                 for (int j = 0; j < NP; ++j) {
-                    // first try: plain load (this CU has not touched these lines yet; served by the XCD's L2); a retry must not be
-                    // served from the CU's L1, which now holds the stale line: sc1
-                    if (spins == 0) pv[j] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, toff + poff[j], 0, 0);
-                    else pv[j] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, toff + poff[j], 0, 16);
+                    pv[j] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, toff + poff[j], 0, kPollAux);
                     mx = max(max(mx, pv[j][0]), max(max(pv[j][1], pv[j][2]), pv[j][3]));
                 }
                 if (__all(mx != kHandoffSentinel) || timed_out) break;
@@ -903,9 +916,15 @@ __global__ __launch_bounds__(256) void lstm_fwd_chain4v(const float* __restrict_
             if (h != h) h = __uint_as_float(0x7FC00000u);                                // never the hand-off pattern
             if (step == s1 - 1 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
                 h = __uint_as_float(0x7FC00000u);                                        // a hand-off timed out: fail loudly
-            float* xo = hx + ((long)(t * nch + chain) * 4 * H + (member * 4 + bl) * 16 + cu);
-            if (local) __hip_atomic_store(xo, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // stays in this XCD's L2
-            else __hip_atomic_store(xo, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                // write-through (sc1)
+            float* xo = hx + ((long)((step & 3) * nch + chain) * 4 * H + (member * 4 + bl) * 16 + cu);
+            float* xr = hx + ((long)(((step - 2) & 3) * nch + chain) * 4 * H + (member * 4 + bl) * 16 + cu);
+            if (local) {
+                __hip_atomic_store(xo, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // stays in this XCD's L2
+                if (step >= 2) __hip_atomic_store((unsigned*)xr, kHandoffSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                __hip_atomic_store(xo, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // write-through (sc1)
+                if (step >= 2) __hip_atomic_store((unsigned*)xr, kHandoffSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             *yo = h;
             *go = gv;
             cell[sidx] = c;
@@ -1369,6 +1388,212 @@ __global__ __launch_bounds__(512) void lstm_bwd_kowner8(const float* __restrict_
     }
 }
 
+// Backward sweep on 4-row chains with a self-validating hand-off ("bwd chain4v"): the K-owner form of lstm_bwd_kowner8
+// (a workgroup multiplies its OWN 64 gate gradients into partial dh for all H units and every consumer sums the 32 partial
+// blocks of its 16 units in a fixed order) on the geometry of lstm_fwd_chain4v: 2*ceil(B/4) <= 16 chains, workgroups of 4
+// waves, two per CU above 8 chains.
+//   MFMA: D[unit][row] orientation - A = W_hh^T (lane = unit, resident: 4 gates x 16 k x UW/64 column blocks = 128 VGPRs at
+//   H = 512), B = the 4 rows of own dgates.  The instruction's B lane-group broadcast (blgp = 4 + g: every 16-lane group
+//   takes group g's lanes; probe scripts/mfma_blgp_probe.hip) lets one VGPR carry 4 different k, so the whole B operand of a
+//   step is 4 16-byte LDS reads per lane; a lane ends up with 4 consecutive units of one row = one 16-byte store, and the 16
+//   lanes of a consumer's block write its 256 bytes = two whole lines in one instruction.
+//   Hand-off: partial blocks live in a ring of 4 step slots [slot][chain][consumer][producer][4 rows][16 units] that is all
+//   0xFFFFFFFF before the sweep.  Wave 0 (one cell per lane) re-issues its 32 block loads (sc1: never from the CU's L1, the
+//   ring reuses addresses) until no dword holds the pattern; behind the barrier that follows the cell gradients, waves 1-3
+//   put the pattern back into the blocks just consumed.  Why that is ordered before the producers' next writes to the slot
+//   (3 steps later): the resetting waves wait for their stores' acknowledgements before the NEXT step's barrier, this
+//   workgroup's partials of the next step are stored behind that barrier, and a producer writes slot s+4 only after it has
+//   consumed everybody's partials of step s+3 > s+1.  No flags, no store drain, one barrier per step.
+template <int NCH>
+__global__ __launch_bounds__(256) void lstm_bwd_chain4v(const float* __restrict__ dy, const float* __restrict__ whht_f,
+                                                        const float* __restrict__ whht_r, const int32_t* __restrict__ lens,
+                                                        const float* __restrict__ gates, const float* __restrict__ cell,
+                                                        float* __restrict__ dgates, float* ring, unsigned* ids, unsigned* status,
+                                                        unsigned* health, float* bias_part, int T, int B, int NT4, int force_wt, int prio) {
+    constexpr int H = 128 * NCH;
+    constexpr int members = H / 16;
+    constexpr int UW = H / 4;                         // units per wave
+    constexpr int NCB = UW / 64;                      // 64-unit column blocks per wave
+    constexpr int DP = 68;
+    __shared__ float dgl[2 * 4 * DP + 4];             // own dgates [parity][row][gate*16 + local unit] (+ one scratch word)
+    const int nch = 2 * NT4;
+    const int chain = nch > 8 ? (int)(blockIdx.x & 7) + 8 * (int)((blockIdx.x >> 3) & 1) : (int)(blockIdx.x & 7);
+    const int member = nch > 8 ? blockIdx.x >> 4 : blockIdx.x >> 3;
+    if (chain >= nch) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int dir = chain / NT4, bt = chain % NT4, unit0 = member * 16, b0 = bt * 4;
+    const bool local = chain_is_xcd_local(ids + chain * 32, members, member, status, health, (unsigned*)(dgl + 2 * 4 * DP)) && !force_wt;
+
+    // resident A operand: lane = unit u of the wave's column block cb; aw[cb][gate][i][e] = W_hh[gate*H + unit0 + 4i + e][u]
+    f32x4 aw[NCB][4][4];
+    {
+        const float* whht = dir ? whht_r : whht_f;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            const int u = wave * UW + 64 * cb + lane;
+#pragma unroll
+            for (int gate = 0; gate < 4; ++gate) {
+                const f32x4* wp = (const f32x4*)(whht + (long)u * 4 * H + gate * H + unit0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) aw[cb][gate][i] = wp[i];
+            }
+        }
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int gate = 0; gate < 4; ++gate)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(aw[cb][gate][i]));     // complete before the loop (see lstm_fwd_chain4v)
+    }
+    const bool cellw = tid < 64;                      // wave 0: one cell (row, unit) per lane
+    const int erow = lane >> 4, ej = lane & 15, eb = b0 + erow, eunit = unit0 + ej;
+    const bool ev = cellw && eb < B;
+    const int ebs = eb < B ? eb : b0;
+    const int len = lens[ebs];
+    float dcar = 0.f;
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+    bool timed_out = false;
+    const int ring_bytes = 4 * nch * 32 * 32 * 256;
+    const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ring, 0, ring_bytes, 0x00020000);
+
+    // the records of a step (gates, c, c_prev, dy of the lane's cell) are fetched one step ahead, behind the polls: loads
+    // return in order, a poll issued behind an HBM round trip would wait it out
+    f32x4 gv_n = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float c_n = 0.f, cprev_n = 0.f, dy_n = 0.f;
+    auto fetch = [&](int st) {
+        const int tt = dir == 0 ? T - 1 - st : st;
+        gv_n = (f32x4){0.f, 0.f, 0.f, 0.f};
+        c_n = cprev_n = dy_n = 0.f;
+        if (ev && tt < len) {
+            const long sidx = (((long)dir * T + tt) * B + ebs) * H + eunit;
+            gv_n = *(const f32x4*)(gates + sidx * 4);
+            c_n = cell[sidx];
+            const int tp = dir == 0 ? tt - 1 : tt + 1;
+            if (tp >= 0 && tp < len) cprev_n = cell[(((long)dir * T + tp) * B + ebs) * H + eunit];
+            dy_n = dy[((long)tt * B + ebs) * 2 * H + dir * H + eunit];
+        }
+    };
+    if (cellw) fetch(0);
+
+    for (int step = 0; step < T; ++step) {
+        const int t = dir == 0 ? T - 1 - step : step;
+        float* dgw = dgl + (step & 1) * 4 * DP;
+        if (cellw) {
+            if (prio & 1) __builtin_amdgcn_s_setprio(3);
+            const bool act = ev && t < len;
+            const f32x4 gv = gv_n;
+            const float c = c_n, cprev = cprev_n, dyv = dy_n;
+            float rs = 0.f;
+            if (step > 0) {
+                // this workgroup's block of every member's partials of the previous step
+                const int pbase = (((((step - 1) & 3) * nch + chain) * 32 + member) * 32 * 64 + lane) * 4;
+                float pv[members];
+                unsigned spins = 0;
+                for (;;) {
+                    POLL_FENCE();
+                    unsigned mx = 0u;
+#pragma unroll
+                    for (int m = 0; m < members; ++m) {
+                        const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(prsrc, pbase + m * 256, 0, kPollAux);
+                        pv[m] = __uint_as_float(v);
+                        mx = max(mx, v);
+                    }
+                    if (__all(mx != kHandoffSentinel) || timed_out) break;
+                    if (++spins > (1u << 22)) {
+                        if (lane == 0) raise_timeout(status, health);
+                        timed_out = true;
+                        break;
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < members; ++m) rs += pv[m];
+            }
+            if (step + 1 < T) fetch(step + 1);
+            float dg[4] = {0.f, 0.f, 0.f, 0.f};
+            if (act) dcar = lstm_cell_grad(dyv + rs, dcar, gv[0], gv[1], gv[2], gv[3], c, cprev, dg);
+            else dcar = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (dg[g] != dg[g]) dg[g] = __uint_as_float(0x7FC00000u);              // never the hand-off pattern
+            if (step == T - 1 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+                dg[0] = dg[1] = dg[2] = dg[3] = __uint_as_float(0x7FC00000u);        // a hand-off timed out: fail loudly
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dgw[erow * DP + g * 16 + ej] = dg[g];
+            if (ev) {
+                const long gbase = (((long)dir * T + t) * B + eb) * 4 * H + eunit;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    dgates[gbase + (long)g * H] = dg[g];     // for the weight/input-gradient GEMMs: plain stores
+                    bs[g] += dg[g];
+                }
+            }
+        } else {
+            __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): last step's resets are acknowledged before this step's barrier
+        }
+        if (prio & 1) __builtin_amdgcn_s_setprio(0);
+        __syncthreads();
+        if (step + 1 < T) {
+            // B operand: lane = (16-lane group g, .., row j = lane & 3): bv[q][e] = dgates[row j][k = 16q + 4g + e]
+            f32x4 bv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bv[q] = *(const f32x4*)&dgw[(lane & 3) * DP + 16 * q + 4 * (lane >> 4)];
+            f32x4 acc[NCB];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                static_for<4>([&](auto gc) {
+                    constexpr int g = decltype(gc)::value;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int cb = 0; cb < NCB; ++cb)
+                            acc[cb] = __builtin_amdgcn_mfma_f32_4x4x1f32(aw[cb][q][g][e], bv[q][e], acc[cb], 0, 0, 4 + g);
+                });
+            // acc[cb][r] = partial of (unit wave*UW + 64cb + 4b + r, row j) for lane 4b + j: 4 consecutive units of one row
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                u32x4_t raw;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) raw[e] = __float_as_uint(acc[cb][e]);
+                const int ug = wave * UW + 64 * cb + 4 * (lane >> 2);
+                const int soff = ((((((step & 3) * nch + chain) * 32 + (ug >> 4)) * 32 + member) * 4 + (lane & 3)) * 16 + (ug & 15)) * 4;
+                if (local) __builtin_amdgcn_raw_buffer_store_b128(raw, prsrc, soff, 0, 1);        // sc0: stays in this XCD's L2
+                else __builtin_amdgcn_raw_buffer_store_b128(raw, prsrc, soff, 0, 16);            // write-through (sc1)
+            }
+        }
+        if (!cellw && step > 0) {
+            // the blocks wave 0 consumed in front of the barrier go back to "not written yet" (members * 256 bytes, contiguous)
+            const u32x4_t pat = {kHandoffSentinel, kHandoffSentinel, kHandoffSentinel, kHandoffSentinel};
+            const int rbase = ((((step - 1) & 3) * nch + chain) * 32 + member) * 32 * 256;
+#pragma unroll
+            for (int n = 0; n < (members * 256 + 3071) / 3072; ++n) {
+                const int off = (n * 192 + (tid - 64)) * 16;
+                if (off < members * 256) {
+                    if (local) __builtin_amdgcn_raw_buffer_store_b128(pat, prsrc, rbase + off, 0, 1);
+                    else __builtin_amdgcn_raw_buffer_store_b128(pat, prsrc, rbase + off, 0, 16);
+                }
+            }
+        }
+    }
+    // bias gradient of this chain's rows: sum the 4 rows in a fixed order -> bias_part[chain][gate*H + unit]
+    if (bias_part) {
+        __syncthreads();
+        if (cellw) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dgl[erow * DP + g * 16 + ej] = bs[g];
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int g = tid >> 4, u = tid & 15;
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v += dgl[r * DP + g * 16 + u];
+            bias_part[(long)chain * 4 * H + g * H + unit0 + u] = v;
+        }
+    }
+}
+
 // dbias[dir][j] = sum over the direction's batch-tile chains, fixed order
 __global__ void lstm_bias_combine_kernel(const float* __restrict__ part, float* __restrict__ dbias, int G, int nt) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x, dir = blockIdx.y;
@@ -1410,7 +1635,7 @@ int resident_workgroup_capacity() {
 }  // namespace
 
 static size_t lstm_ws_handoff_offset(int b, int h) {
-    const size_t o = (size_t)6 * 2 * b * h * sizeof(float) + 4096 + ((size_t)16 << 20) + (size_t)8 * 4 * h * sizeof(float) +
+    const size_t o = (size_t)6 * 2 * b * h * sizeof(float) + 4096 + ((size_t)16 << 20) + (size_t)16 * 4 * h * sizeof(float) +
                      (size_t)64 * 4 * h * sizeof(float);
     return (o + 255) / 256 * 256;
 }
@@ -1421,9 +1646,9 @@ extern "C" size_t vocr_lstm_workspace_bytes(int t, int b, int h) {
     // sweep (2 parities x 8 chains x 32 consumers x 32 producers x 1 KiB)
     // + per-chain bias-gradient rows [8][4H]
     // + 64 partial rows [4H] for the fixed-order column sums of the bias gradient (paths without in-sweep accumulation)
-    // + the forward chain sweeps' hand-off buffer hx[t][2 directions][rows padded to 8][H] (must survive from one
-    //   vocr_lstm_fwd_range call of a sweep to the next)
-    return lstm_ws_handoff_offset(b, h) + (size_t)t * 2 * ((b + 7) / 8 * 8) * h * sizeof(float);
+    // + the forward chain sweep's hand-off ring [4 step slots][16 chains][4 rows][H] (must survive from one vocr_lstm_fwd_range
+    //   call of a sweep to the next)
+    return lstm_ws_handoff_offset(b, h) + (size_t)4 * 16 * 4 * h * sizeof(float);
 }
 
 extern "C" int vocr_lstm_fwd_range(const float* xproj, const float* whh_fwd, const float* whh_rev, const int32_t* lens, float* y,
@@ -1458,10 +1683,10 @@ extern "C" int vocr_lstm_fwd_range(const float* xproj, const float* whh_fwd, con
         static const int selfval = getenv("VOCR_LSTM_SELFVAL") ? atoi(getenv("VOCR_LSTM_SELFVAL")) : 1;     // 0: flag hand-off (lstm_fwd_chain8 / lstm_fwd_chain)
         const int nt4 = (b + 3) / 4;
         if (selfval && 2 * nt4 <= 16 && !(persistent_mode & 32) && (h == 512 || h == 256) &&
-            (2 * nt4 > 8 ? 16 : 8) * (h / 16) <= 2 * resident_workgroup_capacity() && (long)t * 2 * nt4 * 4 * h * 4 < (1l << 31)) {
+            (2 * nt4 > 8 ? 16 : 8) * (h / 16) <= 2 * resident_workgroup_capacity()) {
             // 4-row chains; the hand-off buffer starts as the "not written yet" pattern (first range of a sweep only)
             float* hx = (float*)((char*)workspace + lstm_ws_handoff_offset(b, h));
-            if (step_begin == 0 && hipMemsetAsync(hx, 0xFF, (size_t)t * 2 * nt4 * 4 * h * sizeof(float), s) != hipSuccess) {
+            if (step_begin == 0 && hipMemsetAsync(hx, 0xFF, (size_t)4 * 2 * nt4 * 4 * h * sizeof(float), s) != hipSuccess) {
                 vocr_set_error("vocr_lstm_fwd: memset failed");
                 return VOCR_ELAUNCH;
             }
@@ -1520,7 +1745,7 @@ extern "C" int vocr_lstm_bwd(const float* dy, const float* whht_fwd, const float
 static int lstm_bias_by_colsum(const float* dgates, float* dbias, void* workspace, int t, int b, int h, void* stream) {
     if (!dbias) return VOCR_OK;
     // partial rows live in the last 64 x 4H floats of the LSTM workspace (vocr_lstm_workspace_bytes)
-    void* cws = (char*)workspace + (size_t)6 * 2 * b * h * sizeof(float) + 4096 + ((size_t)16 << 20) + (size_t)8 * 4 * h * sizeof(float);
+    void* cws = (char*)workspace + (size_t)6 * 2 * b * h * sizeof(float) + 4096 + ((size_t)16 << 20) + (size_t)16 * 4 * h * sizeof(float);
     for (int dir = 0; dir < 2; ++dir) {
         const int rc = vocr_colsum(dgates + (size_t)dir * t * b * 4 * h, dbias + (size_t)dir * 4 * h, t * b, 4 * h, cws, stream);
         if (rc != VOCR_OK) return rc;
@@ -1553,6 +1778,31 @@ extern "C" int vocr_lstm_bwd_bias(const float* dy, const float* whht_fwd, const 
         // K-owner form: partial sums [parity][chain][consumer][producer][16 x 16] behind the flags/status words
         float* partials = (float*)((char*)workspace + 4096);
         const int nt8 = (b + 7) / 8;
+        static const int selfval = getenv("VOCR_LSTM_SELFVAL") ? atoi(getenv("VOCR_LSTM_SELFVAL")) : 1;     // bit 1 clear / bit 2 set: flag hand-off in the backward sweep
+        const int nt4 = (b + 3) / 4;
+        if (selfval && !(selfval & 4) && 2 * nt4 <= 16 && !(persistent_mode & 32) && (h == 512 || h == 256) &&
+            (2 * nt4 > 8 ? 16 : 8) * (h / 16) <= 2 * resident_workgroup_capacity()) {
+            // 4-row chains; the ring of partial blocks starts as the "not written yet" pattern
+            const int nch = 2 * nt4;
+            if (hipMemsetAsync(partials, 0xFF, (size_t)4 * nch * 32 * 32 * 256, s) != hipSuccess) {
+                vocr_set_error("vocr_lstm_bwd: memset failed");
+                return VOCR_ELAUNCH;
+            }
+            float* bpart = dbias ? (float*)((char*)workspace + 4096 + ((size_t)16 << 20)) : nullptr;     // [chain][4H]
+            const dim3 g4((nch > 8 ? 16 : 8) * (h / 16));
+            const int fwt4 = (persistent_mode & 8) ? 1 : 0;
+            static const int prio4 = getenv("VOCR_LSTM_PRIO") ? atoi(getenv("VOCR_LSTM_PRIO")) : 0;
+            if (h == 512)
+                lstm_bwd_chain4v<4><<<g4, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, status, hword, bpart, t, b, nt4, fwt4, prio4);
+            else
+                lstm_bwd_chain4v<2><<<g4, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, status, hword, bpart, t, b, nt4, fwt4, prio4);
+            VOCR_CHECK_LAUNCH("vocr_lstm_bwd(k-owner, 4-row chains, self-validating)");
+            if (dbias) {
+                lstm_bias_combine_kernel<<<dim3(vocr_cdiv(4 * h, 256), 2), 256, 0, s>>>(bpart, dbias, 4 * h, nt4);
+                VOCR_CHECK_LAUNCH("vocr_lstm_bwd(bias combine)");
+            }
+            return VOCR_OK;
+        }
         if (2 * nt8 <= 8 && !(persistent_mode & 32) && (h == 512 || h == 256)) {      // 8-row chains on all 8 XCDs, 4x4x1 MFMA
             const int fwt8 = (persistent_mode & 8) ? 1 : 0;
             float* bpart = dbias ? (float*)((char*)workspace + 4096 + ((size_t)16 << 20)) : nullptr;     // [chain][4H]
