@@ -939,6 +939,184 @@ __global__ __launch_bounds__(256) void lstm_fwd_chain4v(const float* __restrict_
 #endif
 }
 
+// Forward sweep for 16 < B <= 32 at H = 512 ("chain4w": 4-row chains with WIDE members): 16 chains of 16 members with 32
+// units (128 gate columns) each = ONE 8-wave workgroup per CU.  Same FLOPs per CU and step as two lstm_fwd_chain4v workgroups,
+// but nothing shares the CU: a chain no longer moves at the pace of its most-disturbed member (with two workgroups per CU the
+// polls took 1470 instead of 690 ticks and the barrier behind them 930 instead of 235), the hand-off has 16 producers instead of
+// 32, and every wave has two independent accumulator chains by construction.  K = H split over the 8 waves (64 k each), lane =
+// gate column of a 64-column block, two blocks: 128 VGPRs of W_hh per lane, no duplicates; A straight from the hand-off load (one
+// 16-byte load per lane and step) through the instruction's A broadcast.  Epilogue: wave w reduces and activates gate w & 3 of
+// rows 2(w >> 2), +1 (a wave-uniform activation function), waves 0-1 update the 128 cells.  Ring and reset: lstm_fwd_chain4v.
+template <int KQ4>
+__global__ __launch_bounds__(512) void lstm_fwd_chain4w(const float* __restrict__ xproj, const float* __restrict__ whh_f,
+                                                        const float* __restrict__ whh_r, const int32_t* __restrict__ lens,
+                                                        float* y, float* __restrict__ gates, float* __restrict__ cell,
+                                                        float* hx, unsigned* ids, unsigned* status, unsigned* health, int T, int B, int NT4,
+                                                        int force_wt, int s0, int s1, int nap) {
+    constexpr int H = 64 * KQ4;
+    constexpr int members = H >> 5;                   // 32 units each
+    constexpr int KW = H / 8;                         // k per wave
+    constexpr int NL = KW / 4;                        // 16-byte pieces of a row's k-slice = A blocks in use
+    static_assert(NL == 16, "one 16-byte load per lane covers the wave's k-slice only at H = 512");
+    constexpr int RP = 132;                           // pitch of a partial-tile row (128 columns)
+    __shared__ float lds[8 * 4 * RP + 4 + 4 * 128];
+    float (*red)[4][RP] = (float (*)[4][RP])lds;                            // [wave][row][column]
+    float (*actb)[128] = (float (*)[128])(lds + 8 * 4 * RP + 4);            // [row][gate*32 + unit]
+    __shared__ int sig[2];                                                  // step count of the two cell waves' last h store
+    const int nch = 2 * NT4;
+    const int chain = (int)(blockIdx.x & 7) + 8 * (int)((blockIdx.x >> 3) & 1), member = blockIdx.x >> 4;
+    if (chain >= nch) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int dir = chain / NT4, bt = chain % NT4;
+    const int unit0 = member * 32, b0 = bt * 4;
+    const int nrows = min(B - b0, 4);
+    const int kbase = wave * KW;
+    const float* whh = dir ? whh_r : whh_f;
+    const bool local = chain_is_xcd_local(ids + chain * 32, members, member, status, health, (unsigned*)(lds + 8 * 4 * RP)) && !force_wt;
+
+    // resident B operand: column 64*cb + lane of the workgroup's 128 = (gate, local unit) = (col >> 5, col & 31)
+    f32x4 wv[2][NL];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int col = 64 * cb + lane;
+        const f32x4* wp = (const f32x4*)(whh + ((long)(col >> 5) * H + unit0 + (col & 31)) * H + kbase);
+#pragma unroll
+        for (int i = 0; i < NL; ++i) wv[cb][i] = wp[i];
+    }
+    const int egate = __builtin_amdgcn_readfirstlane(wave) & 3;
+    const int erow = 2 * (wave >> 2) + (lane >> 5), eu = lane & 31, ecol = egate * 32 + eu;
+    const bool erowok = erow < nrows;
+    const int crow = tid >> 5, cu = tid & 31, cb_ = b0 + crow, unit = unit0 + cu;       // cell threads: waves 0, 1
+    const bool cellthr = tid < 128 && crow < nrows;
+    const int len_b = cellthr ? lens[cb_] : 0;
+    float cstate = 0.f;
+    if (s0 > 0 && cellthr) {
+        const int tp0 = dir == 0 ? s0 - 1 : T - s0;
+        cstate = cell[(((long)dir * T + tp0) * B + cb_) * H + unit];
+    }
+    bool timed_out = false;
+    if (tid < 2) sig[tid] = s0;                       // read by the other waves from step s0 + 1 on: behind step s0's barriers
+    // ring hx[step & 3][chain][member][4 rows][32 units]: a member's block of a step = 512 contiguous bytes
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)hx, 0, 4 * nch * 4 * H * 4, 0x00020000);
+    int poff;
+    {
+        const int prow = (lane & 3) < nrows ? (lane & 3) : 0;             // rows clamped, never masked
+        const int kk = kbase + 4 * (lane >> 2);
+        poff = (((kk >> 5) * 4 + prow) * 32 + (kk & 31)) * 4;
+    }
+    const int xb = erowok ? b0 + erow : b0;
+    auto x_load = [&](int st) {
+        const int tt = dir == 0 ? st : T - 1 - st;
+        return xproj[(((long)dir * T + tt) * B + xb) * 4 * H + (long)egate * H + unit0 + eu];
+    };
+    float xn = x_load(s0);
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int i = 0; i < NL; ++i) asm volatile("" : "+v"(wv[cb][i]));      // complete before the loop (see lstm_fwd_chain4v)
+
+    LSTM_STAMP_DECL;
+    for (int step = s0; step < s1; ++step) {
+        const int t = dir == 0 ? step : T - 1 - step;
+        LSTM_STAMP(7);
+        const float xp = xn;
+        f32x4 acc[2];
+        acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        u32x4_t pv;
+        if (step > 0) {
+            const int toff = (((step - 1) & 3) * nch + chain) * 4 * H * 4;
+            unsigned spins = 0;
+            // the waves without cells are here a cell update + a store's flight before anything can have arrived: a poll issued now
+            // comes back empty and the one that counts queues behind it (2.24 us per step).  They wait (LDS, no memory traffic)
+            // until this workgroup's own cell waves have stored (2.12; a further fixed nap has a narrow optimum and is left at 0)
+            if (tid >= 128 && step > s0 && nap >= 0) {
+                while (__hip_atomic_load(&sig[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < step ||
+                       __hip_atomic_load(&sig[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < step)
+                    __builtin_amdgcn_s_sleep(1);
+                for (int i = 0; i < nap; ++i) __builtin_amdgcn_s_sleep(2);
+            }
+            for (;;) {
+                POLL_FENCE();
+                pv = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, toff + poff, 0, kPollAux);
+                const unsigned mx = max(max(pv[0], pv[1]), max(pv[2], pv[3]));
+                if (__all(mx != kHandoffSentinel) || timed_out) break;
+                if (++spins > (1u << 22)) {
+                    if (lane == 0) raise_timeout(status, health);
+                    timed_out = true;
+                    break;
+                }
+            }
+        }
+        LSTM_STAMP(0);              // own slice of h_{t-1} arrived (polls)
+        xn = x_load(step + 1 < T ? step + 1 : step);           // behind the polls: loads return in order
+        if (step > 0) {
+            static_for<NL>([&](auto bc) {
+                constexpr int b = decltype(bc)::value;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb)
+                        acc[cb] = __builtin_amdgcn_mfma_f32_4x4x1f32(__uint_as_float(pv[e]), wv[cb][b][e], acc[cb], 4, b, 0);
+            });
+        }
+        // acc[cb][r] = partial of (row r, column 64cb + lane)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][r][64 * cb + lane] = acc[cb][r];
+        LSTM_STAMP(1);              // MFMA + partial tile to LDS
+        __syncthreads();
+        LSTM_STAMP(2);
+        {
+            const float pre = (((red[0][erow][ecol] + red[1][erow][ecol]) + (red[2][erow][ecol] + red[3][erow][ecol])) +
+                               ((red[4][erow][ecol] + red[5][erow][ecol]) + (red[6][erow][ecol] + red[7][erow][ecol]))) + xp;
+            actb[erow][ecol] = egate == 2 ? tanhf(pre) : sigmoidf_(pre);           // wave-uniform choice
+            asm volatile("" : "+v"(xn));      // no load pending at the back edge (see lstm_fwd_chain4v)
+        }
+        LSTM_STAMP(3);              // reduce + activation
+        __syncthreads();
+        LSTM_STAMP(4);
+        if (cellthr) {
+            const bool active = t < len_b;
+            const long sidx = (((long)dir * T + t) * B + cb_) * H + unit;
+            float* yo = y + ((long)t * B + cb_) * 2 * H + dir * H + unit;
+            f32x4* go = (f32x4*)(gates + sidx * 4);
+            float h = 0.f, c = 0.f;
+            f32x4 gv = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (active) {
+                const float ig = actb[crow][cu], fg = actb[crow][32 + cu], gg = actb[crow][64 + cu], og = actb[crow][96 + cu];
+                c = fg * cstate + ig * gg;
+                h = og * tanhf(c);
+                gv = (f32x4){ig, fg, gg, og};
+            }
+            cstate = c;
+            if (h != h) h = __uint_as_float(0x7FC00000u);                                // never the hand-off pattern
+            if (step == s1 - 1 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+                h = __uint_as_float(0x7FC00000u);                                        // a hand-off timed out: fail loudly
+            float* xo = hx + ((long)((step & 3) * nch + chain) * 4 * H + (member * 4 + crow) * 32 + cu);
+            float* xr = hx + ((long)(((step - 2) & 3) * nch + chain) * 4 * H + (member * 4 + crow) * 32 + cu);
+            if (local) {
+                __hip_atomic_store(xo, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // stays in this XCD's L2
+                if (step >= 2) __hip_atomic_store((unsigned*)xr, kHandoffSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                __hip_atomic_store(xo, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // write-through (sc1)
+                if (step >= 2) __hip_atomic_store((unsigned*)xr, kHandoffSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            *yo = h;
+            *go = gv;
+            cell[sidx] = c;
+        }
+        if (tid < 128 && lane == 0) __hip_atomic_store(&sig[wave], step + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        LSTM_STAMP(5);              // cell update + stores issued (waves 0, 1)
+    }
+#ifdef VOCR_LSTM_STAMPS
+    if (lane == 0 && (wave == 0 || wave == 7) && g_lstm_stamp_out) {
+        unsigned long long* o = g_lstm_stamp_out + ((size_t)blockIdx.x * 2 + (wave == 7)) * 8;
+        for (int k = 0; k < 8; ++k) o[k] = st_acc[k];
+    }
+#endif
+}
+
 // Gradient of one LSTM cell; shared by the per-step and the persistent backward kernels so both contract the same
 // expressions (the two sweeps are compared bit for bit).  Returns the dc carried to the previous step.
 __device__ __forceinline__ float lstm_cell_grad(float dh, float dcar, float ig, float fg, float gg, float og, float c, float cprev,
@@ -1594,6 +1772,183 @@ __global__ __launch_bounds__(256) void lstm_bwd_chain4v(const float* __restrict_
     }
 }
 
+// Backward sweep for 16 < B <= 32 at H = 512 ("bwd chain4w"): lstm_bwd_chain4v's protocol on the geometry of lstm_fwd_chain4w -
+// 16 chains of 16 members with 32 units each, ONE 8-wave workgroup per CU.  A member owns 128 gate gradients (k = gate*32 + unit):
+// A = W_hh^T slice (lane = unit of the wave's 64, 4 gates x 32 k: 128 VGPRs, resident), B = own dgates through the B lane-group
+// broadcast (8 LDS reads per lane and step), two accumulators (even / odd 16-k groups).  A consumer sums 16 partial blocks of
+// [4 rows][32 units] (512 bytes, written whole by one store instruction); cells on waves 0-1, resets by waves 2-7.
+template <int NCH>
+__global__ __launch_bounds__(512) void lstm_bwd_chain4w(const float* __restrict__ dy, const float* __restrict__ whht_f,
+                                                        const float* __restrict__ whht_r, const int32_t* __restrict__ lens,
+                                                        const float* __restrict__ gates, const float* __restrict__ cell,
+                                                        float* __restrict__ dgates, float* ring, unsigned* ids, unsigned* status,
+                                                        unsigned* health, float* bias_part, int T, int B, int NT4, int force_wt) {
+    constexpr int H = 128 * NCH;
+    static_assert(H == 512, "8 waves x 64 units");
+    constexpr int members = H / 32;
+    constexpr int DP = 132;
+    __shared__ float dgl[2 * 4 * DP + 4];             // own dgates [parity][row][gate*32 + local unit] (+ one scratch word)
+    const int nch = 2 * NT4;
+    const int chain = (int)(blockIdx.x & 7) + 8 * (int)((blockIdx.x >> 3) & 1), member = blockIdx.x >> 4;
+    if (chain >= nch) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int dir = chain / NT4, bt = chain % NT4, unit0 = member * 32, b0 = bt * 4;
+    const bool local = chain_is_xcd_local(ids + chain * 32, members, member, status, health, (unsigned*)(dgl + 2 * 4 * DP)) && !force_wt;
+
+    // resident A operand: lane = unit u = 64*wave + lane; aw[gate][i][e] = W_hh[gate*H + unit0 + 4i + e][u], i < 8
+    f32x4 aw[4][8];
+    {
+        const float* whht = dir ? whht_r : whht_f;
+        const int u = 64 * wave + lane;
+#pragma unroll
+        for (int gate = 0; gate < 4; ++gate) {
+            const f32x4* wp = (const f32x4*)(whht + (long)u * 4 * H + gate * H + unit0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) aw[gate][i] = wp[i];
+        }
+#pragma unroll
+        for (int gate = 0; gate < 4; ++gate)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(aw[gate][i]));     // complete before the loop
+    }
+    const bool cellw = tid < 128;                     // waves 0-1: one cell (row, unit) per thread
+    const int erow = tid >> 5, ej = tid & 31, eb = b0 + erow, eunit = unit0 + ej;
+    const bool ev = cellw && eb < B;
+    const int ebs = eb < B ? eb : b0;
+    const int len = lens[cellw ? ebs : b0];
+    float dcar = 0.f;
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+    bool timed_out = false;
+    // ring [slot][chain][consumer][producer][4 rows][32 units]
+    const int ring_bytes = 4 * nch * 16 * 16 * 512;
+    const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ring, 0, ring_bytes, 0x00020000);
+
+    f32x4 gv_n = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float c_n = 0.f, cprev_n = 0.f, dy_n = 0.f;
+    auto fetch = [&](int st) {
+        const int tt = dir == 0 ? T - 1 - st : st;
+        gv_n = (f32x4){0.f, 0.f, 0.f, 0.f};
+        c_n = cprev_n = dy_n = 0.f;
+        if (ev && tt < len) {
+            const long sidx = (((long)dir * T + tt) * B + ebs) * H + eunit;
+            gv_n = *(const f32x4*)(gates + sidx * 4);
+            c_n = cell[sidx];
+            const int tp = dir == 0 ? tt - 1 : tt + 1;
+            if (tp >= 0 && tp < len) cprev_n = cell[(((long)dir * T + tp) * B + ebs) * H + eunit];
+            dy_n = dy[((long)tt * B + ebs) * 2 * H + dir * H + eunit];
+        }
+    };
+    if (cellw) fetch(0);
+
+    for (int step = 0; step < T; ++step) {
+        const int t = dir == 0 ? T - 1 - step : step;
+        float* dgw = dgl + (step & 1) * 4 * DP;
+        if (cellw) {
+            const bool act = ev && t < len;
+            const f32x4 gv = gv_n;
+            const float c = c_n, cprev = cprev_n, dyv = dy_n;
+            float rs = 0.f;
+            if (step > 0) {
+                const int pbase = (((((step - 1) & 3) * nch + chain) * 16 + member) * 16 * 128 + tid) * 4;
+                float pv[members];
+                unsigned spins = 0;
+                for (;;) {
+                    POLL_FENCE();
+                    unsigned mx = 0u;
+#pragma unroll
+                    for (int m = 0; m < members; ++m) {
+                        const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(prsrc, pbase + m * 512, 0, kPollAux);
+                        pv[m] = __uint_as_float(v);
+                        mx = max(mx, v);
+                    }
+                    if (__all(mx != kHandoffSentinel) || timed_out) break;
+                    if (++spins > (1u << 22)) {
+                        if (lane == 0) raise_timeout(status, health);
+                        timed_out = true;
+                        break;
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < members; ++m) rs += pv[m];
+            }
+            if (step + 1 < T) fetch(step + 1);
+            float dg[4] = {0.f, 0.f, 0.f, 0.f};
+            if (act) dcar = lstm_cell_grad(dyv + rs, dcar, gv[0], gv[1], gv[2], gv[3], c, cprev, dg);
+            else dcar = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (dg[g] != dg[g]) dg[g] = __uint_as_float(0x7FC00000u);              // never the hand-off pattern
+            if (step == T - 1 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+                dg[0] = dg[1] = dg[2] = dg[3] = __uint_as_float(0x7FC00000u);        // a hand-off timed out: fail loudly
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dgw[erow * DP + g * 32 + ej] = dg[g];
+            if (ev) {
+                const long gbase = (((long)dir * T + t) * B + eb) * 4 * H + eunit;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    dgates[gbase + (long)g * H] = dg[g];
+                    bs[g] += dg[g];
+                }
+            }
+        } else {
+            __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): last step's resets are acknowledged before this step's barrier
+        }
+        __syncthreads();
+        if (step + 1 < T) {
+            // B operand: lane = (16-lane group g, row j = lane & 3): bv[q][e] = dgates[row j][k = 16q + 4g + e], q < 8
+            f32x4 bv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) bv[q] = *(const f32x4*)&dgw[(lane & 3) * DP + 16 * q + 4 * (lane >> 4)];
+            f32x4 acc[2];
+            acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                static_for<4>([&](auto gc) {
+                    constexpr int g = decltype(gc)::value;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)     // k = 16q + 4g + e = gate (q >> 1), 4*(4*(q & 1) + g) + e within the gate
+                        acc[q & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(aw[q >> 1][4 * (q & 1) + g][e], bv[q][e], acc[q & 1], 0, 0, 4 + g);
+                });
+            // acc[r] = partial of (unit 64*wave + 4b + r, row j) for lane 4b + j
+            u32x4_t raw;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) raw[e] = __float_as_uint(acc[0][e] + acc[1][e]);
+            const int ug = 64 * wave + 4 * (lane >> 2);
+            const int soff = ((((((step & 3) * nch + chain) * 16 + (ug >> 5)) * 16 + member) * 4 + (lane & 3)) * 32 + (ug & 31)) * 4;
+            if (local) __builtin_amdgcn_raw_buffer_store_b128(raw, prsrc, soff, 0, 1);        // sc0: stays in this XCD's L2
+            else __builtin_amdgcn_raw_buffer_store_b128(raw, prsrc, soff, 0, 16);            // write-through (sc1)
+        }
+        if (!cellw && step > 0) {
+            // the 16 blocks waves 0-1 consumed in front of the barrier go back to "not written yet" (8 KB, contiguous)
+            const u32x4_t pat = {kHandoffSentinel, kHandoffSentinel, kHandoffSentinel, kHandoffSentinel};
+            const int rbase = ((((step - 1) & 3) * nch + chain) * 16 + member) * 16 * 512;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int off = (n * 384 + (tid - 128)) * 16;
+                if (off < 16 * 512) {
+                    if (local) __builtin_amdgcn_raw_buffer_store_b128(pat, prsrc, rbase + off, 0, 1);
+                    else __builtin_amdgcn_raw_buffer_store_b128(pat, prsrc, rbase + off, 0, 16);
+                }
+            }
+        }
+    }
+    if (bias_part) {
+        __syncthreads();
+        if (cellw) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dgl[erow * DP + g * 32 + ej] = bs[g];
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int g = tid >> 5, u = tid & 31;
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v += dgl[r * DP + g * 32 + u];
+            bias_part[(long)chain * 4 * H + g * H + unit0 + u] = v;
+        }
+    }
+}
+
 // dbias[dir][j] = sum over the direction's batch-tile chains, fixed order
 __global__ void lstm_bias_combine_kernel(const float* __restrict__ part, float* __restrict__ dbias, int G, int nt) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x, dir = blockIdx.y;
@@ -1682,6 +2037,18 @@ extern "C" int vocr_lstm_fwd_range(const float* xproj, const float* whh_fwd, con
         const int nt8 = (b + 7) / 8;
         static const int selfval = getenv("VOCR_LSTM_SELFVAL") ? atoi(getenv("VOCR_LSTM_SELFVAL")) : 1;     // 0: flag hand-off (lstm_fwd_chain8 / lstm_fwd_chain)
         const int nt4 = (b + 3) / 4;
+        static const int nap4w = getenv("VOCR_LSTM_NAP") ? atoi(getenv("VOCR_LSTM_NAP")) : 0;      // -1: polls start at once (experiments)
+        if (selfval && !(selfval & 8) && h == 512 && nt4 > 4 && nt4 <= 8 && !(persistent_mode & 32) && 256 <= resident_workgroup_capacity()) {
+            // 16 < B <= 32: 4-row chains of 16 wide members, one 8-wave workgroup per CU
+            float* hx = (float*)((char*)workspace + lstm_ws_handoff_offset(b, h));
+            if (step_begin == 0 && hipMemsetAsync(hx, 0xFF, (size_t)4 * 2 * nt4 * 4 * h * sizeof(float), s) != hipSuccess) {
+                vocr_set_error("vocr_lstm_fwd: memset failed");
+                return VOCR_ELAUNCH;
+            }
+            lstm_fwd_chain4w<8><<<256, 512, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, hx, flags, status, hword, t, b, nt4, fwt, step_begin, step_end, nap4w);
+            VOCR_CHECK_LAUNCH("vocr_lstm_fwd(4-row chains, wide members, self-validating)");
+            return VOCR_OK;
+        }
         if (selfval && 2 * nt4 <= 16 && !(persistent_mode & 32) && (h == 512 || h == 256) &&
             (2 * nt4 > 8 ? 16 : 8) * (h / 16) <= 2 * resident_workgroup_capacity()) {
             // 4-row chains; the hand-off buffer starts as the "not written yet" pattern (first range of a sweep only)
@@ -1780,6 +2147,22 @@ extern "C" int vocr_lstm_bwd_bias(const float* dy, const float* whht_fwd, const 
         const int nt8 = (b + 7) / 8;
         static const int selfval = getenv("VOCR_LSTM_SELFVAL") ? atoi(getenv("VOCR_LSTM_SELFVAL")) : 1;     // bit 1 clear / bit 2 set: flag hand-off in the backward sweep
         const int nt4 = (b + 3) / 4;
+        if (selfval && !(selfval & 4) && !(selfval & 16) && h == 512 && nt4 > 4 && nt4 <= 8 && !(persistent_mode & 32) && 256 <= resident_workgroup_capacity()) {
+            // 16 < B <= 32: 4-row chains of 16 wide members, one 8-wave workgroup per CU
+            const int nch = 2 * nt4;
+            if (hipMemsetAsync(partials, 0xFF, (size_t)4 * nch * 16 * 16 * 512, s) != hipSuccess) {
+                vocr_set_error("vocr_lstm_bwd: memset failed");
+                return VOCR_ELAUNCH;
+            }
+            float* bpart = dbias ? (float*)((char*)workspace + 4096 + ((size_t)16 << 20)) : nullptr;     // [chain][4H]
+            lstm_bwd_chain4w<4><<<256, 512, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, status, hword, bpart, t, b, nt4, (persistent_mode & 8) ? 1 : 0);
+            VOCR_CHECK_LAUNCH("vocr_lstm_bwd(k-owner, 4-row chains, wide members, self-validating)");
+            if (dbias) {
+                lstm_bias_combine_kernel<<<dim3(vocr_cdiv(4 * h, 256), 2), 256, 0, s>>>(bpart, dbias, 4 * h, nt4);
+                VOCR_CHECK_LAUNCH("vocr_lstm_bwd(bias combine)");
+            }
+            return VOCR_OK;
+        }
         if (selfval && !(selfval & 4) && 2 * nt4 <= 16 && !(persistent_mode & 32) && (h == 512 || h == 256) &&
             (2 * nt4 > 8 ? 16 : 8) * (h / 16) <= 2 * resident_workgroup_capacity()) {
             // 4-row chains; the ring of partial blocks starts as the "not written yet" pattern
