@@ -270,7 +270,7 @@ def _ref_bilstm(x, lens, params, H):
 
 
 @pytest.mark.parametrize("T,B,D,H,lens", [(20, 4, 32, 48, [20, 17, 9, 1]), (37, 32, 128, 256, None), (12, 40, 64, 32, None),
-                                          (9, 1, 16, 16, [9])])
+                                          (9, 1, 16, 16, [9]), (26, 22, 64, 512, None), (14, 6, 32, 512, None)])
 def test_bilstm_layer(dev, T, B, D, H, lens):
     from vistaocr_amd import ops
     if lens is None:
@@ -302,7 +302,7 @@ def test_bilstm_layer(dev, T, B, D, H, lens):
 
 
 @pytest.mark.parametrize("T,B,H", [(40, 20, 128), (25, 5, 64), (33, 32, 512), (12, 40, 256), (9, 64, 128), (21, 27, 256), (15, 7, 512),
-                                   (1, 1, 256), (2, 3, 512), (3, 64, 512)])
+                                   (1, 1, 256), (2, 3, 512), (3, 64, 512), (19, 21, 512), (7, 17, 512)])
 def test_persistent_sweeps_match_per_step_launches(dev, T, B, H):
     """Persistent sweeps (weights in registers; forward hand-off by self-validating payload on 4-row chains, or - VOCR_LSTM_SELFVAL=0 -
     by arrival flags on 8/16-row chains; backward by flags) against one launch per step: forward (y, gates, cell) and backward
@@ -427,7 +427,8 @@ def test_lstm_backward_bias_gradient_is_the_column_sum_of_dgates(dev, T, B, H):
     assert float((db.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-6       # fp32 summation-order tolerance
 
 
-@pytest.mark.parametrize("T,B,H,cut", [(40, 20, 128, 20), (33, 32, 512, 7), (12, 40, 256, 11), (25, 5, 64, 12), (21, 27, 256, 9)])
+@pytest.mark.parametrize("T,B,H,cut", [(40, 20, 128, 20), (33, 32, 512, 7), (12, 40, 256, 11), (25, 5, 64, 12), (21, 27, 256, 9), (19, 21, 512, 1),
+                                       (23, 13, 512, 21)])
 def test_lstm_forward_step_ranges_resume_bit_exactly(dev, T, B, H, cut):
     """vocr_lstm_fwd_range: steps [0, cut) then [cut, T) leave exactly what one whole sweep leaves (y, gates, cell)."""
     from vistaocr_amd import _lib
