@@ -40,6 +40,29 @@ int main(int argc, char** argv) {
         printf("wave %d, s_memtime ticks per step (total %.1f => one tick = %.2f ns):\n", w ? (eight ? 7 : 3) : 0, tot, ms * 1e6 / T / tot);
         for (int k = 0; k < 8; ++k) printf("   %-38s %8.1f  %5.1f %%\n", names[k], s[k], 100 * s[k] / tot);
     }
+    if (eight) {           // ---- backward sweep (lstm_bwd_chain4w): stamps land behind the forward ones
+        float *dyb, *wtf, *wtr, *dgt;
+        hipMalloc(&dyb, (size_t)T * B * 2 * H * 4); hipMalloc(&wtf, (size_t)4 * H * H * 4); hipMalloc(&wtr, (size_t)4 * H * H * 4); hipMalloc(&dgt, (size_t)2 * T * B * 4 * H * 4);
+        hipMemset(dyb, 0, (size_t)T * B * 2 * H * 4); hipMemset(wtf, 0, (size_t)4 * H * H * 4); hipMemset(wtr, 0, (size_t)4 * H * H * 4);
+        for (int rep = 0; rep < 3; ++rep) {
+            hipEventRecord(e0, nullptr);
+            int rc = vocr_lstm_bwd(dyb, wtf, wtr, lens, gates, cell, dgt, ws, T, B, H, nullptr, nullptr);
+            hipEventRecord(e1, nullptr); hipDeviceSynchronize(); hipEventElapsedTime(&ms, e0, e1);
+            if (rc) { printf("bwd rc %d\n", rc); return 1; }
+        }
+        std::vector<unsigned long long> hb(512 * 2 * 8);
+        hipMemcpy(hb.data(), dbg, 512 * 2 * 8 * 8, hipMemcpyDeviceToHost);
+        const char* bn[8] = {"partial blocks arrived (polls; waves 0, 1)", "sum + cell gradient + dgates out", "barrier", "LDS fragments + MFMA + partial stores issued",
+                             "-", "-", "-", "resets + loop top"};
+        printf("backward sweep %.3f ms = %.2f us per step\n", ms, ms * 1e3 / T);
+        for (int w = 0; w < 2; ++w) {
+            double s2[8] = {0}, tot = 0;
+            for (int b = 0; b < 256; ++b) for (int k = 0; k < 8; ++k) s2[k] += (double)hb[((256 + b) * 2 + w) * 8 + k] / 256 / T;
+            for (int k = 0; k < 8; ++k) tot += s2[k];
+            printf("wave %d, s_memtime ticks per step (total %.1f):\n", w ? 7 : 0, tot);
+            for (int k = 0; k < 8; ++k) printf("   %-46s %8.1f  %5.1f %%\n", bn[k], s2[k], 100 * s2[k] / tot);
+        }
+    }
     if (nwg == 512) {      // two workgroups per CU: do the two chains of an XCD (slot = bit 3 of the block index) progress alike?
         for (int slot = 0; slot < 2; ++slot) {
             double tot = 0, poll = 0; int n = 0;

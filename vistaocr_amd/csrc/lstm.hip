@@ -1587,7 +1587,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_chain4v(const float* __restrict_
                                                         const float* __restrict__ whht_r, const int32_t* __restrict__ lens,
                                                         const float* __restrict__ gates, const float* __restrict__ cell,
                                                         float* __restrict__ dgates, float* ring, unsigned* ids, unsigned* status,
-                                                        unsigned* health, float* bias_part, int T, int B, int NT4, int force_wt, int prio) {
+                                                        unsigned* health, float* bias_part, int T, int B, int NT4, int force_wt) {
     constexpr int H = 128 * NCH;
     constexpr int members = H / 16;
     constexpr int UW = H / 4;                         // units per wave
@@ -1656,40 +1656,60 @@ __global__ __launch_bounds__(256) void lstm_bwd_chain4v(const float* __restrict_
     for (int step = 0; step < T; ++step) {
         const int t = dir == 0 ? T - 1 - step : step;
         float* dgw = dgl + (step & 1) * 4 * DP;
+        float dg[4] = {0.f, 0.f, 0.f, 0.f};
         if (cellw) {
-            if (prio & 1) __builtin_amdgcn_s_setprio(3);
             const bool act = ev && t < len;
             const f32x4 gv = gv_n;
             const float c = c_n, cprev = cprev_n, dyv = dy_n;
+            float pv[members];
+            // this workgroup's block of every member's partials of the previous step
+            const int pbase = (((((step - 1) & 3) * nch + chain) * 32 + member) * 32 * 64 + lane) * 4;
+            if (step > 0) {
+#pragma unroll
+                for (int m = 0; m < members; ++m) pv[m] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(prsrc, pbase + m * 256, 0, kPollAux));
+            }
+            // everything that does not depend on dh_t is computed while the first round of block loads is in flight (tanh(c) is most
+            // of a cell's arithmetic; this section was 1740 of a step's 5760 ticks when it ran behind the polls):
+            // dc = dcar + dh*ka, dgates = dc*k0, dc*k1, dc*k2, dh*k3
+            const float tc = tanhf(c);
+            const float ka = gv[3] * (1.f - tc * tc);
+            const float k0 = gv[2] * gv[0] * (1.f - gv[0]), k1 = cprev * gv[1] * (1.f - gv[1]), k2 = gv[0] * (1.f - gv[2] * gv[2]);
+            const float k3 = tc * gv[3] * (1.f - gv[3]);
             float rs = 0.f;
             if (step > 0) {
-                // this workgroup's block of every member's partials of the previous step
-                const int pbase = (((((step - 1) & 3) * nch + chain) * 32 + member) * 32 * 64 + lane) * 4;
-                float pv[members];
                 unsigned spins = 0;
                 for (;;) {
-                    POLL_FENCE();
                     unsigned mx = 0u;
 #pragma unroll
-                    for (int m = 0; m < members; ++m) {
-                        const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(prsrc, pbase + m * 256, 0, kPollAux);
-                        pv[m] = __uint_as_float(v);
-                        mx = max(mx, v);
-                    }
+                    for (int m = 0; m < members; ++m) mx = max(mx, __float_as_uint(pv[m]));
                     if (__all(mx != kHandoffSentinel) || timed_out) break;
                     if (++spins > (1u << 22)) {
                         if (lane == 0) raise_timeout(status, health);
                         timed_out = true;
                         break;
                     }
-                }
+                    POLL_FENCE();
 #pragma unroll
-                for (int m = 0; m < members; ++m) rs += pv[m];
+                    for (int m = 0; m < members; ++m) pv[m] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(prsrc, pbase + m * 256, 0, kPollAux));
+                }
+                // fixed order: a balanced tree over the producers
+#pragma unroll
+                for (int w = 1; w < members; w *= 2)
+#pragma unroll
+                    for (int m = 0; m + w < members; m += 2 * w) pv[m] += pv[m + w];
+                rs = pv[0];
             }
-            if (step + 1 < T) fetch(step + 1);
-            float dg[4] = {0.f, 0.f, 0.f, 0.f};
-            if (act) dcar = lstm_cell_grad(dyv + rs, dcar, gv[0], gv[1], gv[2], gv[3], c, cprev, dg);
-            else dcar = 0.f;
+            if (act) {
+                const float dh = dyv + rs;
+                const float dc = dcar + dh * ka;
+                dg[0] = dc * k0;
+                dg[1] = dc * k1;
+                dg[2] = dc * k2;
+                dg[3] = dh * k3;
+                dcar = dc * gv[1];
+            } else {
+                dcar = 0.f;
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 if (dg[g] != dg[g]) dg[g] = __uint_as_float(0x7FC00000u);              // never the hand-off pattern
@@ -1697,19 +1717,22 @@ __global__ __launch_bounds__(256) void lstm_bwd_chain4v(const float* __restrict_
                 dg[0] = dg[1] = dg[2] = dg[3] = __uint_as_float(0x7FC00000u);        // a hand-off timed out: fail loudly
 #pragma unroll
             for (int g = 0; g < 4; ++g) dgw[erow * DP + g * 16 + ej] = dg[g];
+        } else {
+            __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): last step's resets are acknowledged before this step's barrier
+        }
+        __syncthreads();
+        if (cellw) {
+            // off the critical path (the other waves are already multiplying): next step's records, this step's dgates for the GEMMs
+            if (step + 1 < T) fetch(step + 1);
             if (ev) {
                 const long gbase = (((long)dir * T + t) * B + eb) * 4 * H + eunit;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    dgates[gbase + (long)g * H] = dg[g];     // for the weight/input-gradient GEMMs: plain stores
+                    dgates[gbase + (long)g * H] = dg[g];
                     bs[g] += dg[g];
                 }
             }
-        } else {
-            __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): last step's resets are acknowledged before this step's barrier
         }
-        if (prio & 1) __builtin_amdgcn_s_setprio(0);
-        __syncthreads();
         if (step + 1 < T) {
             // B operand: lane = (16-lane group g, .., row j = lane & 3): bv[q][e] = dgates[row j][k = 16q + 4g + e]
             f32x4 bv[4];
@@ -1840,41 +1863,66 @@ __global__ __launch_bounds__(512) void lstm_bwd_chain4w(const float* __restrict_
     };
     if (cellw) fetch(0);
 
+    LSTM_STAMP_DECL;
     for (int step = 0; step < T; ++step) {
         const int t = dir == 0 ? T - 1 - step : step;
         float* dgw = dgl + (step & 1) * 4 * DP;
+        LSTM_STAMP(7);
+        float dg[4] = {0.f, 0.f, 0.f, 0.f};
         if (cellw) {
             const bool act = ev && t < len;
             const f32x4 gv = gv_n;
             const float c = c_n, cprev = cprev_n, dyv = dy_n;
+            float pv[members];
+            // this workgroup's block of every member's partials of the previous step
+            const int pbase = (((((step - 1) & 3) * nch + chain) * 16 + member) * 16 * 128 + tid) * 4;
+            if (step > 0) {
+#pragma unroll
+                for (int m = 0; m < members; ++m) pv[m] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(prsrc, pbase + m * 512, 0, kPollAux));
+            }
+            // everything that does not depend on dh_t is computed while the first round of block loads is in flight (tanh(c) is most
+            // of a cell's arithmetic; this section was 1740 of a step's 5760 ticks when it ran behind the polls):
+            // dc = dcar + dh*ka, dgates = dc*k0, dc*k1, dc*k2, dh*k3
+            const float tc = tanhf(c);
+            const float ka = gv[3] * (1.f - tc * tc);
+            const float k0 = gv[2] * gv[0] * (1.f - gv[0]), k1 = cprev * gv[1] * (1.f - gv[1]), k2 = gv[0] * (1.f - gv[2] * gv[2]);
+            const float k3 = tc * gv[3] * (1.f - gv[3]);
             float rs = 0.f;
             if (step > 0) {
-                const int pbase = (((((step - 1) & 3) * nch + chain) * 16 + member) * 16 * 128 + tid) * 4;
-                float pv[members];
                 unsigned spins = 0;
                 for (;;) {
-                    POLL_FENCE();
                     unsigned mx = 0u;
 #pragma unroll
-                    for (int m = 0; m < members; ++m) {
-                        const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(prsrc, pbase + m * 512, 0, kPollAux);
-                        pv[m] = __uint_as_float(v);
-                        mx = max(mx, v);
-                    }
+                    for (int m = 0; m < members; ++m) mx = max(mx, __float_as_uint(pv[m]));
                     if (__all(mx != kHandoffSentinel) || timed_out) break;
                     if (++spins > (1u << 22)) {
                         if (lane == 0) raise_timeout(status, health);
                         timed_out = true;
                         break;
                     }
-                }
+                    POLL_FENCE();
 #pragma unroll
-                for (int m = 0; m < members; ++m) rs += pv[m];
+                    for (int m = 0; m < members; ++m) pv[m] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(prsrc, pbase + m * 512, 0, kPollAux));
+                }
+                LSTM_STAMP(0);      // partial blocks of the previous step arrived (polls)
+                // fixed order: a balanced tree over the producers
+#pragma unroll
+                for (int w = 1; w < members; w *= 2)
+#pragma unroll
+                    for (int m = 0; m + w < members; m += 2 * w) pv[m] += pv[m + w];
+                rs = pv[0];
             }
-            if (step + 1 < T) fetch(step + 1);
-            float dg[4] = {0.f, 0.f, 0.f, 0.f};
-            if (act) dcar = lstm_cell_grad(dyv + rs, dcar, gv[0], gv[1], gv[2], gv[3], c, cprev, dg);
-            else dcar = 0.f;
+            if (act) {
+                const float dh = dyv + rs;
+                const float dc = dcar + dh * ka;
+                dg[0] = dc * k0;
+                dg[1] = dc * k1;
+                dg[2] = dc * k2;
+                dg[3] = dh * k3;
+                dcar = dc * gv[1];
+            } else {
+                dcar = 0.f;
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 if (dg[g] != dg[g]) dg[g] = __uint_as_float(0x7FC00000u);              // never the hand-off pattern
@@ -1882,6 +1930,14 @@ __global__ __launch_bounds__(512) void lstm_bwd_chain4w(const float* __restrict_
                 dg[0] = dg[1] = dg[2] = dg[3] = __uint_as_float(0x7FC00000u);        // a hand-off timed out: fail loudly
 #pragma unroll
             for (int g = 0; g < 4; ++g) dgw[erow * DP + g * 32 + ej] = dg[g];
+        } else {
+            __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): last step's resets are acknowledged before this step's barrier
+        }
+        LSTM_STAMP(1);              // sum + cell gradient + dgates to LDS and memory (waves 0, 1)
+        __syncthreads();
+        if (cellw) {
+            // off the critical path (the other waves are already multiplying): next step's records, this step's dgates for the GEMMs
+            if (step + 1 < T) fetch(step + 1);
             if (ev) {
                 const long gbase = (((long)dir * T + t) * B + eb) * 4 * H + eunit;
 #pragma unroll
@@ -1890,10 +1946,8 @@ __global__ __launch_bounds__(512) void lstm_bwd_chain4w(const float* __restrict_
                     bs[g] += dg[g];
                 }
             }
-        } else {
-            __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): last step's resets are acknowledged before this step's barrier
         }
-        __syncthreads();
+        LSTM_STAMP(2);
         if (step + 1 < T) {
             // B operand: lane = (16-lane group g, row j = lane & 3): bv[q][e] = dgates[row j][k = 16q + 4g + e], q < 8
             f32x4 bv[8];
@@ -1918,6 +1972,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_chain4w(const float* __restrict_
             if (local) __builtin_amdgcn_raw_buffer_store_b128(raw, prsrc, soff, 0, 1);        // sc0: stays in this XCD's L2
             else __builtin_amdgcn_raw_buffer_store_b128(raw, prsrc, soff, 0, 16);            // write-through (sc1)
         }
+        LSTM_STAMP(3);              // LDS fragments + MFMA + partial stores issued
         if (!cellw && step > 0) {
             // the 16 blocks waves 0-1 consumed in front of the barrier go back to "not written yet" (8 KB, contiguous)
             const u32x4_t pat = {kHandoffSentinel, kHandoffSentinel, kHandoffSentinel, kHandoffSentinel};
@@ -1932,6 +1987,12 @@ __global__ __launch_bounds__(512) void lstm_bwd_chain4w(const float* __restrict_
             }
         }
     }
+#ifdef VOCR_LSTM_STAMPS
+    if (lane == 0 && (wave == 0 || wave == 7) && g_lstm_stamp_out) {
+        unsigned long long* o = g_lstm_stamp_out + ((size_t)(256 + blockIdx.x) * 2 + (wave == 7)) * 8;
+        for (int k = 0; k < 8; ++k) o[k] = st_acc[k];
+    }
+#endif
     if (bias_part) {
         __syncthreads();
         if (cellw) {
@@ -2174,11 +2235,10 @@ extern "C" int vocr_lstm_bwd_bias(const float* dy, const float* whht_fwd, const 
             float* bpart = dbias ? (float*)((char*)workspace + 4096 + ((size_t)16 << 20)) : nullptr;     // [chain][4H]
             const dim3 g4((nch > 8 ? 16 : 8) * (h / 16));
             const int fwt4 = (persistent_mode & 8) ? 1 : 0;
-            static const int prio4 = getenv("VOCR_LSTM_PRIO") ? atoi(getenv("VOCR_LSTM_PRIO")) : 0;
             if (h == 512)
-                lstm_bwd_chain4v<4><<<g4, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, status, hword, bpart, t, b, nt4, fwt4, prio4);
+                lstm_bwd_chain4v<4><<<g4, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, status, hword, bpart, t, b, nt4, fwt4);
             else
-                lstm_bwd_chain4v<2><<<g4, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, status, hword, bpart, t, b, nt4, fwt4, prio4);
+                lstm_bwd_chain4v<2><<<g4, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, status, hword, bpart, t, b, nt4, fwt4);
             VOCR_CHECK_LAUNCH("vocr_lstm_bwd(k-owner, 4-row chains, self-validating)");
             if (dbias) {
                 lstm_bias_combine_kernel<<<dim3(vocr_cdiv(4 * h, 256), 2), 256, 0, s>>>(bpart, dbias, 4 * h, nt4);
