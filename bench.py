@@ -105,8 +105,8 @@ FAMILY = {"vocr_conv3x3_fwd": "conv3x3 forward + data gradient (conv3x3_wino_ker
           "vocr_conv3x3_wgrad_wino": "conv3x3 weight gradient (conv3x3_wgrad_wino_dma_kernel)",
           "vocr_gemm": "dense GEMMs (gemm_dma_kernel / gemm_f32_kernel behind vocr_gemm and vocr_gemm_pair: bridge, LSTM projections, prob, their dX / dW)",
           "vocr_gemm_pair": "dense GEMMs (gemm_dma_kernel / gemm_f32_kernel behind vocr_gemm and vocr_gemm_pair: bridge, LSTM projections, prob, their dX / dW)",
-          "vocr_lstm_fwd": "LSTM sweeps (lstm_fwd_chain8 / lstm_bwd_kowner8)", "vocr_lstm_fwd_range": "LSTM sweeps (lstm_fwd_chain8 / lstm_bwd_kowner8)",
-          "vocr_lstm_bwd_bias": "LSTM sweeps (lstm_fwd_chain8 / lstm_bwd_kowner8)"}
+          "vocr_lstm_fwd": "LSTM sweeps (lstm_fwd_chain4w / lstm_bwd_chain4w)", "vocr_lstm_fwd_range": "LSTM sweeps (lstm_fwd_chain4w / lstm_bwd_chain4w)",
+          "vocr_lstm_bwd_bias": "LSTM sweeps (lstm_fwd_chain4w / lstm_bwd_chain4w)"}
 
 
 def gemm_alone(hidden, din=128):

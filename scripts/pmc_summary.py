@@ -86,7 +86,7 @@ FAMILIES = (      # bench.py's FAMILY names -> kernel-name prefixes
     ("conv3x3 forward + data gradient (conv3x3_wino_kernel / conv3x3_dma_kernel)", ("conv3x3_wino_kernel", "conv3x3_wino8_kernel", "conv3x3_dma_kernel", "conv3x3_kernel", "conv3x3_tail")),
     ("conv3x3 weight gradient (conv3x3_wgrad_wino_dma_kernel)", ("conv3x3_wgrad",)),
     ("dense GEMMs (gemm_dma_kernel / gemm_f32_kernel behind vocr_gemm and vocr_gemm_pair: bridge, LSTM projections, prob, their dX / dW)", ("gemm_dma_kernel", "gemm_f32_kernel")),
-    ("LSTM sweeps (lstm_fwd_chain8 / lstm_bwd_kowner8)", ("lstm_fwd_", "lstm_bwd_")),
+    ("LSTM sweeps (lstm_fwd_chain4w / lstm_bwd_chain4w)", ("lstm_fwd_", "lstm_bwd_")),
 )
 
 
