@@ -190,7 +190,8 @@ int vocr_dropout_fwd(const float* x, float* out, float* mask, size_t count, floa
  * hand h_t (forward) / partial sums (backward) to each other through memory: it needs its grid (<= two workgroups per CU)
  * co-resident, so do not run two sweeps concurrently on one device; a hand-off that times out (seconds) poisons the
  * output with NaN instead of hanging.  VOCR_LSTM_PERSISTENT=0 selects one launch per time step instead.
- * `health` (may be NULL): see the note on health words at the top; the timeout flag the sweep itself tests lives in the workspace. */
+ * `health` (may be NULL): see the note on health words at the top; the timeout flag the sweep itself tests lives in the workspace
+ * (an implementation detail: callers watch `health`). */
 size_t vocr_lstm_workspace_bytes(int t, int b, int h);
 int vocr_lstm_fwd(const float* xproj, const float* whh_fwd, const float* whh_rev, const int32_t* lens, float* y,
                   float* gates, float* cell, void* workspace, int t, int b, int h, int32_t* health, void* stream);

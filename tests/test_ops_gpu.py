@@ -324,12 +324,12 @@ def test_persistent_sweeps_match_per_step_launches(dev, T, B, H):
         "y = torch.empty(T * B, 2 * H, device=dev); gt = torch.empty(2, T * B, 4 * H, device=dev); c = torch.empty(2, T * B, H, device=dev)\n"
         "dg = torch.full((2, T * B, 4 * H), float('nan'), device=dev)\n"
         "ws = torch.zeros(lib.vocr_lstm_workspace_bytes(T, B, H) // 4 + 16, device=dev); s = torch.cuda.current_stream().cuda_stream\n"
-        "call('vocr_lstm_fwd', xp.data_ptr(), wf.data_ptr(), wr.data_ptr(), lens.data_ptr(), y.data_ptr(), gt.data_ptr(), c.data_ptr(), ws.data_ptr(), T, B, H, None, s)\n"
-        "torch.cuda.synchronize(); st = int(ws.view(torch.int32)[512])\n"
+        "hw = torch.zeros(4, dtype=torch.int32, device=dev)\n"          # the caller's health word: a hand-off time-out is reported there
+        "call('vocr_lstm_fwd', xp.data_ptr(), wf.data_ptr(), wr.data_ptr(), lens.data_ptr(), y.data_ptr(), gt.data_ptr(), c.data_ptr(), ws.data_ptr(), T, B, H, hw.data_ptr(), s)\n"
         "if H >= 128:\n"
         "    wtf, wtr = ops.transpose2d(wf), ops.transpose2d(wr)\n"
-        "    call('vocr_lstm_bwd', dy.data_ptr(), wtf.data_ptr(), wtr.data_ptr(), lens.data_ptr(), gt.data_ptr(), c.data_ptr(), dg.data_ptr(), ws.data_ptr(), T, B, H, None, s)\n"
-        "    torch.cuda.synchronize(); st |= int(ws.view(torch.int32)[512]) if int(sys.argv[2]) & 2 else 0\n"
+        "    call('vocr_lstm_bwd', dy.data_ptr(), wtf.data_ptr(), wtr.data_ptr(), lens.data_ptr(), gt.data_ptr(), c.data_ptr(), dg.data_ptr(), ws.data_ptr(), T, B, H, hw.data_ptr(), s)\n"
+        "torch.cuda.synchronize(); st = int(hw[0])\n"
         "print('STATUS', st); torch.save((y.cpu(), gt.cpu(), c.cpu(), dg.cpu()), sys.argv[1])\n"
     ) % (root, T, B, H)
     outs = []

@@ -340,14 +340,19 @@ __device__ __forceinline__ unsigned xcc_id() {
 // A hand-off timed out: the poison decision of THIS sweep reads the per-call status word (workspace, zeroed by the host's
 // memset in front of every launch); the caller's health word only collects the event for reporting.  (The sweeps used to
 // test the caller's sticky word itself: one transient timeout then NaN-poisoned every later sweep of the process.)
+constexpr unsigned kHandoffSentinel = 0xFFFFFFFFu;      // "not written yet" (see the self-validating hand-off below)
+
 __device__ __forceinline__ void raise_timeout(unsigned* status, unsigned* health) {
     __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (health) __hip_atomic_store(health, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Returns true iff all `members` workgroups of this chain report the same XCC id.  ids: one word per member, zeroed
-// by the host.  Called by every thread of the workgroup; scratch is one LDS word.
-__device__ __forceinline__ bool chain_is_xcd_local(unsigned* ids, int members, int member, unsigned* status, unsigned* health, unsigned* scratch) {
+// Returns true iff all `members` workgroups of this chain report the same XCC id.  ids: one word per member, set to
+// `unwritten` by the host (0 for the flag sweeps; 0xFFFFFFFF for the self-validating ones, whose ids, status word and ring
+// are ONE 0xFF fill - a 2-KB fill of its own in front of every sweep was a kernel launch on the step's critical path).
+// Called by every thread of the workgroup; scratch is one LDS word.
+__device__ __forceinline__ bool chain_is_xcd_local(unsigned* ids, int members, int member, unsigned* status, unsigned* health, unsigned* scratch,
+                                                   unsigned unwritten = 0u) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned mine = xcc_id() + 1u;
     if (tid == 0) __hip_atomic_store(ids + member, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -357,7 +362,7 @@ __device__ __forceinline__ bool chain_is_xcd_local(unsigned* ids, int members, i
         for (;;) {
             unsigned v = mine;
             if (lane < members) v = __hip_atomic_load(ids + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__all(v != 0u)) { same = __all(v == mine); break; }
+            if (__all(v != unwritten)) { same = __all(v == mine); break; }
             __builtin_amdgcn_s_sleep(2);
             if (++spins > (1u << 22)) {
                 if (lane == 0) raise_timeout(status, health);
@@ -514,7 +519,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_chain(const float* __restrict__ 
                 cell[sidx] = 0.f;
                 cstate = 0.f;
             }
-            if (step == s1 - 1 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+            if (step == s1 - 1 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u)
                 h = __uint_as_float(0x7FC00000u);                                        // a hand-off timed out: fail loudly
             if (local) __hip_atomic_store(yo, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // stays in this XCD's L2
             else __hip_atomic_store(yo, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                // write-through (sc1)
@@ -699,7 +704,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_chain8(const float* __restrict__
                 cell[sidx] = 0.f;
                 cstate = 0.f;
             }
-            if (step == s1 - 1 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+            if (step == s1 - 1 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u)
                 h = __uint_as_float(0x7FC00000u);                                        // a hand-off timed out: fail loudly
             if (local) __hip_atomic_store(yo, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // stays in this XCD's L2
             else __hip_atomic_store(yo, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                // write-through (sc1)
@@ -734,7 +739,6 @@ __device__ __forceinline__ void static_for(F&& f) {
 // stores.  Against the flag protocol of lstm_fwd_chain8 (flag poll and h loads = two L2 round trips in series, plus a store drain
 // + barrier + flag store on the producing side): no flags, no drain, two barriers per step instead of four, and a wave starts its
 // MFMAs as soon as its own k-slice has arrived.
-constexpr unsigned kHandoffSentinel = 0xFFFFFFFFu;
 // cache policy of a polling load: sc1 (never served from the CU's vector L1, which may hold the line from an earlier look or
 // from the slot's previous use).  Every polling loop opens with POLL_FENCE: to the compiler the load is loop-invariant, and
 // without a memory clobber in the loop it hoists the load and a poll that fails once spins on the same registers until it
@@ -779,7 +783,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_chain4v(const float* __restrict_
     const int nrows = min(B - b0, 4);
     const int kbase = wave * KW;
     const float* whh = dir ? whh_r : whh_f;
-    const bool local = chain_is_xcd_local(ids + chain * 32, members, member, status, health, (unsigned*)(lds + 4 * 4 * 65)) && !force_wt;
+    const bool local = chain_is_xcd_local(ids + chain * 32, members, member, status, health, (unsigned*)(lds + 4 * 4 * 65), kHandoffSentinel) && !force_wt;
 
     // resident B operand: lane = gate column (gate, local unit) = (lane >> 4, lane & 15), the wave's KW k
     f32x4 wv[NL];
@@ -914,7 +918,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_chain4v(const float* __restrict_
             }
             cstate = c;
             if (h != h) h = __uint_as_float(0x7FC00000u);                                // never the hand-off pattern
-            if (step == s1 - 1 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+            if (step == s1 - 1 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u)
                 h = __uint_as_float(0x7FC00000u);                                        // a hand-off timed out: fail loudly
             float* xo = hx + ((long)((step & 3) * nch + chain) * 4 * H + (member * 4 + bl) * 16 + cu);
             float* xr = hx + ((long)(((step - 2) & 3) * nch + chain) * 4 * H + (member * 4 + bl) * 16 + cu);
@@ -972,7 +976,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_chain4w(const float* __restrict_
     const int nrows = min(B - b0, 4);
     const int kbase = wave * KW;
     const float* whh = dir ? whh_r : whh_f;
-    const bool local = chain_is_xcd_local(ids + chain * 32, members, member, status, health, (unsigned*)(lds + 8 * 4 * RP)) && !force_wt;
+    const bool local = chain_is_xcd_local(ids + chain * 32, members, member, status, health, (unsigned*)(lds + 8 * 4 * RP), kHandoffSentinel) && !force_wt;
 
     // resident B operand: column 64*cb + lane of the workgroup's 128 = (gate, local unit) = (col >> 5, col & 31)
     f32x4 wv[2][NL];
@@ -1091,7 +1095,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_chain4w(const float* __restrict_
             }
             cstate = c;
             if (h != h) h = __uint_as_float(0x7FC00000u);                                // never the hand-off pattern
-            if (step == s1 - 1 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+            if (step == s1 - 1 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u)
                 h = __uint_as_float(0x7FC00000u);                                        // a hand-off timed out: fail loudly
             float* xo = hx + ((long)((step & 3) * nch + chain) * 4 * H + (member * 4 + crow) * 32 + cu);
             float* xr = hx + ((long)(((step - 2) & 3) * nch + chain) * 4 * H + (member * 4 + crow) * 32 + cu);
@@ -1335,7 +1339,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kowner(const float* __restrict__
         float dg[4] = {0.f, 0.f, 0.f, 0.f};
         if (act) dcar = lstm_cell_grad(dyv + rs, dcar, ig, fg, gg, og, c, cprev, dg);
         else dcar = 0.f;
-        if (step == T - 1 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+        if (step == T - 1 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u)
             dg[0] = dg[1] = dg[2] = dg[3] = __uint_as_float(0x7FC00000u);        // a hand-off timed out: fail loudly
         if (ev) {
             const long gbase = (((long)dir * T + t) * B + eb) * 4 * H + eunit;
@@ -1485,7 +1489,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_kowner8(const float* __restrict_
             float dg[4] = {0.f, 0.f, 0.f, 0.f};
             if (act) dcar = lstm_cell_grad(dyv + rs, dcar, ig, fg, gg, og, c, cprev, dg);
             else dcar = 0.f;
-            if (step == T - 1 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+            if (step == T - 1 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u)
                 dg[0] = dg[1] = dg[2] = dg[3] = __uint_as_float(0x7FC00000u);        // a hand-off timed out: fail loudly
             if (ev) {
                 const long gbase = (((long)dir * T + t) * B + eb) * 4 * H + eunit;
@@ -1600,7 +1604,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_chain4v(const float* __restrict_
     if (chain >= nch) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int dir = chain / NT4, bt = chain % NT4, unit0 = member * 16, b0 = bt * 4;
-    const bool local = chain_is_xcd_local(ids + chain * 32, members, member, status, health, (unsigned*)(dgl + 2 * 4 * DP)) && !force_wt;
+    const bool local = chain_is_xcd_local(ids + chain * 32, members, member, status, health, (unsigned*)(dgl + 2 * 4 * DP), kHandoffSentinel) && !force_wt;
 
     // resident A operand: lane = unit u of the wave's column block cb; aw[cb][gate][i][e] = W_hh[gate*H + unit0 + 4i + e][u]
     f32x4 aw[NCB][4][4];
@@ -1713,7 +1717,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_chain4v(const float* __restrict_
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 if (dg[g] != dg[g]) dg[g] = __uint_as_float(0x7FC00000u);              // never the hand-off pattern
-            if (step == T - 1 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+            if (step == T - 1 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u)
                 dg[0] = dg[1] = dg[2] = dg[3] = __uint_as_float(0x7FC00000u);        // a hand-off timed out: fail loudly
 #pragma unroll
             for (int g = 0; g < 4; ++g) dgw[erow * DP + g * 16 + ej] = dg[g];
@@ -1816,7 +1820,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_chain4w(const float* __restrict_
     if (chain >= nch) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int dir = chain / NT4, bt = chain % NT4, unit0 = member * 32, b0 = bt * 4;
-    const bool local = chain_is_xcd_local(ids + chain * 32, members, member, status, health, (unsigned*)(dgl + 2 * 4 * DP)) && !force_wt;
+    const bool local = chain_is_xcd_local(ids + chain * 32, members, member, status, health, (unsigned*)(dgl + 2 * 4 * DP), kHandoffSentinel) && !force_wt;
 
     // resident A operand: lane = unit u = 64*wave + lane; aw[gate][i][e] = W_hh[gate*H + unit0 + 4i + e][u], i < 8
     f32x4 aw[4][8];
@@ -1926,7 +1930,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_chain4w(const float* __restrict_
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 if (dg[g] != dg[g]) dg[g] = __uint_as_float(0x7FC00000u);              // never the hand-off pattern
-            if (step == T - 1 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+            if (step == T - 1 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u)
                 dg[0] = dg[1] = dg[2] = dg[3] = __uint_as_float(0x7FC00000u);        // a hand-off timed out: fail loudly
 #pragma unroll
             for (int g = 0; g < 4; ++g) dgw[erow * DP + g * 32 + ej] = dg[g];
@@ -2050,6 +2054,17 @@ int resident_workgroup_capacity() {
 
 }  // namespace
 
+// The self-validating forward sweeps keep a 4-KB block [XCC ids 512 words | status word | ...] directly in front of their hand-off
+// ring, so that one 0xFF fill prepares all three.
+static int lstm_fwd_selfval_prep(void* block, size_t ring_bytes, bool first_range, hipStream_t s) {
+    // a later range of a sweep keeps the ring, but its workgroups may sit on other CUs: the ids (and the status word) start over
+    if (hipMemsetAsync(block, 0xFF, first_range ? 4096 + ring_bytes : 4096, s) != hipSuccess) {
+        vocr_set_error("vocr_lstm_fwd: memset failed");
+        return VOCR_ELAUNCH;
+    }
+    return VOCR_OK;
+}
+
 static size_t lstm_ws_handoff_offset(int b, int h) {
     const size_t o = (size_t)6 * 2 * b * h * sizeof(float) + 4096 + ((size_t)16 << 20) + (size_t)16 * 4 * h * sizeof(float) +
                      (size_t)64 * 4 * h * sizeof(float);
@@ -2064,7 +2079,7 @@ extern "C" size_t vocr_lstm_workspace_bytes(int t, int b, int h) {
     // + 64 partial rows [4H] for the fixed-order column sums of the bias gradient (paths without in-sweep accumulation)
     // + the forward chain sweep's hand-off ring [4 step slots][16 chains][4 rows][H] (must survive from one vocr_lstm_fwd_range
     //   call of a sweep to the next)
-    return lstm_ws_handoff_offset(b, h) + (size_t)4 * 16 * 4 * h * sizeof(float);
+    return lstm_ws_handoff_offset(b, h) + 4096 + (size_t)4 * 16 * 4 * h * sizeof(float);
 }
 
 extern "C" int vocr_lstm_fwd_range(const float* xproj, const float* whh_fwd, const float* whh_rev, const int32_t* lens, float* y,
@@ -2089,10 +2104,6 @@ extern "C" int vocr_lstm_fwd_range(const float* xproj, const float* whh_fwd, con
         // the sweep's own status word is per call (zeroed here); a timeout is also reported in the caller's health word
         unsigned* status = flags + 512;
         unsigned* hword = (unsigned*)health;
-        if (hipMemsetAsync(flags, 0, 520 * sizeof(unsigned), s) != hipSuccess) {
-            vocr_set_error("vocr_lstm_fwd: memset failed");
-            return VOCR_ELAUNCH;
-        }
         const dim3 cg(8 * (h / 16));
         const int fwt = (persistent_mode & 8) ? 1 : 0;       // experiments: write-through hand-off even on one XCD
         const int nt8 = (b + 7) / 8;
@@ -2101,28 +2112,28 @@ extern "C" int vocr_lstm_fwd_range(const float* xproj, const float* whh_fwd, con
         static const int nap4w = getenv("VOCR_LSTM_NAP") ? atoi(getenv("VOCR_LSTM_NAP")) : 0;      // -1: polls start at once (experiments)
         if (selfval && !(selfval & 8) && h == 512 && nt4 > 4 && nt4 <= 8 && !(persistent_mode & 32) && 256 <= resident_workgroup_capacity()) {
             // 16 < B <= 32: 4-row chains of 16 wide members, one 8-wave workgroup per CU
-            float* hx = (float*)((char*)workspace + lstm_ws_handoff_offset(b, h));
-            if (step_begin == 0 && hipMemsetAsync(hx, 0xFF, (size_t)4 * 2 * nt4 * 4 * h * sizeof(float), s) != hipSuccess) {
-                vocr_set_error("vocr_lstm_fwd: memset failed");
-                return VOCR_ELAUNCH;
-            }
-            lstm_fwd_chain4w<8><<<256, 512, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, hx, flags, status, hword, t, b, nt4, fwt, step_begin, step_end, nap4w);
+            unsigned* blk = (unsigned*)((char*)workspace + lstm_ws_handoff_offset(b, h));
+            float* hx = (float*)(blk + 1024);
+            if (lstm_fwd_selfval_prep(blk, (size_t)4 * 2 * nt4 * 4 * h * sizeof(float), step_begin == 0, s) != VOCR_OK) return VOCR_ELAUNCH;
+            lstm_fwd_chain4w<8><<<256, 512, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, hx, blk, blk + 512, hword, t, b, nt4, fwt, step_begin, step_end, nap4w);
             VOCR_CHECK_LAUNCH("vocr_lstm_fwd(4-row chains, wide members, self-validating)");
             return VOCR_OK;
         }
         if (selfval && 2 * nt4 <= 16 && !(persistent_mode & 32) && (h == 512 || h == 256) &&
             (2 * nt4 > 8 ? 16 : 8) * (h / 16) <= 2 * resident_workgroup_capacity()) {
             // 4-row chains; the hand-off buffer starts as the "not written yet" pattern (first range of a sweep only)
-            float* hx = (float*)((char*)workspace + lstm_ws_handoff_offset(b, h));
-            if (step_begin == 0 && hipMemsetAsync(hx, 0xFF, (size_t)4 * 2 * nt4 * 4 * h * sizeof(float), s) != hipSuccess) {
-                vocr_set_error("vocr_lstm_fwd: memset failed");
-                return VOCR_ELAUNCH;
-            }
+            unsigned* blk = (unsigned*)((char*)workspace + lstm_ws_handoff_offset(b, h));
+            float* hx = (float*)(blk + 1024);
+            if (lstm_fwd_selfval_prep(blk, (size_t)4 * 2 * nt4 * 4 * h * sizeof(float), step_begin == 0, s) != VOCR_OK) return VOCR_ELAUNCH;
             const dim3 cg4((2 * nt4 > 8 ? 16 : 8) * (h / 16));
-            if (h == 512) lstm_fwd_chain4v<8><<<cg4, 256, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, hx, flags, status, hword, t, b, nt4, fwt, step_begin, step_end);
-            else lstm_fwd_chain4v<4><<<cg4, 256, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, hx, flags, status, hword, t, b, nt4, fwt, step_begin, step_end);
+            if (h == 512) lstm_fwd_chain4v<8><<<cg4, 256, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, hx, blk, blk + 512, hword, t, b, nt4, fwt, step_begin, step_end);
+            else lstm_fwd_chain4v<4><<<cg4, 256, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, hx, blk, blk + 512, hword, t, b, nt4, fwt, step_begin, step_end);
             VOCR_CHECK_LAUNCH("vocr_lstm_fwd(chain, 4-row, self-validating)");
             return VOCR_OK;
+        }
+        if (hipMemsetAsync(flags, 0, 520 * sizeof(unsigned), s) != hipSuccess) {
+            vocr_set_error("vocr_lstm_fwd: memset failed");
+            return VOCR_ELAUNCH;
         }
         if (2 * nt8 <= 8 && !(persistent_mode & 32) && (h == 512 || h == 256)) {      // 8-row chains on all 8 XCDs, 4x4x1 MFMA
             if (h == 512)
@@ -2198,10 +2209,6 @@ extern "C" int vocr_lstm_bwd_bias(const float* dy, const float* whht_fwd, const 
         unsigned* flags = (unsigned*)workspace;
         unsigned* status = flags + 512;
         unsigned* hword = (unsigned*)health;
-        if (hipMemsetAsync(flags, 0, 520 * sizeof(unsigned), s) != hipSuccess) {
-            vocr_set_error("vocr_lstm_bwd: memset failed");
-            return VOCR_ELAUNCH;
-        }
         const dim3 g(8 * (h / 16));
         // K-owner form: partial sums [parity][chain][consumer][producer][16 x 16] behind the flags/status words
         float* partials = (float*)((char*)workspace + 4096);
@@ -2211,7 +2218,8 @@ extern "C" int vocr_lstm_bwd_bias(const float* dy, const float* whht_fwd, const 
         if (selfval && !(selfval & 4) && !(selfval & 16) && h == 512 && nt4 > 4 && nt4 <= 8 && !(persistent_mode & 32) && 256 <= resident_workgroup_capacity()) {
             // 16 < B <= 32: 4-row chains of 16 wide members, one 8-wave workgroup per CU
             const int nch = 2 * nt4;
-            if (hipMemsetAsync(partials, 0xFF, (size_t)4 * nch * 16 * 16 * 512, s) != hipSuccess) {
+            // one fill: [XCC ids | status word | ... 4 KB][ring]
+            if (hipMemsetAsync(flags, 0xFF, 4096 + (size_t)4 * nch * 16 * 16 * 512, s) != hipSuccess) {
                 vocr_set_error("vocr_lstm_bwd: memset failed");
                 return VOCR_ELAUNCH;
             }
@@ -2228,7 +2236,7 @@ extern "C" int vocr_lstm_bwd_bias(const float* dy, const float* whht_fwd, const 
             (2 * nt4 > 8 ? 16 : 8) * (h / 16) <= 2 * resident_workgroup_capacity()) {
             // 4-row chains; the ring of partial blocks starts as the "not written yet" pattern
             const int nch = 2 * nt4;
-            if (hipMemsetAsync(partials, 0xFF, (size_t)4 * nch * 32 * 32 * 256, s) != hipSuccess) {
+            if (hipMemsetAsync(flags, 0xFF, 4096 + (size_t)4 * nch * 32 * 32 * 256, s) != hipSuccess) {
                 vocr_set_error("vocr_lstm_bwd: memset failed");
                 return VOCR_ELAUNCH;
             }
@@ -2245,6 +2253,10 @@ extern "C" int vocr_lstm_bwd_bias(const float* dy, const float* whht_fwd, const 
                 VOCR_CHECK_LAUNCH("vocr_lstm_bwd(bias combine)");
             }
             return VOCR_OK;
+        }
+        if (hipMemsetAsync(flags, 0, 520 * sizeof(unsigned), s) != hipSuccess) {
+            vocr_set_error("vocr_lstm_bwd: memset failed");
+            return VOCR_ELAUNCH;
         }
         if (2 * nt8 <= 8 && !(persistent_mode & 32) && (h == 512 || h == 256)) {      // 8-row chains on all 8 XCDs, 4x4x1 MFMA
             const int fwt8 = (persistent_mode & 8) ? 1 : 0;
