@@ -210,6 +210,17 @@ int vocr_lstm_bwd(const float* dy, const float* whht_fwd, const float* whht_rev,
 int vocr_lstm_bwd_bias(const float* dy, const float* whht_fwd, const float* whht_rev, const int32_t* lens, const float* gates,
                        const float* cell, float* dgates, float* dbias, void* workspace, int t, int b, int h, int32_t* health,
                        void* stream);
+/* The same sweep for a caller that overlaps: (1) `dy_mask` (NULL: none): dy is multiplied element-wise by it as it is read - the
+ * backward of nn.LSTM's inter-layer dropout (src/train_cnn_lstm.py:331: the mask that scaled this layer's output) without a pass of
+ * its own; (2) the bias gradient stays as per-chain partial rows in the workspace and vocr_lstm_bias_from_parts finishes it on ANY
+ * stream ordered behind this call (the workspace must live until then) - so the data-gradient GEMM that follows the sweep on the
+ * critical path does not queue behind a reduction nobody downstream reads.  Only for shapes the self-validating 4-row sweeps cover:
+ * ask vocr_lstm_bwd_parts_supported (else use vocr_lstm_bwd_bias). */
+int vocr_lstm_bwd_parts_supported(int t, int b, int h);
+int vocr_lstm_bwd_parts(const float* dy, const float* dy_mask, const float* whht_fwd, const float* whht_rev, const int32_t* lens,
+                        const float* gates, const float* cell, float* dgates, void* workspace, int t, int b, int h,
+                        int32_t* health, void* stream);
+int vocr_lstm_bias_from_parts(float* dbias, const void* workspace, int t, int b, int h, void* stream);
 
 /* ---- CTC: warpctc_pytorch.CTCLoss — src/train_cnn_lstm.py:358,138 ------------------------------------------ */
 /* logits[T][B][V] pre-softmax, blank = 0.  labels flat int32 (device), label_offsets[B], label_lens[B],

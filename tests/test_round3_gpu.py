@@ -255,3 +255,40 @@ def test_profile_ranges_are_harmless_and_balanced():
     env = dict(os.environ, VOCR_ROCTX="1")
     r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "smoke ok" in r.stdout, r.stderr[-1500:]
+
+
+@pytest.mark.parametrize("T,B,H", [(21, 32, 512), (17, 9, 512), (13, 30, 256), (9, 40, 128)])
+def test_dropout_inside_the_layer_op_equals_the_separate_op(T, B, H):
+    """BiLstmLayerFn with its output dropout drawn inside - with the backward mask as a multiply of its own, and (VOCR_LSTM_BWD_PARTS=1)
+    riding on the sweep's read of dy with the bias gradient's last reduction beside the weight gradients (vocr_lstm_bwd_parts /
+    vocr_lstm_bias_from_parts) - == the plain layer followed by DropoutFn: same mask function, same products - bit for bit, outputs
+    and every gradient."""
+    from vistaocr_amd import ops
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(5)
+    D = 64
+    x0 = ((torch.rand(T * B, D, generator=g) - 0.5)).to(dev)
+    lens = torch.tensor(sorted([max(1, T - (i * T) // (B + 2)) for i in range(B)], reverse=True), dtype=torch.int32, device=dev)
+    shapes = [(4 * H, D), (4 * H, H), (4 * H,), (4 * H,)] * 2
+    params0 = [((torch.rand(*sh, generator=g) - 0.5) * 0.2).to(dev) for sh in shapes]
+    dout = ((torch.rand(T * B, 2 * H, generator=g) - 0.5)).to(dev)
+    res = []
+    for fused in (True, "parts", False):
+        os.environ["VOCR_LSTM_BWD_PARTS"] = "1" if fused == "parts" else "0"
+        x = x0.clone().requires_grad_(True)
+        ps = [p.clone().requires_grad_(True) for p in params0]
+        if fused:
+            out = ops.BiLstmLayerFn.apply(x, lens, T, B, *ps, None, True, 0.5, 1234)
+        else:
+            out = ops.DropoutFn.apply(ops.BiLstmLayerFn.apply(x, lens, T, B, *ps), 0.5, 1234)
+        out.backward(dout)
+        ops.join_side_stream(dev)
+        torch.cuda.synchronize()
+        res.append([out.detach().cpu(), x.grad.cpu()] + [p.grad.cpu() for p in ps])
+    os.environ.pop("VOCR_LSTM_BWD_PARTS", None)
+    ops.check_health_sync(dev)
+    names = ["out", "dx", "dW_ih", "dW_hh", "db_ih", "db_hh", "dW_ih_r", "dW_hh_r", "db_ih_r", "db_hh_r"]
+    for other in res[:2]:
+        for nm, a, b in zip(names, other, res[2]):
+            assert torch.equal(a, b), "%s differs: max |diff| %.3e" % (nm, float((a - b).abs().max()))
+    assert float((res[0][0] == 0).float().mean()) > 0.3          # the mask did drop

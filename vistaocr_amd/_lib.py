@@ -64,6 +64,9 @@ SIGNATURES = {
     "vocr_lstm_fwd_range": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, P, P]),
     "vocr_lstm_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, P, P]),
     "vocr_lstm_bwd_bias": (I, [P, P, P, P, P, P, P, P, P, I, I, I, P, P]),
+    "vocr_lstm_bwd_parts_supported": (I, [I, I, I]),
+    "vocr_lstm_bwd_parts": (I, [P, P, P, P, P, P, P, P, P, I, I, I, P, P]),
+    "vocr_lstm_bias_from_parts": (I, [P, P, I, I, I, P]),
     "vocr_ctc_workspace_bytes": (Z, [I, I, I, I]),
     "vocr_ctc_loss_grad": (I, [P, P, P, P, P, P, P, P, I, I, I, I, P]),
     "vocr_argmax_rows": (I, [P, P, P, I, I, P]),

@@ -1590,7 +1590,7 @@ template <int NCH>
 __global__ __launch_bounds__(256) void lstm_bwd_chain4v(const float* __restrict__ dy, const float* __restrict__ whht_f,
                                                         const float* __restrict__ whht_r, const int32_t* __restrict__ lens,
                                                         const float* __restrict__ gates, const float* __restrict__ cell,
-                                                        float* __restrict__ dgates, float* ring, unsigned* ids, unsigned* status,
+                                                        const float* __restrict__ dy_mask, float* __restrict__ dgates, float* ring, unsigned* ids, unsigned* status,
                                                         unsigned* health, float* bias_part, int T, int B, int NT4, int force_wt) {
     constexpr int H = 128 * NCH;
     constexpr int members = H / 16;
@@ -1652,7 +1652,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_chain4v(const float* __restrict_
             c_n = cell[sidx];
             const int tp = dir == 0 ? tt - 1 : tt + 1;
             if (tp >= 0 && tp < len) cprev_n = cell[(((long)dir * T + tp) * B + ebs) * H + eunit];
-            dy_n = dy[((long)tt * B + ebs) * 2 * H + dir * H + eunit];
+            const long di = ((long)tt * B + ebs) * 2 * H + dir * H + eunit;
+            dy_n = dy[di];
+            if (dy_mask) dy_n *= dy_mask[di];         // the inter-layer dropout's backward, fused into the read
         }
     };
     if (cellw) fetch(0);
@@ -1808,7 +1810,7 @@ template <int NCH>
 __global__ __launch_bounds__(512) void lstm_bwd_chain4w(const float* __restrict__ dy, const float* __restrict__ whht_f,
                                                         const float* __restrict__ whht_r, const int32_t* __restrict__ lens,
                                                         const float* __restrict__ gates, const float* __restrict__ cell,
-                                                        float* __restrict__ dgates, float* ring, unsigned* ids, unsigned* status,
+                                                        const float* __restrict__ dy_mask, float* __restrict__ dgates, float* ring, unsigned* ids, unsigned* status,
                                                         unsigned* health, float* bias_part, int T, int B, int NT4, int force_wt) {
     constexpr int H = 128 * NCH;
     static_assert(H == 512, "8 waves x 64 units");
@@ -1862,7 +1864,9 @@ __global__ __launch_bounds__(512) void lstm_bwd_chain4w(const float* __restrict_
             c_n = cell[sidx];
             const int tp = dir == 0 ? tt - 1 : tt + 1;
             if (tp >= 0 && tp < len) cprev_n = cell[(((long)dir * T + tp) * B + ebs) * H + eunit];
-            dy_n = dy[((long)tt * B + ebs) * 2 * H + dir * H + eunit];
+            const long di = ((long)tt * B + ebs) * 2 * H + dir * H + eunit;
+            dy_n = dy[di];
+            if (dy_mask) dy_n *= dy_mask[di];         // the inter-layer dropout's backward, fused into the read
         }
     };
     if (cellw) fetch(0);
@@ -2192,9 +2196,51 @@ static int lstm_bias_by_colsum(const float* dgates, float* dbias, void* workspac
     return VOCR_OK;
 }
 
+// which self-validating backward sweep (if any) a shape gets: 2 = wide members, 1 = 4-row chains, 0 = another path
+static int lstm_bwd_selfval_kind(int b, int h) {
+    static const int persistent_mode = getenv("VOCR_LSTM_PERSISTENT") ? atoi(getenv("VOCR_LSTM_PERSISTENT")) : 3;
+    static const int selfval = getenv("VOCR_LSTM_SELFVAL") ? atoi(getenv("VOCR_LSTM_SELFVAL")) : 1;
+    if (!(persistent_mode & 2) || (persistent_mode & 32) || !selfval || (selfval & 4) || b <= 0 || 8 * (h / 16) > resident_workgroup_capacity()) return 0;
+    const int nt4 = (b + 3) / 4;
+    if (!(selfval & 16) && h == 512 && nt4 > 4 && nt4 <= 8 && 256 <= resident_workgroup_capacity()) return 2;
+    if (2 * nt4 <= 16 && (h == 512 || h == 256) && (2 * nt4 > 8 ? 16 : 8) * (h / 16) <= 2 * resident_workgroup_capacity()) return 1;
+    return 0;
+}
+
+static int lstm_bwd_impl(const float* dy, const float* dy_mask, const float* whht_fwd, const float* whht_rev, const int32_t* lens,
+                         const float* gates, const float* cell, float* dgates, float* dbias, bool combine, void* workspace, int t,
+                         int b, int h, int32_t* health, void* stream);
+
 extern "C" int vocr_lstm_bwd_bias(const float* dy, const float* whht_fwd, const float* whht_rev, const int32_t* lens,
                                   const float* gates, const float* cell, float* dgates, float* dbias, void* workspace, int t,
                                   int b, int h, int32_t* health, void* stream) {
+    return lstm_bwd_impl(dy, nullptr, whht_fwd, whht_rev, lens, gates, cell, dgates, dbias, true, workspace, t, b, h, health, stream);
+}
+
+extern "C" int vocr_lstm_bwd_parts_supported(int t, int b, int h) {
+    return t > 0 && lstm_bwd_selfval_kind(b, h) != 0 ? 1 : 0;
+}
+
+extern "C" int vocr_lstm_bwd_parts(const float* dy, const float* dy_mask, const float* whht_fwd, const float* whht_rev, const int32_t* lens,
+                                   const float* gates, const float* cell, float* dgates, void* workspace, int t, int b, int h,
+                                   int32_t* health, void* stream) {
+    VOCR_CHECK_ARG(vocr_lstm_bwd_parts_supported(t, b, h), "vocr_lstm_bwd_parts: no fused path for T=%d B=%d H=%d (ask vocr_lstm_bwd_parts_supported)", t, b, h);
+    VOCR_CHECK_ARG(aligned16(whht_fwd) && aligned16(whht_rev) && aligned16(dgates) && aligned16(gates), "vocr_lstm_bwd_parts: 16-byte alignment");
+    return lstm_bwd_impl(dy, dy_mask, whht_fwd, whht_rev, lens, gates, cell, dgates, (float*)workspace /* any non-null: parts wanted */, false, workspace, t, b, h,
+                         health, stream);
+}
+
+extern "C" int vocr_lstm_bias_from_parts(float* dbias, const void* workspace, int t, int b, int h, void* stream) {
+    VOCR_CHECK_ARG(dbias && workspace && vocr_lstm_bwd_parts_supported(t, b, h), "vocr_lstm_bias_from_parts: bad argument");
+    const float* bpart = (const float*)((const char*)workspace + 4096 + ((size_t)16 << 20));      // [chain][4H], left by vocr_lstm_bwd_parts
+    lstm_bias_combine_kernel<<<dim3(vocr_cdiv(4 * h, 256), 2), 256, 0, (hipStream_t)stream>>>(bpart, dbias, 4 * h, (b + 3) / 4);
+    VOCR_CHECK_LAUNCH("vocr_lstm_bias_from_parts");
+    return VOCR_OK;
+}
+
+static int lstm_bwd_impl(const float* dy, const float* dy_mask, const float* whht_fwd, const float* whht_rev, const int32_t* lens,
+                         const float* gates, const float* cell, float* dgates, float* dbias, bool combine, void* workspace, int t,
+                         int b, int h, int32_t* health, void* stream) {
     const float* whh_fwd = whht_fwd;
     const float* whh_rev = whht_rev;
     VOCR_CHECK_ARG(dy && whh_fwd && whh_rev && lens && gates && cell && dgates && workspace, "vocr_lstm_bwd: null pointer");
@@ -2224,9 +2270,9 @@ extern "C" int vocr_lstm_bwd_bias(const float* dy, const float* whht_fwd, const 
                 return VOCR_ELAUNCH;
             }
             float* bpart = dbias ? (float*)((char*)workspace + 4096 + ((size_t)16 << 20)) : nullptr;     // [chain][4H]
-            lstm_bwd_chain4w<4><<<256, 512, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, status, hword, bpart, t, b, nt4, (persistent_mode & 8) ? 1 : 0);
+            lstm_bwd_chain4w<4><<<256, 512, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dy_mask, dgates, partials, flags, status, hword, bpart, t, b, nt4, (persistent_mode & 8) ? 1 : 0);
             VOCR_CHECK_LAUNCH("vocr_lstm_bwd(k-owner, 4-row chains, wide members, self-validating)");
-            if (dbias) {
+            if (dbias && combine) {
                 lstm_bias_combine_kernel<<<dim3(vocr_cdiv(4 * h, 256), 2), 256, 0, s>>>(bpart, dbias, 4 * h, nt4);
                 VOCR_CHECK_LAUNCH("vocr_lstm_bwd(bias combine)");
             }
@@ -2244,11 +2290,11 @@ extern "C" int vocr_lstm_bwd_bias(const float* dy, const float* whht_fwd, const 
             const dim3 g4((nch > 8 ? 16 : 8) * (h / 16));
             const int fwt4 = (persistent_mode & 8) ? 1 : 0;
             if (h == 512)
-                lstm_bwd_chain4v<4><<<g4, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, status, hword, bpart, t, b, nt4, fwt4);
+                lstm_bwd_chain4v<4><<<g4, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dy_mask, dgates, partials, flags, status, hword, bpart, t, b, nt4, fwt4);
             else
-                lstm_bwd_chain4v<2><<<g4, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, status, hword, bpart, t, b, nt4, fwt4);
+                lstm_bwd_chain4v<2><<<g4, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dy_mask, dgates, partials, flags, status, hword, bpart, t, b, nt4, fwt4);
             VOCR_CHECK_LAUNCH("vocr_lstm_bwd(k-owner, 4-row chains, self-validating)");
-            if (dbias) {
+            if (dbias && combine) {
                 lstm_bias_combine_kernel<<<dim3(vocr_cdiv(4 * h, 256), 2), 256, 0, s>>>(bpart, dbias, 4 * h, nt4);
                 VOCR_CHECK_LAUNCH("vocr_lstm_bwd(bias combine)");
             }

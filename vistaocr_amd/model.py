@@ -285,25 +285,32 @@ class CnnOcrModel(nn.Module):
         for l in range(self.num_lstm_layers):
             f = self.lstm.layer(l, "")
             r = self.lstm.layer(l, "_reverse")
+            # nn.LSTM's inter-layer dropout (every layer's output but the last's); drawn inside the layer op when it is one op
+            draw = drop and l < self.num_lstm_layers - 1 and self.dropout_masks is None
+            fused = draw and b <= 64
+            if draw:
+                self._dropout_calls += 1
             with prof_range("model.lstm.l%d" % l):
-                hseq = self._bilstm_layer(hseq, lens_dev, out_w, T, b, f, r, prep)
+                hseq = self._bilstm_layer(hseq, lens_dev, out_w, T, b, f, r, prep,
+                                          (self.p_lstm_dropout, self.dropout_seed + self._dropout_calls) if fused else None)
             if l < self.num_lstm_layers - 1:
                 if self.dropout_masks is not None:
                     hseq = ops.MulMaskFn.apply(hseq, self.dropout_masks[l].to(dev).reshape(T * b, -1))
-                elif drop:
-                    self._dropout_calls += 1
+                elif draw and not fused:
                     hseq = ops.DropoutFn.apply(hseq, self.p_lstm_dropout, self.dropout_seed + self._dropout_calls)
         pr = getattr(self.prob_layer, "0")
         with prof_range("model.prob"):
             prob_output = ops.LinearFn.apply(hseq, pr.weight, pr.bias, False).view(T, b, -1)
         return prob_output, lens_cpu
 
-    def _bilstm_layer(self, hseq, lens_dev, out_w, T, b, f, r, prep):
+    def _bilstm_layer(self, hseq, lens_dev, out_w, T, b, f, r, prep, drop=None):
         """One bidirectional layer.  The sweep kernels take up to 64 batch rows per call (include/vocr.h); the reference's --batch-size is
         free (src/train_cnn_lstm.py:155), so a larger batch runs as tiles of <= 64 rows: the recurrence never couples batch rows, the
         widths are sorted, so a tile is itself a valid packed batch and only sweeps its own longest sequence.  A tile's weight
         gradients go through autograd (which adds the tiles' contributions) instead of the direct sinks."""
         if b <= 64:
+            if drop is not None:
+                return ops.BiLstmLayerFn.apply(hseq, lens_dev, T, b, f[0], f[1], f[2], f[3], r[0], r[1], r[2], r[3], prep, True, drop[0], drop[1])
             return ops.BiLstmLayerFn.apply(hseq, lens_dev, T, b, f[0], f[1], f[2], f[3], r[0], r[1], r[2], r[3], prep)
         ntile = (b + 63) // 64
         rows = (b + ntile - 1) // ntile

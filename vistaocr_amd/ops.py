@@ -727,7 +727,10 @@ class BiLstmLayerFn(torch.autograd.Function):
     x: [T*B, Din] time-major; returns y: [T*B, 2H] with zeros past each sequence's length."""
 
     @staticmethod
-    def forward(ctx, x, lens_dev, T, B, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r, prep=None, direct_grads=True):
+    def forward(ctx, x, lens_dev, T, B, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r, prep=None, direct_grads=True,
+                drop_p=0.0, drop_seed=0):
+        """drop_p > 0: nn.LSTM's inter-layer dropout on this layer's OUTPUT (counter-based mask of vocr_dropout_fwd, as DropoutFn) -
+        here so that its backward can ride on the backward sweep's read of dy instead of being a pass of its own."""
         _need_gpu(x, lens_dev, w_ih_f, w_hh_f, w_ih_r, w_hh_r)
         x = _f32c(x)
         lib = _lib.load()
@@ -782,13 +785,20 @@ class BiLstmLayerFn(torch.autograd.Function):
         ctx.dims = (T, B, H, din)
         ctx.direct_grads = bool(direct_grads)       # False: the layer runs as several batch tiles, autograd adds their weight gradients
         ctx.b_refs = (b_ih_f, b_hh_f, b_ih_r, b_hh_r)
-        ctx.save_for_backward(x, lens_dev, y, gates, cell, w_ih_f, w_hh_f, w_ih_r, w_hh_r)
-        return y
+        mask = None
+        out = y
+        if drop_p and float(drop_p) > 0.0:
+            out = torch.empty_like(y)
+            mask = torch.empty_like(y)
+            call("vocr_dropout_fwd", _p(y), _p(out), _p(mask), y.numel(), float(drop_p), int(drop_seed), _stream())
+        ctx.has_mask = mask is not None
+        ctx.save_for_backward(x, lens_dev, y, gates, cell, w_ih_f, w_hh_f, w_ih_r, w_hh_r, mask)
+        return out
 
     @staticmethod
     @_ranged("bwd.bilstm")
     def backward(ctx, dy):
-        x, lens_dev, y, gates, cell, w_ih_f, w_hh_f, w_ih_r, w_hh_r = ctx.saved_tensors
+        x, lens_dev, y, gates, cell, w_ih_f, w_hh_f, w_ih_r, w_hh_r, mask = ctx.saved_tensors
         T, B, H, din = ctx.dims
         dy = _f32c(dy)
         lib = _lib.load()
@@ -800,8 +810,23 @@ class BiLstmLayerFn(torch.autograd.Function):
         else:
             wt_f, wt_r = transpose2d(w_hh_f), transpose2d(w_hh_r)        # [H][4H]: contiguous B operand for the sweep
         dbias = torch.empty(2, 4 * H, dtype=torch.float32, device=dev)          # gradient of b_ih (= of b_hh), both directions
-        call("vocr_lstm_bwd_bias", _p(dy), _p(wt_f), _p(wt_r), _p(lens_dev), _p(gates), _p(cell), _p(dg), _p(dbias), _p(ws),
-             T, B, H, _p(health(dev)), _stream())
+        # "parts" form (opt-in, VOCR_LSTM_BWD_PARTS=1; MEASURED SLOWER in the step, 17.70 vs 17.44 ms): the dropout mask rides on the
+        # sweep's read of dy and the bias gradient's last reduction is left to the weight-gradient work on the side stream, so two
+        # small kernels leave the critical path.  The sweeps then reach the chip ahead of the previous layer's weight-gradient GEMMs
+        # (the LSTM-backward window ends 0.2 ms earlier), which pushes those GEMMs into the CNN backward, where a third MFMA kernel
+        # beside the data- and weight-gradient convolutions costs 0.4 ms - the same arithmetic as VOCR_LSTM_DW_DEFER.  Bit-identical
+        # results either way (tests/test_round3_gpu.py).
+        parts = bool(lib.vocr_lstm_bwd_parts_supported(T, B, H)) and _os.environ.get("VOCR_LSTM_BWD_PARTS", "0") == "1"
+        if parts:
+            call("vocr_lstm_bwd_parts", _p(dy), _p(mask), _p(wt_f), _p(wt_r), _p(lens_dev), _p(gates), _p(cell), _p(dg), _p(ws),
+                 T, B, H, _p(health(dev)), _stream())
+        else:
+            if mask is not None:
+                dym = torch.empty_like(dy)
+                call("vocr_mul", _p(dy), _p(mask), _p(dym), dy.numel(), _stream())
+                dy = dym
+            call("vocr_lstm_bwd_bias", _p(dy), _p(wt_f), _p(wt_r), _p(lens_dev), _p(gates), _p(cell), _p(dg), _p(dbias), _p(ws),
+                 T, B, H, _p(health(dev)), _stream())
         G = 4 * H
         # critical path first: dx feeds the layer below
         dx = None
@@ -819,6 +844,8 @@ class BiLstmLayerFn(torch.autograd.Function):
 
         def weight_grads(outs, co=0):
             dwi_f, dwh_f, dbi_f, dbh_f, dwi_r, dwh_r, dbi_r, dbh_r = outs
+            if parts:
+                call("vocr_lstm_bias_from_parts", _p(dbias), _p(ws), T, B, H, _stream())
             gemm_pair(co, 1, 0, G, din, T * B, dg[0], dg[1], G, x, x, din, dwi_f, dwi_r, din)
             if T > 1:
                 # forward dir: h_{t-1} = y[t-1, :, :H];   reverse dir: h_{t+1} = y[t+1, :, H:]  (zero past the length)
@@ -833,27 +860,27 @@ class BiLstmLayerFn(torch.autograd.Function):
             dbh_r.copy_(dbias[1])
 
         if direct and _SIDE_ENABLED and _DEFER_ON:
-            for t_ in (dg, x, y, dbias):
+            for t_ in (dg, x, y, dbias, ws):
                 t_.record_stream(defer_stream())
             defer_work(lambda: weight_grads(sinks))
-            return (dx, None, None, None) + (None,) * 10
+            return (dx, None, None, None) + (None,) * 12
         if direct and _SIDE_ENABLED and _os.environ.get("VOCR_LSTM_DW_OVERLAP", "1") == "1":
             side = side_stream()
             side.wait_stream(torch.cuda.current_stream())
-            for t_ in (dg, x, y, dbias):
+            for t_ in (dg, x, y, dbias, ws):
                 t_.record_stream(side)
             with torch.cuda.stream(side):
                 # under the next layer's persistent sweep: VOCR_DW_TILES=1 asks for the tile kernel, whose workgroups fit on a CU beside a
                 # sweep workgroup (the panel kernel's do not: 144 KB of LDS and 340 registers per lane)
                 weight_grads(sinks, co=4 if _os.environ.get("VOCR_DW_TILES", "0") == "1" else 0)
             mark_side_pending()
-            return (dx, None, None, None) + (None,) * 10
+            return (dx, None, None, None) + (None,) * 12
         if direct:
             weight_grads(sinks)
-            return (dx, None, None, None) + (None,) * 10
+            return (dx, None, None, None) + (None,) * 12
         outs = [torch.empty_like(p) for p in params]
         weight_grads(outs)
-        return (dx, None, None, None) + tuple(outs) + (None, None)
+        return (dx, None, None, None) + tuple(outs) + (None, None, None, None)
 
 
 # ------------------------------------------------------------------------------------------------ CTC
