@@ -292,3 +292,40 @@ def test_dropout_inside_the_layer_op_equals_the_separate_op(T, B, H):
         for nm, a, b in zip(names, other, res[2]):
             assert torch.equal(a, b), "%s differs: max |diff| %.3e" % (nm, float((a - b).abs().max()))
     assert float((res[0][0] == 0).float().mean()) > 0.3          # the mask did drop
+
+
+@pytest.mark.parametrize("B,H", [(32, 512), (12, 512), (27, 256)])
+def test_a_hand_off_that_never_arrives_ends_loudly_not_in_a_hang(B, H):
+    """The self-validating sweeps poll with bounded spins.  Resuming a forward sweep at step 3 on a workspace whose hand-off ring was
+    never written (all "not written yet") is a hand-off that cannot arrive: the call must come back (seconds), raise the caller's
+    health word and poison the output of its last step with NaN - and the next, proper sweep on the same workspace must be clean."""
+    from vistaocr_amd import _lib
+    from vistaocr_amd._lib import call
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    T = 6
+    g = torch.Generator().manual_seed(3)
+    xp = (torch.rand(2, T * B, 4 * H, generator=g) - 0.5).to(dev)
+    wf = ((torch.rand(4 * H, H, generator=g) - 0.5) * 0.2).to(dev)
+    wr = ((torch.rand(4 * H, H, generator=g) - 0.5) * 0.2).to(dev)
+    lens = torch.full((B,), T, dtype=torch.int32, device=dev)
+    y = torch.zeros(T * B, 2 * H, device=dev)
+    gt = torch.zeros(2, T * B, 4 * H, device=dev)
+    c = torch.zeros(2, T * B, H, device=dev)
+    ws = torch.full((lib.vocr_lstm_workspace_bytes(T, B, H) // 4 + 16,), float("nan"), device=dev)
+    ws.view(torch.int32).fill_(-1)                                  # every ring slot: "not written yet"
+    hw = torch.zeros(4, dtype=torch.int32, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    t0 = time.time()
+    call("vocr_lstm_fwd_range", xp.data_ptr(), wf.data_ptr(), wr.data_ptr(), lens.data_ptr(), y.data_ptr(), gt.data_ptr(), c.data_ptr(),
+         ws.data_ptr(), T, B, H, 3, T, hw.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert time.time() - t0 < 60, "the bounded spins took %.0f s" % (time.time() - t0)
+    assert int(hw[0]) == 1, "the time-out was not reported"
+    y3 = y.view(T, B, 2, H)
+    assert torch.isnan(y3[T - 1, :, 0]).any() and torch.isnan(y3[0, :, 1]).any(), "the last step of both directions must be poisoned"
+    hw.zero_()
+    call("vocr_lstm_fwd", xp.data_ptr(), wf.data_ptr(), wr.data_ptr(), lens.data_ptr(), y.data_ptr(), gt.data_ptr(), c.data_ptr(),
+         ws.data_ptr(), T, B, H, hw.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert int(hw[0]) == 0 and torch.isfinite(y).all(), "a proper sweep after a failed one must be clean"
