@@ -123,7 +123,7 @@ def _run_pair(name):
     lo_loss = vo.ctc_criterion(lo, torch.from_numpy(tgt), ln, torch.from_numpy(tl))
     lo_loss.backward()
     assert lens.tolist() == ln.tolist()
-    rel = abs(float(loss) - float(lo_loss)) / abs(float(lo_loss))
+    rel = abs(float(loss.detach()) - float(lo_loss.detach())) / abs(float(lo_loss.detach()))
     assert rel <= case.get("loss_rtol", 1e-3), (float(loss), float(lo_loss))
     lg = logits.detach().cpu()
     T = lg.shape[0]

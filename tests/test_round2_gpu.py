@@ -83,7 +83,7 @@ def test_config1_full_size_vs_oracle():
     lo_loss = vo.ctc_criterion(lo, torch.from_numpy(tgt), ln, torch.from_numpy(tl))
     lo_loss.backward()
     assert tuple(logits.shape) == (T, B, V) and lens.tolist() == ln.tolist() == [T] * B
-    rel = abs(float(loss) - float(lo_loss)) / abs(float(lo_loss))
+    rel = abs(float(loss.detach()) - float(lo_loss.detach())) / abs(float(lo_loss.detach()))
     lg = logits.detach().cpu()
     err = float((lg - lo.detach()).abs().max())
     olabels = vo.greedy_decode(lo.detach(), ln, al.idx_to_char, uxxxx=True)[1]
@@ -149,7 +149,7 @@ def test_config5_full_line_size_60x1200_fp16_conv():
         lo, ln = vo.forward(osd, hp, torch.from_numpy(x), w, (s1, s2), training=True, lstm_training=False)
         lo_loss = vo.ctc_criterion(lo, torch.from_numpy(tgt), ln, torch.from_numpy(tl))
     assert lens.tolist() == ln.tolist() == [294, 273]      # 60 -> 30 halves the width first: T(1200) = T30(600)
-    rel = abs(float(loss) - float(lo_loss)) / abs(float(lo_loss))
+    rel = abs(float(loss.detach()) - float(lo_loss.detach())) / abs(float(lo_loss.detach()))
     lg = logits.detach().cpu()
     T = lg.shape[0]
     valid = torch.arange(T).unsqueeze(1) < ln.unsqueeze(0)
