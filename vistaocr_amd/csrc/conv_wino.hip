@@ -914,6 +914,302 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_wino_dma_kernel(const float
         }
 }
 
+// ---------------------------------------------------------------- weight gradient F(3,2), piece stream, twelve waves (round 4)
+// The same contraction again; what changes against conv3x3_wgrad_wino_dma_kernel, and why:
+//   * THE BUDGET.  On this chip the f32 MFMA peak IS the vector f32 peak, and nothing vector hides behind a v_mfma_f32_32x32x2_f32:
+//     beside a stream of them (64 cycles each) every plain VALU instruction costs 4 - 5 cycles of MFMA time, a packed one
+//     (v_pk_add_f32) the same 5, a ds_read 2, an LDS-DMA 7 - 14 (scripts/mfma_valu_probe.hip, three waves per SIMD).  The segment
+//     kernel spent 40 VALU instructions per 12 MFMAs; this one 7 per 8 (+ 4 LDS reads):
+//       - both transforms as PACKED adds on register pairs that the 16-byte fragment reads deliver aligned: (g0+g1, g0-g1) is one
+//         v_pk_add_f32, (d1+d2, d2-d1) one, (c2-c0, c1-c3) of the two pairs of a piece one; the factor 1/2 of the filter-side
+//         transform moved into the output transform (exact: a power of two);
+//       - every fragment address is a per-lane kernel constant in a register (32 of them), the second LDS buffer is the
+//         instruction's immediate offset (the loop is unrolled over the two buffers), so the k-loop has no address arithmetic;
+//       - a DMA's source offset is one add-and-shift of a per-lane constant and the segment's slot offset plus one select.
+//   * FRAGMENT READS.  There every fragment element was a ds_read_b32 whose 32 lanes (= channels) sit 16 bytes x pieces apart: the
+//     channel XOR moves a lane by whole 16-byte pieces, so lanes c, c+8, c+16, c+24 always share a bank - a 4-way conflict on all
+//     14 reads of a k-step (SQ_LDS_BANK_CONFLICT 6.7e7 per launch, 19x the forward kernel's).  Here a lane reads WHOLE 16-byte
+//     pieces with ds_read_b128 from rows of exactly 16 pieces (256 bytes = one bank row) with the piece position XORed by
+//     (channel & 15): the 16 lanes of every ds_read_b128 lane group then cover the 64 banks exactly once.  One dy piece = pixels
+//     4k .. 4k+3 = two column pairs = two k-steps; lane half lk takes slot 2j + lk of the segment (the MFMA only needs A and B to
+//     agree on k).  The x piece of the same slot holds columns 4k .. 4k+3; the columns 4k-1 and 4k+4 the two pairs also need are
+//     the last / first element of the neighbouring slots' pieces (two ds_read_b32).
+//   * PIECE STREAM.  A row contributes np = ceil(W/4) slots plus ONE all-zero slot (dy = 0, x = 0: it is the zero padding right of
+//     the row's last column AND left of the next row's first one); a segment is any 16 consecutive slots of the stream of all rows
+//     of all images.  Whole 64-pixel segments per row idled 6-8 % of the MFMA work at W = 600 / 420 / 294; this form < 1.5 %.
+//   * TWELVE WAVES.  wave = (filter row kh, output-channel half, input-channel half): 4 accumulator tiles = 64 registers instead of
+//     192, three waves per SIMD.
+// LDS: dy[2][64 co][16 pos][4] | 2 x { x [3 kh][64 ci][16 pos][4] | extras [6][64 ci][4] } (extras: slot -1 and slot 16 of the
+// segment for the three filter rows - the neighbours of its first and last slot); position of logical slot s of channel c =
+// s ^ (c & 15).  A DMA instruction fills 1 KiB = 4 channels x 16 positions; instruction id -> wave so that id & 3 == wave & 3: a lane
+// then only ever moves ONE logical slot of a segment, (lane & 15) ^ (lane >> 4) ^ 4 (wave & 3), and tracks its (image, row, piece)
+// incrementally.
+#ifndef W3_CUT            // diagnostic builds (scripts/wgrad3_var.hip): 1 no DMA in the loop, 2 no fragment reads, 4 no transforms
+#define W3_CUT 0
+#endif
+constexpr int G3_DY = 64 * 64;                   // floats of dy per buffer
+constexpr int G3_X = 3 * 64 * 64;                // floats of x per buffer
+constexpr int G3_XE = 6 * 256;                   // floats of extras per buffer
+constexpr int G3_XB = G3_X + G3_XE;              // x + extras per buffer: 13824 floats = 55296 bytes (< 64 KiB: an immediate offset)
+constexpr int G3_X0 = 2 * G3_DY;                 // first x buffer
+struct W3Geom { int np, S, slots_img, nseg, adv; };
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// The transforms of one dy piece g = (g0..g3) and one x piece c = (c0..c3) as packed adds.  Inline assembly because the compiler only
+// folds some of the half selections / negations into the instruction's modifiers (the others cost a v_xor or v_mov each).  The
+// compiler's hazard recogniser does not look into inline assembly, and a VALU result needs two wait states before an MFMA may read
+// it as A or B: the blocks end in the s_nop that guarantees them for their last result.
+//   a01 = (g0+g1, g0-g1)   b01 = (c0+c1, c1-c0)   bx = (c2-c0, c1-c3)
+__device__ __forceinline__ void w3_xform_first(f32x2 g01, f32x2 c01, f32x2 c23, f32x2& a01, f32x2& b01, f32x2& bx) {
+    asm("v_pk_add_f32 %0, %3, %3 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %1, %4, %4 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %2, %5, %4 neg_lo:[0,1] neg_hi:[1,0]\n\t"
+        "s_nop 1"
+        : "=&v"(a01), "=&v"(b01), "=&v"(bx) : "v"(g01), "v"(c01), "v"(c23));
+}
+//   a23 = (g2+g3, g2-g3)   b23 = (c2+c3, c3-c2)
+__device__ __forceinline__ void w3_xform_second(f32x2 g23, f32x2 c23, f32x2& a23, f32x2& b23) {
+    asm("v_pk_add_f32 %0, %2, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %1, %3, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"
+        "s_nop 1"
+        : "=&v"(a23), "=&v"(b23) : "v"(g23), "v"(c23));
+}
+
+__global__ __launch_bounds__(768) void conv3x3_wgrad_wino3_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                  float* __restrict__ slab, int N, int Cin, int H, int W, int Cout,
+                                                                  W3Geom geo, int segs_per_split) {
+    __shared__ __attribute__((aligned(256))) float lds[2 * G3_DY + 2 * G3_XB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lk = lane >> 5;
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if ((gridDim.z & 7) == 0) {             // the (ci, co) tiles of a split on one XCD (see conv3x3_wgrad_kernel)
+        const int nxy = gridDim.x * gridDim.y;
+        const int b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int k = b & 7, slot = b >> 3;
+        bz = k + 8 * (slot / nxy);
+        const int xy = slot - (slot / nxy) * nxy;
+        bx = xy % gridDim.x;
+        by = xy / gridDim.x;
+    }
+    const int ci0 = bx * 64, co0 = by * 64, split = bz;
+    const int iHW = H * W;
+    // consumer role
+    const int kh = wave >> 2, wco = ((wave >> 1) & 1) * 32, wci = (wave & 1) * 32;
+    // DMA role
+    const int wq = wave >> 2, wr = wave & 3;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+    const int sbeg = split * segs_per_split;
+    const int send = min(geo.nseg, sbeg + segs_per_split);
+    const __amdgpu_buffer_rsrc_t dyrs = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)((long)N * Cout * iHW * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((long)N * Cin * iHW * 4), 0x00020000);
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+
+    // ---- slot states: (image n, row h, piece k) of the stream position this lane moves; k < 0: in front of the stream
+    struct Slot { int n, h, k; };
+    auto decode = [&](int pos) __attribute__((always_inline)) {
+        Slot s;
+        if (pos < 0) { s.n = 0; s.h = 0; s.k = pos; return s; }
+        s.n = pos / geo.slots_img;
+        const int r = pos - s.n * geo.slots_img;
+        s.h = r / geo.S;
+        s.k = r - s.h * geo.S;
+        return s;
+    };
+    // + 16 slots, branch-free (geo.adv = ceil(16 / S) carries, 1 from W = 57 on)
+    auto advance = [&](Slot& s) __attribute__((always_inline)) {
+        s.k += 16;
+        for (int it = 0; it < geo.adv; ++it) {
+            const int c = s.k >= geo.S ? 1 : 0;
+            s.k -= c ? geo.S : 0;
+            s.h += c;
+            const int d = s.h >= H ? 1 : 0;
+            s.h -= d ? H : 0;
+            s.n += d;
+        }
+    };
+    const int my_ls = ((lane & 15) ^ (lane >> 4)) ^ (4 * wr);
+    Slot ms = decode(sbeg * 16 + my_ls);
+    // the wave's extra instruction (ids 64 .. 69 = which * 3 + filter row): waves 4..7 take ids 64 + wr, waves 8, 9 ids 68 + wr
+    const int xt = wq == 1 ? wr : (wq == 2 && wr < 2 ? 4 + wr : -1);            // wave-uniform
+    const int x_which = xt >= 3 ? 1 : 0, x_kh = xt >= 3 ? xt - 3 : xt;
+    Slot es = decode(sbeg * 16 + (x_which ? 16 : -1));                          // wave-uniform: lives in scalar registers
+
+    // ---- DMA maps.  Instruction t (0..5) of a wave is u = wq + 3t: u < 4 a dy instruction (output channels 16u + 4wr + lane/16),
+    // u < 16 an x instruction (i = 4(u-4) + wr: filter row (u-4) / 4, input channels 4(i % 16) + lane/16), u >= 16 the wave's extra.
+    // The loop below is compiled once per wq (a wave-uniform switch around it), so kind and filter row of every instruction are
+    // compile-time constants; per lane and instruction one register: the channel's (and filter row's) BYTE offset, or - channel past
+    // the end - a value that keeps every sum out of the buffer's range (tensors are < 2^31 bytes, so sums neither wrap nor come back).
+    constexpr unsigned FAR = 0x80000000u;
+    unsigned d_off[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        const int u = wq + 3 * t;
+        if (u < 4) {
+            const int co = co0 + 16 * u + 4 * wr + (lane >> 4);
+            d_off[t] = co < Cout ? (unsigned)(co * iHW) * 4u : FAR;
+        } else if (u < 16) {
+            const int i = 4 * (u - 4) + wr, k3 = i >> 4, ci = ci0 + 4 * (i & 15) + (lane >> 4);
+            d_off[t] = ci < Cin ? (unsigned)(ci * iHW + (k3 - 1) * W) * 4u : FAR;
+        } else {
+            const int ci = ci0 + lane;
+            d_off[t] = (xt >= 0 && ci < Cin) ? (unsigned)(ci * iHW + (x_kh - 1) * W) * 4u : FAR;
+        }
+    }
+    auto dma = [&](const __amdgpu_buffer_rsrc_t& rs, float* dst, unsigned vo) __attribute__((always_inline)) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, vo, 0, 0, 0);
+    };
+    auto issue = [&](auto wq_tag, int buf) __attribute__((always_inline)) {
+        constexpr int WQ = decltype(wq_tag)::value;
+        float* const bdy = lds + buf * G3_DY;
+        float* const bx_ = lds + G3_X0 + buf * G3_XB;
+        const bool mok = ms.k >= 0 && ms.k < geo.np && ms.n < N;
+        const int pix = ms.h * W + 4 * ms.k;
+        // the slot's byte offset per operand (and filter row: rows outside the image are out of range)
+        const unsigned dyb = mok ? (unsigned)(ms.n * Cout * iHW + pix) * 4u : FAR;
+        const unsigned xmid = mok ? (unsigned)(ms.n * Cin * iHW + pix) * 4u : FAR;
+        const unsigned xb3[3] = {ms.h >= 1 ? xmid : FAR, xmid, ms.h + 1 < H ? xmid : FAR};
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            const int u = WQ + 3 * t;                                           // compile time
+            if (u < 4) dma(dyrs, bdy + (4 * u + wr) * 256, dyb + d_off[t]);
+            else if (u < 16) dma(xrs, bx_ + (4 * (u - 4) + wr) * 256, xb3[(u - 4) >> 2] + d_off[t]);
+            else if (xt >= 0) {
+                const int row = es.h + x_kh - 1;                                // all wave-uniform
+                const bool eok = es.k >= 0 && es.k < geo.np && es.n < N && row >= 0 && row < H;
+                dma(xrs, bx_ + G3_X + xt * 256, (eok ? (unsigned)(es.n * Cin * iHW + es.h * W + 4 * es.k) * 4u : FAR) + d_off[t]);
+            }
+        }
+    };
+    // a row's last piece carries the next row's first columns when W % 4 != 0: zero them once the DMA has landed
+    auto patch = [&](auto wq_tag, int buf) __attribute__((always_inline)) {
+        constexpr int WQ = decltype(wq_tag)::value;
+        if ((W & 3) == 0) return;
+        float* const bdy = lds + buf * G3_DY;
+        float* const bx_ = lds + G3_X0 + buf * G3_XB;
+        const int nv = W - 4 * (geo.np - 1);                                    // valid elements of a row's last piece (1..3)
+        if (ms.k == geo.np - 1) {
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                const int u = WQ + 3 * t;
+                if (u < 16) {
+                    float* o = (u < 4 ? bdy + (4 * u + wr) * 256 : bx_ + (4 * (u - 4) + wr) * 256) + lane * 4;
+#pragma unroll
+                    for (int e = 1; e < 4; ++e)
+                        if (e >= nv) o[e] = 0.f;
+                }
+            }
+        }
+        if (xt >= 0 && es.k == geo.np - 1) {
+            float* o = bx_ + G3_X + xt * 256 + lane * 4;
+#pragma unroll
+            for (int e = 1; e < 4; ++e)
+                if (e >= nv) o[e] = 0.f;
+        }
+    };
+
+    // ---- fragment addresses (bytes from the start of buffer 0 of the operand; kernel constants per lane, one register each)
+    const int cA = wco + li, cB = wci + li, sA = cA & 15, sB = cB & 15;
+    const char* const ldsb = (const char*)lds;
+    int adA[8], adC[8], adP[8], adN[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int m = 2 * j + lk, p = m - 1, q = m + 1;
+        adA[j] = (cA * 64 + 4 * (m ^ sA)) * 4;
+        adC[j] = (G3_X0 + kh * 4096 + cB * 64 + 4 * (m ^ sB)) * 4;
+        adP[j] = (G3_X0 + (p >= 0 ? kh * 4096 + cB * 64 + 4 * (p ^ sB) : G3_X + kh * 256 + cB * 4) + 3) * 4;
+        adN[j] = (G3_X0 + (q <= 15 ? kh * 4096 + cB * 64 + 4 * (q ^ sB) : G3_X + (3 + kh) * 256 + cB * 4)) * 4;
+    }
+    // one segment out of buffer CUR (compile time: the buffer is the reads' immediate offset)
+    auto segment = [&](auto wq_tag, auto cur_tag, bool more) __attribute__((always_inline)) {
+        constexpr int CUR = decltype(cur_tag)::value;
+        constexpr int OA = CUR * G3_DY * 4, OX = CUR * G3_XB * 4;
+        if (more && !(W3_CUT & 1)) {
+            advance(ms);
+            advance(es);
+            issue(wq_tag, CUR ^ 1);
+        }
+        f32x4 rg, rc, ng, nc;
+        float rp, rn, np_, nn;
+        rg = *(const f32x4*)(ldsb + adA[0] + OA); rc = *(const f32x4*)(ldsb + adC[0] + OX);
+        rp = *(const float*)(ldsb + adP[0] + OX); rn = *(const float*)(ldsb + adN[0] + OX);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            ng = rg; nc = rc; np_ = rp; nn = rn;
+            if (j + 1 < 8 && !(W3_CUT & 2)) {
+                ng = *(const f32x4*)(ldsb + adA[j + 1] + OA);
+                nc = *(const f32x4*)(ldsb + adC[j + 1] + OX);
+                np_ = *(const float*)(ldsb + adP[j + 1] + OX);
+                nn = *(const float*)(ldsb + adN[j + 1] + OX);
+            }
+            __builtin_amdgcn_sched_barrier(0);      // the next double-step's ds_reads stay above this one's MFMAs
+            // the x piece c0..c3 = columns 4k .. 4k+3, p = column 4k-1, n = column 4k+4; the dy piece g0..g3
+            // pair (4k, 4k+1):   a = g0, g0+g1, g0-g1, g1   b = p-c1, c0+c1, c1-c0, c2-c0      (the 1/2 of a1, a2: output transform)
+            // pair (4k+2, 4k+3): a = g2, g2+g3, g2-g3, g3   b = c1-c3, c2+c3, c3-c2, n-c2
+            const f32x2 g01 = {rg[0], rg[1]}, g23 = {rg[2], rg[3]}, c01 = {rc[0], rc[1]}, c23 = {rc[2], rc[3]};
+            f32x2 a0, a1, b0, b1, bx2;
+            float e0, e1;
+            if (W3_CUT & 4) { a0 = g01; a1 = g23; b0 = c01; b1 = c23; bx2 = c01; e0 = rp; e1 = rn; }
+            else {
+                w3_xform_first(g01, c01, c23, a0, b0, bx2);
+                w3_xform_second(g23, c23, a1, b1);
+                e0 = rp - rc[1];
+                e1 = rn - rc[2];
+            }
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(rg[0], e0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[0], b0[0], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[1], b0[1], acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(rg[1], bx2[0], acc[3], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(rg[2], bx2[1], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[0], b1[0], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[1], b1[1], acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(rg[3], e1, acc[3], 0, 0, 0);
+            rg = ng; rc = nc; rp = np_; rn = nn;
+        }
+        if (more && !(W3_CUT & 1)) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);     // the next segment's DMAs have landed
+            patch(wq_tag, CUR ^ 1);
+        }
+        __syncthreads();                            // next buffer complete, this one free
+    };
+
+    auto run = [&](auto wq_tag) __attribute__((always_inline)) {
+        if (sbeg < send) {
+            issue(wq_tag, 0);
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            patch(wq_tag, 0);
+        }
+        __syncthreads();
+        for (int g = sbeg; g < send; g += 2) {
+            segment(wq_tag, std::integral_constant<int, 0>{}, g + 1 < send);
+            if (g + 1 < send) segment(wq_tag, std::integral_constant<int, 1>{}, g + 2 < send);
+        }
+    };
+    if (wq == 0) run(std::integral_constant<int, 0>{});
+    else if (wq == 1) run(std::integral_constant<int, 1>{});
+    else run(std::integral_constant<int, 2>{});
+    // output transform with the filter-side 1/2:  dw(kw=0) = M0 + (M1+M2)/2   dw(1) = (M1-M2)/2   dw(2) = (M1+M2)/2 + M3
+    const long plane = (long)Cout * Cin;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wco + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const int ci = ci0 + wci + li;
+        if (co < Cout && ci < Cin) {
+            const float m0 = acc[0][r], m1 = 0.5f * acc[1][r], m2 = 0.5f * acc[2][r], m3 = acc[3][r];
+            float* o = slab + ((long)split * 9 + kh * 3) * plane + (long)co * Cin + ci;
+            o[0] = (m0 + m1) + m2;
+            o[plane] = m1 - m2;
+            o[2 * plane] = (m1 + m2) + m3;
+        }
+    }
+}
+
+
 const float* wino_zero_page_ptr() {
     static const float* zp[64] = {nullptr};
     int dev = 0;
@@ -1012,10 +1308,36 @@ int wgrad_wino_splits(int n, int cin, int h, int w, int cout, int* segs_per_spli
 }
 }  // namespace
 
+namespace {
+// piece-stream geometry of conv3x3_wgrad_wino3_kernel
+int wgrad_wino3_splits(int n, int cin, int h, int w, int cout, W3Geom* geo, int* segs_per_split) {
+    geo->np = vocr_cdiv(w, 4);
+    geo->S = geo->np + 1;
+    geo->slots_img = h * geo->S;
+    const long nslot = (long)n * geo->slots_img;
+    geo->nseg = (int)((nslot + 15) / 16);
+    geo->adv = vocr_cdiv(16, geo->S);
+    const int tiles = vocr_cdiv(cin, 64) * vocr_cdiv(cout, 64);
+    long s = (256 + tiles - 1) / tiles;                      // one workgroup per CU
+    if (s > geo->nseg) s = geo->nseg;
+    if (s < 1) s = 1;
+    const int sps = (int)((geo->nseg + s - 1) / s);
+    *segs_per_split = sps;
+    return (geo->nseg + sps - 1) / sps;
+}
+// VOCR_WGRAD_WINO_DMA: 2 (default) piece stream / twelve waves, 1 round 3's segment kernel with LDS-DMA, 0 its register-staged form
+int wgrad_wino_mode() {
+    static const int m = getenv("VOCR_WGRAD_WINO_DMA") ? atoi(getenv("VOCR_WGRAD_WINO_DMA")) : 2;
+    return m;
+}
+}  // namespace
+
 extern "C" size_t vocr_conv3x3_wgrad_wino_workspace_bytes(int n, int cin, int h, int w, int cout) {
     if (n <= 0 || cin <= 0 || h <= 0 || w <= 0 || cout <= 0) return 0;
     int sps;
-    return (size_t)wgrad_wino_splits(n, cin, h, w, cout, &sps) * 9 * cout * cin * sizeof(float);
+    W3Geom g3;
+    const int splits = wgrad_wino_mode() == 2 ? wgrad_wino3_splits(n, cin, h, w, cout, &g3, &sps) : wgrad_wino_splits(n, cin, h, w, cout, &sps);
+    return (size_t)splits * 9 * cout * cin * sizeof(float);
 }
 
 extern "C" int vocr_conv3x3_wgrad_wino(const float* x, const float* dy, float* dw, void* workspace, int n, int cin, int h, int w,
@@ -1023,18 +1345,24 @@ extern "C" int vocr_conv3x3_wgrad_wino(const float* x, const float* dy, float* d
     VOCR_CHECK_ARG(x && dy && dw && workspace, "vocr_conv3x3_wgrad_wino: null pointer");
     VOCR_CHECK_ARG(n > 0 && cin >= 4 && h > 0 && w > 0 && cout > 0, "vocr_conv3x3_wgrad_wino: bad shape (needs cin >= 4)");
     VOCR_CHECK_ARG((long)n * (cin > cout ? cin : cout) * h * w < (1l << 29), "vocr_conv3x3_wgrad_wino: tensor exceeds 2^29 elements (32-bit byte offsets)");
-    WGeom geo;
-    geo.nsr = vocr_cdiv(vocr_cdiv(w, 2), TS);
-    geo.per_img = h * geo.nsr;
-    geo.nseg = n * geo.per_img;
-    geo.T = geo.S = geo.slots_img = geo.nslot = 0;
-    int sps;
-    const int splits = wgrad_wino_splits(n, cin, h, w, cout, &sps);
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid(vocr_cdiv(cin, 64), vocr_cdiv(cout, 64), splits);
-    static const int dma = getenv("VOCR_WGRAD_WINO_DMA") ? atoi(getenv("VOCR_WGRAD_WINO_DMA")) : 1;
-    if (dma) conv3x3_wgrad_wino_dma_kernel<<<grid, 256, 0, s>>>(x, dy, (float*)workspace, n, cin, h, w, cout, geo, sps);
-    else conv3x3_wgrad_wino_kernel<<<grid, 256, 0, s>>>(x, dy, (float*)workspace, n, cin, h, w, cout, geo, sps);
+    int sps, splits;
+    if (wgrad_wino_mode() == 2) {
+        W3Geom g3;
+        splits = wgrad_wino3_splits(n, cin, h, w, cout, &g3, &sps);
+        dim3 grid(vocr_cdiv(cin, 64), vocr_cdiv(cout, 64), splits);
+        conv3x3_wgrad_wino3_kernel<<<grid, 768, 0, s>>>(x, dy, (float*)workspace, n, cin, h, w, cout, g3, sps);
+    } else {
+        WGeom geo;
+        geo.nsr = vocr_cdiv(vocr_cdiv(w, 2), TS);
+        geo.per_img = h * geo.nsr;
+        geo.nseg = n * geo.per_img;
+        geo.T = geo.S = geo.slots_img = geo.nslot = 0;
+        splits = wgrad_wino_splits(n, cin, h, w, cout, &sps);
+        dim3 grid(vocr_cdiv(cin, 64), vocr_cdiv(cout, 64), splits);
+        if (wgrad_wino_mode() == 1) conv3x3_wgrad_wino_dma_kernel<<<grid, 256, 0, s>>>(x, dy, (float*)workspace, n, cin, h, w, cout, geo, sps);
+        else conv3x3_wgrad_wino_kernel<<<grid, 256, 0, s>>>(x, dy, (float*)workspace, n, cin, h, w, cout, geo, sps);
+    }
     VOCR_CHECK_LAUNCH("vocr_conv3x3_wgrad_wino");
     vocr_internal_wgrad_reduce((const float*)workspace, dw, cout, cin, splits, s);
     VOCR_CHECK_LAUNCH("vocr_conv3x3_wgrad_wino(reduce)");
