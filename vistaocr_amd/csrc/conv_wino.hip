@@ -283,6 +283,216 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const float* __res
         }
 }
 
+// conv3x3_wino_kernel with buffer-addressed loaders (see the comment at its loaders); everything else is the same.
+template <int CO_T>
+__device__ __forceinline__ void conv3x3_wino2_body(const float* __restrict__ in, const float* __restrict__ wpack,
+                                                           const float* __restrict__ bias, float* __restrict__ out,
+                                                           const float* __restrict__ zero_page, int N, int Cin, int H, int W,
+                                                           int Cout, WGeom geo, int co_tiles, const float* __restrict__ wdirect,
+                                                           int n_tail, int first_tail_tile) {
+    constexpr int WAVES_CO = CO_T / 64;                      // a wave owns 64 output channels (two MFMA row blocks) ...
+    constexpr int NSEG = 4 / WAVES_CO;                       // ... of one segment
+    constexpr int TM = 2;
+    constexpr int WBUF = WR * CO_T;                          // floats per weight buffer
+    constexpr int PBUF = NSEG * PSEG;                        // floats per halo buffer
+    constexpr int ROWS_W = NSEG * 3;                         // halo rows a wave stages per half-chunk (NSEG*12 rows / 4 waves)
+    constexpr int LPR = CO_T / 4;                            // lanes per weight row in one DMA
+    constexpr int RPI = 64 / LPR;                            // weight rows per DMA instruction (2 or 4)
+    constexpr int NDMA = WR / RPI;                           // DMA instructions per half-chunk (24 or 12)
+    constexpr int DPW = NDMA / 4;                            // ... per wave
+    // ONE LDS object: Wt[2][48][CO_T] | P[2][NSEG][4][3][68] | 64 dummy floats | NSEG x 8 ints of segment geometry
+    __shared__ __attribute__((aligned(16))) float lds[2 * WBUF + 2 * PBUF + 64 + NSEG * 8];
+    float* const Wt = lds;
+    float* const P = lds + 2 * WBUF;
+    constexpr int DUMMY = 2 * PBUF;
+    int* const segw = (int*)(lds + 2 * WBUF + 2 * PBUF + 64);
+
+    if ((int)blockIdx.x < n_tail) {
+        // the last partial round of workgroup tiles, cut into 32-channel x 32-pixel pieces computed by the DIRECT form straight
+        // from global memory (conv_tail.h; conv.hip explains why): a tile is (CO_T/32) channel blocks x 2*NSEG pixel blocks
+        constexpr int COSUB = CO_T / 32, PPW = COSUB * 2 * NSEG;
+        const int piece = blockIdx.x, vt = first_tail_tile + piece / PPW, sub = piece % PPW;
+        // piece pixel block pb: 16 slots = 32 lane positions (lane position li = slot li >> 1, pixel parity li & 1)
+        const int pb = sub / COSUB, q0 = ((vt / co_tiles) * NSEG + pb / 2) * TS + (pb & 1) * 16;
+        const int pli = threadIdx.x & 31;
+        const WSlot ps = wslot(q0 + (pli >> 1), geo);
+        const int pcol = 2 * ps.k + (pli & 1);
+        conv3x3_tail_piece_px<4>(lds, ps.n, ps.h, pcol, ps.valid && ps.k < geo.T && pcol < W, q0 < geo.nslot,
+                                 (vt % co_tiles) * CO_T + (sub % COSUB) * 32, in, wdirect, bias, out, zero_page, Cin, H, W, Cout);
+        return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lk = lane >> 5;
+    const int v = xcd_slice_order(blockIdx.x - n_tail, gridDim.x - n_tail);
+    const int co0 = (v % co_tiles) * CO_T;
+    const int seg0 = (v / co_tiles) * NSEG;
+    const long HW = (long)H * W;
+
+    const int wco = (wave / NSEG) * 64;
+    const int wsg = wave % NSEG;
+    f32x16 acc[TM][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][x][r] = 0.f;
+
+    // ---- loaders (round 4).  Nothing vector hides behind an f32 MFMA on this chip (scripts/mfma_valu_probe.hip: every VALU instruction
+    // costs 4 - 5 cycles of MFMA time), and conv3x3_wino_kernel spent ~90 VALU instructions per half-chunk of 48 MFMAs on 64-bit pointer
+    // arithmetic, clamps and 0/1 masks.  Here every load goes through a buffer resource: the per-lane part of an address is a kernel
+    // constant in one register (out-of-image positions: an offset beyond the buffer's range, which reads 0.0), the per-half-chunk part
+    // (channel) is the instruction's SCALAR offset, and a channel past the end selects a resource of length 0 - no vector arithmetic
+    // and no masks between two half-chunks.  (Tensors < 2^29 elements: byte offsets stay below 2^31, FAR + offset never wraps.)
+    constexpr unsigned FAR = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)((long)N * Cin * HW * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t null_rs = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)wpack, 0, Cin * 12 * Cout * 4, 0x00020000);
+    // halo: this wave stages rows [wave*ROWS_W, (wave+1)*ROWS_W) of the (segment, c, kh) rows of a half-chunk (row r lives at P + r * PRW);
+    // a row is 66 columns w0-1 .. w0+64: lanes 0..63 take the first 64, the last two of all the wave's rows share one load.
+    // ROWS_W is a multiple of 3, so row j of a wave has filter row j % 3 (compile time) and channel (wave*ROWS_W % 12 + j) / 3.
+    constexpr int RPS = 12;                                  // rows per segment and half-chunk
+    const int st_seg = (wave * ROWS_W) / RPS;
+    const int c_first = (wave * ROWS_W) % RPS;               // wave-uniform: row j -> channel (c_first + j) / 3
+    // main lanes: entry e = lane >> 1 of the segment's 33 (entry e serves pair e as d0/d1 and pair e-1 as d2/d3), E or O by lane & 1
+    const WSlot ms = wslot((seg0 + st_seg) * TS + (lane >> 1), geo);
+    const int mcol = 2 * ms.k - 1 + (lane & 1);
+    const bool m_ok = ms.valid && mcol >= 0 && mcol < W;
+    unsigned m_vo[3];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int hh = ms.h + kh - 1;
+        m_vo[kh] = (m_ok && hh >= 0 && hh < H) ? (unsigned)(ms.n * Cin * (int)HW + hh * W + mcol) * 4u : FAR;
+    }
+    const int m_lds = wave * ROWS_W * PRW + (lane & 1) * POFF + (lane >> 1);   // even raw index -> E, odd -> O
+    // halo items: lane -> (row j = lane >> 1 of this wave's rows, E or O of entry 32 = the first slot of the next segment)
+    const int hj = min(lane >> 1, ROWS_W - 1);
+    const bool h_lane = lane < 2 * ROWS_W;
+    const WSlot hs = wslot((seg0 + st_seg) * TS + 32, geo);
+    const int hcol = 2 * hs.k - 1 + (lane & 1);
+    const int h_c = ((wave * ROWS_W + hj) % RPS) / 3, h_kh = (wave * ROWS_W + hj) % 3;
+    const int h_hh = hs.h + h_kh - 1;
+    const unsigned h_vo = (hs.valid && h_lane && hcol >= 0 && hcol < W && h_hh >= 0 && h_hh < H)
+                              ? (unsigned)(hs.n * Cin * (int)HW + h_c * (int)HW + h_hh * W + hcol) * 4u : FAR;
+    const int h_lds = h_lane ? ((wave * ROWS_W + hj) * PRW + (lane & 1) * POFF + 32) : -1;
+    float rp[ROWS_W + 1];
+    auto load_patch = [&](int ci0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < ROWS_W; ++j) {
+            const int ch = ci0 + (c_first + j) / 3;                                                  // wave-uniform
+            rp[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ch < Cin ? in_rs : null_rs, m_vo[j % 3], ch * (int)HW * 4, 0));
+        }
+        // the halo item's channel is per lane: only the last half-chunk of a channel count that is not a multiple of 4 has to look
+        const unsigned hv = (ci0 + CI_H <= Cin || ci0 + h_c < Cin) ? h_vo : FAR;
+        rp[ROWS_W] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ci0 < Cin ? in_rs : null_rs, hv, ci0 * (int)HW * 4, 0));
+    };
+    auto store_patch = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < ROWS_W; ++j) P[buf * PBUF + j * PRW + m_lds] = rp[j];
+        P[h_lane ? buf * PBUF + h_lds : DUMMY + lane] = rp[ROWS_W];
+    };
+    // ---- weight DMA: instruction q of a half-chunk moves rows [q*RPI, (q+1)*RPI) x CO_T floats = 1 KiB; rows past the pack's end
+    // are out of the resource's range (zeros)
+    const int drow = lane / LPR, dcol = (lane % LPR) * 4;
+    unsigned w_vo[DPW];
+#pragma unroll
+    for (int d = 0; d < DPW; ++d) w_vo[d] = co0 + dcol < Cout ? (unsigned)(((wave + 4 * d) * RPI + drow) * Cout + co0 + dcol) * 4u : FAR;
+    auto dma_weights = [&](int ci0, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int d = 0; d < DPW; ++d)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (__attribute__((address_space(3))) void*)(Wt + buf * WBUF + (wave + 4 * d) * 256), 16, w_vo[d],
+                                                     ci0 * 12 * Cout * 4, 0, 0);
+    };
+    // ---- K loop of one half-chunk: 6 steps (channel pair cp: lanes 0-31 take channel cp, lanes 32-63 channel cp + 2; row kh),
+    // each 4 transform points x TM row blocks = 8 MFMAs
+    auto kloop = [&](int buf) {
+        const float* wa = Wt + buf * WBUF + wco + li + lk * (2 * 12) * CO_T;
+        const float* pb = P + buf * PBUF + wsg * PSEG + li + lk * 2 * 3 * PRW;
+        float a[4][TM], e0, e1, o0, o1;
+        auto reads = [&](int s, float (&aa)[4][TM], float& E0, float& E1, float& O0, float& O1) {
+            const int cp = s / 3, kh = s % 3;                                            // compile-time after unrolling
+            const float* pr = pb + (cp * 3 + kh) * PRW;
+            E0 = pr[0]; E1 = pr[1]; O0 = pr[POFF]; O1 = pr[POFF + 1];
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) aa[x][i] = wa[((cp * 3 + kh) * 4 + x) * CO_T + 32 * i];
+        };
+        reads(0, a, e0, e1, o0, o1);
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            float an[4][TM], ne0 = 0.f, ne1 = 0.f, no0 = 0.f, no1 = 0.f;
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) an[x][i] = 0.f;
+            if (s + 1 < 6) reads(s + 1, an, ne0, ne1, no0, no1);
+            const float vv[4] = {e0 - e1, o0 + e1, e1 - o0, o0 - o1};
+            __builtin_amdgcn_sched_barrier(0);      // next step's ds_reads are issued BEFORE this step's MFMAs
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i][x] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x][i], vv[x], acc[i][x], 0, 0, 0);
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[x][i] = an[x][i];
+            e0 = ne0; e1 = ne1; o0 = no0; o1 = no1;
+        }
+    };
+
+    const int nh = ((Cin + 2 * CI_H - 1) / (2 * CI_H)) * 2;          // half-chunks, padded to an even count (zero weights)
+    dma_weights(0, 0);
+    load_patch(0);
+    store_patch(0);
+    for (int h = 0; h < nh; h += 2) {
+        __syncthreads();                            // buffer 0 complete (DMA drained: vmcnt(0)), buffer 1 free
+        dma_weights((h + 1) * CI_H, 1);
+        load_patch((h + 1) * CI_H);
+        kloop(0);
+        store_patch(1);
+        __syncthreads();                            // buffer 1 complete, buffer 0 free
+        dma_weights((h + 2) * CI_H, 0);             // past the last channel: zero page / masked rows, never used
+        load_patch((h + 2) * CI_H);
+        kloop(1);
+        store_patch(0);
+    }
+
+    // ---- output transform and stores: lane li = column pair, y(2t) = m0 + m1 + m2, y(2t+1) = m1 - m2 - m3
+    const WSlot os = wslot((seg0 + wsg) * TS + li, geo);
+    const int px = 2 * os.k;
+    if (!os.valid || os.k >= geo.T || px >= W) return;
+    const bool two = px + 1 < W;
+    float* obase = out + (long)os.n * Cout * HW + (long)os.h * W + px;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wco + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (co < Cout) {
+                const float b = bias ? bias[co] : 0.f;
+                const float m0 = acc[i][0][r], m1 = acc[i][1][r], m2 = acc[i][2][r], m3 = acc[i][3][r];
+                float* o = obase + (long)co * HW;
+                o[0] = ((m0 + m1) + m2) + b;
+                if (two) o[1] = ((m1 - m2) - m3) + b;
+            }
+        }
+}
+
+
+// (device-only builtins inside a TEMPLATE kernel make the host pass drop its launch stub, hence the body as a device function)
+__global__ __launch_bounds__(256, 2) void conv3x3_wino2_kernel_128(const float* __restrict__ in, const float* __restrict__ wpack, const float* __restrict__ bias,
+                                                                   float* __restrict__ out, const float* __restrict__ zero_page, int N, int Cin, int H, int W, int Cout,
+                                                                   WGeom geo, int co_tiles, const float* __restrict__ wdirect, int n_tail, int first_tail_tile) {
+    conv3x3_wino2_body<128>(in, wpack, bias, out, zero_page, N, Cin, H, W, Cout, geo, co_tiles, wdirect, n_tail, first_tail_tile);
+}
+__global__ __launch_bounds__(256, 2) void conv3x3_wino2_kernel_64(const float* __restrict__ in, const float* __restrict__ wpack, const float* __restrict__ bias,
+                                                                  float* __restrict__ out, const float* __restrict__ zero_page, int N, int Cin, int H, int W, int Cout,
+                                                                  WGeom geo, int co_tiles, const float* __restrict__ wdirect, int n_tail, int first_tail_tile) {
+    conv3x3_wino2_body<64>(in, wpack, bias, out, zero_page, N, Cin, H, W, Cout, geo, co_tiles, wdirect, n_tail, first_tail_tile);
+}
+
 // The same contraction with ONE workgroup of EIGHT waves per CU and a ring of THREE half-chunk stages (round 3; VOCR_CONV_WINO8=1).
 // What changes against conv3x3_wino_kernel (two 4-wave workgroups per CU, two stages):
 //   * the weights of a half-chunk are shared by 8 waves instead of 4 (CO_T = 128: two channel halves x FOUR segments; CO_T = 64:
@@ -1277,12 +1487,17 @@ extern "C" int vocr_conv3x3_wino_fwd(const float* x, const float* wpack, const f
     // VOCR_CONV_WINO8=1: one 8-wave workgroup per CU with a three-stage ring (measured no faster, see the kernel); default: the
     // two-stage 4-wave kernel, two workgroups per CU
     static const int wino8 = getenv("VOCR_CONV_WINO8") ? atoi(getenv("VOCR_CONV_WINO8")) : 0;
+    // VOCR_CONV_WINO2=0: round 3's loaders (pointer arithmetic and masks) instead of the buffer-addressed ones
+    static const int wino2 = getenv("VOCR_CONV_WINO2") ? atoi(getenv("VOCR_CONV_WINO2")) : 1;
     if (wino8 && wino_pack_x4()) {
         if (cout > 64) VOCR_WINO_LAUNCH((conv3x3_wino8_kernel<128, true>), 512, 128, 4, vocr_cdiv(cout, 128));
         else VOCR_WINO_LAUNCH((conv3x3_wino8_kernel<64, true>), 512, 64, 8, 1);
     } else if (wino8) {
         if (cout > 64) VOCR_WINO_LAUNCH((conv3x3_wino8_kernel<128, false>), 512, 128, 4, vocr_cdiv(cout, 128));
         else VOCR_WINO_LAUNCH((conv3x3_wino8_kernel<64, false>), 512, 64, 8, 1);
+    } else if (wino2 && (long)n * (cin > cout ? cin : cout) * h * w < (1l << 29)) {
+        if (cout > 64) VOCR_WINO_LAUNCH(conv3x3_wino2_kernel_128, 256, 128, 2, vocr_cdiv(cout, 128));
+        else VOCR_WINO_LAUNCH(conv3x3_wino2_kernel_64, 256, 64, 4, 1);
     } else {
         if (cout > 64) VOCR_WINO_LAUNCH(conv3x3_wino_kernel<128>, 256, 128, 2, vocr_cdiv(cout, 128));
         else VOCR_WINO_LAUNCH(conv3x3_wino_kernel<64>, 256, 64, 4, 1);
