@@ -37,6 +37,11 @@ extern "C" {
  * before raising; vistaocr_amd.ops.reset_health() clears it explicitly). */
 
 const char* vocr_last_error(void);
+/* The contract this header describes.  History: 2 = round 2 (caller-owned health word); 3 = round 3/4 (health words report-only and
+ * cleared by the caller, LSTM workspace survives between the vocr_lstm_fwd_range calls of a sweep, larger vocr_gemm_workspace_bytes,
+ * vocr_gemm_pair / vocr_lstm_bwd_parts / vocr_profile_range_*, x-fastest conv weight pack).  A binding compares vocr_abi_version()
+ * with the VOCR_ABI_VERSION it was written against and refuses a library that answers anything else. */
+#define VOCR_ABI_VERSION 3
 int  vocr_abi_version(void);
 /* Named ranges on the profiler's timeline (rocprofv3 --marker-trace), nested push / pop on the calling thread.  roctx is dlopen'ed on
  * first use; returns 0 when the range was recorded, 1 when roctx is not available (not an error), negative on a bad argument.  The

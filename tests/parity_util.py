@@ -55,12 +55,29 @@ def grad_rel_errors(named_hip_grads, oracle_state, skip_bn_shadowed_bias=True):
     return out
 
 
+# fp32 against fp32 agrees to 1e-5 .. 1e-4 where nothing amplifies the rounding: every gradient that the GEMM, LSTM and CTC kernels produce
+# (prob layer, LSTM, bridge) is held to 1e-3, so a systematic percent-level error in one of those kernels (a dropped K tail, a missing
+# slab) fails.  The conv stack sits behind seven batch-statistics BatchNorms whose backward divides by sigma and subtracts two
+# near-equal sums: measured HIP-vs-oracle 5e-5 at prob_layer growing to a few 1e-3 at cnn.0 (scripts/diag_golden.py), and two fp32
+# CPU builds differ by as much; those tensors keep 1e-2 (their kernels are held to 1e-4 directly in tests/test_ops_gpu.py).
+_RTOL_BY_PREFIX = (("cnn.", 1e-2), ("rapid_ds", 1e-2), ("", 1e-3))
+
+
+def _rtol_for(name, cap):
+    for prefix, tol in _RTOL_BY_PREFIX:
+        if name.startswith(prefix):
+            return min(tol, cap)
+    return cap
+
+
 def assert_grads_close(model, oracle_state, rtol=1e-2, atol_norm=1e-5):
-    """Element-wise gradient comparison of every parameter; returns (worst name, worst relative error)."""
+    """Element-wise gradient comparison of every parameter (rtol: an upper cap on the per-family tolerances above); returns
+    (worst name, worst relative error)."""
     errs = grad_rel_errors(((k, p.grad) for k, p in model.named_parameters()), oracle_state)
     worst = ("", 0.0)
     for k, (rel, rn) in errs.items():
         if rel > worst[1]:
             worst = (k, rel)
-        assert rel * rn <= rtol * rn + atol_norm, "gradient of %s differs element-wise: rel L2 error %.3e (|g| = %.3e)" % (k, rel, rn)
+        tol = _rtol_for(k, rtol)
+        assert rel * rn <= tol * rn + atol_norm, "gradient of %s differs element-wise: rel L2 error %.3e > %.0e (|g| = %.3e)" % (k, rel, tol, rn)
     return worst

@@ -23,7 +23,8 @@ def test_library_builds_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "libvocr.so does not export %s" % name
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
-    assert lib.vocr_abi_version() == 2
+    assert lib.vocr_abi_version() == _lib.ABI_VERSION == 3
+    assert re.search(r"#define VOCR_ABI_VERSION\s+3\b", open(os.path.join(ROOT, "include", "vocr.h")).read())
 
 
 def test_argument_validation_without_gpu():

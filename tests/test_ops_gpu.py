@@ -238,6 +238,48 @@ def test_gemm_variants(dev, m, n, k):
     _close(ops.colsum(a.to(dev)), a.double().sum(0), 1e-5, 1e-5 * m, "colsum")
 
 
+@pytest.mark.parametrize("T,B,H,din", [(294, 32, 512, 1024), (37, 5, 64, 128)])
+def test_gemm_pair_on_the_steps_strided_views_fp64(dev, T, B, H, din):
+    """vocr_gemm_pair produces every LSTM data gradient and weight gradient of a step.  The three call shapes of
+    vistaocr_amd/ops.py's BiLSTM backward - including the recurrent weight gradient's operands, which are VIEWS (dg[0][B:] is a row
+    offset, y[B:, H:] a column offset with ld = 2H) and a K that is not a multiple of the K-tile - against float64 at ~1e-5 of the
+    result's scale: a dropped K tail, a missing split-K slab or one wrong leading dimension is a percent-level error."""
+    from vistaocr_amd import ops
+    G, M = 4 * H, T * B
+    dg = _rand((2, M, G), 1, 0.5).to(dev)
+    x = _rand((M, din), 2).to(dev)
+    y = _rand((M, 2 * H), 3).to(dev)
+    wf, wr = _rand((G, din), 4, 0.1).to(dev), _rand((G, din), 5, 0.1).to(dev)
+    dgd, xd, yd = dg.double().cpu(), x.double().cpu(), y.double().cpu()
+
+    def close(got, want, what):
+        scale = float(want.abs().max())
+        err = float((got.double().cpu() - want).abs().max())
+        assert err <= 2e-5 * scale, "%s: max abs error %.3e at scale %.3e" % (what, err, scale)
+
+    # data gradient: ONE product whose K runs through both directions' pairs
+    dx = torch.empty(M, din, device=dev)
+    ops.gemm_pair(1, 0, 0, M, din, G, dg[0], dg[1], G, wf, wr, din, dx, None, din)
+    close(dx, dgd[0] @ wf.double().cpu() + dgd[1] @ wr.double().cpu(), "dx = dg_f W_f + dg_r W_r")
+    # input weight gradients: two TN products, K = T*B
+    dwf, dwr = torch.empty(G, din, device=dev), torch.empty(G, din, device=dev)
+    ops.gemm_pair(0, 1, 0, G, din, M, dg[0], dg[1], G, x, x, din, dwf, dwr, din)
+    close(dwf, dgd[0].t() @ xd, "dW_ih forward")
+    close(dwr, dgd[1].t() @ xd, "dW_ih reverse")
+    # recurrent weight gradients on views: forward h_{t-1} = y[t-1, :, :H] against dg[t], reverse h_{t+1} = y[t+1, :, H:] against dg[t]
+    m = (T - 1) * B
+    dhf, dhr = torch.empty(G, H, device=dev), torch.empty(G, H, device=dev)
+    ops.gemm_pair(0, 1, 0, G, H, m, dg[0][B:], dg[1], G, y, y[B:, H:], 2 * H, dhf, dhr, H)
+    close(dhf, dgd[0][B:].t() @ yd[:m, :H], "dW_hh forward (row-offset view)")
+    close(dhr, dgd[1][:m].t() @ yd[B:, H:], "dW_hh reverse (column-offset view, ld = 2H)")
+    # x-projections: two NT products with bias
+    bf, br = _rand((G,), 6).to(dev), _rand((G,), 7).to(dev)
+    xp = torch.empty(2, M, G, device=dev)
+    ops.gemm_pair(0, 0, 1, M, G, din, x, x, din, wf, wr, din, xp[0], xp[1], G, bias0=bf, bias1=br)
+    close(xp[0], xd @ wf.double().cpu().t() + bf.double().cpu(), "x-projection forward")
+    close(xp[1], xd @ wr.double().cpu().t() + br.double().cpu(), "x-projection reverse")
+
+
 def test_permute_and_elementwise(dev):
     from vistaocr_amd import ops
     x = _rand((3, 16, 7, 37), 0)

@@ -79,6 +79,8 @@ SIGNATURES = {
     "vocr_comm_destroy": (I, [P]),
 }
 
+ABI_VERSION = 3          # include/vocr.h: VOCR_ABI_VERSION
+
 _lib = None
 
 
@@ -91,6 +93,11 @@ def load():
         raise RuntimeError("libvocr.so not found at %s — run `python -m vistaocr_amd.build` (needs hipcc). "
                            "vistaocr_amd has no CPU fallback." % LIB_PATH)
     lib = ctypes.CDLL(LIB_PATH)
+    lib.vocr_abi_version.restype = ctypes.c_int
+    got = lib.vocr_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError("libvocr.so at %s answers ABI version %d, this package was written for %d (include/vocr.h: VOCR_ABI_VERSION) "
+                           "— a stale binary; rebuild with `python -m vistaocr_amd.build --force`" % (LIB_PATH, got, ABI_VERSION))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
         fn.restype = res

@@ -1,5 +1,12 @@
 """Build libvocr.so (HIP kernels + C-ABI) for gfx950 in-tree with hipcc.  No JIT cache: the .so sits next to
-the sources so it travels with the repo snapshot to the GPU box."""
+the sources so it travels with the repo snapshot to the GPU box.
+
+The build is gated by a HASH, not by file times: the SHA-256 over every source and header, the compiler flags and hipcc's
+version string is written to csrc/build/libvocr.stamp next to the library.  A tree whose sources differ from what the
+library was built from (a fresh checkout with a shipped .so, a box with another ROCm) rebuilds; an unchanged tree does
+not.  `build_report()` says which of the two happened (the driver's "build exercised" question)."""
+import hashlib
+import json
 import os
 import shutil
 import subprocess
@@ -8,37 +15,72 @@ from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 SOURCES = ["gemm.hip", "gemm_dma.hip", "conv.hip", "conv_wino.hip", "conv_f16.hip", "bn_pool.hip", "lstm.hip", "ctc.hip", "misc.cpp", "comm.cpp"]
+HEADERS = [os.path.join(CSRC, "vocr_common.h"), os.path.join(CSRC, "conv_tail.h"), os.path.join(CSRC, "gemm_dma.h"),
+           os.path.join(CSRC, "..", "..", "include", "vocr.h")]
 LIB = os.path.join(CSRC, "libvocr.so")
+STAMP = os.path.join(CSRC, "build", "libvocr.stamp")
 ARCH = "gfx950"
+FLAGS = ["-O3", "--offload-arch=" + ARCH, "-fPIC", "-std=c++17", "-Wno-pass-failed"]
+_REPORT = {"built": False, "reason": "not asked"}
 
 
 def _hipcc():
     for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
             return cand
-    raise RuntimeError("hipcc not found: libvocr.so cannot be built")
+    return None
 
 
-def _stale():
+def _tree_hash(hipcc):
+    h = hashlib.sha256()
+    for path in [os.path.join(CSRC, s) for s in SOURCES] + HEADERS:
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(FLAGS).encode())
+    if hipcc:
+        try:
+            h.update(subprocess.run([hipcc, "--version"], capture_output=True, text=True, timeout=60).stdout.encode())
+        except Exception:
+            pass
+    return h.hexdigest()
+
+
+def _stale(want):
     if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "vocr_common.h"), os.path.join(CSRC, "conv_tail.h"), os.path.join(CSRC, "gemm_dma.h"),
-                                                      os.path.join(CSRC, "..", "..", "include", "vocr.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+        return "no library"
+    try:
+        st = json.load(open(STAMP))
+    except Exception:
+        return "no stamp"
+    if st.get("tree") != want:
+        return "sources, flags or compiler changed"
+    with open(LIB, "rb") as f:
+        if hashlib.sha256(f.read()).hexdigest() != st.get("lib"):
+            return "library is not the one the stamp describes"
+    return None
+
+
+def build_report():
+    """{'built': bool, 'reason': str} of the last build() call in this process."""
+    return dict(_REPORT)
 
 
 def build(force=False, verbose=False):
-    if not force and not _stale():
-        return LIB
     hipcc = _hipcc()
+    want = _tree_hash(hipcc)
+    why = "forced" if force else _stale(want)
+    if why is None:
+        _REPORT.update(built=False, reason="stamp matches sources, flags and compiler")
+        return LIB
+    if hipcc is None:
+        raise RuntimeError("hipcc not found: libvocr.so cannot be built (%s)" % why)
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
-    flags = ["-O3", "--offload-arch=" + ARCH, "-fPIC", "-std=c++17", "-Wno-pass-failed"]
 
     def cc(src):
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
-        cmd = [hipcc] + flags + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, r.stderr))
@@ -51,8 +93,12 @@ def build(force=False, verbose=False):
     r = subprocess.run([hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs + ["-ldl"], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stderr)
+    with open(LIB, "rb") as f:
+        libsum = hashlib.sha256(f.read()).hexdigest()
+    json.dump({"tree": want, "lib": libsum}, open(STAMP, "w"))
+    _REPORT.update(built=True, reason=why)
     return LIB
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True), build_report())

@@ -63,12 +63,19 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
     }
 }
 
+// VOCR_CONV_WINO2 (default 1): conv3x3_wino2_body, which reads the x-fastest pack; 0: round 3's kernels (VOCR_CONV_PACK4 then picks the
+// pack for the VOCR_CONV_WINO8=1 experiments)
+static int wino2_mode() {
+    static const int v = getenv("VOCR_CONV_WINO2") ? atoi(getenv("VOCR_CONV_WINO2")) : 1;
+    return v;
+}
 static int wino_pack_x4() {
-    static const int v = getenv("VOCR_CONV_PACK4") ? atoi(getenv("VOCR_CONV_PACK4")) : 0;      // experiments: needs VOCR_CONV_WINO8=1
+    static const int v = wino2_mode() ? 1 : (getenv("VOCR_CONV_PACK4") ? atoi(getenv("VOCR_CONV_PACK4")) : 0);
     return v;
 }
 
 typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 // Forward / data-gradient geometry: the column pairs of all image rows form ONE stream - a row contributes its T = ceil(W/2) pairs and
 // one gap slot (the pair after the last one of a row must not see the next row's first columns) - and a segment is any 32 consecutive
 // slots, so only 1 of T+1 lane positions is idle (whole 32-pair segments per row idled 8 % of them at W = 294, 6 % at 420 / 600).
@@ -392,53 +399,57 @@ __device__ __forceinline__ void conv3x3_wino2_body(const float* __restrict__ in,
         for (int j = 0; j < ROWS_W; ++j) P[buf * PBUF + j * PRW + m_lds] = rp[j];
         P[h_lane ? buf * PBUF + h_lds : DUMMY + lane] = rp[ROWS_W];
     };
-    // ---- weight DMA: instruction q of a half-chunk moves rows [q*RPI, (q+1)*RPI) x CO_T floats = 1 KiB; rows past the pack's end
-    // are out of the resource's range (zeros)
-    const int drow = lane / LPR, dcol = (lane % LPR) * 4;
+    // ---- weight DMA.  The pack is x-fastest, pf[(ci*3 + kh)][co][4 transform points]: a half-chunk is 12 rows of CO_T x 16 bytes, an
+    // instruction moves 64 output channels of one row (lane = channel); rows past the pack's end are out of the resource's range
+    constexpr int IPR = CO_T / 64;                           // instructions per row
     unsigned w_vo[DPW];
 #pragma unroll
-    for (int d = 0; d < DPW; ++d) w_vo[d] = co0 + dcol < Cout ? (unsigned)(((wave + 4 * d) * RPI + drow) * Cout + co0 + dcol) * 4u : FAR;
+    for (int d = 0; d < DPW; ++d) {
+        const int q = wave + 4 * d, row = q / IPR, co = co0 + (q % IPR) * 64 + lane;
+        w_vo[d] = co < Cout ? (unsigned)(row * Cout + co) * 16u : FAR;
+    }
     auto dma_weights = [&](int ci0, int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int d = 0; d < DPW; ++d)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (__attribute__((address_space(3))) void*)(Wt + buf * WBUF + (wave + 4 * d) * 256), 16, w_vo[d],
-                                                     ci0 * 12 * Cout * 4, 0, 0);
+                                                     ci0 * 3 * Cout * 16, 0, 0);
     };
     // ---- K loop of one half-chunk: 6 steps (channel pair cp: lanes 0-31 take channel cp, lanes 32-63 channel cp + 2; row kh),
-    // each 4 transform points x TM row blocks = 8 MFMAs
-    auto kloop = [&](int buf) {
-        const float* wa = Wt + buf * WBUF + wco + li + lk * (2 * 12) * CO_T;
+    // each 4 transform points x TM row blocks = 8 MFMAs.  Per step: two 16-byte reads of the weights (the four transform points of a
+    // channel block), two 8-byte-pair reads of the raw row, three VALU instructions for the input transform (one of them packed).
+    auto kloop = [&](int buf) __attribute__((always_inline)) {
+        const float* wa = Wt + buf * WBUF + ((lk * 2 * 3) * CO_T + wco + li) * 4;
         const float* pb = P + buf * PBUF + wsg * PSEG + li + lk * 2 * 3 * PRW;
-        float a[4][TM], e0, e1, o0, o1;
-        auto reads = [&](int s, float (&aa)[4][TM], float& E0, float& E1, float& O0, float& O1) {
+        f32x4 a[TM];
+        f32x2 ev, ov;
+        auto reads = [&](int s, f32x4 (&aa)[TM], f32x2& E, f32x2& O) __attribute__((always_inline)) {
             const int cp = s / 3, kh = s % 3;                                            // compile-time after unrolling
             const float* pr = pb + (cp * 3 + kh) * PRW;
-            E0 = pr[0]; E1 = pr[1]; O0 = pr[POFF]; O1 = pr[POFF + 1];
+            E = f32x2{pr[0], pr[1]};
+            O = f32x2{pr[POFF], pr[POFF + 1]};
 #pragma unroll
-            for (int x = 0; x < 4; ++x)
-#pragma unroll
-                for (int i = 0; i < TM; ++i) aa[x][i] = wa[((cp * 3 + kh) * 4 + x) * CO_T + 32 * i];
+            for (int i = 0; i < TM; ++i) aa[i] = *(const f32x4*)(wa + ((cp * 3 + kh) * CO_T + 32 * i) * 4);
         };
-        reads(0, a, e0, e1, o0, o1);
+        reads(0, a, ev, ov);
 #pragma unroll
         for (int s = 0; s < 6; ++s) {
-            float an[4][TM], ne0 = 0.f, ne1 = 0.f, no0 = 0.f, no1 = 0.f;
+            f32x4 an[TM];
+            f32x2 ne = ev, no = ov;
 #pragma unroll
-            for (int x = 0; x < 4; ++x)
-#pragma unroll
-                for (int i = 0; i < TM; ++i) an[x][i] = 0.f;
-            if (s + 1 < 6) reads(s + 1, an, ne0, ne1, no0, no1);
-            const float vv[4] = {e0 - e1, o0 + e1, e1 - o0, o0 - o1};
+            for (int i = 0; i < TM; ++i) an[i] = a[i];
+            if (s + 1 < 6) reads(s + 1, an, ne, no);
+            // v0 = e0 - e1   v1 = o0 + e1   v2 = e1 - o0   v3 = o0 - o1
+            f32x2 v12;
+            asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[1,0]\n\ts_nop 1" : "=v"(v12) : "v"(ov), "v"(ev));
+            const float vv[4] = {ev[0] - ev[1], v12[0], v12[1], ov[0] - ov[1]};
             __builtin_amdgcn_sched_barrier(0);      // next step's ds_reads are issued BEFORE this step's MFMAs
 #pragma unroll
             for (int x = 0; x < 4; ++x)
 #pragma unroll
-                for (int i = 0; i < TM; ++i) acc[i][x] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x][i], vv[x], acc[i][x], 0, 0, 0);
+                for (int i = 0; i < TM; ++i) acc[i][x] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][x], vv[x], acc[i][x], 0, 0, 0);
 #pragma unroll
-            for (int x = 0; x < 4; ++x)
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a[x][i] = an[x][i];
-            e0 = ne0; e1 = ne1; o0 = no0; o1 = no1;
+            for (int i = 0; i < TM; ++i) a[i] = an[i];
+            ev = ne; ov = no;
         }
     };
 
@@ -1163,7 +1174,6 @@ constexpr int G3_XE = 6 * 256;                   // floats of extras per buffer
 constexpr int G3_XB = G3_X + G3_XE;              // x + extras per buffer: 13824 floats = 55296 bytes (< 64 KiB: an immediate offset)
 constexpr int G3_X0 = 2 * G3_DY;                 // first x buffer
 struct W3Geom { int np, S, slots_img, nseg, adv; };
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 // The transforms of one dy piece g = (g0..g3) and one x piece c = (c0..c3) as packed adds.  Inline assembly because the compiler only
 // folds some of the half selections / negations into the instruction's modifiers (the others cost a v_xor or v_mov each).  The
 // compiler's hazard recogniser does not look into inline assembly, and a VALU result needs two wait states before an MFMA may read
@@ -1487,8 +1497,7 @@ extern "C" int vocr_conv3x3_wino_fwd(const float* x, const float* wpack, const f
     // VOCR_CONV_WINO8=1: one 8-wave workgroup per CU with a three-stage ring (measured no faster, see the kernel); default: the
     // two-stage 4-wave kernel, two workgroups per CU
     static const int wino8 = getenv("VOCR_CONV_WINO8") ? atoi(getenv("VOCR_CONV_WINO8")) : 0;
-    // VOCR_CONV_WINO2=0: round 3's loaders (pointer arithmetic and masks) instead of the buffer-addressed ones
-    static const int wino2 = getenv("VOCR_CONV_WINO2") ? atoi(getenv("VOCR_CONV_WINO2")) : 1;
+    const int wino2 = wino2_mode();
     if (wino8 && wino_pack_x4()) {
         if (cout > 64) VOCR_WINO_LAUNCH((conv3x3_wino8_kernel<128, true>), 512, 128, 4, vocr_cdiv(cout, 128));
         else VOCR_WINO_LAUNCH((conv3x3_wino8_kernel<64, true>), 512, 64, 8, 1);

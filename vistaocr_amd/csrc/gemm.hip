@@ -572,6 +572,7 @@ extern "C" int vocr_gemm_pair(int mode, int transa, int transb, int m, int n, in
     VOCR_CHECK_ARG(m > 0 && n > 0 && k > 0, "vocr_gemm_pair: bad shape m=%d n=%d k=%d", m, n, k);
     VOCR_CHECK_ARG(a0 && a1 && b0 && b1 && c0 && (mode == 1 || c1), "vocr_gemm_pair: null pointer");
     VOCR_CHECK_ARG(mode == 0 || (c1 == nullptr && bias1 == nullptr), "vocr_gemm_pair: mode 1 has one output and one bias");
+    VOCR_CHECK_ARG(lda >= (transa ? m : k) && ldb >= (transb ? k : n) && ldc >= n, "vocr_gemm_pair: bad leading dimension");
     hipStream_t s = (hipStream_t)stream;
     const uintptr_t al = ((uintptr_t)a0) | ((uintptr_t)a1) | ((uintptr_t)b0) | ((uintptr_t)b1) | ((uintptr_t)c0) | ((uintptr_t)c1) |
                          ((uintptr_t)bias0) | ((uintptr_t)bias1);

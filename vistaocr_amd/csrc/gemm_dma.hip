@@ -422,8 +422,12 @@ int launch(const Plan& p, int transa, int transb, int m, int n, int k, const flo
     g.nprob = nprob; g.nseg = nseg;
     g.panels = p.panels; g.groups = p.groups; g.ksplit = p.ksplit; g.kps = p.kps;
     g.relu = relu;
+#ifdef VOCR_GEMM_DIAG      // diagnostic builds only (scripts/gemm_dbg.py): parts of the loop switched off, WRONG results - never in libvocr.so
     static const int dbg = getenv("VOCR_GEMM_DBG") ? atoi(getenv("VOCR_GEMM_DBG")) : 0;
     g.dbg = dbg;
+#else
+    g.dbg = 0;
+#endif
     g.slab = p.ksplit > 1 ? slab : nullptr;
     const dim3 grid(nprob * p.panels * p.groups * p.ksplit);
     if (!transa && transb) gemm_dma_kernel<true, true><<<grid, 512, 0, s>>>(g);

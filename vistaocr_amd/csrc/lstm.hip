@@ -2030,7 +2030,11 @@ __global__ void lstm_bias_combine_kernel(const float* __restrict__ part, float* 
 template <int KQ4>
 bool launch_fwd_fast(int rt, dim3 grid, hipStream_t s, const float* xproj, const float* wf, const float* wr, const int32_t* lens,
                      float* y, float* gates, float* cell, int T, int B, int step) {
-    static const int dbg = getenv("VOCR_LSTM_DEBUG") ? atoi(getenv("VOCR_LSTM_DEBUG")) : 0;   // timing experiments only
+#ifdef VOCR_LSTM_DIAG      // diagnostic builds only: parts of the per-step kernels switched off, WRONG results - never in libvocr.so
+    static const int dbg = getenv("VOCR_LSTM_DEBUG") ? atoi(getenv("VOCR_LSTM_DEBUG")) : 0;
+#else
+    constexpr int dbg = 0;
+#endif
     switch (rt) {
         case 1: lstm_fwd_step_fast<KQ4, 1><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, T, B, step, dbg); return true;
         case 2: lstm_fwd_step_fast<KQ4, 2><<<grid, 256, 0, s>>>(xproj, wf, wr, lens, y, gates, cell, T, B, step, dbg); return true;
@@ -2327,7 +2331,11 @@ static int lstm_bwd_impl(const float* dy, const float* dy_mask, const float* whh
     }
     for (int step = 0; step < t; ++step) {
         if (fast) {
-            static const int dbg = getenv("VOCR_LSTM_DEBUG") ? atoi(getenv("VOCR_LSTM_DEBUG")) : 0;   // timing experiments only
+#ifdef VOCR_LSTM_DIAG
+            static const int dbg = getenv("VOCR_LSTM_DEBUG") ? atoi(getenv("VOCR_LSTM_DEBUG")) : 0;
+#else
+            constexpr int dbg = 0;
+#endif
             const bool half = (dbg & 8) != 0;          // 8 units per workgroup (256 WGs at B=32): measured no faster than 16
             const dim3 g(2 * (h / (half ? 8 : 16)) * rt);
 #define VOCR_BWD(NCH, UT) lstm_bwd_step_fast<NCH, 4, UT><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, dcb, t, b, step, rt, dbg)

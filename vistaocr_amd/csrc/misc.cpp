@@ -15,7 +15,7 @@ void vocr_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* vocr_last_error(void) { return g_err; }
-extern "C" int vocr_abi_version(void) { return 2; }
+extern "C" int vocr_abi_version(void) { return VOCR_ABI_VERSION; }
 extern "C" int vocr_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {

@@ -3,6 +3,7 @@ src/lr_scheduler.py and src/datautils.py that drive train()/test_on_val() — re
 the same control flow: width-grouped sampling, sort-by-width collation, plateau LR schedule with "reload best on LR
 drop", validation with CER/WER, and the reference's checkpoint dictionary.  Pure host logic; the arithmetic stays in
 the HIP path (model / criterion / decoder)."""
+import itertools
 import logging
 import shutil
 import warnings
@@ -15,98 +16,91 @@ from .textutils import compute_cer_wer, form_target_transcription
 logger = logging.getLogger("root")
 
 
-class ReduceLROnPlateau(object):
-    """src/lr_scheduler.py:10-98.  step(metric) returns True when the LR was lowered (or could not be lowered any
-    further, which sets .finished).  Works with any optimiser exposing .param_groups (FlatClampAdam, torch.optim.*)."""
+class ReduceLROnPlateau:
+    """The plateau schedule the reference trains with (behaviour of src/lr_scheduler.py:10-98, pinned by the traces in
+    tests/golden/host_logic.npz): a metric that has not improved on the best one by more than `epsilon` for more than `patience`
+    calls lowers every group's lr by `factor` (not below `min_lr`) and opens a `cooldown` window in which nothing is counted.
+    step(metric) -> True when the lr was lowered on this call - or could not be lowered any further, which sets `.finished`.
+    Works with any optimiser exposing .param_groups (FlatClampAdam, torch.optim.*)."""
 
     def __init__(self, optimizer, mode="min", factor=0.1, patience=10, epsilon=1e-4, cooldown=0, min_lr=0):
         if not hasattr(optimizer, "param_groups"):
             raise AssertionError("optimizer has no param_groups")
         if factor >= 1.0:
             raise ValueError("ReduceLROnPlateau does not support a factor>=1.0")
+        if mode not in ("min", "max"):
+            raise RuntimeError("ReduceLROnPlateau mode:%s not valid." % mode)
+        self.optimizer, self.mode = optimizer, mode
+        self.factor, self.patience, self.epsilon, self.cooldown, self.min_lr = factor, patience, epsilon, cooldown, min_lr
         self.finished = False
-        self.factor, self.min_lr, self.epsilon, self.patience, self.cooldown = factor, min_lr, epsilon, patience, cooldown
-        self.cooldown_counter = 0
-        self.wait = 0
-        self.best = 0
-        self.mode = mode
-        self.optimizer = optimizer
-        self._reset()
-
-    def _reset(self):
-        if self.mode not in ["min", "max"]:
-            raise RuntimeError("ReduceLROnPlateau mode:%s not valid." % self.mode)
-        if self.mode == "min":
-            self.monitor_op = lambda a, b: np.less(a, b - self.epsilon)
-            self.best = np.inf
-        else:
-            self.monitor_op = lambda a, b: np.less(a, b + self.epsilon)      # (sic) the reference's max mode
-            self.best = -np.inf
-        self.cooldown_counter = 0
-        self.wait = 0
-        self.lr_epsilon = self.min_lr * 1e-4
+        self.reset()
 
     def reset(self):
-        self._reset()
+        """Forget the best metric and every counter (the lr stays where it is)."""
+        self.best = float("inf") if self.mode == "min" else -float("inf")
+        self.wait = 0                   # calls without improvement since the last improvement / lr drop
+        self.cooldown_counter = 0       # calls left in the window after an lr drop
 
     def in_cooldown(self):
         return self.cooldown_counter > 0
 
+    def _improves(self, metric):
+        # "max" compares the way the reference does (metric < best + epsilon): kept, its traces are the contract
+        return metric < (self.best - self.epsilon if self.mode == "min" else self.best + self.epsilon)
+
+    def _lower(self):
+        floor = self.min_lr + self.min_lr * 1e-4
+        for group in self.optimizer.param_groups:
+            lr = float(group["lr"])
+            if lr > floor:
+                group["lr"] = max(lr * self.factor, self.min_lr)
+                self.cooldown_counter, self.wait = self.cooldown, 0
+            else:
+                self.finished = True
+
     def step(self, metrics):
-        current = metrics
-        if current is None:
+        if metrics is None:
             warnings.warn("Learning Rate Plateau Reducing requires metrics.", RuntimeWarning)
             return False
-        if self.in_cooldown():
+        if self.cooldown_counter > 0:
             self.cooldown_counter -= 1
             self.wait = 0
-        if self.monitor_op(current, self.best):
-            self.best = current
-            self.wait = 0
-        elif not self.in_cooldown():
-            if self.wait >= self.patience:
-                for group in self.optimizer.param_groups:
-                    old_lr = float(group["lr"])
-                    if old_lr > self.min_lr + self.lr_epsilon:
-                        group["lr"] = max(old_lr * self.factor, self.min_lr)
-                        self.cooldown_counter = self.cooldown
-                        self.wait = 0
-                    else:
-                        self.finished = True
-                return True
+        if self._improves(metrics):
+            self.best, self.wait = metrics, 0
+            return False
+        if self.cooldown_counter > 0:
+            return False
+        if self.wait < self.patience:
             self.wait += 1
-        return False
+            return False
+        self._lower()
+        return True
 
 
 class GroupedSampler(torch.utils.data.Sampler):
-    """src/datautils.py:4-51 — visit width groups in order, random within a group.  (The reference's generator
-    raises StopIteration inside a generator, a RuntimeError since PEP 479; this one simply returns.)"""
+    """Width-grouped sampling (behaviour of src/datautils.py:4-51): the groups of `data_source.size_group_keys` one after the other,
+    the members of a group in a fresh random order (`rand`), in one random order drawn once per group (`fixed_rand`) or as stored;
+    at most `max_items` indices when that is positive.  A group's permutation is drawn when the iteration reaches the group, so the
+    torch RNG is consumed exactly as the reference consumes it."""
 
     def __init__(self, data_source, rand=True, max_items=-1, fixed_rand=False):
         self.size_group_keys = data_source.size_group_keys
         self.size_groups = data_source.size_groups
         self.num_samples = len(data_source)
         self.rand, self.fixed_rand, self.max_items = rand, fixed_rand, max_items
-        self.rand_perm = dict()
+        self.rand_perm = {}
+
+    def _visit_order(self, key):
+        n = len(self.size_groups[key])
+        if self.fixed_rand:
+            if key not in self.rand_perm:
+                self.rand_perm[key] = torch.randperm(n).long()
+            return self.rand_perm[key].tolist()
+        return torch.randperm(n).long().tolist() if self.rand else range(n)
 
     def __iter__(self):
-        n_items = 0
-        for g in self.size_group_keys:
-            if len(self.size_groups[g]) == 0:
-                continue
-            if self.fixed_rand:
-                if g not in self.rand_perm:
-                    self.rand_perm[g] = torch.randperm(len(self.size_groups[g])).long()
-                order = self.rand_perm[g]
-            elif self.rand:
-                order = torch.randperm(len(self.size_groups[g])).long()
-            else:
-                order = range(len(self.size_groups[g]))
-            for g_idx in order:
-                n_items += 1
-                if self.max_items > 0 and n_items > self.max_items:
-                    return
-                yield self.size_groups[g][int(g_idx)]
+        members = (self.size_groups[key][pos] for key in self.size_group_keys if len(self.size_groups[key]) for pos in self._visit_order(key))
+        return itertools.islice(members, self.max_items) if self.max_items > 0 else members
 
     def __len__(self):
         return self.num_samples
@@ -213,6 +207,15 @@ def fit(model, criterion, optimizer, train_dataloader, validation_dataloader, tr
     import gc
     gc.collect()
     gc.freeze()
+    try:
+        return _fit_loop(model, criterion, optimizer, train_dataloader, validation_dataloader, train_fn, snapshot_path, best_model_path,
+                         batch_size, n_epochs, snapshot_every_n_iterations, rtl, line_height, validate_fn, scheduler, lr_alpha, hist)
+    finally:
+        gc.unfreeze()       # the freeze is this call's, not the process's: a host that calls fit() again, or lives on, collects as before
+
+
+def _fit_loop(model, criterion, optimizer, train_dataloader, validation_dataloader, train_fn, snapshot_path, best_model_path, batch_size,
+              n_epochs, snapshot_every_n_iterations, rtl, line_height, validate_fn, scheduler, lr_alpha, hist):
     iteration = 0
     best_val_wer = float("inf")
     for _epoch in range(1, n_epochs + 1):

@@ -55,48 +55,47 @@ def edit_distance(A, B):
 
 
 def form_tokenized_words(chars, with_spaces=False):
-    """src/textutils.py:290-323 — split on u0020, punctuation and digits become single-char words."""
-    words = []
-    start = 0
-    for i in range(len(chars)):
-        if chars[i] == "u0020":
-            if start != i:
-                words.append("_".join(chars[start:i]))
-                if with_spaces:
-                    words.append("u0020")
-            start = i + 1
-            continue
-        if chars[i] in _PUNCT or chars[i] in _DIGITS:
-            if start != i:
-                words.append("_".join(chars[start:i]))
-            words.append(chars[i])
-            start = i + 1
-            continue
-        if i == len(chars) - 1:
-            if start == i:
-                words.append(chars[start])
-            else:
-                words.append("_".join(chars[start:]))
+    """Words of a uxxxx character sequence as the reference's scorer forms them (behaviour of src/textutils.py:290-323): u0020
+    separates words, every punctuation mark and digit is a word of its own, the characters of a word are joined by "_".  With
+    `with_spaces` a u0020 token follows each word that a space ended."""
+    words, letters = [], []
+
+    def close_word():
+        if letters:
+            words.append("_".join(letters))
+            del letters[:]
+            return True
+        return False
+
+    for ch in chars:
+        if ch == "u0020":
+            if close_word() and with_spaces:
+                words.append("u0020")
+        elif ch in _PUNCT or ch in _DIGITS:
+            close_word()
+            words.append(ch)
+        else:
+            letters.append(ch)
+    close_word()
     return words
 
 
+def _without_outer_spaces(words):
+    lo, hi = 0, len(words)
+    while lo < hi and words[lo] == "u0020":
+        lo += 1
+    while hi > lo and words[hi - 1] == "u0020":
+        hi -= 1
+    return words[lo:hi]
+
+
 def compute_cer_wer(hyp_transcription, ref_transcription):
-    """src/textutils.py:326-351 — inputs in uxxxx form; returns (CER, WER)."""
-    hyp_chars = hyp_transcription.split(" ")
-    ref_chars = ref_transcription.split(" ")
-    char_dist = edit_distance(hyp_chars, ref_chars)
-    hyp_words = form_tokenized_words(hyp_chars)
-    ref_words = form_tokenized_words(ref_chars)
-    while len(hyp_words) > 0 and hyp_words[0] == "u0020":
-        hyp_words = hyp_words[1:]
-    while len(hyp_words) > 0 and hyp_words[-1] == "u0020":
-        hyp_words = hyp_words[:-1]
-    while len(ref_words) > 0 and ref_words[0] == "u0020":
-        ref_words = ref_words[1:]
-    while len(ref_words) > 0 and ref_words[-1] == "u0020":
-        ref_words = ref_words[:-1]
-    word_dist = edit_distance(hyp_words, ref_words)
-    return float(char_dist) / len(ref_chars), float(word_dist) / len(ref_words)
+    """(CER, WER) of a hypothesis against a reference, both in uxxxx form (behaviour of src/textutils.py:326-351): character and word
+    edit distances, each over the reference's length."""
+    hyp_chars, ref_chars = hyp_transcription.split(" "), ref_transcription.split(" ")
+    hyp_words = _without_outer_spaces(form_tokenized_words(hyp_chars))
+    ref_words = _without_outer_spaces(form_tokenized_words(ref_chars))
+    return float(edit_distance(hyp_chars, ref_chars)) / len(ref_chars), float(edit_distance(hyp_words, ref_words)) / len(ref_words)
 
 
 def form_target_transcription(target, alphabet):
