@@ -34,18 +34,63 @@ HBM_PEAK_GBS = 8000.0
 HP = dict(num_in_channels=1, input_line_height=30, rds_line_height=30, lstm_input_dim=128, num_lstm_layers=3,
           num_lstm_hidden_units=512, p_lstm_dropout=0.5)
 B, HIMG, WIMG, LABELS = 32, 30, 600, 20
-CPU_BASELINE_THREADS = 32     # oneDNN/ATen stop scaling (and collapse on the per-time-step LSTM ops) far below 256 threads
+CPU_THREAD_SWEEP = (8, 16, 32, 64, 128)   # the CPU leg times one step at each (while the budget lasts) and reports the best
 CPU_TIMED_STEPS = 2
 PROFILE_STEPS = 5             # un-timed pass that records HIP events around every entry point (breakdown only)
+
+
+def madcat_widths(n, wmax, seed):
+    """n line widths from the width distribution the reference measured on MADCAT (src/madcat.py:58-66: 10 % of the lines up to
+    150 px, 20 % up to 200, 45 % up to 300, 70 % up to 350, 90 % up to 450, 99 % up to 600), scaled so that 600 px becomes `wmax`
+    (BASELINE configs[3]: "wider ~1200-px lines"), drawn by inverse CDF from seeded uniforms and sorted descending like
+    SortByWidthCollater does.  One batch mixes all width classes - more ragged than the reference's width-grouped batches."""
+    import numpy as np
+    xs = np.array([60, 150, 200, 300, 350, 450, 600, 640], dtype=np.float64) * (wmax / 600.0)
+    cdf = np.array([0.0, 0.10, 0.20, 0.45, 0.70, 0.90, 0.99, 1.0])
+    u = np.random.RandomState(seed).uniform(size=n)
+    w = np.interp(u, cdf, xs)
+    return sorted((int(min(wmax, max(16, round(v)))) for v in w), reverse=True)
+
+
+# configs[1] is the headline; c4 / c5 are BASELINE configs[3] / configs[4] as SIDE lines of the same JSON shape (own workload string, own
+# parity leg).  `widths`: per-line widths of a batch, `labels`: labels per line.
+WORKLOADS = {
+    "c1": dict(hp=HP, alphabet="english", himg=30, widths=[600] * B, labels=[20] * B, conv_dtype="fp32", parity_seed=56,
+               what="configs[1]: 32 synthetic 1x30x600 grey lines per GPU, 20 labels/line, V=96"),
+    "c4": dict(hp=HP, alphabet="arabic", himg=30, widths=madcat_widths(B, 1200, 4), labels=None, conv_dtype="fp32", parity_seed=93,
+               what="configs[3]: MADCAT-style Arabic alphabet (V=166), 32 synthetic 1x30xW grey lines per GPU with W from the MADCAT width "
+                    "distribution of src/madcat.py:58-66 scaled to <= 1200 px (one ragged batch across all width classes, sorted descending, "
+                    "zero-padded to the widest), W // 30 labels/line"),
+    "c5": dict(hp=dict(HP, input_line_height=60), alphabet="english", himg=60, widths=[1200] * B, labels=[40] * B, conv_dtype="fp16", parity_seed=1,
+               what="configs[4]: 32 synthetic 1x60x1200 grey lines per GPU (ASAR'18-style high resolution: rapid_ds 60 -> 30), 40 labels/line, "
+                    "V=96, fp16 conv operands with fp32 accumulation, everything else fp32"),
+}
+for _w in WORKLOADS.values():
+    if _w["labels"] is None:
+        _w["labels"] = [max(1, v // 30) for v in _w["widths"]]
+WL = WORKLOADS["c1"]
+
+
+def select_workload(name):
+    global WL
+    WL = WORKLOADS[name]
+    return WL
+
+
+def alphabet_of(wl):
+    import vistaocr_amd as va
+    return va.english_alphabet() if wl["alphabet"] == "english" else va.arabic_alphabet()
 
 
 def make_batch(rank, vocab):
     import torch
     g = torch.Generator().manual_seed(1234 + rank)
-    x = torch.rand(B, 1, HIMG, WIMG, generator=g)
-    widths = torch.full((B,), WIMG, dtype=torch.int32)
-    tgt = torch.randint(1, vocab, (B * LABELS,), generator=g).to(torch.int32)
-    tl = torch.full((B,), LABELS, dtype=torch.int32)
+    widths = torch.tensor(WL["widths"], dtype=torch.int32)
+    x = torch.rand(B, 1, WL["himg"], int(widths.max()), generator=g)
+    for b, w in enumerate(WL["widths"]):                  # the collater's zero padding right of each line
+        x[b, :, :, w:] = 0.0
+    tl = torch.tensor(WL["labels"], dtype=torch.int32)
+    tgt = torch.randint(1, vocab, (int(tl.sum()),), generator=g).to(torch.int32)
     return x, tgt, widths, tl
 
 
@@ -60,16 +105,17 @@ def parity_samples():
 # widened so that ~6000 labels come out of the 32 lines) and a closed-form batch whose seed was chosen on the ORACLE side for a
 # greedy-decode margin >= 1e-3 (scripts/margin_search.py bench 1 300); the oracle re-computes and reports the margin on the box.
 PARITY_STATE_KW = dict(lstm_scale=0.08, prob_scale=2.0)
-PARITY_BATCH_SEED = 56          # scripts/margin_search.py bench 1 300: oracle decode margin 1.02e-3 (the best of 299 seeds)
+PARITY_BATCH_SEED = None        # override of the workload's parity_seed (scripts/margin_search.py bench; c1: seed 56 of 299, margin 1.02e-3)
 
 
 def parity_inputs(hidden, vocab):
     """(state dict as numpy, x, widths, targets, target_lens) of the parity leg - closed forms shared with tests/ (oracle/closed_form.py
     holds no arithmetic of the path: seeded tensors only)."""
     from oracle import closed_form as cf
-    hp = dict(HP, num_lstm_hidden_units=hidden)
+    hp = dict(WL["hp"], num_lstm_hidden_units=hidden)
     sd_np = cf.closed_form_state(hp, vocab, **PARITY_STATE_KW)
-    x, w, tgt, tl = cf.closed_form_batch(B, 1, HIMG, [WIMG] * B, vocab, [LABELS] * B, seed=PARITY_BATCH_SEED)
+    seed = PARITY_BATCH_SEED if PARITY_BATCH_SEED is not None else WL["parity_seed"]
+    x, w, tgt, tl = cf.closed_form_batch(B, 1, WL["himg"], WL["widths"], vocab, WL["labels"], seed=seed)
     return sd_np, x, w, tgt, tl
 
 
@@ -143,24 +189,26 @@ def gemm_alone(hidden, din=128):
 
 
 # ------------------------------------------------------------------------------------------------ CPU leg (child process)
-def cpu_baseline_worker(parity_file):
+def cpu_baseline_worker(parity_file, config, budget_s):
     """The oracle (CPU restatement of the same step on PyTorch-CPU).  (1) parity: ONE forward of the parity batch with the closed-form
     weights the GPU side used and the same pool samples (dropout off on both sides) -> loss / greedy labels vs the HIP path's;
-    (2) baseline: CPU_TIMED_STEPS timed train steps (fwd+CTC+bwd+clamp+Adam) of the bench workload."""
+    (2) baseline: timed train steps (fwd+CTC+bwd+clamp+Adam) of the bench workload - one step at each thread count of
+    CPU_THREAD_SWEEP while the time budget lasts (an estimate from the steps already timed decides whether the next count still fits),
+    then a second step at the best count; the best count's mean is reported."""
     import torch
-    import vistaocr_amd as va
     from oracle import vista_oracle as vo
     from vistaocr_amd.textutils import compute_cer_wer
-    al = va.english_alphabet()
+    t_start = time.time()
+    wl = select_workload(config)
+    al = alphabet_of(wl)
     vocab = len(al)
     n_cores = os.cpu_count() or 1
-    n_thr = min(n_cores, CPU_BASELINE_THREADS)
-    torch.set_num_threads(n_thr)
+    torch.set_num_threads(min(n_cores, 32))
     out = {}
-    hp = dict(HP)
+    hp = dict(wl["hp"])
     if parity_file and os.path.exists(parity_file):
         blob = torch.load(parity_file, map_location="cpu", weights_only=True)
-        hp = dict(HP, num_lstm_hidden_units=int(blob["hidden"]))
+        hp = dict(wl["hp"], num_lstm_hidden_units=int(blob["hidden"]))
         sd_np, xp, wp, tgtp, tlp = parity_inputs(int(blob["hidden"]), vocab)
         sd = vo.state_from_numpy(sd_np, requires_grad=False)
         u = parity_samples()
@@ -169,9 +217,11 @@ def cpu_baseline_worker(parity_file):
             lo, ln = vo.forward(sd, hp, torch.from_numpy(xp), wp, u, training=True, lstm_training=False)
             loss_o = float(vo.ctc_criterion(lo, torch.from_numpy(tgtp), ln, torch.from_numpy(tlp)))
         strs_o, labels_o = vo.greedy_decode(lo, ln, al.idx_to_char, uxxxx=True)
+        T = lo.shape[0]
+        valid = torch.arange(T).unsqueeze(1) < torch.as_tensor(ln).to(torch.int64).unsqueeze(0)
         top2 = torch.topk(lo, 2, dim=2)
-        gap = top2.values[:, :, 0] - top2.values[:, :, 1]
-        thr = (top2.values[:, :, 0] - 3.0 / vocab).abs()[top2.indices[:, :, 0] != 0]      # the decoder's raw-logit threshold (cnnlstm.py:481,515)
+        gap = (top2.values[:, :, 0] - top2.values[:, :, 1])[valid]
+        thr = (top2.values[:, :, 0] - 3.0 / vocab).abs()[valid & (top2.indices[:, :, 0] != 0)]      # the decoder's raw-logit threshold (cnnlstm.py:481,515)
         margin = min(float(gap.min()), float(thr.min()) if thr.numel() else float("inf"))
         loss_h = float(blob["loss"])
         labels_h = [[int(v) for v in row] for row in blob["labels"]]
@@ -184,9 +234,9 @@ def cpu_baseline_worker(parity_file):
                              lines=len(labels_o), labels_emitted=sum(len(l) for l in labels_o), cer=cer, hip_loss=loss_h, oracle_loss=loss_o,
                              lens_equal=bool(ln.tolist() == list(blob["lens"])), oracle_decode_margin=margin,
                              oracle_forward_s=round(time.time() - t0, 1),
-                             what="one forward of the closed-form parity batch (32 lines of 30x600, seed %d) with closed-form weights (recurrent "
+                             what="one forward of the closed-form parity batch of this workload (seed %d) with closed-form weights (recurrent "
                                   "weights +-0.08, output layer widened so the lines emit labels), same pool samples, dropout off on both "
-                                  "sides; oracle = PyTorch-CPU restatement" % PARITY_BATCH_SEED)
+                                  "sides; oracle = PyTorch-CPU restatement (fp32 throughout)" % wl["parity_seed"])
     x, tgt, widths, tl = make_batch(0, vocab)
     state = vo.init_uniform_state(hp, vocab, seed=0)
     opt = torch.optim.Adam([p for _, p in vo.trainable(state)], lr=1e-3)
@@ -194,33 +244,45 @@ def cpu_baseline_worker(parity_file):
     # tiny warm-up (thread pools, oneDNN primitive caches) on 2 short lines, not timed
     vo.train_step(state, hp, opt, x[:2, :, :, :120].contiguous(), [120, 120], tgt[:8], torch.tensor([4, 4], dtype=torch.int32),
                   (u[0][:2], u[1][:2]))
-    times = []
-    for _ in range(CPU_TIMED_STEPS):
+    per_thr = {}
+
+    def one_step(n):
+        torch.set_num_threads(n)
         t0 = time.time()
         vo.train_step(state, hp, opt, x, widths.tolist(), tgt, tl, u)
-        times.append(time.time() - t0)
-    dt = sum(times) / len(times)
-    out["cpu_baseline"] = dict(value=round(B / dt, 3), unit="line-images/sec", cores=n_thr, host_cores=n_cores, kind="port",
-                               sample="%d timed train steps (fwd+CTC+bwd+clamp+Adam) of the same batch-32 30x600 workload on the "
-                                      "oracle (PyTorch-CPU restatement), %s s, torch.set_num_threads(%d) of os.cpu_count()=%d"
-                                      % (len(times), "/".join("%.1f" % t for t in times), n_thr, n_cores))
+        per_thr.setdefault(n, []).append(time.time() - t0)
+
+    for n in [t for t in CPU_THREAD_SWEEP if t <= n_cores] or [n_cores]:
+        worst = max((max(v) for v in per_thr.values()), default=0.0)
+        if per_thr and time.time() - t_start + 1.3 * worst > budget_s:
+            break
+        one_step(n)
+    best = min(per_thr, key=lambda n: min(per_thr[n]))
+    if time.time() - t_start + 1.2 * min(per_thr[best]) < budget_s and CPU_TIMED_STEPS > 1:
+        one_step(best)
+    dt = sum(per_thr[best]) / len(per_thr[best])
+    out["cpu_baseline"] = dict(value=round(B / dt, 3), unit="line-images/sec", cores=best, host_cores=n_cores, kind="port",
+                               seconds_per_step_by_threads={str(n): [round(t, 1) for t in v] for n, v in sorted(per_thr.items())},
+                               sample="timed train steps (fwd+CTC+bwd+clamp+Adam) of the same batch-32 workload on the oracle (PyTorch-CPU "
+                                      "restatement): one step at each of torch.set_num_threads(n), n in %s, as far as the %d s budget allowed, "
+                                      "a second one at the best n = %d (%s s); os.cpu_count() = %d"
+                                      % (list(CPU_THREAD_SWEEP), budget_s, best, "/".join("%.1f" % t for t in per_thr[best]), n_cores))
     return out
 
 
-def cpu_leg(parity_file, limit_s=240):
+def cpu_leg(parity_file, config, limit_s=240):
     """Run the CPU leg in a child process with a hard time limit so a slow host can never stall the bench."""
-    n_thr = min(os.cpu_count() or 1, CPU_BASELINE_THREADS)
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", parity_file or ""], capture_output=True,
-                           text=True, timeout=limit_s, env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", parity_file or "", config, str(int(limit_s * 0.85))],
+                           capture_output=True, text=True, timeout=limit_s, env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
         for line in reversed(r.stdout.strip().splitlines()):
             if line.startswith("{"):
                 return json.loads(line)
         return dict(cpu_baseline=dict(value=None, unit="line-images/sec", cores=0, kind="port", sample="worker failed: " + r.stderr[-300:]))
     except subprocess.TimeoutExpired:
-        return dict(cpu_baseline=dict(value=round(B / (limit_s / (CPU_TIMED_STEPS + 1.0)), 3), unit="line-images/sec", cores=n_thr,
+        return dict(cpu_baseline=dict(value=round(B / (limit_s / 2.0), 3), unit="line-images/sec", cores=0,
                                       host_cores=os.cpu_count(), kind="port",
-                                      sample="upper bound: parity forward + %d steps did not finish within %d s" % (CPU_TIMED_STEPS, limit_s)))
+                                      sample="upper bound: parity forward + one step did not finish within %d s" % limit_s))
 
 
 # ------------------------------------------------------------------------------------------------ self-launch of N ranks
@@ -310,10 +372,12 @@ def run_rank(args):
 
     import vistaocr_amd as va
     from vistaocr_amd import _lib
-    hp = dict(HP, num_lstm_hidden_units=args.hidden)
-    if args.conv_dtype != "fp32":
-        hp["conv_dtype"] = args.conv_dtype
-    al = va.english_alphabet()
+    wl = select_workload(args.config)
+    conv_dtype = args.conv_dtype or wl["conv_dtype"]
+    hp = dict(wl["hp"], num_lstm_hidden_units=args.hidden)
+    if conv_dtype != "fp32":
+        hp["conv_dtype"] = conv_dtype
+    al = alphabet_of(wl)
     torch.manual_seed(0)                                  # same init on every rank (replicas)
     model = va.CnnOcrModel(alphabet=al, verbose=False, **hp)
     crit = va.CTCLoss()
@@ -327,7 +391,7 @@ def run_rank(args):
     # samples and dropout off; the CPU oracle (child process) repeats it and compares loss / greedy labels
     parity_file = None
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
-    if want_cpu and args.conv_dtype == "fp32":
+    if want_cpu:
         init_state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
         sd_np, xp, wp, tgtp, tlp = parity_inputs(args.hidden, len(al))
         psd = model.state_dict()
@@ -410,9 +474,19 @@ def run_rank(args):
     torch.cuda.synchronize()
     prof = _lib.timing_records()
     _lib.enable_timing(None)
+    # host side of a step: how long the Python + ctypes layer takes to ENQUEUE one step (train_async(): no readback of the loss), measured
+    # on an idle queue over 4 steps - far fewer launches than the queue holds, so nothing here waits for the device.  If this number
+    # approaches ms_per_step the step is launch-bound and faster kernels buy nothing.
+    torch.cuda.synchronize()
+    enq = []
+    for _ in range(4):
+        t_e = time.perf_counter()
+        va.train_async(batch_dev, model, crit, opt)
+        enq.append(1000.0 * (time.perf_counter() - t_e))
+    torch.cuda.synchronize()
     opt.check_health()
     ranks_seen = dist.get_world_size() if use_dist else 1
-    alone = gemm_alone(args.hidden) if rank == 0 and args.hidden == 512 and not args.no_gemm_alone else None
+    alone = gemm_alone(args.hidden) if rank == 0 and args.hidden == 512 and args.config == "c1" and not args.no_gemm_alone else None
 
     out = None
     parity_failed = None
@@ -476,18 +550,23 @@ def run_rank(args):
             if lst:
                 breakdown[name] = round(sum(e0.elapsed_time(e1) for _, e0, e1 in lst) / PROFILE_STEPS, 3)
         out = {
-            "metric": "line-images/sec (train, batch 32, 30x600 grey)", "value": round(value, 2), "unit": "line-images/sec",
+            "metric": "line-images/sec (train, batch 32, 30x600 grey)" if args.config == "c1" else
+                      "line-images/sec (train, batch 32) - SIDE line for BASELINE %s, not the headline metric" % {"c4": "configs[3]", "c5": "configs[4]"}[args.config],
+            "value": round(value, 2), "unit": "line-images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.conv_dtype == "fp32" else "f32 with fp16 conv operands (fp32 accumulate)", "data": "synthetic",
-            "config": {"workload": "configs[1]: 32 synthetic 1x30x600 grey lines per GPU, 20 labels/line, V=96, "
-                                   "3xBiLSTM-%d, train() = H2D of the batch + fwd+CTC+bwd+allreduce+clamp+Adam, loss returned as a float" % args.hidden,
+            "dtype": "f32" if conv_dtype == "fp32" else "f32 with fp16 conv operands (fp32 accumulate)", "data": "synthetic",
+            "config": {"workload": wl["what"] + ", 3xBiLSTM-%d, train() = H2D of the batch + fwd+CTC+bwd+allreduce+clamp+Adam, loss returned as a float" % args.hidden,
+                       "name": args.config, "widths": "%d .. %d px, mean %.0f" % (min(wl["widths"]), max(wl["widths"]), sum(wl["widths"]) / float(B)),
+                       "conv_dtype": conv_dtype,
                        "global_batch": B * world, "parallelism": "dp%d" % world, "ranks_seen": ranks_seen,
                        "backend": (args.backend + ("/RCCL" if args.backend == "nccl" else "")) if use_dist else "none",
                        "final_loss": round(float(final_loss), 3), "per_rank_rng": "seed 1234 + 1000*rank after an identical init"},
             "resident_input": {"value": round(B * world * args.steps / dt_res, 2), "ms_per_step": round(1000.0 * dt_res / args.steps, 3),
                                "what": "same K steps with the image batch already in HBM (no H2D inside train()); runs before the headline loop"},
             "allreduce_ms_per_step": comm_ms,
+            "host_enqueue_ms_per_step": {"mean": round(sum(enq) / len(enq), 3), "min": round(min(enq), 3), "share_of_step": round(sum(enq) / len(enq) / ms, 3),
+                                         "what": "wall time of train_async() (enqueue only, no loss readback) on an idle queue, 4 steps, no profiler"},
             "roofline": {"bound": "mfma",
                          "kernel": dom[0] + " - the kernel family with the most device time in the step (HIP events around every launch of the "
                                             "MFMA families in every %d-th timed step; families overlap on two streams, so their times add up to more "
@@ -506,10 +585,16 @@ def run_rank(args):
             "ms_per_step_by_entry_point": breakdown,
         }
         if want_cpu:
-            out.update(cpu_leg(parity_file))
+            out.update(cpu_leg(parity_file, args.config))
             par = out.get("parity")
-            if par is not None and (par["label_mismatches"] > 0 or par["loss_rel_err"] > 1e-3 or not par["lens_equal"] or par["labels_emitted"] < 10 * B):
-                parity_failed = "parity leg failed: %s" % json.dumps(par)
+            if par is not None:
+                if conv_dtype == "fp32":        # north_star's bar: greedy labels bit-exact, CTC loss within 1e-3
+                    bad = par["label_mismatches"] > 0 or par["loss_rel_err"] > 1e-3 or not par["lens_equal"] or par["labels_emitted"] < 10 * B
+                else:                           # fp16 conv operands against the fp32 oracle: the loss bar of tests/test_round2_gpu.py (1e-2); labels are reported
+                    bad = par["loss_rel_err"] > 1e-2 or not par["lens_equal"]
+                    par["what"] += "; fp16 conv operands: loss held to 1e-2, label agreement reported, not required"
+                if bad:
+                    parity_failed = "parity leg failed: %s" % json.dumps(par)
     if parity_file and os.path.exists(parity_file):
         os.unlink(parity_file)
     if use_dist:
@@ -534,7 +619,9 @@ def main():
     if "--cpu-baseline-worker" in sys.argv:
         i = sys.argv.index("--cpu-baseline-worker")
         pf = sys.argv[i + 1] if i + 1 < len(sys.argv) else ""
-        print(json.dumps(cpu_baseline_worker(pf)))
+        cfg = sys.argv[i + 2] if i + 2 < len(sys.argv) else "c1"
+        budget = int(sys.argv[i + 3]) if i + 3 < len(sys.argv) else 200
+        print(json.dumps(cpu_baseline_worker(pf, cfg, budget)))
         return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -544,8 +631,10 @@ def main():
     ap.add_argument("--no-gemm-alone", action="store_true", help="skip the alone-on-the-chip GEMM launches (profiling passes that average per launch)")
     ap.add_argument("--event-every", type=int, default=10, help="HIP events around the dominant kernel in every n-th timed step (0: none)")
     ap.add_argument("--hidden", type=int, default=512)
-    ap.add_argument("--conv-dtype", default="fp32", choices=["fp32", "fp16"],
-                    help="fp16 = BASELINE config 5's fp16-operand conv MFMA (fp32 accumulate); the headline metric is fp32")
+    ap.add_argument("--config", default="c1", choices=sorted(WORKLOADS),
+                    help="c1 = BASELINE configs[1], the headline metric; c4 / c5 = configs[3] / configs[4] as side lines of the same JSON shape")
+    ap.add_argument("--conv-dtype", default=None, choices=["fp32", "fp16"],
+                    help="fp16 = BASELINE config 5's fp16-operand conv MFMA (fp32 accumulate); default: what the --config names (c1, c4: fp32)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: plumbing tests on boxes without N GPUs")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks on device 0 (plumbing test of the launcher; needs --backend gloo)")
     args = ap.parse_args()

@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-T=${1:-r03a}
+T=${1:-r04a}
 mkdir -p gpurun_out/$T
 hipcc --offload-arch=gfx950 -O3 -w -o /tmp/clock_calib scripts/clock_calib.hip && /tmp/clock_calib > gpurun_out/$T/clock_calib.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$T/trace -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-gemm-alone > gpurun_out/$T/bench_profiled.json 2> gpurun_out/$T/bench_profiled.err

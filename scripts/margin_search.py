@@ -28,17 +28,19 @@ if len(sys.argv) > 1 and sys.argv[1] == "cases":          # oracle-side seed sea
         except AssertionError as e:
             print("%-16s %s" % (name, e), flush=True)
     sys.exit(0)
-if len(sys.argv) > 1 and sys.argv[1] == "bench":          # the parity leg of bench.py: its own pool samples, dropout off
+if len(sys.argv) > 1 and sys.argv[1] == "bench":          # the parity leg of bench.py: its own pool samples, dropout off;  bench <first> <last> [c1|c4|c5]
     import bench
     torch.set_num_threads(os.cpu_count() or 1)
-    V = len(gu.alphabet_chars("english"))
+    wl = bench.select_workload(sys.argv[4] if len(sys.argv) > 4 else "c1")
+    V = len(gu.alphabet_chars(wl["alphabet"]))
     for seed in range(int(sys.argv[2]), int(sys.argv[3])):
         bench.PARITY_BATCH_SEED = seed
         sd_np, x, w, tgt, tl = bench.parity_inputs(512, V)
+        t0 = time.time()
         with torch.no_grad():
-            lo, ln = vo.forward(vo.state_from_numpy(sd_np, requires_grad=False), dict(bench.HP), torch.from_numpy(x), w, bench.parity_samples(),
+            lo, ln = vo.forward(vo.state_from_numpy(sd_np, requires_grad=False), dict(wl["hp"]), torch.from_numpy(x), w, bench.parity_samples(),
                                 training=True, lstm_training=False)
-        print("bench parity seed %d: oracle decode margin %.3e" % (seed, decode_margin(lo, ln, V)), flush=True)
+        print("bench %s parity seed %d: oracle decode margin %.3e  (%.1f s)" % (sys.argv[4] if len(sys.argv) > 4 else "c1", seed, decode_margin(lo, ln, V), time.time() - t0), flush=True)
     sys.exit(0)
 prob_scale = float(sys.argv[1]) if len(sys.argv) > 1 else 0.5
 blank_bias = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0

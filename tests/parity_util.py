@@ -55,24 +55,28 @@ def grad_rel_errors(named_hip_grads, oracle_state, skip_bn_shadowed_bias=True):
     return out
 
 
-# fp32 against fp32 agrees to 1e-5 .. 1e-4 where nothing amplifies the rounding: every gradient that the GEMM, LSTM and CTC kernels produce
-# (prob layer, LSTM, bridge) is held to 1e-3, so a systematic percent-level error in one of those kernels (a dropped K tail, a missing
+# fp32 against fp32 agrees to 1e-5 .. 1e-4 per kernel (tests/test_ops_gpu.py holds gemm_pair to 2e-5 of fp64 on the step's own views), but
+# a weight gradient sums T x B outer products behind up to 588 recurrent steps, each side with its own summation order: measured
+# HIP-vs-oracle up to 1.0e-3 on lstm.weight_ih_l1 of the ragged T = 588 case.  Every gradient that the GEMM, LSTM and CTC kernels produce
+# (prob layer, LSTM, bridge) is held to 3e-3, so a systematic percent-level error in one of those kernels (a dropped K tail, a missing
 # slab) fails.  The conv stack sits behind seven batch-statistics BatchNorms whose backward divides by sigma and subtracts two
 # near-equal sums: measured HIP-vs-oracle 5e-5 at prob_layer growing to a few 1e-3 at cnn.0 (scripts/diag_golden.py), and two fp32
 # CPU builds differ by as much; those tensors keep 1e-2 (their kernels are held to 1e-4 directly in tests/test_ops_gpu.py).
-_RTOL_BY_PREFIX = (("cnn.", 1e-2), ("rapid_ds", 1e-2), ("", 1e-3))
+_RTOL_BY_PREFIX = (("cnn.", 1e-2), ("rapid_ds", 1e-2), ("", 3e-3))
 
 
-def _rtol_for(name, cap):
+def _rtol_for(name, override):
+    if override is not None:
+        return override
     for prefix, tol in _RTOL_BY_PREFIX:
         if name.startswith(prefix):
-            return min(tol, cap)
-    return cap
+            return tol
+    return 1e-2
 
 
-def assert_grads_close(model, oracle_state, rtol=1e-2, atol_norm=1e-5):
-    """Element-wise gradient comparison of every parameter (rtol: an upper cap on the per-family tolerances above); returns
-    (worst name, worst relative error)."""
+def assert_grads_close(model, oracle_state, rtol=None, atol_norm=1e-5):
+    """Element-wise gradient comparison of every parameter (rtol=None: the per-family tolerances above; a number: that tolerance for
+    every tensor - the fp16-operand configuration's looser bar); returns (worst name, worst relative error)."""
     errs = grad_rel_errors(((k, p.grad) for k, p in model.named_parameters()), oracle_state)
     worst = ("", 0.0)
     for k, (rel, rn) in errs.items():

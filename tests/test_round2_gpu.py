@@ -97,7 +97,7 @@ def test_config1_full_size_vs_oracle():
     assert err <= margin / 4, "logit error %.2e is not small against the decode margin %.2e" % (err, margin)
     assert mism == 0, "greedy label sequences differ"
     assert labels == olabels
-    worst = pu.assert_grads_close(model, osd, rtol=1e-2)
+    worst = pu.assert_grads_close(model, osd)
     print("full-size configs[1]: worst per-tensor element-wise gradient error %.2e (%s)" % (worst[1], worst[0]))
 
 

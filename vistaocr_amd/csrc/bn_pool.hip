@@ -152,24 +152,43 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
     const long total = (long)N * HW;
     const long beg = j * per, end = min(total, beg + per);
     double s1 = 0.0, s2 = 0.0;
+    // This pass sits on the backward's critical path and usually shares the chip with a weight-gradient kernel on the side stream,
+    // whose workgroups leave room for ONE of ours per CU (56 registers per lane): with one load per tensor in flight it then ran at a
+    // fifth of its stand-alone rate.  Four iterations' loads are issued before the first is consumed (same summation order), and the
+    // waves ask for issue priority over the co-resident MFMA waves.
+    __builtin_amdgcn_s_setprio(3);
+    constexpr int U = 4;
     ChanWalk wk(beg + (long)threadIdx.x * V, HW);
-    for (long e = beg + (long)threadIdx.x * V; e < end; e += 256 * V, wk.advance(256 * V, HW)) {
-        const long a = wk.addr(c, C, HW);
-        const vec yv = *(const vec*)(y + a);
-        const vec dv = *(const vec*)(da + a);
-        // the V elements of one load are summed in fp32 first (<= 4 terms: exact to ~1 ulp), then carried in double:
-        // a quarter of the fp64 conversions/adds of the per-element form
-        float p1 = 0.f, p2 = 0.f;
+    for (long e = beg + (long)threadIdx.x * V; e < end; e += (long)U * 256 * V) {
+        vec yv[U], dv[U];
+        bool ok[U];
+        const long a0 = wk.addr(c, C, HW);
 #pragma unroll
-        for (int k = 0; k < V; ++k) {
-            const float xh = (vget<V>(yv, k) - mu) * is;
-            const float o = xh * g + b;
-            const float dz = o > 0.f ? vget<V>(dv, k) : 0.f;
-            p1 += dz;
-            p2 += dz * xh;
+        for (int u = 0; u < U; ++u) {
+            ok[u] = e + (long)u * 256 * V < end;
+            const long a = ok[u] ? wk.addr(c, C, HW) : a0;
+            yv[u] = *(const vec*)(y + a);
+            dv[u] = *(const vec*)(da + a);
+            wk.advance(256 * V, HW);
         }
-        s1 += (double)p1;
-        s2 += (double)p2;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            // the V elements of one load are summed in fp32 first (<= 4 terms: exact to ~1 ulp), then carried in double:
+            // a quarter of the fp64 conversions/adds of the per-element form
+            float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const float xh = (vget<V>(yv[u], k) - mu) * is;
+                const float o = xh * g + b;
+                const float dz = o > 0.f ? vget<V>(dv[u], k) : 0.f;
+                p1 += dz;
+                p2 += dz * xh;
+            }
+            if (ok[u]) {
+                s1 += (double)p1;
+                s2 += (double)p2;
+            }
+        }
     }
     block_reduce2(s1, s2, red);
     if (threadIdx.x == 0) {
@@ -278,17 +297,29 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const vec* dp = (const vec*)(da + plane * HW);
     vec* op = (vec*)(dy + plane * HW);
     const long nv = HW / V;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
-        const vec yv = yp[i], dv = dp[i];
-        vec o;
+    __builtin_amdgcn_s_setprio(3);                   // see bn_bwd_partial_kernel
+    constexpr int U = V == 4 ? 3 : 4;                // three 16-byte pairs in flight keep the kernel at <= 56 registers (four: 58)
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += U * stride) {
+        vec yv[U], dv[U];
 #pragma unroll
-        for (int k = 0; k < V; ++k) {
-            const float xh = (vget<V>(yv, k) - mu) * is;
-            const float ov = xh * g + b;
-            const float dz = ov > 0.f ? vget<V>(dv, k) : 0.f;
-            vset<V>(o, k, gs * (dz - k1 - xh * k2));
+        for (int u = 0; u < U; ++u) {
+            const long iu = i + u * stride < nv ? i + u * stride : i;
+            yv[u] = yp[iu];
+            dv[u] = dp[iu];
         }
-        op[i] = o;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            vec o;
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const float xh = (vget<V>(yv[u], k) - mu) * is;
+                const float ov = xh * g + b;
+                const float dz = ov > 0.f ? vget<V>(dv[u], k) : 0.f;
+                vset<V>(o, k, gs * (dz - k1 - xh * k2));
+            }
+            if (i + u * stride < nv) op[i + u * stride] = o;
+        }
     }
 }
 

@@ -1342,7 +1342,7 @@ __global__ __launch_bounds__(768) void conv3x3_wgrad_wino3_kernel(const float* _
         const int m = 2 * j + lk, p = m - 1, q = m + 1;
         adA[j] = (cA * 64 + 4 * (m ^ sA)) * 4;
         adC[j] = (G3_X0 + kh * 4096 + cB * 64 + 4 * (m ^ sB)) * 4;
-        adP[j] = (G3_X0 + (p >= 0 ? kh * 4096 + cB * 64 + 4 * (p ^ sB) : G3_X + kh * 256 + cB * 4) + 3) * 4;
+        adP[j] = (G3_X0 + (p >= 0 ? kh * 4096 + cB * 64 + 4 * (p ^ sB) : G3_X + kh * 256 + cB * 4)) * 4;
         adN[j] = (G3_X0 + (q <= 15 ? kh * 4096 + cB * 64 + 4 * (q ^ sB) : G3_X + (3 + kh) * 256 + cB * 4)) * 4;
     }
     // one segment out of buffer CUR (compile time: the buffer is the reads' immediate offset)
@@ -1354,18 +1354,19 @@ __global__ __launch_bounds__(768) void conv3x3_wgrad_wino3_kernel(const float* _
             advance(es);
             issue(wq_tag, CUR ^ 1);
         }
-        f32x4 rg, rc, ng, nc;
-        float rp, rn, np_, nn;
+        // (the neighbours' pieces are read whole although only one element of each is used: a 4-byte read across channel lanes
+        // that sit a multiple of 16 bytes apart is a 4-way bank conflict, the 16-byte read is conflict-free and costs the same issue slot)
+        f32x4 rg, rc, ng, nc, rp4, rn4, np4, nn4;
         rg = *(const f32x4*)(ldsb + adA[0] + OA); rc = *(const f32x4*)(ldsb + adC[0] + OX);
-        rp = *(const float*)(ldsb + adP[0] + OX); rn = *(const float*)(ldsb + adN[0] + OX);
+        rp4 = *(const f32x4*)(ldsb + adP[0] + OX); rn4 = *(const f32x4*)(ldsb + adN[0] + OX);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            ng = rg; nc = rc; np_ = rp; nn = rn;
+            ng = rg; nc = rc; np4 = rp4; nn4 = rn4;
             if (j + 1 < 8 && !(W3_CUT & 2)) {
                 ng = *(const f32x4*)(ldsb + adA[j + 1] + OA);
                 nc = *(const f32x4*)(ldsb + adC[j + 1] + OX);
-                np_ = *(const float*)(ldsb + adP[j + 1] + OX);
-                nn = *(const float*)(ldsb + adN[j + 1] + OX);
+                np4 = *(const f32x4*)(ldsb + adP[j + 1] + OX);
+                nn4 = *(const f32x4*)(ldsb + adN[j + 1] + OX);
             }
             __builtin_amdgcn_sched_barrier(0);      // the next double-step's ds_reads stay above this one's MFMAs
             // the x piece c0..c3 = columns 4k .. 4k+3, p = column 4k-1, n = column 4k+4; the dy piece g0..g3
@@ -1374,6 +1375,7 @@ __global__ __launch_bounds__(768) void conv3x3_wgrad_wino3_kernel(const float* _
             const f32x2 g01 = {rg[0], rg[1]}, g23 = {rg[2], rg[3]}, c01 = {rc[0], rc[1]}, c23 = {rc[2], rc[3]};
             f32x2 a0, a1, b0, b1, bx2;
             float e0, e1;
+            const float rp = rp4[3], rn = rn4[0];
             if (W3_CUT & 4) { a0 = g01; a1 = g23; b0 = c01; b1 = c23; bx2 = c01; e0 = rp; e1 = rn; }
             else {
                 w3_xform_first(g01, c01, c23, a0, b0, bx2);
@@ -1389,7 +1391,7 @@ __global__ __launch_bounds__(768) void conv3x3_wgrad_wino3_kernel(const float* _
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[0], b1[0], acc[1], 0, 0, 0);
             acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[1], b1[1], acc[2], 0, 0, 0);
             acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(rg[3], e1, acc[3], 0, 0, 0);
-            rg = ng; rc = nc; rp = np_; rn = nn;
+            rg = ng; rc = nc; rp4 = np4; rn4 = nn4;
         }
         if (more && !(W3_CUT & 1)) {
             __builtin_amdgcn_s_waitcnt(0x0F70);     // the next segment's DMAs have landed
