@@ -305,7 +305,7 @@ def launch_ranks(args, argv, limit_s=3600):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY="0")
         if args.share_gpu:      # two persistent LSTM sweeps from two processes must not compete for one GPU's CUs
-            env.setdefault("VOCR_LSTM_PERSISTENT", "0")
+            env.setdefault("VOCR_LSTM_SWEEP", "step")
         err = tempfile.TemporaryFile(mode="w+")
         logs.append(err)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,

@@ -1,4 +1,4 @@
-"""Micro-benchmark (GPU box): per-step time of the LSTM recurrent sweeps at the BASELINE shape (VOCR_LSTM_PERSISTENT=0 for one launch per step)."""
+"""Micro-benchmark (GPU box): per-step time of the LSTM recurrent sweeps at the BASELINE shape (VOCR_LSTM_SWEEP=step for one launch per step, chain8 / chain16 for the older generations)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,4 +1,4 @@
-// Diagnostic build (never shipped): the 4-row forward chain sweep (lstm_fwd_chain4v; 16 < B <= 32: lstm_fwd_chain4w unless VOCR_LSTM_SELFVAL=9) with s_memtime stamps around the phases
+// Diagnostic build (never shipped): the 4-row forward chain sweep (lstm_fwd_chain4v; 16 < B <= 32: lstm_fwd_chain4w unless VOCR_LSTM_SWEEP_FWD=chain4) with s_memtime stamps around the phases
 // of a time step.  usage: lstm_stamp4 [B]
 #define VOCR_LSTM_STAMPS 1
 #include "../vistaocr_amd/csrc/lstm.hip"
@@ -25,7 +25,7 @@ int main(int argc, char** argv) {
         hipEventRecord(e1, nullptr); hipDeviceSynchronize(); hipEventElapsedTime(&ms, e0, e1);
         if (rc) { printf("rc %d\n", rc); return 1; }
     }
-    const bool four = getenv("VOCR_LSTM_SELFVAL") && (atoi(getenv("VOCR_LSTM_SELFVAL")) & 8);      // lstm_fwd_chain4v (two workgroups per CU) also above B = 16
+    const bool four = getenv("VOCR_LSTM_SWEEP_FWD") && !strcmp(getenv("VOCR_LSTM_SWEEP_FWD"), "chain4");      // lstm_fwd_chain4v (two workgroups per CU) also above B = 16
     const bool eight = B > 16 && !four;             // lstm_fwd_chain4w: 8 waves, stamps of waves 0 and 7
     const int nwg = eight ? 256 : B > 16 ? 512 : 256;
     std::vector<unsigned long long> h(512 * 2 * 8);

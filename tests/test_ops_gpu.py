@@ -346,9 +346,10 @@ def test_bilstm_layer(dev, T, B, D, H, lens):
 @pytest.mark.parametrize("T,B,H", [(40, 20, 128), (25, 5, 64), (33, 32, 512), (12, 40, 256), (9, 64, 128), (21, 27, 256), (15, 7, 512),
                                    (1, 1, 256), (2, 3, 512), (3, 64, 512), (19, 21, 512), (7, 17, 512)])
 def test_persistent_sweeps_match_per_step_launches(dev, T, B, H):
-    """Persistent sweeps (weights in registers; forward hand-off by self-validating payload on 4-row chains, or - VOCR_LSTM_SELFVAL=0 -
-    by arrival flags on 8/16-row chains; backward by flags) against one launch per step: forward (y, gates, cell) and backward
-    (dgates), bit-identical where the summation order is the same, to rounding where it is another fixed order."""
+    """Every generation of persistent sweep (VOCR_LSTM_SWEEP: self-validating hand-off on 4-row chains - wide members at 16 < B <= 32,
+    H = 512 -, arrival flags on 8-row and 16-row chains; each also with the write-through hand-off of a chain spread over XCDs) against
+    one launch per step: forward (y, gates, cell) and backward (dgates), bit-identical where the summation order is the same, to
+    rounding where it is another fixed order."""
     import os
     import subprocess
     import sys
@@ -375,14 +376,13 @@ def test_persistent_sweeps_match_per_step_launches(dev, T, B, H):
         "print('STATUS', st); torch.save((y.cpu(), gt.cpu(), c.cpu(), dg.cpu()), sys.argv[1])\n"
     ) % (root, T, B, H)
     outs = []
-    # per-step | default sweeps (8-row 4x4x1 chains where they apply, else as 35) | 16-row chains | forced write-through
-    # hand-off, 8-row and 16-row
-    # "/f" = flag hand-off in the forward sweep too
-    modes = ("0", "3", "3/f", "35", "11", "11/f", "43")
+    # per-step | default (newest generation the shape fits) | 4-row chains without wide members | 8-row flag chains | 16-row flag chains |
+    # the same with the write-through hand-off
+    modes = ("step", "wide4", "chain4", "chain8", "chain16", "wide4/wt", "chain8/wt", "chain16/wt")
     for mode_ in modes:
         mode = mode_.split("/")[0]
         f = tempfile.mktemp(suffix=".pt")
-        r = subprocess.run([sys.executable, "-c", code, f, mode], env=dict(os.environ, VOCR_LSTM_PERSISTENT=mode, VOCR_LSTM_SELFVAL="0" if "/f" in mode_ else "1"),
+        r = subprocess.run([sys.executable, "-c", code, f, mode], env=dict(os.environ, VOCR_LSTM_SWEEP=mode, VOCR_LSTM_WRITE_THROUGH="1" if "/wt" in mode_ else "0"),
                            capture_output=True, text=True, timeout=120)
         assert r.returncode == 0, r.stderr[-500:]
         assert "STATUS 0" in r.stdout, r.stdout
@@ -394,7 +394,7 @@ def test_persistent_sweeps_match_per_step_launches(dev, T, B, H):
         for nm, a, b in zip(("y", "gates", "cell", "dgates"), outs[0], other):
             if H < 128 and nm == "dgates":
                 continue                      # no backward fast path below H = 128: dgates untouched in both runs
-            reordered = (not int(mode) & 32 and eight_row) or nm == "dgates"       # 4x4x1 kernels / K-owner backward
+            reordered = (mode != "chain16" and eight_row) or nm == "dgates"       # 4x4x1 kernels / K-owner backward
             if reordered:
                 # same arithmetic, different fp32 summation order: rounding differences only
                 tol = 3e-5 * float(a.abs().max())

@@ -32,7 +32,7 @@ def _run_ranks(n, backend, share_gpu, out, limit_s=900):
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY="0")
         if share_gpu:
-            env["VOCR_LSTM_PERSISTENT"] = "0"          # two processes' persistent sweeps must not compete for one GPU's CUs
+            env["VOCR_LSTM_SWEEP"] = "step"         # two processes' persistent sweeps must not compete for one GPU's CUs
         cmd = [sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), "--backend", backend, "--out", out] + (["--share-gpu"] if share_gpu else [])
         procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     t0 = time.time()

@@ -11,6 +11,7 @@
 //                  the gate-gradient computation of the 16 owned units.
 // h / dh ping-pong between two small global buffers (the only cross-workgroup traffic, L2 resident).
 #include "vocr_common.h"
+#include <string.h>
 #include <stdlib.h>
 #include <type_traits>
 
@@ -2065,6 +2066,52 @@ int resident_workgroup_capacity() {
 
 }  // namespace
 
+// ---- which sweep a shape runs on.  Five generations of kernels, newest first; a shape takes the first one it fits:
+//   wide4    lstm_fwd_chain4w / lstm_bwd_chain4w   16 < B <= 32, H = 512: 4-row chains of 16 wide members, one 8-wave workgroup per CU,
+//                                                  self-validating hand-off (round 3; the BASELINE configuration)
+//   chain4   lstm_fwd_chain4v / lstm_bwd_chain4v   B <= 32, H in {256, 512}: 4-row chains, self-validating hand-off (round 3)
+//   chain8   lstm_fwd_chain8 / lstm_bwd_kowner8    B <= 32, H in {256, 512}: 8-row chains, arrival flags (round 2)
+//   chain16  lstm_fwd_chain / lstm_bwd_kowner      B <= 64, H in {64 (forward only), 128, 256, 512}: 16-row chains, arrival flags (round 1)
+//   step     lstm_*_step_fast / lstm_*_step_kernel one launch per time step (any shape; also when the grid cannot be co-resident)
+// VOCR_LSTM_SWEEP=<name> starts the search at that generation for both directions (A/B of the generations, tests), VOCR_LSTM_SWEEP_FWD /
+// VOCR_LSTM_SWEEP_BWD for one direction; VOCR_LSTM_WRITE_THROUGH=1 forces the hand-off mode of a chain spread over several XCDs.
+enum SweepKind { SWEEP_WIDE4 = 0, SWEEP_CHAIN4 = 1, SWEEP_CHAIN8 = 2, SWEEP_CHAIN16 = 3, SWEEP_STEP = 4 };
+
+static SweepKind sweep_floor(bool backward) {
+    static int cache[2] = {-1, -1};
+    if (cache[backward] < 0) {
+        const char* v = getenv(backward ? "VOCR_LSTM_SWEEP_BWD" : "VOCR_LSTM_SWEEP_FWD");
+        if (!v) v = getenv("VOCR_LSTM_SWEEP");
+        int k = SWEEP_WIDE4;
+        if (v) {
+            if (!strcmp(v, "chain4")) k = SWEEP_CHAIN4;
+            else if (!strcmp(v, "chain8")) k = SWEEP_CHAIN8;
+            else if (!strcmp(v, "chain16")) k = SWEEP_CHAIN16;
+            else if (!strcmp(v, "step")) k = SWEEP_STEP;
+        }
+        cache[backward] = k;
+    }
+    return (SweepKind)cache[backward];
+}
+
+static bool sweep_write_through() {
+    static const int v = getenv("VOCR_LSTM_WRITE_THROUGH") ? atoi(getenv("VOCR_LSTM_WRITE_THROUGH")) : 0;
+    return v != 0;
+}
+
+// `persistent_ok`: the shape and its buffers allow a persistent sweep at all (fast path, alignment, 32-bit offsets, co-residency)
+static SweepKind lstm_sweep_kind(bool backward, int b, int h, bool persistent_ok) {
+    const SweepKind floor_ = sweep_floor(backward);
+    if (!persistent_ok || floor_ == SWEEP_STEP || b <= 0) return SWEEP_STEP;
+    const int cap = resident_workgroup_capacity();
+    const int nt4 = (b + 3) / 4, nt8 = (b + 7) / 8;
+    const bool h45 = h == 512 || h == 256;
+    if (floor_ <= SWEEP_WIDE4 && h == 512 && nt4 > 4 && nt4 <= 8 && 256 <= cap) return SWEEP_WIDE4;
+    if (floor_ <= SWEEP_CHAIN4 && 2 * nt4 <= 16 && h45 && (2 * nt4 > 8 ? 16 : 8) * (h / 16) <= 2 * cap) return SWEEP_CHAIN4;
+    if (floor_ <= SWEEP_CHAIN8 && 2 * nt8 <= 8 && h45) return SWEEP_CHAIN8;
+    return SWEEP_CHAIN16;
+}
+
 // The self-validating forward sweeps keep a 4-KB block [XCC ids 512 words | status word | ...] directly in front of their hand-off
 // ring, so that one 0xFF fill prepares all three.
 static int lstm_fwd_selfval_prep(void* block, size_t ring_bytes, bool first_range, hipStream_t s) {
@@ -2105,48 +2152,38 @@ extern "C" int vocr_lstm_fwd_range(const float* xproj, const float* whh_fwd, con
                       aligned16(gates);
     VOCR_CHECK_ARG(aligned16(gates), "vocr_lstm_fwd: gates must be 16-byte aligned");
     const dim3 grid(2 * (h / 4));
-    // persistent sweep by default (VOCR_LSTM_PERSISTENT: bit 0 forward, bit 1 backward; 0 = one launch per step)
-    static const int persistent_mode = getenv("VOCR_LSTM_PERSISTENT") ? atoi(getenv("VOCR_LSTM_PERSISTENT")) : 3;
     // the chain kernels address y through a buffer descriptor with 32-bit byte offsets
     const bool fits32 = (long)t * b * 2 * h * 4 < (1l << 31);
-    if (fast && fits32 && (persistent_mode & 1) && 8 * (h / 16) <= resident_workgroup_capacity()) {
-        // chain sweep.  arrival flags: [chain <= 8][32 workgroups] at [0..255], XCC ids at [256..511]; status words at [512..]
+    const SweepKind kind = lstm_sweep_kind(false, b, h, fast && fits32 && 8 * (h / 16) <= resident_workgroup_capacity());
+    if (kind != SWEEP_STEP) {
+        // arrival flags: [chain <= 8][32 workgroups] at [0..255], XCC ids at [256..511]; status words at [512..]
         unsigned* flags = (unsigned*)workspace;
-        // the sweep's own status word is per call (zeroed here); a timeout is also reported in the caller's health word
-        unsigned* status = flags + 512;
+        unsigned* status = flags + 512;          // the sweep's own status word is per call; a timeout is also reported in the caller's health word
         unsigned* hword = (unsigned*)health;
         const dim3 cg(8 * (h / 16));
-        const int fwt = (persistent_mode & 8) ? 1 : 0;       // experiments: write-through hand-off even on one XCD
-        const int nt8 = (b + 7) / 8;
-        static const int selfval = getenv("VOCR_LSTM_SELFVAL") ? atoi(getenv("VOCR_LSTM_SELFVAL")) : 1;     // 0: flag hand-off (lstm_fwd_chain8 / lstm_fwd_chain)
-        const int nt4 = (b + 3) / 4;
-        static const int nap4w = getenv("VOCR_LSTM_NAP") ? atoi(getenv("VOCR_LSTM_NAP")) : 0;      // -1: polls start at once (experiments)
-        if (selfval && !(selfval & 8) && h == 512 && nt4 > 4 && nt4 <= 8 && !(persistent_mode & 32) && 256 <= resident_workgroup_capacity()) {
-            // 16 < B <= 32: 4-row chains of 16 wide members, one 8-wave workgroup per CU
+        const int fwt = sweep_write_through() ? 1 : 0;
+        const int nt8 = (b + 7) / 8, nt4 = (b + 3) / 4;
+        if (kind == SWEEP_WIDE4 || kind == SWEEP_CHAIN4) {
+            // self-validating hand-off: the ring starts as the "not written yet" pattern (first range of a sweep only)
             unsigned* blk = (unsigned*)((char*)workspace + lstm_ws_handoff_offset(b, h));
             float* hx = (float*)(blk + 1024);
             if (lstm_fwd_selfval_prep(blk, (size_t)4 * 2 * nt4 * 4 * h * sizeof(float), step_begin == 0, s) != VOCR_OK) return VOCR_ELAUNCH;
-            lstm_fwd_chain4w<8><<<256, 512, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, hx, blk, blk + 512, hword, t, b, nt4, fwt, step_begin, step_end, nap4w);
-            VOCR_CHECK_LAUNCH("vocr_lstm_fwd(4-row chains, wide members, self-validating)");
-            return VOCR_OK;
-        }
-        if (selfval && 2 * nt4 <= 16 && !(persistent_mode & 32) && (h == 512 || h == 256) &&
-            (2 * nt4 > 8 ? 16 : 8) * (h / 16) <= 2 * resident_workgroup_capacity()) {
-            // 4-row chains; the hand-off buffer starts as the "not written yet" pattern (first range of a sweep only)
-            unsigned* blk = (unsigned*)((char*)workspace + lstm_ws_handoff_offset(b, h));
-            float* hx = (float*)(blk + 1024);
-            if (lstm_fwd_selfval_prep(blk, (size_t)4 * 2 * nt4 * 4 * h * sizeof(float), step_begin == 0, s) != VOCR_OK) return VOCR_ELAUNCH;
-            const dim3 cg4((2 * nt4 > 8 ? 16 : 8) * (h / 16));
-            if (h == 512) lstm_fwd_chain4v<8><<<cg4, 256, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, hx, blk, blk + 512, hword, t, b, nt4, fwt, step_begin, step_end);
-            else lstm_fwd_chain4v<4><<<cg4, 256, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, hx, blk, blk + 512, hword, t, b, nt4, fwt, step_begin, step_end);
-            VOCR_CHECK_LAUNCH("vocr_lstm_fwd(chain, 4-row, self-validating)");
+            if (kind == SWEEP_WIDE4) {
+                static const int nap4w = getenv("VOCR_LSTM_NAP") ? atoi(getenv("VOCR_LSTM_NAP")) : 0;      // -1: polls start at once (experiments)
+                lstm_fwd_chain4w<8><<<256, 512, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, hx, blk, blk + 512, hword, t, b, nt4, fwt, step_begin, step_end, nap4w);
+            } else {
+                const dim3 cg4((2 * nt4 > 8 ? 16 : 8) * (h / 16));
+                if (h == 512) lstm_fwd_chain4v<8><<<cg4, 256, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, hx, blk, blk + 512, hword, t, b, nt4, fwt, step_begin, step_end);
+                else lstm_fwd_chain4v<4><<<cg4, 256, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, hx, blk, blk + 512, hword, t, b, nt4, fwt, step_begin, step_end);
+            }
+            VOCR_CHECK_LAUNCH("vocr_lstm_fwd(4-row chains, self-validating)");
             return VOCR_OK;
         }
         if (hipMemsetAsync(flags, 0, 520 * sizeof(unsigned), s) != hipSuccess) {
             vocr_set_error("vocr_lstm_fwd: memset failed");
             return VOCR_ELAUNCH;
         }
-        if (2 * nt8 <= 8 && !(persistent_mode & 32) && (h == 512 || h == 256)) {      // 8-row chains on all 8 XCDs, 4x4x1 MFMA
+        if (kind == SWEEP_CHAIN8) {      // 8-row chains on all 8 XCDs, 4x4x1 MFMA
             if (h == 512)
                 lstm_fwd_chain8<8><<<cg, 512, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, flags, flags + 256, status, hword, t, b, nt8, fwt,
                                                       step_begin, step_end);
@@ -2205,13 +2242,8 @@ static int lstm_bias_by_colsum(const float* dgates, float* dbias, void* workspac
 
 // which self-validating backward sweep (if any) a shape gets: 2 = wide members, 1 = 4-row chains, 0 = another path
 static int lstm_bwd_selfval_kind(int b, int h) {
-    static const int persistent_mode = getenv("VOCR_LSTM_PERSISTENT") ? atoi(getenv("VOCR_LSTM_PERSISTENT")) : 3;
-    static const int selfval = getenv("VOCR_LSTM_SELFVAL") ? atoi(getenv("VOCR_LSTM_SELFVAL")) : 1;
-    if (!(persistent_mode & 2) || (persistent_mode & 32) || !selfval || (selfval & 4) || b <= 0 || 8 * (h / 16) > resident_workgroup_capacity()) return 0;
-    const int nt4 = (b + 3) / 4;
-    if (!(selfval & 16) && h == 512 && nt4 > 4 && nt4 <= 8 && 256 <= resident_workgroup_capacity()) return 2;
-    if (2 * nt4 <= 16 && (h == 512 || h == 256) && (2 * nt4 > 8 ? 16 : 8) * (h / 16) <= 2 * resident_workgroup_capacity()) return 1;
-    return 0;
+    const SweepKind k = lstm_sweep_kind(true, b, h, (h == 128 || h == 256 || h == 512) && 8 * (h / 16) <= resident_workgroup_capacity());
+    return k == SWEEP_WIDE4 ? 2 : k == SWEEP_CHAIN4 ? 1 : 0;
 }
 
 static int lstm_bwd_impl(const float* dy, const float* dy_mask, const float* whht_fwd, const float* whht_rev, const int32_t* lens,
@@ -2256,8 +2288,8 @@ static int lstm_bwd_impl(const float* dy, const float* dy_mask, const float* whh
     float* dcb = (float*)workspace;
     const int rt = (b + 15) / 16;
     const bool fast = (h == 128 || h == 256 || h == 512) && aligned16(whh_fwd) && aligned16(whh_rev) && aligned16(dgates);
-    static const int persistent_mode = getenv("VOCR_LSTM_PERSISTENT") ? atoi(getenv("VOCR_LSTM_PERSISTENT")) : 3;
-    if (fast && (persistent_mode & 2) && 8 * (h / 16) <= resident_workgroup_capacity() && aligned16(gates)) {
+    const SweepKind kind = lstm_sweep_kind(true, b, h, fast && 8 * (h / 16) <= resident_workgroup_capacity() && aligned16(gates));
+    if (kind != SWEEP_STEP) {
         // arrival flags: [chain <= 8][32 workgroups] at [0..255]; status words at [512..]
         unsigned* flags = (unsigned*)workspace;
         unsigned* status = flags + 512;
@@ -2265,41 +2297,26 @@ static int lstm_bwd_impl(const float* dy, const float* dy_mask, const float* whh
         const dim3 g(8 * (h / 16));
         // K-owner form: partial sums [parity][chain][consumer][producer][16 x 16] behind the flags/status words
         float* partials = (float*)((char*)workspace + 4096);
-        const int nt8 = (b + 7) / 8;
-        static const int selfval = getenv("VOCR_LSTM_SELFVAL") ? atoi(getenv("VOCR_LSTM_SELFVAL")) : 1;     // bit 1 clear / bit 2 set: flag hand-off in the backward sweep
-        const int nt4 = (b + 3) / 4;
-        if (selfval && !(selfval & 4) && !(selfval & 16) && h == 512 && nt4 > 4 && nt4 <= 8 && !(persistent_mode & 32) && 256 <= resident_workgroup_capacity()) {
-            // 16 < B <= 32: 4-row chains of 16 wide members, one 8-wave workgroup per CU
+        const int nt8 = (b + 7) / 8, nt4 = (b + 3) / 4;
+        const int fwt = sweep_write_through() ? 1 : 0;
+        float* bpart = dbias ? (float*)((char*)workspace + 4096 + ((size_t)16 << 20)) : nullptr;     // [chain][4H]
+        if (kind == SWEEP_WIDE4 || kind == SWEEP_CHAIN4) {
+            // self-validating hand-off.  One fill: [XCC ids | status word | ... 4 KB][ring of partial blocks = "not written yet"]
             const int nch = 2 * nt4;
-            // one fill: [XCC ids | status word | ... 4 KB][ring]
-            if (hipMemsetAsync(flags, 0xFF, 4096 + (size_t)4 * nch * 16 * 16 * 512, s) != hipSuccess) {
+            const size_t ring = kind == SWEEP_WIDE4 ? (size_t)4 * nch * 16 * 16 * 512 : (size_t)4 * nch * 32 * 32 * 256;
+            if (hipMemsetAsync(flags, 0xFF, 4096 + ring, s) != hipSuccess) {
                 vocr_set_error("vocr_lstm_bwd: memset failed");
                 return VOCR_ELAUNCH;
             }
-            float* bpart = dbias ? (float*)((char*)workspace + 4096 + ((size_t)16 << 20)) : nullptr;     // [chain][4H]
-            lstm_bwd_chain4w<4><<<256, 512, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dy_mask, dgates, partials, flags, status, hword, bpart, t, b, nt4, (persistent_mode & 8) ? 1 : 0);
-            VOCR_CHECK_LAUNCH("vocr_lstm_bwd(k-owner, 4-row chains, wide members, self-validating)");
-            if (dbias && combine) {
-                lstm_bias_combine_kernel<<<dim3(vocr_cdiv(4 * h, 256), 2), 256, 0, s>>>(bpart, dbias, 4 * h, nt4);
-                VOCR_CHECK_LAUNCH("vocr_lstm_bwd(bias combine)");
+            if (kind == SWEEP_WIDE4) {
+                lstm_bwd_chain4w<4><<<256, 512, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dy_mask, dgates, partials, flags, status, hword, bpart, t, b, nt4, fwt);
+            } else {
+                const dim3 g4((nch > 8 ? 16 : 8) * (h / 16));
+                if (h == 512)
+                    lstm_bwd_chain4v<4><<<g4, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dy_mask, dgates, partials, flags, status, hword, bpart, t, b, nt4, fwt);
+                else
+                    lstm_bwd_chain4v<2><<<g4, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dy_mask, dgates, partials, flags, status, hword, bpart, t, b, nt4, fwt);
             }
-            return VOCR_OK;
-        }
-        if (selfval && !(selfval & 4) && 2 * nt4 <= 16 && !(persistent_mode & 32) && (h == 512 || h == 256) &&
-            (2 * nt4 > 8 ? 16 : 8) * (h / 16) <= 2 * resident_workgroup_capacity()) {
-            // 4-row chains; the ring of partial blocks starts as the "not written yet" pattern
-            const int nch = 2 * nt4;
-            if (hipMemsetAsync(flags, 0xFF, 4096 + (size_t)4 * nch * 32 * 32 * 256, s) != hipSuccess) {
-                vocr_set_error("vocr_lstm_bwd: memset failed");
-                return VOCR_ELAUNCH;
-            }
-            float* bpart = dbias ? (float*)((char*)workspace + 4096 + ((size_t)16 << 20)) : nullptr;     // [chain][4H]
-            const dim3 g4((nch > 8 ? 16 : 8) * (h / 16));
-            const int fwt4 = (persistent_mode & 8) ? 1 : 0;
-            if (h == 512)
-                lstm_bwd_chain4v<4><<<g4, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dy_mask, dgates, partials, flags, status, hword, bpart, t, b, nt4, fwt4);
-            else
-                lstm_bwd_chain4v<2><<<g4, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dy_mask, dgates, partials, flags, status, hword, bpart, t, b, nt4, fwt4);
             VOCR_CHECK_LAUNCH("vocr_lstm_bwd(k-owner, 4-row chains, self-validating)");
             if (dbias && combine) {
                 lstm_bias_combine_kernel<<<dim3(vocr_cdiv(4 * h, 256), 2), 256, 0, s>>>(bpart, dbias, 4 * h, nt4);
@@ -2311,13 +2328,11 @@ static int lstm_bwd_impl(const float* dy, const float* dy_mask, const float* whh
             vocr_set_error("vocr_lstm_bwd: memset failed");
             return VOCR_ELAUNCH;
         }
-        if (2 * nt8 <= 8 && !(persistent_mode & 32) && (h == 512 || h == 256)) {      // 8-row chains on all 8 XCDs, 4x4x1 MFMA
-            const int fwt8 = (persistent_mode & 8) ? 1 : 0;
-            float* bpart = dbias ? (float*)((char*)workspace + 4096 + ((size_t)16 << 20)) : nullptr;     // [chain][4H]
+        if (kind == SWEEP_CHAIN8) {      // 8-row chains on all 8 XCDs, 4x4x1 MFMA
             if (h == 512)
-                lstm_bwd_kowner8<4><<<g, 512, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, hword, bpart, t, b, nt8, fwt8);
+                lstm_bwd_kowner8<4><<<g, 512, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, hword, bpart, t, b, nt8, fwt);
             else
-                lstm_bwd_kowner8<2><<<g, 512, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, hword, bpart, t, b, nt8, fwt8);
+                lstm_bwd_kowner8<2><<<g, 512, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, hword, bpart, t, b, nt8, fwt);
             VOCR_CHECK_LAUNCH("vocr_lstm_bwd(k-owner, 8-row chains)");
             if (dbias) {
                 lstm_bias_combine_kernel<<<dim3(vocr_cdiv(4 * h, 256), 2), 256, 0, s>>>(bpart, dbias, 4 * h, nt8);
@@ -2325,7 +2340,6 @@ static int lstm_bwd_impl(const float* dy, const float* dy_mask, const float* whh
             }
             return VOCR_OK;
         }
-        const int fwt = (persistent_mode & 8) ? 1 : 0;       // experiments: write-through hand-off even on one XCD
         if (h == 128) lstm_bwd_kowner<1><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, hword, t, b, rt, fwt);
         else if (h == 256) lstm_bwd_kowner<2><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, hword, t, b, rt, fwt);
         else lstm_bwd_kowner<4><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, hword, t, b, rt, fwt);

@@ -187,7 +187,7 @@ def check_health(values, device=None):
         reset_health(device)
     if bad0:
         raise RuntimeError("vistaocr_amd: a hand-off inside a persistent LSTM sweep timed out (its output is NaN-poisoned); "
-                           "is another persistent sweep running on this GPU?  VOCR_LSTM_PERSISTENT=0 selects per-step launches")
+                           "is another persistent sweep running on this GPU?  VOCR_LSTM_SWEEP=step selects per-step launches")
     if bad1:
         raise RuntimeError("vistaocr_amd: a NaN gradient reached the optimiser (the reference's clamp_ would propagate it too)")
 
