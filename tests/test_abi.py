@@ -27,6 +27,36 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert re.search(r"#define VOCR_ABI_VERSION\s+3\b", open(os.path.join(ROOT, "include", "vocr.h")).read())
 
 
+def test_stale_or_foreign_library_is_refused(monkeypatch):
+    """A libvocr.so that answers another ABI version than the binding was written for must not be used (the version was
+    never compared; a stale shipped binary was only caught if a symbol was missing)."""
+    from vistaocr_amd import _lib
+    _lib.load()
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "ABI_VERSION", _lib.ABI_VERSION + 1)
+    with pytest.raises(RuntimeError, match="ABI version"):
+        _lib.load()
+
+
+def test_build_is_gated_by_a_hash_not_by_file_times(tmp_path, monkeypatch):
+    """vistaocr_amd/build.py: an unchanged tree does not rebuild; a tree whose hash differs from the stamp does, whatever the file times
+    say (a fresh checkout with a shipped .so, another compiler)."""
+    import json
+    import os as _os
+    from vistaocr_amd import build
+    build.build()
+    assert build._stale(build._tree_hash(build._hipcc())) is None
+    build.build()
+    assert build.build_report()["built"] is False
+    _os.utime(_os.path.join(build.CSRC, "misc.cpp"), None)                     # newer source file, same content: still up to date
+    assert build._stale(build._tree_hash(build._hipcc())) is None
+    assert build._stale("0" * 64) == "sources, flags or compiler changed"      # another tree hash: stale
+    stamp = json.load(open(build.STAMP))
+    monkeypatch.setattr(build, "STAMP", str(tmp_path / "stamp.json"))
+    json.dump(dict(stamp, lib="0" * 64), open(build.STAMP, "w"))
+    assert build._stale(stamp["tree"]) == "library is not the one the stamp describes"
+
+
 def test_argument_validation_without_gpu():
     from vistaocr_amd import _lib
     lib = _lib.load()
@@ -34,6 +64,10 @@ def test_argument_validation_without_gpu():
     assert rc == -1 and b"vocr_gemm" in lib.vocr_last_error()
     rc = lib.vocr_lstm_fwd(None, None, None, None, None, None, None, None, 4, 4, 16, None, None)
     assert rc == -1
+    # vocr_gemm_pair validates its leading dimensions before it builds buffer ranges from them
+    one = ctypes.c_void_p(16)
+    rc = lib.vocr_gemm_pair(0, 0, 0, 256, 256, 64, one, one, 8, one, one, 256, one, one, 256, None, None, 0, None, 0, None)
+    assert rc == -1 and b"leading dimension" in lib.vocr_last_error()
     assert lib.vocr_conv3x3_wgrad_workspace_bytes(32, 256, 7, 294, 256) > 0
     assert lib.vocr_ctc_workspace_bytes(294, 32, 96, 20) > 0
 
