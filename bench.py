@@ -466,7 +466,8 @@ def run_rank(args):
     sampled_steps = max(1, len(range(0, args.steps, args.event_every)) if args.event_every else 0)
     _lib.enable_timing(None)
     opt.time_comm(False)
-    names = MFMA_NAMES + ["vocr_bn_train_stats", "vocr_bn_relu_apply", "vocr_bn_relu_fracpool2x2_fwd", "vocr_bn_relu_bwd",
+    names = MFMA_NAMES + ["vocr_bn_train_stats", "vocr_bn_relu_apply", "vocr_bn_relu_fracpool2x2_fwd", "vocr_bn_train_relu_apply",
+                          "vocr_bn_train_relu_fracpool2x2_fwd", "vocr_bn_relu_bwd",
                           "vocr_fracpool2x2_bwd", "vocr_bn_relu_fracpool2x2_bwd", "vocr_ctc_loss_grad", "vocr_clamp_adam", "vocr_bchw_to_wbch", "vocr_wbch_to_bchw"]
     _lib.enable_timing(names)
     for _ in range(PROFILE_STEPS):

@@ -109,6 +109,19 @@ int vocr_bn_eval_stats(const float* running_mean, const float* running_var, int 
 /* out = relu((y-mean)*invstd*gamma + beta) */
 int vocr_bn_relu_apply(const float* y, const float* mean, const float* invstd, const float* gamma,
                        const float* beta, float* out, int n, int c, int hw, void* stream);
+/* Training-mode BatchNorm2d + ReLU of a layer in TWO launches instead of three (round 4): the statistics pass leaves per-chunk
+ * partial sums in `workspace` (vocr_bn_workspace_bytes) and every workgroup of the apply pass adds its channel's chunks itself, in
+ * chunk order - bit-identical to vocr_bn_train_stats followed by vocr_bn_relu_apply (src/models/cnnlstm.py:265-266), without the
+ * "final" launch and its two kernel boundaries on the forward's critical path.  mean / invstd / xhat_sum (saved for the backward)
+ * and the running statistics / num_batches_tracked are written as vocr_bn_train_stats writes them. */
+int vocr_bn_train_relu_apply(const float* y, const float* gamma, const float* beta, float* out, int n, int c, int hw, float eps,
+                             float momentum, float* mean, float* invstd, float* running_mean, float* running_var,
+                             int64_t* num_batches_tracked, float* xhat_sum, void* workspace, void* stream);
+/* The same for a layer followed by FractionalMaxPool2d (vocr_bn_relu_fracpool2x2_fwd's pass, src/models/cnnlstm.py:127,130). */
+int vocr_bn_train_relu_fracpool2x2_fwd(const float* y, const float* gamma, const float* beta, const float* samples, float* out,
+                                       int32_t* idx, int n, int c, int h, int w, int oh, int ow, float eps, float momentum,
+                                       float* mean, float* invstd, float* running_mean, float* running_var,
+                                       int64_t* num_batches_tracked, float* xhat_sum, void* workspace, void* stream);
 /* given da = dL/d(out): dgamma, dbeta and dy = dL/d(y) (training-mode batch-stat backward through ReLU);
  * dconv_bias (may be NULL) receives sum_{n,h,w} dy per channel = the gradient of the conv bias in front (rounding
  * noise around zero, from the fixed-order reduction: no float atomics anywhere in this call). */

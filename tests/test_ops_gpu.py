@@ -403,6 +403,39 @@ def test_persistent_sweeps_match_per_step_launches(dev, T, B, H):
             assert torch.equal(a, b), "%s (mode %s) differs: max |diff| %.3e at %d of %d" % (nm, mode_, float((a - b).abs().max()), int((a != b).sum()), a.numel())
 
 
+@pytest.mark.parametrize("n,c,h,w,pooled", [(4, 64, 30, 50, False), (3, 128, 7, 33, False), (32, 8, 30, 600, False), (2, 16, 15, 42, True), (3, 8, 30, 76, True)])
+def test_bn_two_launch_form_is_bit_identical_to_three(dev, n, c, h, w, pooled, monkeypatch):
+    """Round 4 folds the "final" step of the BatchNorm statistics (forward) and of its two backward sums into the pass that consumes
+    them (every workgroup adds its channel's chunks in chunk order).  Same arithmetic, same order: outputs, saved statistics, running
+    statistics, num_batches_tracked and all gradients must equal the three-launch form bit for bit - also with more than one chunk per
+    channel (32 x 30 x 600: 36 chunks)."""
+    from vistaocr_amd import ops
+    g = torch.Generator().manual_seed(11)
+    cin = 4
+    x = (torch.rand(n, cin, h, w, generator=g) - 0.4).to(dev)
+    wt = ((torch.rand(c, cin, 3, 3, generator=g) - 0.5) * 0.3).to(dev)
+    bias = (torch.rand(c, generator=g) - 0.5).to(dev)
+    gamma = (torch.rand(c, generator=g) * 0.5 + 0.75).to(dev)
+    beta = ((torch.rand(c, generator=g) - 0.5) * 0.4).to(dev)
+    oh, ow = (int(h * 0.5), int(w * 0.7)) if pooled else (0, 0)
+    samples = torch.rand(n, c, 2, generator=g).to(dev) if pooled else None
+    dout = torch.rand((n, c, oh, ow) if pooled else (n, c, h, w), generator=g).to(dev) - 0.5
+    results = []
+    for fused in (False, True):
+        monkeypatch.setattr(ops, "_BN_FUSED_FINAL", fused)
+        xs = x.clone().requires_grad_(True)
+        ws = wt.clone().requires_grad_(True)
+        bs, gs, bes = bias.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+        nbt = torch.zeros((), dtype=torch.int64, device=dev)
+        out = ops.ConvBnReluFn.apply(xs, ws, bs, gs, bes, rm, rv, True, 1e-5, 0.1, False, samples, oh, ow, nbt, None)
+        out.backward(dout)
+        results.append([t.detach().cpu() for t in (out, rm, rv, nbt, xs.grad, ws.grad, bs.grad, gs.grad, bes.grad)])
+    for name, a, b in zip(("out", "running_mean", "running_var", "num_batches_tracked", "dx", "dw", "dbias", "dgamma", "dbeta"), *results):
+        assert torch.equal(a, b), "%s differs between the three-launch and the two-launch form: max |diff| %.3e" % (name, float((a.double() - b.double()).abs().max()))
+    assert int(results[1][3]) == 1
+
+
 @pytest.mark.parametrize("n,cin,cout,h,w", [(3, 5, 8, 30, 75), (2, 64, 64, 15, 42)])
 def test_fused_bn_relu_fracpool_equals_the_two_separate_passes(dev, n, cin, cout, h, w):
     """ConvBnReluFn with pool_samples (one pass: BN-apply + ReLU + FractionalMaxPool) == ConvBnReluFn then FracPoolFn: bit for bit

@@ -38,6 +38,8 @@ SIGNATURES = {
     "vocr_bn_train_stats": (I, [P, I, I, I, F, F, P, P, P, P, P, P, P, P]),
     "vocr_bn_eval_stats": (I, [P, P, I, F, P, P, P]),
     "vocr_bn_relu_apply": (I, [P, P, P, P, P, P, I, I, I, P]),
+    "vocr_bn_train_relu_apply": (I, [P, P, P, P, I, I, I, F, F, P, P, P, P, P, P, P, P]),
+    "vocr_bn_train_relu_fracpool2x2_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, F, F, P, P, P, P, P, P, P, P]),
     "vocr_bn_relu_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, P, P]),
     "vocr_bn_relu_fracpool2x2_bwd_supported": (I, [I, I, I, I]),
     "vocr_bn_relu_fracpool2x2_bwd": (I, [P] * 13 + [I] * 6 + [P, P]),

@@ -112,17 +112,89 @@ __global__ void bn_eval_stats_kernel(const float* __restrict__ rmean, const floa
     invstd[c] = 1.0f / sqrtf(rvar[c] + eps);
 }
 
+// ---- the "final" step of a two-pass reduction, done by every workgroup of the pass that consumes it (round 4).  The partial-sum pass
+// leaves part[c][nchunk][2] (double); bn_stats_final_kernel / bn_bwd_final_kernel used to add a channel's chunks in chunk order in a
+// launch of their own - 7 forward + 7 backward launches of ~6 us with a kernel boundary on either side, all on the step's critical
+// path.  Here the consuming workgroup stages its channel's chunks in LDS (one load per thread) and thread 0 adds them in the SAME
+// order, so every workgroup of a channel obtains bit-identical sums; the workgroup (first chunk, first image) also stores the
+// per-channel results the later passes and the optimiser read.
+constexpr int BN_MAX_CHUNKS = 512;
+__device__ __forceinline__ void combine_partials(const double* __restrict__ part, int c, int nchunk, double* stage /* [2 * BN_MAX_CHUNKS + 2] */,
+                                                 double& s, double& q) {
+    for (int j = threadIdx.x; j < nchunk; j += blockDim.x) {
+        stage[2 * j] = part[((long)c * nchunk + j) * 2];
+        stage[2 * j + 1] = part[((long)c * nchunk + j) * 2 + 1];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (int j = 0; j < nchunk; ++j) {
+            a += stage[2 * j];
+            b += stage[2 * j + 1];
+        }
+        stage[2 * BN_MAX_CHUNKS] = a;
+        stage[2 * BN_MAX_CHUNKS + 1] = b;
+    }
+    __syncthreads();
+    s = stage[2 * BN_MAX_CHUNKS];
+    q = stage[2 * BN_MAX_CHUNKS + 1];
+}
+
+// mean / invstd of a channel from its combined sums, exactly as bn_stats_final_kernel computes them; `writer`: also store them and
+// update the running statistics
+__device__ __forceinline__ void bn_train_stats_of(double s, double q, long count, float eps, float momentum, int c, bool writer,
+                                                  float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ rmean,
+                                                  float* __restrict__ rvar, long long* __restrict__ nbt, float* __restrict__ xhat_sum,
+                                                  float& mu, float& is) {
+    const double m = s / (double)count;
+    double var = q / (double)count - m * m;
+    if (var < 0.0) var = 0.0;
+    mu = (float)m;
+    is = (float)(1.0 / sqrt(var + (double)eps));
+    if (writer && threadIdx.x == 0) {
+        if (c == 0 && nbt) *nbt += 1;
+        mean[c] = mu;
+        invstd[c] = is;
+        if (xhat_sum) xhat_sum[c] = (float)((s - (double)count * (double)mu) * (double)is);
+        if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
+        if (rvar) {
+            const double unbiased = count > 1 ? var * (double)count / (double)(count - 1) : var;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+        }
+    }
+}
+
+struct BnFusedStats {          // non-null part: take mean / invstd from the partial sums instead of the mean / invstd arrays
+    const double* part;
+    int nchunk;
+    long count;
+    float eps, momentum;
+    float *mean, *invstd, *rmean, *rvar, *xhat_sum;
+    long long* nbt;
+};
+
 // grid: (chunks over HW, N*C planes)
 template <int V>
 __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const float* __restrict__ y, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ out,
-                                                            int C, long HW) {
+                                                            int C, long HW, BnFusedStats fs) {
     typedef typename VecT<V>::type vec;
+    __shared__ double stage[2 * BN_MAX_CHUNKS + 2];
     const long plane = blockIdx.y;
     const int c = (int)(plane % C);
-    const float mu = mean[c], is = invstd[c], g = gamma[c], b = beta[c];
+    float mu, is;
+    if (fs.part) {
+        double s_, q_;
+        combine_partials(fs.part, c, fs.nchunk, stage, s_, q_);
+        bn_train_stats_of(s_, q_, fs.count, fs.eps, fs.momentum, c, blockIdx.x == 0 && plane < C, fs.mean, fs.invstd, fs.rmean, fs.rvar, fs.nbt,
+                          fs.xhat_sum, mu, is);
+    } else {
+        mu = mean[c];
+        is = invstd[c];
+    }
+    const float g = gamma[c], b = beta[c];
     const vec* yp = (const vec*)(y + plane * HW);
     vec* op = (vec*)(out + plane * HW);
     const long nv = HW / V;
@@ -285,14 +357,26 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta,
-                                                           const float* __restrict__ dgamma,
-                                                           const float* __restrict__ dbeta, float* __restrict__ dy,
-                                                           int C, long HW, float inv_count) {
+                                                           float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, float* __restrict__ dy,
+                                                           int C, long HW, float inv_count, const double* __restrict__ part, int nchunk,
+                                                           double inv_count_d, const float* __restrict__ xhat_sum,
+                                                           float* __restrict__ dconv_bias) {
     typedef typename VecT<V>::type vec;
+    __shared__ double stage[2 * BN_MAX_CHUNKS + 2];
     const long plane = blockIdx.y;
     const int c = (int)(plane % C);
     const float mu = mean[c], is = invstd[c], g = gamma[c], b = beta[c];
-    const float k1 = dbeta[c] * inv_count, k2 = dgamma[c] * inv_count, gs = g * is;
+    // dbeta / dgamma of this channel from the partial sums (what bn_bwd_final_kernel did in a launch of its own, same order)
+    double s1, s2;
+    combine_partials(part, c, nchunk, stage, s1, s2);
+    const float dbeta_c = (float)s1, dgamma_c = (float)s2;
+    if (blockIdx.x == 0 && plane < C && threadIdx.x == 0) {
+        dbeta[c] = dbeta_c;
+        dgamma[c] = dgamma_c;
+        if (dconv_bias) dconv_bias[c] = xhat_sum ? (float)(-(double)g * (double)is * (s2 * inv_count_d) * (double)xhat_sum[c]) : 0.f;
+    }
+    const float k1 = dbeta_c * inv_count, k2 = dgamma_c * inv_count, gs = g * is;
     const vec* yp = (const vec*)(y + plane * HW);
     const vec* dp = (const vec*)(da + plane * HW);
     vec* op = (vec*)(dy + plane * HW);
@@ -379,10 +463,21 @@ __global__ __launch_bounds__(256) void bn_relu_fracpool_fwd_kernel(const float* 
                                                                    const float* __restrict__ beta,
                                                                    const float* __restrict__ samples, float* __restrict__ out,
                                                                    int32_t* __restrict__ idx, int C, int H, int W, int OH, int OW,
-                                                                   float alpha_h, float alpha_w) {
+                                                                   float alpha_h, float alpha_w, BnFusedStats fs) {
+    __shared__ double stage[2 * BN_MAX_CHUNKS + 2];
     const long plane = blockIdx.y;
     const int c = (int)(plane % C);
-    const float mu = mean[c], is = invstd[c], g = gamma[c], b = beta[c];
+    float mu, is;
+    if (fs.part) {
+        double s_, q_;
+        combine_partials(fs.part, c, fs.nchunk, stage, s_, q_);
+        bn_train_stats_of(s_, q_, fs.count, fs.eps, fs.momentum, c, blockIdx.x == 0 && plane < C, fs.mean, fs.invstd, fs.rmean, fs.rvar, fs.nbt,
+                          fs.xhat_sum, mu, is);
+    } else {
+        mu = mean[c];
+        is = invstd[c];
+    }
+    const float g = gamma[c], b = beta[c];
     const float uw = samples[plane * 2], uh = samples[plane * 2 + 1];
     const float* yp = y + plane * (long)H * W;
     const int total = OH * OW;
@@ -465,9 +560,12 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float* __r
                                                                 const float* __restrict__ samples, const float* __restrict__ y,
                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                 float* __restrict__ dy, int C, int H, int W, int OH, int OW,
-                                                                float alpha_h, float alpha_w, float inv_count) {
+                                                                float alpha_h, float alpha_w, float inv_count, const double* __restrict__ part,
+                                                                int nchunk, double inv_count_d, const float* __restrict__ xhat_sum,
+                                                                float* __restrict__ dconv_bias) {
+    __shared__ double stage[2 * BN_MAX_CHUNKS + 2];
     extern __shared__ int inv[];                 // wa[W + 4], wb[W + 4], ha[H], hb[H]
     int* wa = inv;
     int* wb = inv + W + 4;
@@ -491,7 +589,15 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float* __r
     }
     __syncthreads();
     const float mu = mean[c], is = invstd[c], g = gamma[c], b = beta[c];
-    const float k1 = dbeta[c] * inv_count, k2 = dgamma[c] * inv_count, gs = g * is;
+    double s1, s2;                               // see bn_bwd_apply_kernel
+    combine_partials(part, c, nchunk, stage, s1, s2);
+    const float dbeta_c = (float)s1, dgamma_c = (float)s2;
+    if (plane < C && tid == 0) {
+        dbeta[c] = dbeta_c;
+        dgamma[c] = dgamma_c;
+        if (dconv_bias) dconv_bias[c] = xhat_sum ? (float)(-(double)g * (double)is * (s2 * inv_count_d) * (double)xhat_sum[c]) : 0.f;
+    }
+    const float k1 = dbeta_c * inv_count, k2 = dgamma_c * inv_count, gs = g * is;
     const float* dp = dout + plane * (long)OH * OW;
     const int32_t* ip = idx + plane * (long)OH * OW;
     const f32x4* yp = (const f32x4*)(y + plane * (long)H * W);
@@ -646,10 +752,45 @@ extern "C" int vocr_bn_relu_apply(const float* y, const float* mean, const float
     VOCR_CHECK_ARG((long)n * c <= 65535, "vocr_bn_relu_apply: n*c > 65535 planes");
     const int V = vec_width(hw, y, out);
     const dim3 grid = plane_grid((long)n * c, hw / V);
-    if (V == 4) bn_relu_apply_kernel<4><<<grid, 256, 0, (hipStream_t)stream>>>(y, mean, invstd, gamma, beta, out, c, hw);
-    else if (V == 2) bn_relu_apply_kernel<2><<<grid, 256, 0, (hipStream_t)stream>>>(y, mean, invstd, gamma, beta, out, c, hw);
-    else bn_relu_apply_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(y, mean, invstd, gamma, beta, out, c, hw);
+    const BnFusedStats none = {nullptr, 0, 0, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (V == 4) bn_relu_apply_kernel<4><<<grid, 256, 0, (hipStream_t)stream>>>(y, mean, invstd, gamma, beta, out, c, hw, none);
+    else if (V == 2) bn_relu_apply_kernel<2><<<grid, 256, 0, (hipStream_t)stream>>>(y, mean, invstd, gamma, beta, out, c, hw, none);
+    else bn_relu_apply_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(y, mean, invstd, gamma, beta, out, c, hw, none);
     VOCR_CHECK_LAUNCH("vocr_bn_relu_apply");
+    return VOCR_OK;
+}
+
+namespace {
+// the statistics pass of a training-mode layer: partial sums only; the pass that follows combines them (BnFusedStats)
+int bn_launch_partial(const float* y, int n, int c, int hw, void* workspace, hipStream_t s, int* nchunk_out) {
+    const int nchunk = bn_nchunk((long)n * hw);
+    const int V = vec_width(hw, y, y);
+    const long per = chunk_len((long)n * hw, nchunk);
+    if (V == 4) bn_stats_partial_kernel<4><<<dim3(c, nchunk), 256, 0, s>>>(y, (double*)workspace, n, c, hw, nchunk, per);
+    else if (V == 2) bn_stats_partial_kernel<2><<<dim3(c, nchunk), 256, 0, s>>>(y, (double*)workspace, n, c, hw, nchunk, per);
+    else bn_stats_partial_kernel<1><<<dim3(c, nchunk), 256, 0, s>>>(y, (double*)workspace, n, c, hw, nchunk, per);
+    *nchunk_out = nchunk;
+    return VOCR_OK;
+}
+}  // namespace
+
+extern "C" int vocr_bn_train_relu_apply(const float* y, const float* gamma, const float* beta, float* out, int n, int c, int hw, float eps,
+                                        float momentum, float* mean, float* invstd, float* running_mean, float* running_var,
+                                        int64_t* num_batches_tracked, float* xhat_sum, void* workspace, void* stream) {
+    VOCR_CHECK_ARG(y && gamma && beta && out && mean && invstd && workspace && n > 0 && c > 0 && hw > 0, "vocr_bn_train_relu_apply: bad argument");
+    VOCR_CHECK_ARG((long)n * c <= 65535, "vocr_bn_train_relu_apply: n*c > 65535 planes");
+    hipStream_t s = (hipStream_t)stream;
+    int nchunk = 0;
+    bn_launch_partial(y, n, c, hw, workspace, s, &nchunk);
+    VOCR_CHECK_LAUNCH("vocr_bn_train_relu_apply(partial)");
+    const BnFusedStats fs = {(const double*)workspace, nchunk, (long)n * hw, eps, momentum, mean, invstd, running_mean, running_var, xhat_sum,
+                             (long long*)num_batches_tracked};
+    const int V = vec_width(hw, y, out);
+    const dim3 grid = plane_grid((long)n * c, hw / V);
+    if (V == 4) bn_relu_apply_kernel<4><<<grid, 256, 0, s>>>(y, mean, invstd, gamma, beta, out, c, hw, fs);
+    else if (V == 2) bn_relu_apply_kernel<2><<<grid, 256, 0, s>>>(y, mean, invstd, gamma, beta, out, c, hw, fs);
+    else bn_relu_apply_kernel<1><<<grid, 256, 0, s>>>(y, mean, invstd, gamma, beta, out, c, hw, fs);
+    VOCR_CHECK_LAUNCH("vocr_bn_train_relu_apply(apply)");
     return VOCR_OK;
 }
 
@@ -666,14 +807,14 @@ extern "C" int vocr_bn_relu_bwd(const float* da, const float* y, const float* me
     else if (V == 2) bn_bwd_partial_kernel<2><<<dim3(c, nchunk), 256, 0, s>>>(da, y, mean, invstd, gamma, beta, (double*)workspace, n, c, hw, nchunk, per);
     else bn_bwd_partial_kernel<1><<<dim3(c, nchunk), 256, 0, s>>>(da, y, mean, invstd, gamma, beta, (double*)workspace, n, c, hw, nchunk, per);
     VOCR_CHECK_LAUNCH("vocr_bn_relu_bwd(partial)");
-    bn_bwd_final_kernel<<<vocr_cdiv(c, 64), 64, 0, s>>>((const double*)workspace, c, nchunk, 1.0 / (double)((long)n * hw), gamma, invstd,
-                                                        xhat_sum, dgamma, dbeta, dconv_bias);
-    VOCR_CHECK_LAUNCH("vocr_bn_relu_bwd(final)");
+    // (the chunks of a channel are added by every workgroup of the apply pass, in chunk order: no launch of its own for that)
     const dim3 grid = plane_grid((long)n * c, hw / V);
     const float inv_count = 1.0f / (float)((long)n * hw);
-    if (V == 4) bn_bwd_apply_kernel<4><<<grid, 256, 0, s>>>(da, y, mean, invstd, gamma, beta, dgamma, dbeta, dy, c, hw, inv_count);
-    else if (V == 2) bn_bwd_apply_kernel<2><<<grid, 256, 0, s>>>(da, y, mean, invstd, gamma, beta, dgamma, dbeta, dy, c, hw, inv_count);
-    else bn_bwd_apply_kernel<1><<<grid, 256, 0, s>>>(da, y, mean, invstd, gamma, beta, dgamma, dbeta, dy, c, hw, inv_count);
+    const double inv_count_d = 1.0 / (double)((long)n * hw);
+    const double* part = (const double*)workspace;
+    if (V == 4) bn_bwd_apply_kernel<4><<<grid, 256, 0, s>>>(da, y, mean, invstd, gamma, beta, dgamma, dbeta, dy, c, hw, inv_count, part, nchunk, inv_count_d, xhat_sum, dconv_bias);
+    else if (V == 2) bn_bwd_apply_kernel<2><<<grid, 256, 0, s>>>(da, y, mean, invstd, gamma, beta, dgamma, dbeta, dy, c, hw, inv_count, part, nchunk, inv_count_d, xhat_sum, dconv_bias);
+    else bn_bwd_apply_kernel<1><<<grid, 256, 0, s>>>(da, y, mean, invstd, gamma, beta, dgamma, dbeta, dy, c, hw, inv_count, part, nchunk, inv_count_d, xhat_sum, dconv_bias);
     VOCR_CHECK_LAUNCH("vocr_bn_relu_bwd(apply)");
     return VOCR_OK;
 }
@@ -701,13 +842,10 @@ extern "C" int vocr_bn_relu_fracpool2x2_bwd(const float* dout, const int32_t* id
     bn_pool_bwd_partial_kernel<<<dim3(c, nchunk), 256, 0, s>>>(dout, idx, y, mean, invstd, gamma, beta, (double*)workspace, n, c, hw, op,
                                                               nchunk, per);
     VOCR_CHECK_LAUNCH("vocr_bn_relu_fracpool2x2_bwd(partial)");
-    bn_bwd_final_kernel<<<vocr_cdiv(c, 64), 64, 0, s>>>((const double*)workspace, c, nchunk, 1.0 / (double)((long)n * hw), gamma, invstd,
-                                                        xhat_sum, dgamma, dbeta, dconv_bias);
-    VOCR_CHECK_LAUNCH("vocr_bn_relu_fracpool2x2_bwd(final)");
     const float alpha_h = (float)(h - 2) / (float)(oh - 1), alpha_w = (float)(w - 2) / (float)(ow - 1);
     bn_pool_bwd_apply_kernel<<<(unsigned)(n * c), 256, (size_t)(2 * w + 8 + 2 * h) * sizeof(int), s>>>(
         dout, idx, samples, y, mean, invstd, gamma, beta, dgamma, dbeta, dy, c, h, w, oh, ow, alpha_h, alpha_w,
-        1.0f / (float)((long)n * hw));
+        1.0f / (float)((long)n * hw), (const double*)workspace, nchunk, 1.0 / (double)((long)n * hw), xhat_sum, dconv_bias);
     VOCR_CHECK_LAUNCH("vocr_bn_relu_fracpool2x2_bwd(apply)");
     return VOCR_OK;
 }
@@ -734,9 +872,31 @@ extern "C" int vocr_bn_relu_fracpool2x2_fwd(const float* y, const float* mean, c
                    "vocr_bn_relu_fracpool2x2_fwd: bad shape h=%d w=%d oh=%d ow=%d", h, w, oh, ow);
     const float alpha_h = oh > 1 ? (float)(h - 2) / (float)(oh - 1) : 0.f;
     const float alpha_w = ow > 1 ? (float)(w - 2) / (float)(ow - 1) : 0.f;
+    const BnFusedStats none = {nullptr, 0, 0, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bn_relu_fracpool_fwd_kernel<<<plane_grid((long)n * c, (long)oh * ow), 256, 0, (hipStream_t)stream>>>(
-        y, mean, invstd, gamma, beta, samples, out, idx, c, h, w, oh, ow, alpha_h, alpha_w);
+        y, mean, invstd, gamma, beta, samples, out, idx, c, h, w, oh, ow, alpha_h, alpha_w, none);
     VOCR_CHECK_LAUNCH("vocr_bn_relu_fracpool2x2_fwd");
+    return VOCR_OK;
+}
+
+extern "C" int vocr_bn_train_relu_fracpool2x2_fwd(const float* y, const float* gamma, const float* beta, const float* samples, float* out,
+                                                  int32_t* idx, int n, int c, int h, int w, int oh, int ow, float eps, float momentum,
+                                                  float* mean, float* invstd, float* running_mean, float* running_var,
+                                                  int64_t* num_batches_tracked, float* xhat_sum, void* workspace, void* stream) {
+    VOCR_CHECK_ARG(y && gamma && beta && samples && out && idx && mean && invstd && workspace, "vocr_bn_train_relu_fracpool2x2_fwd: null pointer");
+    VOCR_CHECK_ARG(n > 0 && c > 0 && h >= 2 && w >= 2 && oh >= 1 && ow >= 1 && oh <= h - 1 && ow <= w - 1 && (long)n * c <= 65535,
+                   "vocr_bn_train_relu_fracpool2x2_fwd: bad shape h=%d w=%d oh=%d ow=%d", h, w, oh, ow);
+    hipStream_t s = (hipStream_t)stream;
+    int nchunk = 0;
+    bn_launch_partial(y, n, c, h * w, workspace, s, &nchunk);
+    VOCR_CHECK_LAUNCH("vocr_bn_train_relu_fracpool2x2_fwd(partial)");
+    const BnFusedStats fs = {(const double*)workspace, nchunk, (long)n * h * w, eps, momentum, mean, invstd, running_mean, running_var, xhat_sum,
+                             (long long*)num_batches_tracked};
+    const float alpha_h = oh > 1 ? (float)(h - 2) / (float)(oh - 1) : 0.f;
+    const float alpha_w = ow > 1 ? (float)(w - 2) / (float)(ow - 1) : 0.f;
+    bn_relu_fracpool_fwd_kernel<<<plane_grid((long)n * c, (long)oh * ow), 256, 0, s>>>(y, mean, invstd, gamma, beta, samples, out, idx, c, h, w, oh, ow,
+                                                                                       alpha_h, alpha_w, fs);
+    VOCR_CHECK_LAUNCH("vocr_bn_train_relu_fracpool2x2_fwd(apply)");
     return VOCR_OK;
 }
 

@@ -1187,25 +1187,35 @@ __global__ void wgrad_reduce_scalar_kernel(const float* __restrict__ slab, float
 // Same reduction with four times the loads in flight: a workgroup sums 64 float4 columns, its four waves take the slabs
 // sp = wave, wave+4, ... and the partial sums are combined in a fixed order ((w0+w1)+(w2+w3)): bitwise reproducible.
 // Needs Cout*Cin % 4 == 0 (a float4 then never straddles two taps).
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cout, int Cin,
-                                                           int splits) {
-    __shared__ f32x4 red[4][64];
+// G = waves per workgroup = groups of slabs summed side by side.  G = 16 (round 4) for small weight tensors: the first layer's 576 values
+// in 1024 slabs made 3 workgroups of 4 waves with 256 dependent-latency loads each - 68 us at the very end of the step, in front of the
+// optimiser; 16 waves with 64 loads each: ~10.
+template <int G>
+__global__ __launch_bounds__(64 * G) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cout, int Cin,
+                                                              int splits) {
+    __shared__ f32x4 red[G][64];
     const long plane = (long)Cout * Cin;
     const long total4 = 9 * plane / 4;
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
     const long o = (long)blockIdx.x * 64 + lane;
     f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (o < total4)
-        for (int sp = g; sp < splits; sp += 4) s += *(const f32x4*)(slab + (long)sp * 9 * plane + o * 4);
+        for (int sp = g; sp < splits; sp += G) s += *(const f32x4*)(slab + (long)sp * 9 * plane + o * 4);
     red[g][lane] = s;
     __syncthreads();
     if (g == 0 && o < total4) {
-        const f32x4 v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        f32x4 v[G];
+#pragma unroll
+        for (int i = 0; i < G; ++i) v[i] = red[i][lane];
+#pragma unroll
+        for (int w = 1; w < G; w *= 2)                // fixed balanced tree: ((w0+w1)+(w2+w3)) ...
+#pragma unroll
+            for (int i = 0; i + w < G; i += 2 * w) v[i] += v[i + w];
         const long i = o * 4;
         const int t = (int)(i / plane);
         const long r = i - (long)t * plane;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dw[(r + e) * 9 + t] = v[e];
+        for (int e = 0; e < 4; ++e) dw[(r + e) * 9 + t] = v[0][e];
     }
 }
 
@@ -1253,8 +1263,11 @@ const float* zero_page_ptr() {
 
 void launch_wgrad_reduce(const float* slab, float* dw, int cout, int cin, int splits, hipStream_t s) {
     const long total = 9l * cout * cin;
-    if (((long)cout * cin) % 4 == 0 && (((uintptr_t)slab) & 15) == 0)
-        wgrad_reduce_kernel<<<(unsigned)((total / 4 + 63) / 64), 256, 0, s>>>(slab, dw, cout, cin, splits);
+    if (((long)cout * cin) % 4 == 0 && (((uintptr_t)slab) & 15) == 0) {
+        const unsigned wgs = (unsigned)((total / 4 + 63) / 64);
+        if (wgs < 64 && splits >= 64) wgrad_reduce_kernel<16><<<wgs, 1024, 0, s>>>(slab, dw, cout, cin, splits);
+        else wgrad_reduce_kernel<4><<<wgs, 256, 0, s>>>(slab, dw, cout, cin, splits);
+    }
     else
         wgrad_reduce_scalar_kernel<<<vocr_cdiv(total, 256), 256, 0, s>>>(slab, dw, cout, cin, splits);
 }

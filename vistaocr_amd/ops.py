@@ -289,6 +289,7 @@ def forward_prep(conv_weights, lstm_layers, with_transposes):
 
 
 # ------------------------------------------------------------------------------------------------ conv + BN + ReLU
+_BN_FUSED_FINAL = _os.environ.get("VOCR_BN_FUSED_FINAL", "1") == "1"
 _WINO = _os.environ.get("VOCR_CONV_WINO", "1") == "1"
 _WINO_WGRAD = _os.environ.get("VOCR_WGRAD_WINO", "1") == "1"
 
@@ -396,11 +397,16 @@ class ConvBnReluFn(torch.autograd.Function):
         mean = torch.empty(cout, dtype=torch.float32, device=x.device)
         invstd = torch.empty(cout, dtype=torch.float32, device=x.device)
         xhat_sum = None
+        # training mode: statistics pass + apply pass in two launches (the apply pass adds each channel's partial sums itself; VOCR_BN_FUSED_FINAL=0:
+        # round 3's three launches - bit-identical results)
+        fused_final = training and _BN_FUSED_FINAL
+        ws = None
         if training:
             ws = _ws(lib.vocr_bn_workspace_bytes(n, cout, h * w), x.device)
             xhat_sum = torch.empty(cout, dtype=torch.float32, device=x.device)
-            call("vocr_bn_train_stats", _p(y), n, cout, h * w, eps, momentum, _p(mean), _p(invstd), _p(running_mean),
-                 _p(running_var), _p(num_batches_tracked), _p(xhat_sum), _p(ws), _stream())
+            if not fused_final:
+                call("vocr_bn_train_stats", _p(y), n, cout, h * w, eps, momentum, _p(mean), _p(invstd), _p(running_mean),
+                     _p(running_var), _p(num_batches_tracked), _p(xhat_sum), _p(ws), _stream())
         else:
             call("vocr_bn_eval_stats", _p(running_mean), _p(running_var), cout, eps, _p(mean), _p(invstd), _stream())
         ctx.pool = None
@@ -411,12 +417,20 @@ class ConvBnReluFn(torch.autograd.Function):
                 raise RuntimeError("fractional pool samples must have shape (N, C, 2)")
             out = torch.empty(n, cout, pool_oh, pool_ow, dtype=torch.float32, device=x.device)
             idx = torch.empty(n, cout, pool_oh, pool_ow, dtype=torch.int32, device=x.device)
-            call("vocr_bn_relu_fracpool2x2_fwd", _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(samples), _p(out), _p(idx),
-                 n, cout, h, w, pool_oh, pool_ow, _stream())
+            if fused_final:
+                call("vocr_bn_train_relu_fracpool2x2_fwd", _p(y), _p(gamma), _p(beta), _p(samples), _p(out), _p(idx), n, cout, h, w, pool_oh, pool_ow,
+                     eps, momentum, _p(mean), _p(invstd), _p(running_mean), _p(running_var), _p(num_batches_tracked), _p(xhat_sum), _p(ws), _stream())
+            else:
+                call("vocr_bn_relu_fracpool2x2_fwd", _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(samples), _p(out), _p(idx),
+                     n, cout, h, w, pool_oh, pool_ow, _stream())
             ctx.pool = (pool_oh, pool_ow)
         else:
             out = torch.empty_like(y)
-            call("vocr_bn_relu_apply", _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(out), n, cout, h * w, _stream())
+            if fused_final:
+                call("vocr_bn_train_relu_apply", _p(y), _p(gamma), _p(beta), _p(out), n, cout, h * w, eps, momentum, _p(mean), _p(invstd),
+                     _p(running_mean), _p(running_var), _p(num_batches_tracked), _p(xhat_sum), _p(ws), _stream())
+            else:
+                call("vocr_bn_relu_apply", _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(out), n, cout, h * w, _stream())
         ctx.training = training
         ctx.prefs = (weight, bias, gamma, beta)
         ctx.save_for_backward(x, y, mean, invstd, gamma, beta, pd, idx, samples, xhat_sum)
