@@ -139,16 +139,25 @@ def lstm_flops(args, first_dim_arg):
     return 2.0 * 2 * t * b * h * 4 * h           # both directions: [B, H] x [H, 4H] per time step
 
 
-# MFMA FLOPs a launch EXECUTES per algorithmic FLOP: the F(2,3) / F(3,2) kernels issue 4 multiplications where the direct form needs 6
-EXECUTED_SHARE = {"vocr_conv3x3_wino_fwd": 2.0 / 3.0, "vocr_conv3x3_wgrad_wino": 2.0 / 3.0}
+# MFMA FLOPs a launch EXECUTES per algorithmic FLOP: the F(2,3) / F(3,2) kernels issue 4 multiplications where the direct form needs 6, the
+# F(4,3) kernel (forward / data-gradient launches with >= 128 output channels unless VOCR_CONV_WINO4=0) 6 where it needs 12
+_WINO4 = os.environ.get("VOCR_CONV_WINO4", "1") != "0"
+
+
+def executed_share(name, args):
+    if name == "vocr_conv3x3_wino_fwd":
+        return 0.5 if (_WINO4 and args[8] >= 128) else 2.0 / 3.0
+    if name == "vocr_conv3x3_wgrad_wino":
+        return 2.0 / 3.0
+    return 1.0
 FLOPS_OF = {"vocr_conv3x3_fwd": conv_flops, "vocr_conv3x3_wino_fwd": conv_flops, "vocr_conv3x3_wgrad": conv_flops,
             "vocr_conv3x3_wgrad_wino": conv_flops, "vocr_gemm": gemm_flops, "vocr_gemm_pair": gemm_pair_flops,
             "vocr_lstm_fwd": lambda a: lstm_flops(a, 8), "vocr_lstm_fwd_range": lambda a: lstm_flops(a, 8),
             "vocr_lstm_bwd_bias": lambda a: lstm_flops(a, 9)}
-FAMILY = {"vocr_conv3x3_fwd": "conv3x3 forward + data gradient (conv3x3_wino_kernel / conv3x3_dma_kernel)",
-          "vocr_conv3x3_wino_fwd": "conv3x3 forward + data gradient (conv3x3_wino_kernel / conv3x3_dma_kernel)",
-          "vocr_conv3x3_wgrad": "conv3x3 weight gradient (conv3x3_wgrad_wino_dma_kernel)",
-          "vocr_conv3x3_wgrad_wino": "conv3x3 weight gradient (conv3x3_wgrad_wino_dma_kernel)",
+FAMILY = {"vocr_conv3x3_fwd": "conv3x3 forward + data gradient (conv3x3_wino4 / conv3x3_wino2 kernels: F(4,3) / F(2,3) along the row)",
+          "vocr_conv3x3_wino_fwd": "conv3x3 forward + data gradient (conv3x3_wino4 / conv3x3_wino2 kernels: F(4,3) / F(2,3) along the row)",
+          "vocr_conv3x3_wgrad": "conv3x3 weight gradient (conv3x3_wgrad_wino3_kernel: F(3,2), piece stream)",
+          "vocr_conv3x3_wgrad_wino": "conv3x3 weight gradient (conv3x3_wgrad_wino3_kernel: F(3,2), piece stream)",
           "vocr_gemm": "dense GEMMs (gemm_dma_kernel / gemm_f32_kernel behind vocr_gemm and vocr_gemm_pair: bridge, LSTM projections, prob, their dX / dW)",
           "vocr_gemm_pair": "dense GEMMs (gemm_dma_kernel / gemm_f32_kernel behind vocr_gemm and vocr_gemm_pair: bridge, LSTM projections, prob, their dX / dW)",
           "vocr_lstm_fwd": "LSTM sweeps (lstm_fwd_chain4w / lstm_bwd_chain4w)", "vocr_lstm_fwd_range": "LSTM sweeps (lstm_fwd_chain4w / lstm_bwd_chain4w)",
@@ -506,7 +515,7 @@ def run_rank(args):
                     fl = FLOPS_OF[name](a)
                     f["ms"] += e0.elapsed_time(e1)
                     f["flop"] += fl
-                    f["exe"] += fl * EXECUTED_SHARE.get(name, 1.0)
+                    f["exe"] += fl * executed_share(name, a)
                     f["n"] += 1
             outf = {}
             for k, f in fam.items():
@@ -526,18 +535,18 @@ def run_rank(args):
         fwd_only = [(a, e0, e1) for n_ in ("vocr_conv3x3_fwd", "vocr_conv3x3_wino_fwd") for (a, e0, e1) in timed_recs.get(n_, []) if a[2] is not None]
         cf_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in fwd_only)
         cf_fl = sum(conv_flops(a) for a, _, _ in fwd_only)
-        cf_ex = sum(conv_flops(a) * EXECUTED_SHARE.get(n_, 1.0) for n_ in ("vocr_conv3x3_fwd", "vocr_conv3x3_wino_fwd")
+        cf_ex = sum(conv_flops(a) * executed_share(n_, a) for n_ in ("vocr_conv3x3_fwd", "vocr_conv3x3_wino_fwd")
                     for (a, _, _) in timed_recs.get(n_, []) if a[2] is not None)
         conv_fwd = dict(achieved=round(cf_fl / (cf_ms * 1e-3) / 1e12, 2) if cf_ms > 0 else 0.0,
                         executed_achieved=round(cf_ex / (cf_ms * 1e-3) / 1e12, 2) if cf_ms > 0 else 0.0,
                         avg_launch_ms=round(cf_ms / max(1, len(fwd_only)), 4), launches_timed=len(fwd_only),
-                        what="forward-pass launches of conv3x3_wino_kernel only (nothing else on the chip); achieved = algorithmic direct-convolution "
-                             "FLOPs / time, executed = the 2/3 of them the F(2,3) kernel issues")
+                        what="forward-pass launches of the conv kernels only (nothing else on the chip); achieved = algorithmic direct-convolution "
+                             "FLOPs / time, executed = what the kernels issue: 1/2 of them in the F(4,3) launches (>= 128 output channels), 2/3 in the F(2,3) ones")
         conv_fwd["frac"] = round(conv_fwd["achieved"] / peak, 4)
         conv_fwd["executed_frac"] = round(conv_fwd["executed_achieved"] / peak, 4)
         # whole step: algorithmic and executed MFMA FLOPs from the shapes of the calls the step made (un-timed profile pass)
         step_flop = sum(FLOPS_OF[n_](a) for n_ in MFMA_NAMES for a, _, _ in prof.get(n_, [])) / PROFILE_STEPS
-        step_exe = sum(FLOPS_OF[n_](a) * EXECUTED_SHARE.get(n_, 1.0) for n_ in MFMA_NAMES for a, _, _ in prof.get(n_, [])) / PROFILE_STEPS
+        step_exe = sum(FLOPS_OF[n_](a) * executed_share(n_, a) for n_ in MFMA_NAMES for a, _, _ in prof.get(n_, [])) / PROFILE_STEPS
         traffic = None
         try:        # HBM-side bytes per launch from the committed PMC passes (cannot be collected live), keyed by kernel family
             tj = json.load(open(os.path.join(ROOT, "profiles", "kernel_traffic.json")))

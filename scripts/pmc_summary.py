@@ -31,7 +31,7 @@ def traffic(paths):
         for r in sorted(rows, key=lambda r: int(r["Dispatch_Id"])):
             k = short(r["Kernel_Name"])
             per.setdefault(k, []).append(float(r["Counter_Value"]))
-            if k.startswith("conv3x3_wino_kernel<") or k.startswith("conv3x3_wino2_kernel") or k.startswith("conv3x3_dma_kernel<") or k.startswith("conv3x3_kernel<"):
+            if k.startswith("conv3x3_wino_kernel<") or k.startswith("conv3x3_wino2_kernel") or k.startswith("conv3x3_wino4") or k.startswith("conv3x3_dma_kernel<") or k.startswith("conv3x3_kernel<"):
                 conv.append(float(r["Counter_Value"]))
         print(cname)
         for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1]))[:14]:
@@ -52,7 +52,7 @@ def busy(paths):
         rows, dur = load(path)
         for r in rows:
             k = short(r["Kernel_Name"])
-            key = "conv forward (%s)" % k.split("<")[0] if (k.startswith("conv3x3_dma_kernel") or k.startswith("conv3x3_wino_kernel") or k.startswith("conv3x3_wino2_kernel")) \
+            key = "conv forward (%s)" % k.split("<")[0] if (k.startswith("conv3x3_dma_kernel") or k.startswith("conv3x3_wino_kernel") or k.startswith("conv3x3_wino2_kernel") or k.startswith("conv3x3_wino4")) \
                 else "conv weight gradient (%s)" % k.split("<")[0] if (k.startswith("conv3x3_wgrad_kernel") or k.startswith("conv3x3_wgrad_wino")) \
                 else "GEMM tile kernel (%s)" % k[:60] if k.startswith("gemm_f32_kernel") \
                 else "GEMM panel kernel (%s)" % k[:60] if k.startswith("gemm_dma_kernel") else None
@@ -83,8 +83,8 @@ def busy(paths):
 
 
 FAMILIES = (      # bench.py's FAMILY names -> kernel-name prefixes
-    ("conv3x3 forward + data gradient (conv3x3_wino_kernel / conv3x3_dma_kernel)", ("conv3x3_wino_kernel", "conv3x3_wino2_kernel", "conv3x3_wino8_kernel", "conv3x3_dma_kernel", "conv3x3_kernel", "conv3x3_tail")),
-    ("conv3x3 weight gradient (conv3x3_wgrad_wino_dma_kernel)", ("conv3x3_wgrad",)),
+    ("conv3x3 forward + data gradient (conv3x3_wino4 / conv3x3_wino2 kernels: F(4,3) / F(2,3) along the row)", ("conv3x3_wino_kernel", "conv3x3_wino2_kernel", "conv3x3_wino4", "conv3x3_wino8_kernel", "conv3x3_dma_kernel", "conv3x3_kernel", "conv3x3_tail")),
+    ("conv3x3 weight gradient (conv3x3_wgrad_wino3_kernel: F(3,2), piece stream)", ("conv3x3_wgrad",)),
     ("dense GEMMs (gemm_dma_kernel / gemm_f32_kernel behind vocr_gemm and vocr_gemm_pair: bridge, LSTM projections, prob, their dX / dW)", ("gemm_dma_kernel", "gemm_f32_kernel")),
     ("LSTM sweeps (lstm_fwd_chain4w / lstm_bwd_chain4w)", ("lstm_fwd_", "lstm_bwd_")),
 )

@@ -56,7 +56,7 @@ def test_forward_loss_labels_vs_reference_goldens(name, alpha):
     loss = va.CTCLoss()(logits, torch.from_numpy(tgt), lens, torch.from_numpy(tl))
     assert tuple(loss.shape) == (1,)
     ref_loss = float(g["loss"][0])
-    assert abs(float(loss) - ref_loss) <= LOSS_RTOL * abs(ref_loss), (float(loss), ref_loss)
+    assert abs(float(loss.detach()) - ref_loss) <= LOSS_RTOL * abs(ref_loss), (float(loss.detach()), ref_loss)
     # integer label sequences: bit-exact
     labels = model.decode_labels(logits, lens)
     assert labels == gu.split_labels(g), "greedy label sequences differ from the reference"

@@ -43,11 +43,15 @@ def _close(a, b, rtol, atol, what="", max_bad_frac=0.0):
                                             (3, 8, 13, 65, 32), (2, 16, 5, 47, 64), (1, 8, 6, 48, 16), (2, 8, 1, 38, 8), (1, 8, 3, 15, 8),
                                             # more than 256 workgroup tiles with a short last round: conv3x3_tail_kernel computes it
                                             # (326 tiles of 128co x 2 segments, the last one half empty; 297 of 64co x 4; 293 with Cout = 72)
-                                            (5, 20, 7, 294, 256), (6, 12, 15, 420, 64), (9, 8, 7, 294, 72)])
+                                            (5, 20, 7, 294, 256), (6, 12, 15, 420, 64), (9, 8, 7, 294, 72),
+                                            # batch-32 launches: enough tiles for the EIGHT-wave F(4,3) workgroups (>= one per CU), with a cut
+                                            # last round (264 tiles of 128co x 4 segments) and without (398)
+                                            (32, 16, 7, 294, 256), (32, 8, 15, 420, 128)])
 @pytest.mark.parametrize("form", ["transform", "direct"])
 def test_conv3x3_fwd_dgrad_wgrad(dev, n, cin, h, w, cout, form, monkeypatch):
-    """Both forms of the three conv kernels against F.conv2d: "transform" = F(2,3) / F(3,2) along the row (conv_wino.hip, the default
-    for Cin >= 4), "direct" = conv.hip (VOCR_CONV_WINO=0 / VOCR_WGRAD_WINO=0, and what Cin < 4 always uses)."""
+    """Both forms of the three conv kernels against F.conv2d: "transform" = minimal filtering along the row (conv_wino.hip, the default
+    for Cin >= 4: F(4,3) for forward / data-gradient launches with >= 128 output channels, F(2,3) below, F(3,2) weight gradient),
+    "direct" = conv.hip (VOCR_CONV_WINO=0 / VOCR_WGRAD_WINO=0, and what Cin < 4 always uses)."""
     from vistaocr_amd import ops
     monkeypatch.setattr(ops, "_WINO", form == "transform")
     monkeypatch.setattr(ops, "_WINO_WGRAD", form == "transform")

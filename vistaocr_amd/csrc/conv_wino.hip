@@ -69,6 +69,15 @@ static int wino2_mode() {
     static const int v = getenv("VOCR_CONV_WINO2") ? atoi(getenv("VOCR_CONV_WINO2")) : 1;
     return v;
 }
+// VOCR_CONV_WINO4 (default 1): F(4,3) along the row (conv3x3_wino4_body) for the forward / data-gradient launches with >= 128 output
+// channels: own pack (18 transformed + 9 direct rows per channel); 0: F(2,3) everywhere (round 3 / early round 4)
+static int wino4_mode() {
+    static const int v = getenv("VOCR_CONV_WINO4") ? atoi(getenv("VOCR_CONV_WINO4")) : 1;
+    return v;
+}
+// which packs / launches take the F(4,3) kernel: convolutions with at least 128 OUTPUT channels (the forward of a layer with Cout >= 128, the
+// data gradient of a layer with Cin >= 128); measured slower than F(2,3) with 64 (eight segments per workgroup)
+static bool wino4_for(int cout) { return wino4_mode() != 0 && cout >= 128; }
 static int wino_pack_x4() {
     static const int v = wino2_mode() ? 1 : (getenv("VOCR_CONV_PACK4") ? atoi(getenv("VOCR_CONV_PACK4")) : 0);
     return v;
@@ -503,6 +512,309 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino2_kernel_64(const float* _
                                                                   WGeom geo, int co_tiles, const float* __restrict__ wdirect, int n_tail, int first_tail_tile) {
     conv3x3_wino2_body<64>(in, wpack, bias, out, zero_page, N, Cin, H, W, Cout, geo, co_tiles, wdirect, n_tail, first_tail_tile);
 }
+
+// ---------------------------------------------------------------- forward / data gradient with F(4,3) ALONG THE ROW (round 4, VOCR_CONV_WINO4=1)
+// Four neighbouring outputs of a row from six multiplications per (ci, kh) instead of the eight of two F(2,3) pairs: the MFMA does 1/2
+// of the direct kernel's work instead of 2/3.
+//   d0..d5 = input columns 4q-1 .. 4q+4
+//   v0 = 4 d0 - 5 d2 + d4        v1 = (d4 - 4 d2) + (d3 - 4 d1)      v2 = (d4 - 4 d2) - (d3 - 4 d1)
+//   v3 = (d4 - d2) + 2 (d3 - d1) v4 = (d4 - d2) - 2 (d3 - d1)        v5 = 4 d1 - 5 d3 + d5
+//   g0..g2 = the taps of filter row kh:
+//   u0 = g0/4   u1 = -(g0+g1+g2)/6   u2 = -(g0-g1+g2)/6   u3 = g0/24 + g1/12 + g2/6   u4 = g0/24 - g1/12 + g2/6   u5 = g2
+//   m_x = sum over (ci, kh) of u_x v_x
+//   y(4q) = m0+m1+m2+m3+m4   y(4q+1) = (m1-m2) + 2 (m3-m4)   y(4q+2) = (m1+m2) + 4 (m3+m4)   y(4q+3) = (m1-m2) + 8 (m3-m4) + m5
+// Rounding: measured 2.7 - 3x the F(2,3) error on 64 .. 256-channel sums of non-negative activations (1.4e-6 of the result's scale
+// against 5e-7, direct fp32 7e-7: scripts/README.md); the full-size oracle test decides whether it may be the default.
+// Six accumulator tiles per 32 output channels and 32 quads: 96 registers - one wave per SIMD with BIG register tiles (the budget of
+// §5: the input transform's 12 VALU instructions are paid once per quad row and serve TM x 6 MFMAs).  Workgroup = 4 waves = one
+// per SIMD, one workgroup per CU; a wave owns ALL CO_T output channels (TM = CO_T / 32 row blocks) of TN segments of 32 quads =
+// 128 pixels: CO_T = 128: TM 4, TN 1 (4 segments per workgroup), CO_T = 64: TM 2, TN 2 (8 segments).  The raw halo rows of a wave's
+// segments are staged by that wave alone (no other wave reads them); the weights of a stage (4 input channels: 12 filter rows of
+// CO_T x 6 transformed values, as [row][co][4] + [row][co][2] so that a fragment is one 16-byte and one 8-byte read) arrive by
+// LDS-DMA for all four waves, two stages.
+constexpr int Q4_TS = 32;                   // quads per segment
+constexpr int Q4_PRW = 132;                 // floats per staged halo row: raw index r = 4 e + c <-> column 4 k_e - 1 + c, r < 130
+constexpr int Q4_PSEG = 12 * Q4_PRW;        // floats of halo per segment and stage
+__global__ void wino4_pack_kernel(const float* __restrict__ w, float* __restrict__ pf, float* __restrict__ pd, int cout, int cin) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = cout * cin * 3;
+    if (i >= total) return;
+    const int kh = i % 3, ci = (i / 3) % cin, co = i / (3 * cin);
+    const float* g = w + ((long)(co * cin + ci) * 3 + kh) * 3;
+    auto put = [](float* p4, float* p2, float g0, float g1, float g2) {
+        p4[0] = 0.25f * g0;
+        p4[1] = -((g0 + g2) + g1) * (1.f / 6.f);
+        p4[2] = -((g0 + g2) - g1) * (1.f / 6.f);
+        p4[3] = (g0 * (1.f / 24.f) + g2 * (1.f / 6.f)) + g1 * (1.f / 12.f);
+        p2[0] = (g0 * (1.f / 24.f) + g2 * (1.f / 6.f)) - g1 * (1.f / 12.f);
+        p2[1] = g2;
+    };
+    if (pf) {           // pf: [(ci*3 + kh)][co][4] | [(ci*3 + kh)][co][2]
+        float* p4 = pf + ((long)(ci * 3 + kh) * cout + co) * 4;
+        float* p2 = pf + (long)cin * 3 * cout * 4 + ((long)(ci * 3 + kh) * cout + co) * 2;
+        put(p4, p2, g[0], g[1], g[2]);
+    }
+    if (pd) {           // data gradient: filter row 2-kh, taps (g2, g1, g0), channels transposed
+        float* p4 = pd + ((long)(co * 3 + (2 - kh)) * cin + ci) * 4;
+        float* p2 = pd + (long)cout * 3 * cin * 4 + ((long)(co * 3 + (2 - kh)) * cin + ci) * 2;
+        put(p4, p2, g[2], g[1], g[0]);
+    }
+}
+
+template <int CO_T, int NW>
+__device__ __forceinline__ void conv3x3_wino4_body(const float* __restrict__ in, const float* __restrict__ wpack, const float* __restrict__ bias,
+                                                   float* __restrict__ out, const float* __restrict__ zero_page, int N, int Cin, int H, int W, int Cout,
+                                                   WGeom geo, int co_tiles, const float* __restrict__ wdirect, int n_tail, int first_tail_tile) {
+    constexpr int TM = 2, TN = 1;                            // a wave: 64 output channels x one segment (12 accumulator tiles = 192 registers,
+                                                             // all of them AGPRs; 24 tiles made the compiler shuttle them through VGPRs)
+    constexpr int WAVES_CO = CO_T / 64;
+    constexpr int NSEG = NW / WAVES_CO;                      // segments per workgroup (NW waves: 4 = one per SIMD, 8 = two)
+    constexpr int ROWS_W = NSEG * 12 / NW;                   // halo rows a wave stages per stage: 6 or 12
+    constexpr int W4 = 12 * CO_T * 4, W2 = 12 * CO_T * 2;    // floats of a weight stage
+    constexpr int WBUF = W4 + W2;
+    constexpr int PBUF = NSEG * Q4_PSEG;
+    constexpr int NDMA = WBUF / 256;                         // 36 or 18 instructions of 1 KiB per stage
+    constexpr int DPW = (NDMA + NW - 1) / NW;                // per wave (instructions past NDMA are dummies)
+    __shared__ __attribute__((aligned(16))) float lds[2 * WBUF + 2 * PBUF + 256 + 64];
+    float* const Wt = lds;
+    float* const P = lds + 2 * WBUF;
+    constexpr int DMA_DUMMY = 2 * WBUF + 2 * PBUF, ST_DUMMY = DMA_DUMMY + 256;
+
+    if ((int)blockIdx.x < n_tail) {
+        // the last partial round of tiles as direct-form pieces of 32 channels x 32 pixels (conv_tail.h): a tile is (CO_T/32) channel
+        // blocks x 4*NSEG pixel blocks; lane position li of a piece = quad li >> 2 of its 8, pixel li & 3
+        constexpr int COSUB = CO_T / 32, PPW = COSUB * 4 * NSEG;
+        const int piece = blockIdx.x, vt = first_tail_tile + piece / PPW, sub = piece % PPW;
+        const int pb = sub / COSUB, q0 = ((vt / co_tiles) * NSEG + pb / 4) * Q4_TS + (pb & 3) * 8;
+        const int pli = threadIdx.x & 31;
+        const WSlot ps = wslot(q0 + (pli >> 2), geo);
+        const int pcol = 4 * ps.k + (pli & 3);
+        conv3x3_tail_piece_px<NW>(lds, ps.n, ps.h, pcol, ps.valid && ps.k < geo.T && pcol < W, q0 < geo.nslot,
+                                 (vt % co_tiles) * CO_T + (sub % COSUB) * 32, in, wdirect, bias, out, zero_page, Cin, H, W, Cout);
+        return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lk = lane >> 5;
+    const int v = xcd_slice_order(blockIdx.x - n_tail, gridDim.x - n_tail);
+    const int co0 = (v % co_tiles) * CO_T;
+    const int wco = (wave / NSEG) * 64, wsg = wave % NSEG;    // this wave's channels and segment
+    const int sega = (v / co_tiles) * NSEG;                  // the workgroup's first segment
+    const int seg0 = sega + wsg;
+    const int iHW = H * W;
+
+    f32x16 acc[TM][TN][6];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int x = 0; x < 6; ++x)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][n][x][r] = 0.f;
+
+    constexpr unsigned FAR = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)((long)N * Cin * iHW * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t null_rs = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)wpack, 0, Cin * 18 * Cout * 4, 0x00020000);
+    // ---- halo: per segment 12 rows (c, kh) of 130 raw values, row r of the workgroup's NSEG * 12 at P + r * PRW.  This wave stages rows
+    // [wave * ROWS_W, + ROWS_W) (one segment's, ROWS_W a multiple of 3: row j has filter row j % 3): the 128 columns of a row go
+    // global -> LDS by two 4-byte LDS-DMAs (lane = raw index r, quad r >> 2, column 4 k - 1 + (r & 3); nothing passes through registers),
+    // raw 128 / 129 (the first two columns of the NEXT segment's first quad) of the wave's rows by one load (lanes 0 .. 2 ROWS_W - 1)
+    const int st_seg = (wave * ROWS_W) / 12, c_first = (wave * ROWS_W) % 12;
+    unsigned m_vo[2][3];
+#pragma unroll
+    for (int hlf = 0; hlf < 2; ++hlf) {
+        const int r = lane + 64 * hlf;
+        const WSlot ms = wslot((sega + st_seg) * Q4_TS + (r >> 2), geo);
+        const int col = 4 * ms.k - 1 + (r & 3);
+        const bool ok = ms.valid && col >= 0 && col < W;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int hh = ms.h + kh - 1;
+            m_vo[hlf][kh] = (ok && hh >= 0 && hh < H) ? (unsigned)(ms.n * Cin * iHW + hh * W + col) * 4u : FAR;
+        }
+    }
+    const int hj = min(lane >> 1, ROWS_W - 1), h_c = (c_first + hj) / 3, h_kh = (c_first + hj) % 3;
+    const bool h_lane = lane < 2 * ROWS_W;
+    unsigned h_vo;
+    {
+        const WSlot hs = wslot((sega + st_seg) * Q4_TS + 32, geo);
+        const int col = 4 * hs.k - 1 + (lane & 1), hh = hs.h + h_kh - 1;
+        h_vo = (hs.valid && h_lane && col >= 0 && col < W && hh >= 0 && hh < H) ? (unsigned)(hs.n * Cin * iHW + h_c * iHW + hh * W + col) * 4u : FAR;
+    }
+    const int p_rows = wave * ROWS_W * Q4_PRW;               // this wave's rows inside a halo stage
+    float rh;
+    auto load_patch = [&](int ci0, int buf) __attribute__((always_inline)) {
+        float* pp = P + buf * PBUF + p_rows;
+#pragma unroll
+        for (int j = 0; j < ROWS_W; ++j) {
+            const int ch = ci0 + (c_first + j) / 3;                                              // wave-uniform
+#pragma unroll
+            for (int hlf = 0; hlf < 2; ++hlf)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ch < Cin ? in_rs : null_rs, (__attribute__((address_space(3))) void*)(pp + j * Q4_PRW + 64 * hlf), 4,
+                                                         m_vo[hlf][j % 3], ch * iHW * 4, 0, 0);
+        }
+        const unsigned hv = (ci0 + 4 <= Cin || ci0 + h_c < Cin) ? h_vo : FAR;
+        rh = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ci0 < Cin ? in_rs : null_rs, hv, ci0 * iHW * 4, 0));
+    };
+    auto store_patch = [&](int buf) __attribute__((always_inline)) {
+        float* hd = h_lane ? P + buf * PBUF + p_rows + hj * Q4_PRW + 128 + (lane & 1) : lds + ST_DUMMY + lane;
+        *hd = rh;
+    };
+    // ---- weight DMA: instruction q < NDMA of a stage; q < W4/256: row q / (CO_T/64) of the [row][co][4] part, 64 channels; else the
+    // [row][co][2] part: 128 channels (two per lane... one lane = 16 bytes = two channels) of row (q - W4/256) / (CO_T/128 or 1)
+    unsigned w_vo[DPW];
+#pragma unroll
+    for (int d = 0; d < DPW; ++d) {
+        const int q = wave + NW * d;
+        if (q < W4 / 256) {
+            const int row = q / (CO_T / 64), co = co0 + (q % (CO_T / 64)) * 64 + lane;
+            w_vo[d] = co < Cout ? (unsigned)(row * Cout + co) * 16u : FAR;
+        } else if (q < NDMA) {
+            constexpr int IPR2 = CO_T / 128 > 0 ? CO_T / 128 : 1;      // instructions per row of the 2-value part (CO_T = 64: one covers TWO rows)
+            const int q2 = q - W4 / 256;
+            int row, co;
+            if (CO_T >= 128) { row = q2 / IPR2; co = co0 + (q2 % IPR2) * 128 + 2 * lane; }
+            else { row = 2 * q2 + (lane >> 5); co = co0 + 2 * (lane & 31); }
+            w_vo[d] = co < Cout ? (unsigned)(Cin * 3 * Cout * 4 + (row * Cout + co) * 2) * 4u : FAR;
+        } else {
+            w_vo[d] = FAR;
+        }
+    }
+    auto dma_weights = [&](int ci0, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int d = 0; d < DPW; ++d) {
+            const int q = wave + NW * d;                      // wave-uniform
+            float* dst = q < NDMA ? Wt + buf * WBUF + q * 256 : lds + DMA_DUMMY;
+            // the scalar offset advances by 3 rows per channel: 16 bytes per (row, channel) in the first part, 8 in the second
+            const int so = q < W4 / 256 ? ci0 * 3 * Cout * 16 : ci0 * 3 * Cout * 8;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (__attribute__((address_space(3))) void*)dst, 16, w_vo[d], so, 0, 0);
+        }
+    };
+    // ---- K loop of one stage: 6 steps (channel pair cp: lanes 0-31 channel cp, lanes 32-63 channel cp + 2; filter row kh), each
+    // 6 transform points x TM row blocks x TN segments MFMAs
+    auto kloop = [&](int buf) __attribute__((always_inline)) {
+        const float* wa4 = Wt + buf * WBUF + ((lk * 2 * 3) * CO_T + wco + li) * 4;
+        const float* wa2 = Wt + buf * WBUF + W4 + ((lk * 2 * 3) * CO_T + wco + li) * 2;
+        const float* pb = P + buf * PBUF + wsg * Q4_PSEG + lk * 2 * 3 * Q4_PRW + 4 * li;
+        f32x4 d4[TN], a4[TM];
+        f32x2 d2[TN], a2[TM];
+        auto reads = [&](int s, f32x4 (&A4)[TM], f32x2 (&A2)[TM], f32x4 (&D4)[TN], f32x2 (&D2)[TN]) __attribute__((always_inline)) {
+            const int row = (s / 3) * 3 + s % 3;                                         // (cp, kh), compile-time
+#pragma unroll
+            for (int n = 0; n < TN; ++n) {
+                D4[n] = *(const f32x4*)(pb + n * Q4_PSEG + row * Q4_PRW);
+                D2[n] = *(const f32x2*)(pb + n * Q4_PSEG + row * Q4_PRW + 4);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                A4[i] = *(const f32x4*)(wa4 + (row * CO_T + 32 * i) * 4);
+                A2[i] = *(const f32x2*)(wa2 + (row * CO_T + 32 * i) * 2);
+            }
+        };
+        reads(0, a4, a2, d4, d2);
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            // one wave per SIMD: nobody else covers an LDS latency, so the fragments of step s + 1 are in flight under the MFMAs of step s
+            f32x4 nd4[TN], na4[TM];
+            f32x2 nd2[TN], na2[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) { na4[i] = a4[i]; na2[i] = a2[i]; }
+#pragma unroll
+            for (int n = 0; n < TN; ++n) { nd4[n] = d4[n]; nd2[n] = d2[n]; }
+            if (s + 1 < 6) reads(s + 1, na4, na2, nd4, nd2);
+            float vv[TN][6];
+#pragma unroll
+            for (int n = 0; n < TN; ++n) {
+                const float e0 = d4[n][0], e1 = d4[n][1], e2 = d4[n][2], e3 = d4[n][3], e4 = d2[n][0], e5 = d2[n][1];
+                const float ta = __builtin_fmaf(-4.f, e2, e4), tb = __builtin_fmaf(-4.f, e1, e3);
+                const float tc = e4 - e2, td = e3 - e1;
+                vv[n][0] = __builtin_fmaf(4.f, e0, __builtin_fmaf(-5.f, e2, e4));
+                vv[n][1] = ta + tb;
+                vv[n][2] = ta - tb;
+                vv[n][3] = __builtin_fmaf(2.f, td, tc);
+                vv[n][4] = __builtin_fmaf(-2.f, td, tc);
+                vv[n][5] = __builtin_fmaf(4.f, e1, __builtin_fmaf(-5.f, e3, e5));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int x = 0; x < 6; ++x)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n)
+                        acc[i][n][x] = __builtin_amdgcn_mfma_f32_32x32x2f32(x < 4 ? a4[i][x] : a2[i][x - 4], vv[n][x], acc[i][n][x], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) { a4[i] = na4[i]; a2[i] = na2[i]; }
+#pragma unroll
+            for (int n = 0; n < TN; ++n) { d4[n] = nd4[n]; d2[n] = nd2[n]; }
+        }
+    };
+
+    const int nh = ((Cin + 7) / 8) * 2;                     // stages of 4 channels, padded to an even count (zero weights)
+    dma_weights(0, 0);
+    load_patch(0, 0);
+    store_patch(0);
+    for (int h = 0; h < nh; h += 2) {
+        __syncthreads();                            // buffer 0 complete (DMA drained: vmcnt(0)), buffer 1 free
+        dma_weights((h + 1) * 4, 1);
+        load_patch((h + 1) * 4, 1);
+        kloop(0);
+        store_patch(1);
+        __syncthreads();                            // buffer 1 complete, buffer 0 free
+        dma_weights((h + 2) * 4, 0);                // past the last channel: out of range / null resource, never used
+        load_patch((h + 2) * 4, 0);
+        kloop(1);
+        store_patch(0);
+    }
+
+    // ---- output transform and stores: lane li = quad, 4 pixels 4k .. 4k+3
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+        const WSlot os = wslot((seg0 + n) * Q4_TS + li, geo);
+        const int px = 4 * os.k;
+        if (!os.valid || os.k >= geo.T || px >= W) continue;
+        const int nvalid = min(4, W - px);
+        float* obase = out + (long)os.n * Cout * iHW + (long)os.h * W + px;
+        const bool vec = nvalid == 4 && ((W & 3) == 0) && ((((uintptr_t)out) & 15) == 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wco + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (co < Cout) {
+                    const float b = bias ? bias[co] : 0.f;
+                    const float m0 = acc[i][n][0][r], m1 = acc[i][n][1][r], m2 = acc[i][n][2][r], m3 = acc[i][n][3][r], m4 = acc[i][n][4][r], m5 = acc[i][n][5][r];
+                    const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+                    f32x4 y;
+                    y[0] = ((m0 + s12) + s34) + b;
+                    y[1] = __builtin_fmaf(2.f, d34, d12) + b;
+                    y[2] = __builtin_fmaf(4.f, s34, s12) + b;
+                    y[3] = (__builtin_fmaf(8.f, d34, d12) + m5) + b;
+                    float* o = obase + (long)co * iHW;
+                    if (vec) *(f32x4*)o = y;
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (e < nvalid) o[e] = y[e];
+                    }
+                }
+            }
+    }
+}
+#define VOCR_WINO4_KERNEL(NAME, CO_T, NW)                                                                                                         \
+    __global__ __launch_bounds__(64 * NW) void NAME(const float* __restrict__ in, const float* __restrict__ wpack, const float* __restrict__ bias,   \
+                                                   float* __restrict__ out, const float* __restrict__ zero_page, int N, int Cin, int H, int W,       \
+                                                   int Cout, WGeom geo, int co_tiles, const float* __restrict__ wdirect, int n_tail,               \
+                                                   int first_tail_tile) {                                                                           \
+        conv3x3_wino4_body<CO_T, NW>(in, wpack, bias, out, zero_page, N, Cin, H, W, Cout, geo, co_tiles, wdirect, n_tail, first_tail_tile);         \
+    }
+VOCR_WINO4_KERNEL(conv3x3_wino4_kernel_128, 128, 4)
+VOCR_WINO4_KERNEL(conv3x3_wino4_kernel_64, 64, 4)
+VOCR_WINO4_KERNEL(conv3x3_wino4w8_kernel_128, 128, 8)
+VOCR_WINO4_KERNEL(conv3x3_wino4w8_kernel_64, 64, 8)
+#undef VOCR_WINO4_KERNEL
 
 // The same contraction with ONE workgroup of EIGHT waves per CU and a ring of THREE half-chunk stages (round 3; VOCR_CONV_WINO8=1).
 // What changes against conv3x3_wino_kernel (two 4-wave workgroups per CU, two stages):
@@ -1449,17 +1761,24 @@ const float* wino_zero_page_ptr() {
 extern "C" int vocr_conv3x3_wino_supported(int cin, int cout) { return cin >= 1 && cout % 4 == 0 ? 1 : 0; }
 
 // a pack = 12 transformed rows per contraction channel, followed by the direct pack's 9 rows per channel (for the tail pieces)
-extern "C" size_t vocr_conv3x3_wino_pack_floats(int cout, int cin) { return (size_t)cout * cin * 21; }
+extern "C" size_t vocr_conv3x3_wino_pack_floats(int cout, int cin) { return (size_t)cout * cin * (wino4_for(cout) ? 27 : 21); }
 
 extern "C" int vocr_conv3x3_wino_pack_weights(const float* w, float* wpack_fwd, float* wpack_dgrad, int cout, int cin, void* stream) {
     VOCR_CHECK_ARG(w && (wpack_fwd || wpack_dgrad), "vocr_conv3x3_wino_pack_weights: null pointer");
     VOCR_CHECK_ARG(cout > 0 && cin > 0, "vocr_conv3x3_wino_pack_weights: bad shape");
     const int total = cout * cin * 3;
-    wino_pack_kernel<<<vocr_cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(w, wpack_fwd, wpack_dgrad, cout, cin, wino_pack_x4());
+    // the forward pack serves a convolution with `cout` outputs, the data-gradient pack one with `cin` outputs: each in the format of ITS kernel
+    const bool f4f = wpack_fwd && wino4_for(cout), f4d = wpack_dgrad && wino4_for(cin);
+    hipStream_t s = (hipStream_t)stream;
+    if (f4f || f4d) wino4_pack_kernel<<<vocr_cdiv(total, 256), 256, 0, s>>>(w, f4f ? wpack_fwd : nullptr, f4d ? wpack_dgrad : nullptr, cout, cin);
+    if ((wpack_fwd && !f4f) || (wpack_dgrad && !f4d))
+        wino_pack_kernel<<<vocr_cdiv(total, 256), 256, 0, s>>>(w, f4f ? nullptr : wpack_fwd, f4d ? nullptr : wpack_dgrad, cout, cin, wino_pack_x4());
     VOCR_CHECK_LAUNCH("vocr_conv3x3_wino_pack_weights");
     // the direct pack behind the transformed rows
-    return vocr_conv3x3_pack_weights(w, wpack_fwd ? wpack_fwd + (size_t)cout * cin * 12 : nullptr,
-                                     wpack_dgrad ? wpack_dgrad + (size_t)cout * cin * 12 : nullptr, cout, cin, stream);
+    int rc = VOCR_OK;
+    if (wpack_fwd) rc = vocr_conv3x3_pack_weights(w, wpack_fwd + (size_t)cout * cin * (f4f ? 18 : 12), nullptr, cout, cin, stream);
+    if (rc == VOCR_OK && wpack_dgrad) rc = vocr_conv3x3_pack_weights(w, nullptr, wpack_dgrad + (size_t)cout * cin * (f4d ? 18 : 12), cout, cin, stream);
+    return rc;
 }
 
 extern "C" int vocr_conv3x3_wino_fwd(const float* x, const float* wpack, const float* bias, float* y, int n, int cin, int h,
@@ -1468,8 +1787,10 @@ extern "C" int vocr_conv3x3_wino_fwd(const float* x, const float* wpack, const f
     VOCR_CHECK_ARG(n > 0 && cin > 0 && h > 0 && w > 0 && cout > 0, "vocr_conv3x3_wino_fwd: bad shape");
     VOCR_CHECK_ARG(cout % 4 == 0 && ((((uintptr_t)wpack) & 15) == 0), "vocr_conv3x3_wino_fwd: needs Cout %% 4 == 0 and a 16-byte aligned pack");
     VOCR_CHECK_ARG((long)n * (cin > cout ? cin : cout) * h * w < (1l << 31), "vocr_conv3x3_wino_fwd: tensor exceeds 2^31 elements");
+    const bool f43 = wino4_for(cout);
+    VOCR_CHECK_ARG(!f43 || (long)n * (cin > cout ? cin : cout) * h * w < (1l << 29), "vocr_conv3x3_wino_fwd: the F(4,3) kernel needs tensors below 2^29 elements");
     WGeom geo;
-    geo.T = vocr_cdiv(w, 2);
+    geo.T = vocr_cdiv(w, f43 ? 4 : 2);
     geo.S = geo.T + 1;
     geo.slots_img = h * geo.S;
     geo.nslot = n * geo.slots_img;
@@ -1478,7 +1799,7 @@ extern "C" int vocr_conv3x3_wino_fwd(const float* x, const float* wpack, const f
     const float* zp = wino_zero_page_ptr();
     VOCR_CHECK_ARG(zp != nullptr, "vocr_conv3x3_wino_fwd: no device zero page");
     hipStream_t s = (hipStream_t)stream;
-    const float* wdirect = wpack + (size_t)cin * 12 * cout;
+    const float* wdirect = wpack + (size_t)cin * (f43 ? 18 : 12) * cout;
     // VOCR_CONV_TAIL: 1 (default) the last partial round of tiles is cut into direct-form pieces that lead the launch, 0 whole tiles only
     static const int tail_mode = getenv("VOCR_CONV_TAIL") ? atoi(getenv("VOCR_CONV_TAIL")) : 1;
     int ncu = 256;
@@ -1500,7 +1821,25 @@ extern "C" int vocr_conv3x3_wino_fwd(const float* x, const float* wpack, const f
     // two-stage 4-wave kernel, two workgroups per CU
     static const int wino8 = getenv("VOCR_CONV_WINO8") ? atoi(getenv("VOCR_CONV_WINO8")) : 0;
     const int wino2 = wino2_mode();
-    if (wino8 && wino_pack_x4()) {
+    if (f43) {
+        // one 4-wave workgroup per CU; a piece of the tail is 1/(CO_T/32 * 4 NSEG) of a tile
+        // eight waves (two per SIMD, 128 channels x 4 segments per workgroup) unless that leaves CUs without a workgroup: then four waves
+        // (x 2 segments: twice the tiles).  VOCR_CONV_WINO4=3 / 4: always four / always eight (experiments)
+        const int t8 = vocr_cdiv(geo.nseg, 4) * vocr_cdiv(cout, 128);
+        const int nw = wino4_mode() == 3 ? 4 : wino4_mode() == 4 ? 8 : (t8 >= ncu ? 8 : 4);
+        const int tiles4 = cout > 64 ? vocr_cdiv(geo.nseg, nw / 2) * vocr_cdiv(cout, 128) : vocr_cdiv(geo.nseg, nw);
+        const int rem4 = tiles4 % ncu;
+        const bool cut4 = tail_mode == 1 && tiles4 > ncu && rem4 > 0 && rem4 <= ncu / 2;
+        const int n_main4 = cut4 ? tiles4 - rem4 : tiles4;
+        const int n_tail4 = cut4 ? rem4 * 4 * 4 * nw : 0;                      // (CO_T / 32) x 4 NSEG pieces per tile: 16 nw either way
+        if (cout > 64) {
+            if (nw == 8) conv3x3_wino4w8_kernel_128<<<dim3(n_tail4 + n_main4), 512, 0, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, geo, vocr_cdiv(cout, 128), wdirect, n_tail4, n_main4);
+            else conv3x3_wino4_kernel_128<<<dim3(n_tail4 + n_main4), 256, 0, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, geo, vocr_cdiv(cout, 128), wdirect, n_tail4, n_main4);
+        } else {
+            if (nw == 8) conv3x3_wino4w8_kernel_64<<<dim3(n_tail4 + n_main4), 512, 0, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, geo, 1, wdirect, n_tail4, n_main4);
+            else conv3x3_wino4_kernel_64<<<dim3(n_tail4 + n_main4), 256, 0, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, geo, 1, wdirect, n_tail4, n_main4);
+        }
+    } else if (wino8 && wino_pack_x4()) {
         if (cout > 64) VOCR_WINO_LAUNCH((conv3x3_wino8_kernel<128, true>), 512, 128, 4, vocr_cdiv(cout, 128));
         else VOCR_WINO_LAUNCH((conv3x3_wino8_kernel<64, true>), 512, 64, 8, 1);
     } else if (wino8) {

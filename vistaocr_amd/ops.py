@@ -309,8 +309,13 @@ def conv3x3_pack(weight):
     cout, cin = weight.shape[0], weight.shape[1]
     dev = weight.device
     wf, wd = _wino_ok(cin, cout), _wino_ok(cout, cin)
-    pf = torch.empty(cin * (21 if wf else 9), cout, dtype=torch.float32, device=dev)
-    pd = torch.empty(cout * (21 if wd else 9), cin, dtype=torch.float32, device=dev)
+    # rows per contraction channel: 21 (F(2,3): 12 transformed + 9 direct) or 27 (F(4,3): 18 + 9) - the library says which kernel a
+    # convolution with that many output channels gets (forward: cout outputs; data gradient: cin outputs)
+    lib = _lib.load()
+    rows_f = lib.vocr_conv3x3_wino_pack_floats(cout, cin) // (cout * cin)
+    rows_d = lib.vocr_conv3x3_wino_pack_floats(cin, cout) // (cout * cin)
+    pf = torch.empty(cin * (rows_f if wf else 9), cout, dtype=torch.float32, device=dev)
+    pd = torch.empty(cout * (rows_d if wd else 9), cin, dtype=torch.float32, device=dev)
     if wf or wd:
         call("vocr_conv3x3_wino_pack_weights", _p(weight), _p(pf) if wf else None, _p(pd) if wd else None, cout, cin, _stream())
     if not (wf and wd):
@@ -340,9 +345,9 @@ def conv3x3_forward(x, wpack, bias, cout):
     y = torch.empty(n, cout, h, w, dtype=torch.float32, device=x.device)
     # the pack says which kernel it is for: 12 transformed + 9 direct rows per input channel (conv_wino.hip) or 9 taps (conv.hip);
     # the shape survives save_for_backward, a Python attribute on the tensor would not
-    if wpack.dim() != 2 or wpack.shape[0] not in (9 * cin, 21 * cin) or wpack.shape[1] != cout:
+    if wpack.dim() != 2 or wpack.shape[0] not in (9 * cin, 21 * cin, 27 * cin) or wpack.shape[1] != cout:
         raise ValueError("conv3x3_forward: weight pack %s does not fit cin=%d cout=%d" % (tuple(wpack.shape), cin, cout))
-    fn = "vocr_conv3x3_wino_fwd" if wpack.shape[0] == 21 * cin else "vocr_conv3x3_fwd"
+    fn = "vocr_conv3x3_wino_fwd" if wpack.shape[0] != 9 * cin else "vocr_conv3x3_fwd"
     call(fn, _p(x), _p(wpack), _p(bias), _p(y), n, cin, h, w, cout, _stream())
     return y
 
