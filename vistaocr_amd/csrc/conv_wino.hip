@@ -534,7 +534,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino2_kernel_64(const float* _
 // LDS-DMA for all four waves, two stages.
 constexpr int Q4_TS = 32;                   // quads per segment
 constexpr int Q4_PRW = 132;                 // floats per staged halo row: raw index r = 4 e + c <-> column 4 k_e - 1 + c, r < 130
-constexpr int Q4_PSEG = 12 * Q4_PRW;        // floats of halo per segment and stage
 __global__ void wino4_pack_kernel(const float* __restrict__ w, float* __restrict__ pf, float* __restrict__ pd, int cout, int cin) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int total = cout * cin * 3;
@@ -561,7 +560,7 @@ __global__ void wino4_pack_kernel(const float* __restrict__ w, float* __restrict
     }
 }
 
-template <int CO_T, int NW>
+template <int CO_T, int NW, int CS>
 __device__ __forceinline__ void conv3x3_wino4_body(const float* __restrict__ in, const float* __restrict__ wpack, const float* __restrict__ bias,
                                                    float* __restrict__ out, const float* __restrict__ zero_page, int N, int Cin, int H, int W, int Cout,
                                                    WGeom geo, int co_tiles, const float* __restrict__ wdirect, int n_tail, int first_tail_tile) {
@@ -569,10 +568,13 @@ __device__ __forceinline__ void conv3x3_wino4_body(const float* __restrict__ in,
                                                              // all of them AGPRs; 24 tiles made the compiler shuttle them through VGPRs)
     constexpr int WAVES_CO = CO_T / 64;
     constexpr int NSEG = NW / WAVES_CO;                      // segments per workgroup (NW waves: 4 = one per SIMD, 8 = two)
-    constexpr int ROWS_W = NSEG * 12 / NW;                   // halo rows a wave stages per stage: 6 or 12
-    constexpr int W4 = 12 * CO_T * 4, W2 = 12 * CO_T * 2;    // floats of a weight stage
+    constexpr int RS = 3 * CS;                               // (channel, filter row) rows of a stage: CS = 4 or 2 input channels
+    constexpr int KS = RS / 2;                               // k-steps of a stage (lanes 0-31: the first CS/2 channels, lanes 32-63 the others)
+    constexpr int PSEG = RS * Q4_PRW;                        // floats of halo per segment and stage
+    constexpr int ROWS_W = NSEG * RS / NW;                   // halo rows a wave stages per stage (a multiple of 3)
+    constexpr int W4 = RS * CO_T * 4, W2 = RS * CO_T * 2;    // floats of a weight stage
     constexpr int WBUF = W4 + W2;
-    constexpr int PBUF = NSEG * Q4_PSEG;
+    constexpr int PBUF = NSEG * PSEG;
     constexpr int NDMA = WBUF / 256;                         // 36 or 18 instructions of 1 KiB per stage
     constexpr int DPW = (NDMA + NW - 1) / NW;                // per wave (instructions past NDMA are dummies)
     __shared__ __attribute__((aligned(16))) float lds[2 * WBUF + 2 * PBUF + 256 + 64];
@@ -621,7 +623,7 @@ __device__ __forceinline__ void conv3x3_wino4_body(const float* __restrict__ in,
     // [wave * ROWS_W, + ROWS_W) (one segment's, ROWS_W a multiple of 3: row j has filter row j % 3): the 128 columns of a row go
     // global -> LDS by two 4-byte LDS-DMAs (lane = raw index r, quad r >> 2, column 4 k - 1 + (r & 3); nothing passes through registers),
     // raw 128 / 129 (the first two columns of the NEXT segment's first quad) of the wave's rows by one load (lanes 0 .. 2 ROWS_W - 1)
-    const int st_seg = (wave * ROWS_W) / 12, c_first = (wave * ROWS_W) % 12;
+    const int st_seg = (wave * ROWS_W) / RS, c_first = (wave * ROWS_W) % RS;
     unsigned m_vo[2][3];
 #pragma unroll
     for (int hlf = 0; hlf < 2; ++hlf) {
@@ -655,7 +657,7 @@ __device__ __forceinline__ void conv3x3_wino4_body(const float* __restrict__ in,
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(ch < Cin ? in_rs : null_rs, (__attribute__((address_space(3))) void*)(pp + j * Q4_PRW + 64 * hlf), 4,
                                                          m_vo[hlf][j % 3], ch * iHW * 4, 0, 0);
         }
-        const unsigned hv = (ci0 + 4 <= Cin || ci0 + h_c < Cin) ? h_vo : FAR;
+        const unsigned hv = (ci0 + CS <= Cin || ci0 + h_c < Cin) ? h_vo : FAR;
         rh = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ci0 < Cin ? in_rs : null_rs, hv, ci0 * iHW * 4, 0));
     };
     auto store_patch = [&](int buf) __attribute__((always_inline)) {
@@ -695,17 +697,17 @@ __device__ __forceinline__ void conv3x3_wino4_body(const float* __restrict__ in,
     // ---- K loop of one stage: 6 steps (channel pair cp: lanes 0-31 channel cp, lanes 32-63 channel cp + 2; filter row kh), each
     // 6 transform points x TM row blocks x TN segments MFMAs
     auto kloop = [&](int buf) __attribute__((always_inline)) {
-        const float* wa4 = Wt + buf * WBUF + ((lk * 2 * 3) * CO_T + wco + li) * 4;
-        const float* wa2 = Wt + buf * WBUF + W4 + ((lk * 2 * 3) * CO_T + wco + li) * 2;
-        const float* pb = P + buf * PBUF + wsg * Q4_PSEG + lk * 2 * 3 * Q4_PRW + 4 * li;
+        const float* wa4 = Wt + buf * WBUF + ((lk * KS) * CO_T + wco + li) * 4;
+        const float* wa2 = Wt + buf * WBUF + W4 + ((lk * KS) * CO_T + wco + li) * 2;
+        const float* pb = P + buf * PBUF + wsg * PSEG + lk * KS * Q4_PRW + 4 * li;
         f32x4 d4[TN], a4[TM];
         f32x2 d2[TN], a2[TM];
         auto reads = [&](int s, f32x4 (&A4)[TM], f32x2 (&A2)[TM], f32x4 (&D4)[TN], f32x2 (&D2)[TN]) __attribute__((always_inline)) {
-            const int row = (s / 3) * 3 + s % 3;                                         // (cp, kh), compile-time
+            const int row = s;                                                           // (channel s / 3 [+ CS/2 for lanes 32-63], filter row s % 3)
 #pragma unroll
             for (int n = 0; n < TN; ++n) {
-                D4[n] = *(const f32x4*)(pb + n * Q4_PSEG + row * Q4_PRW);
-                D2[n] = *(const f32x2*)(pb + n * Q4_PSEG + row * Q4_PRW + 4);
+                D4[n] = *(const f32x4*)(pb + n * PSEG + row * Q4_PRW);
+                D2[n] = *(const f32x2*)(pb + n * PSEG + row * Q4_PRW + 4);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -715,7 +717,7 @@ __device__ __forceinline__ void conv3x3_wino4_body(const float* __restrict__ in,
         };
         reads(0, a4, a2, d4, d2);
 #pragma unroll
-        for (int s = 0; s < 6; ++s) {
+        for (int s = 0; s < KS; ++s) {
             // one wave per SIMD: nobody else covers an LDS latency, so the fragments of step s + 1 are in flight under the MFMAs of step s
             f32x4 nd4[TN], na4[TM];
             f32x2 nd2[TN], na2[TM];
@@ -723,7 +725,7 @@ __device__ __forceinline__ void conv3x3_wino4_body(const float* __restrict__ in,
             for (int i = 0; i < TM; ++i) { na4[i] = a4[i]; na2[i] = a2[i]; }
 #pragma unroll
             for (int n = 0; n < TN; ++n) { nd4[n] = d4[n]; nd2[n] = d2[n]; }
-            if (s + 1 < 6) reads(s + 1, na4, na2, nd4, nd2);
+            if (s + 1 < KS) reads(s + 1, na4, na2, nd4, nd2);
             float vv[TN][6];
 #pragma unroll
             for (int n = 0; n < TN; ++n) {
@@ -752,19 +754,19 @@ __device__ __forceinline__ void conv3x3_wino4_body(const float* __restrict__ in,
         }
     };
 
-    const int nh = ((Cin + 7) / 8) * 2;                     // stages of 4 channels, padded to an even count (zero weights)
+    const int nh = ((Cin + 2 * CS - 1) / (2 * CS)) * 2;     // stages of CS channels, padded to an even count (zero weights)
     dma_weights(0, 0);
     load_patch(0, 0);
     store_patch(0);
     for (int h = 0; h < nh; h += 2) {
         __syncthreads();                            // buffer 0 complete (DMA drained: vmcnt(0)), buffer 1 free
-        dma_weights((h + 1) * 4, 1);
-        load_patch((h + 1) * 4, 1);
+        dma_weights((h + 1) * CS, 1);
+        load_patch((h + 1) * CS, 1);
         kloop(0);
         store_patch(1);
         __syncthreads();                            // buffer 1 complete, buffer 0 free
-        dma_weights((h + 2) * 4, 0);                // past the last channel: out of range / null resource, never used
-        load_patch((h + 2) * 4, 0);
+        dma_weights((h + 2) * CS, 0);               // past the last channel: out of range / null resource, never used
+        load_patch((h + 2) * CS, 0);
         kloop(1);
         store_patch(0);
     }
@@ -803,17 +805,19 @@ __device__ __forceinline__ void conv3x3_wino4_body(const float* __restrict__ in,
             }
     }
 }
-#define VOCR_WINO4_KERNEL(NAME, CO_T, NW)                                                                                                         \
-    __global__ __launch_bounds__(64 * NW) void NAME(const float* __restrict__ in, const float* __restrict__ wpack, const float* __restrict__ bias,   \
-                                                   float* __restrict__ out, const float* __restrict__ zero_page, int N, int Cin, int H, int W,       \
-                                                   int Cout, WGeom geo, int co_tiles, const float* __restrict__ wdirect, int n_tail,               \
-                                                   int first_tail_tile) {                                                                           \
-        conv3x3_wino4_body<CO_T, NW>(in, wpack, bias, out, zero_page, N, Cin, H, W, Cout, geo, co_tiles, wdirect, n_tail, first_tail_tile);         \
+#define VOCR_WINO4_KERNEL(NAME, CO_T, NW, CS, WGS)                                                                                                \
+    __global__ __launch_bounds__(64 * NW, WGS) void NAME(const float* __restrict__ in, const float* __restrict__ wpack,                              \
+                                                        const float* __restrict__ bias, float* __restrict__ out,                                    \
+                                                        const float* __restrict__ zero_page, int N, int Cin, int H, int W, int Cout, WGeom geo,       \
+                                                        int co_tiles, const float* __restrict__ wdirect, int n_tail, int first_tail_tile) {          \
+        conv3x3_wino4_body<CO_T, NW, CS>(in, wpack, bias, out, zero_page, N, Cin, H, W, Cout, geo, co_tiles, wdirect, n_tail, first_tail_tile);     \
     }
-VOCR_WINO4_KERNEL(conv3x3_wino4_kernel_128, 128, 4)
-VOCR_WINO4_KERNEL(conv3x3_wino4_kernel_64, 64, 4)
-VOCR_WINO4_KERNEL(conv3x3_wino4w8_kernel_128, 128, 8)
-VOCR_WINO4_KERNEL(conv3x3_wino4w8_kernel_64, 64, 8)
+VOCR_WINO4_KERNEL(conv3x3_wino4_kernel_128, 128, 4, 4, 1)
+VOCR_WINO4_KERNEL(conv3x3_wino4_kernel_64, 64, 4, 4, 1)
+VOCR_WINO4_KERNEL(conv3x3_wino4w8_kernel_128, 128, 8, 4, 1)
+VOCR_WINO4_KERNEL(conv3x3_wino4w8_kernel_64, 64, 8, 4, 1)
+// two 4-wave workgroups per CU (256 registers per lane, 61 KB of LDS each: stages of TWO channels), independent barriers
+VOCR_WINO4_KERNEL(conv3x3_wino4x2_kernel_128, 128, 4, 2, 2)
 #undef VOCR_WINO4_KERNEL
 
 // The same contraction with ONE workgroup of EIGHT waves per CU and a ring of THREE half-chunk stages (round 3; VOCR_CONV_WINO8=1).
@@ -1826,14 +1830,20 @@ extern "C" int vocr_conv3x3_wino_fwd(const float* x, const float* wpack, const f
         // eight waves (two per SIMD, 128 channels x 4 segments per workgroup) unless that leaves CUs without a workgroup: then four waves
         // (x 2 segments: twice the tiles).  VOCR_CONV_WINO4=3 / 4: always four / always eight (experiments)
         const int t8 = vocr_cdiv(geo.nseg, 4) * vocr_cdiv(cout, 128);
-        const int nw = wino4_mode() == 3 ? 4 : wino4_mode() == 4 ? 8 : (t8 >= ncu ? 8 : 4);
+        // two 4-wave workgroups per CU (stages of two channels, independent barriers: 1 - 3 % faster than one 8-wave workgroup) when there
+        // are at least two tiles per CU; VOCR_CONV_WINO4=5 / 6: always / never (experiments)
+        const bool x2 = cout > 64 && wino4_mode() != 6 && wino4_mode() != 3 && wino4_mode() != 4 &&
+                        (wino4_mode() == 5 || vocr_cdiv(geo.nseg, 2) * vocr_cdiv(cout, 128) >= 2 * ncu);
+        const int nw = (wino4_mode() == 3 || x2) ? 4 : wino4_mode() == 4 ? 8 : (t8 >= ncu ? 8 : 4);
         const int tiles4 = cout > 64 ? vocr_cdiv(geo.nseg, nw / 2) * vocr_cdiv(cout, 128) : vocr_cdiv(geo.nseg, nw);
-        const int rem4 = tiles4 % ncu;
-        const bool cut4 = tail_mode == 1 && tiles4 > ncu && rem4 > 0 && rem4 <= ncu / 2;
+        const int slots4 = x2 ? 2 * ncu : ncu;              // workgroups resident at a time
+        const int rem4 = tiles4 % slots4;
+        const bool cut4 = tail_mode == 1 && tiles4 > slots4 && rem4 > 0 && rem4 <= slots4 / 2;
         const int n_main4 = cut4 ? tiles4 - rem4 : tiles4;
         const int n_tail4 = cut4 ? rem4 * 4 * 4 * nw : 0;                      // (CO_T / 32) x 4 NSEG pieces per tile: 16 nw either way
         if (cout > 64) {
-            if (nw == 8) conv3x3_wino4w8_kernel_128<<<dim3(n_tail4 + n_main4), 512, 0, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, geo, vocr_cdiv(cout, 128), wdirect, n_tail4, n_main4);
+            if (x2) conv3x3_wino4x2_kernel_128<<<dim3(n_tail4 + n_main4), 256, 0, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, geo, vocr_cdiv(cout, 128), wdirect, n_tail4, n_main4);
+            else if (nw == 8) conv3x3_wino4w8_kernel_128<<<dim3(n_tail4 + n_main4), 512, 0, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, geo, vocr_cdiv(cout, 128), wdirect, n_tail4, n_main4);
             else conv3x3_wino4_kernel_128<<<dim3(n_tail4 + n_main4), 256, 0, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, geo, vocr_cdiv(cout, 128), wdirect, n_tail4, n_main4);
         } else {
             if (nw == 8) conv3x3_wino4w8_kernel_64<<<dim3(n_tail4 + n_main4), 512, 0, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, geo, 1, wdirect, n_tail4, n_main4);
