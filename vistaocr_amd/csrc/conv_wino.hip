@@ -77,7 +77,11 @@ static int wino4_mode() {
 }
 // which packs / launches take the F(4,3) kernel: convolutions with at least 128 OUTPUT channels (the forward of a layer with Cout >= 128, the
 // data gradient of a layer with Cin >= 128); measured slower than F(2,3) with 64 (eight segments per workgroup)
-static bool wino4_for(int cout) { return wino4_mode() != 0 && cout >= 128; }
+static int wino4_min_cout() {
+    static const int v = getenv("VOCR_CONV_WINO4_MINCO") ? atoi(getenv("VOCR_CONV_WINO4_MINCO")) : 128;      // experiments: 64
+    return v;
+}
+static bool wino4_for(int cout) { return wino4_mode() != 0 && cout >= wino4_min_cout() && cout % 4 == 0; }
 static int wino_pack_x4() {
     static const int v = wino2_mode() ? 1 : (getenv("VOCR_CONV_PACK4") ? atoi(getenv("VOCR_CONV_PACK4")) : 0);
     return v;
@@ -818,6 +822,7 @@ VOCR_WINO4_KERNEL(conv3x3_wino4w8_kernel_128, 128, 8, 4, 1)
 VOCR_WINO4_KERNEL(conv3x3_wino4w8_kernel_64, 64, 8, 4, 1)
 // two 4-wave workgroups per CU (256 registers per lane, 61 KB of LDS each: stages of TWO channels), independent barriers
 VOCR_WINO4_KERNEL(conv3x3_wino4x2_kernel_128, 128, 4, 2, 2)
+VOCR_WINO4_KERNEL(conv3x3_wino4x2_kernel_64, 64, 4, 2, 2)
 #undef VOCR_WINO4_KERNEL
 
 // The same contraction with ONE workgroup of EIGHT waves per CU and a ring of THREE half-chunk stages (round 3; VOCR_CONV_WINO8=1).
@@ -1832,8 +1837,8 @@ extern "C" int vocr_conv3x3_wino_fwd(const float* x, const float* wpack, const f
         const int t8 = vocr_cdiv(geo.nseg, 4) * vocr_cdiv(cout, 128);
         // two 4-wave workgroups per CU (stages of two channels, independent barriers: 1 - 3 % faster than one 8-wave workgroup) when there
         // are at least two tiles per CU; VOCR_CONV_WINO4=5 / 6: always / never (experiments)
-        const bool x2 = cout > 64 && wino4_mode() != 6 && wino4_mode() != 3 && wino4_mode() != 4 &&
-                        (wino4_mode() == 5 || vocr_cdiv(geo.nseg, 2) * vocr_cdiv(cout, 128) >= 2 * ncu);
+        const bool x2 = wino4_mode() != 6 && wino4_mode() != 3 && wino4_mode() != 4 &&
+                        (wino4_mode() == 5 || (cout > 64 ? vocr_cdiv(geo.nseg, 2) * vocr_cdiv(cout, 128) : vocr_cdiv(geo.nseg, 4)) >= 2 * ncu);
         const int nw = (wino4_mode() == 3 || x2) ? 4 : wino4_mode() == 4 ? 8 : (t8 >= ncu ? 8 : 4);
         const int tiles4 = cout > 64 ? vocr_cdiv(geo.nseg, nw / 2) * vocr_cdiv(cout, 128) : vocr_cdiv(geo.nseg, nw);
         const int slots4 = x2 ? 2 * ncu : ncu;              // workgroups resident at a time
@@ -1846,7 +1851,8 @@ extern "C" int vocr_conv3x3_wino_fwd(const float* x, const float* wpack, const f
             else if (nw == 8) conv3x3_wino4w8_kernel_128<<<dim3(n_tail4 + n_main4), 512, 0, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, geo, vocr_cdiv(cout, 128), wdirect, n_tail4, n_main4);
             else conv3x3_wino4_kernel_128<<<dim3(n_tail4 + n_main4), 256, 0, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, geo, vocr_cdiv(cout, 128), wdirect, n_tail4, n_main4);
         } else {
-            if (nw == 8) conv3x3_wino4w8_kernel_64<<<dim3(n_tail4 + n_main4), 512, 0, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, geo, 1, wdirect, n_tail4, n_main4);
+            if (x2) conv3x3_wino4x2_kernel_64<<<dim3(n_tail4 + n_main4), 256, 0, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, geo, 1, wdirect, n_tail4, n_main4);
+            else if (nw == 8) conv3x3_wino4w8_kernel_64<<<dim3(n_tail4 + n_main4), 512, 0, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, geo, 1, wdirect, n_tail4, n_main4);
             else conv3x3_wino4_kernel_64<<<dim3(n_tail4 + n_main4), 256, 0, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, geo, 1, wdirect, n_tail4, n_main4);
         }
     } else if (wino8 && wino_pack_x4()) {
