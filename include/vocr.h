@@ -63,11 +63,14 @@ int vocr_conv3x3_fwd(const float* x, const float* wpack, const float* bias, floa
 size_t vocr_conv3x3_wgrad_workspace_bytes(int n, int cin, int h, int w, int cout);
 int vocr_conv3x3_wgrad(const float* x, const float* dy, float* dw, void* workspace,
                        int n, int cin, int h, int w, int cout, void* stream);
-/* Same op with the minimal-filtering transform F(2,3) along the row (conv_wino.hip): fp32 operands and accumulation, 2/3 of the
- * multiplications.  Weight packs hold the transformed filter rows: fwd [(ci*12 + kh*4 + x)][co], dgrad [(co*12 + kh*4 + x)][ci]
- * (taps flipped), each followed by the direct pack's 9 rows per channel (used for the last partial round of tiles): cout*cin*21
- * floats per pack (vocr_conv3x3_wino_pack_floats), 16-byte aligned.  Needs cout % 4 == 0 (input channels are padded to 4 inside)
- * (vocr_conv3x3_wino_supported).  dgrad = vocr_conv3x3_wino_fwd(dy, wpack_dgrad, NULL, dx, n, cout, h, w, cin). */
+/* Same op with a minimal-filtering transform ALONG THE ROW (conv_wino.hip), fp32 operands and accumulation: F(4,3) - half of the
+ * direct form's multiplications - for a convolution with at least 128 output channels, F(2,3) - two thirds - below.  A weight pack is
+ * OPAQUE: the transformed filter rows in the layout of the kernel that vocr_conv3x3_wino_fwd will pick for a convolution with THAT
+ * many output channels, followed by the direct pack's 9 rows per channel (the last partial round of tiles is computed in the direct
+ * form).  vocr_conv3x3_wino_pack_floats(cout, cin) = floats of the pack of a convolution with `cout` outputs and `cin` inputs
+ * (cout*cin*27 or *21; the data-gradient pack of a layer is the pack of the convolution with cin outputs: ..._pack_floats(cin, cout)),
+ * 16-byte aligned.  Needs cout % 4 == 0 (input channels are padded inside) (vocr_conv3x3_wino_supported).
+ * dgrad = vocr_conv3x3_wino_fwd(dy, wpack_dgrad, NULL, dx, n, cout, h, w, cin).  Tensors below 2^29 elements. */
 int vocr_conv3x3_wino_supported(int cin, int cout);
 size_t vocr_conv3x3_wino_pack_floats(int cout, int cin);
 int vocr_conv3x3_wino_pack_weights(const float* w, float* wpack_fwd, float* wpack_dgrad, int cout, int cin, void* stream);
