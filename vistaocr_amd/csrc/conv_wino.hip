@@ -1752,6 +1752,397 @@ __global__ __launch_bounds__(768) void conv3x3_wgrad_wino3_kernel(const float* _
     }
 }
 
+// ---------------------------------------------------------------- weight gradient F(3,2) x F(3,2): rows in PAIRS, eight waves (round 4)
+// conv3x3_wgrad_wino3_kernel applies the minimal-filtering transform along the row only and runs the three filter rows as
+// three separate contractions: per output-row pair 3 x 2 = 6 row products.  The same transform ACROSS rows needs 4: with
+// r = 2p, the x rows r-1 .. r+2 and the dy rows r, r+1 of a pair p
+//     X0 = x(r-1) - x(r+1)   X1 = x(r) + x(r+1)      X2 = x(r+1) - x(r)     X3 = x(r+2) - x(r)
+//     D0 = d(r)              D1 = d(r) + d(r+1)      D2 = d(r) - d(r+1)     D3 = d(r+1)
+//     V_v = (row-wise F(3,2) contraction of D_v with X_v, exactly the one-row kernel's)      v = 0..3
+//     dw(kh=0) = V0 + (V1+V2)/2      dw(1) = (V1-V2)/2      dw(2) = (V1+V2)/2 + V3
+// so the matrix pipe does 4/6 of the one-row kernel's work (4/9 of the direct contraction), x 8/7 and 16/15 where the height
+// is odd (the pair's missing row is zero).  The row combinations are one packed add per register pair on top of that kernel's
+// transforms; a wave = (v, input-channel half) owns 64 co x 32 ci x 4 row-wise points = 8 accumulator tiles, so the x-side
+// work (the larger half) is done once per 16 MFMAs: 13 - 17 VALU and 8 - 10 LDS reads per 16 MFMAs.
+// Piece stream as there, over row PAIRS (np = ceil(W/4) slots + one all-zero slot per pair), in segments of 8 slots.
+// LDS (floats; every region's second buffer 8192 floats = 32 KiB further, the reads' immediate offset):
+//     x   [4 rows][64 ci][8 pos][4]            0 .. 8192     (row plane 8 KiB)
+//     xe  [2: slot -1 / slot 8][4 rows][64 ci][4]   16384 .. 18432
+//     dy  [2 rows][64 co][8 pos][4]            18432 .. 22528
+// position of logical slot m of channel c = m ^ ((c >> 1) & 7): the 16 lanes of a ds_read_b128 group (16 consecutive channels,
+// 128 bytes apart) cover the 64 banks exactly once.  A DMA instruction fills 1 KiB = 8 channels x 8 positions; wave (wq, pw)
+// moves channel group 2 wq + pw of all six planes, so a lane only ever moves ONE logical slot, (lane & 7) ^ (lane >> 4 | 4 pw).
+// The slab holds [split][v][kw] planes; wgrad_reduce2d_kernel adds the splits and applies the row-pair output transform.
+constexpr int G4_PLANE = 64 * 8 * 4;
+constexpr int G4_BUF = 8192;
+constexpr int G4_X0 = 0;
+constexpr int G4_XE0 = 16384;
+constexpr int G4_DY0 = 18432;
+constexpr int G4_LDS = 30720;                    // 120 KiB
+constexpr int G4_TAB = 64 * 8 * 8;               // + the slot table: [64 segments][8 slots][8 ints] = 16 KiB
+
+//   b01 = (c0+c1, c1-c0)   bx = (c2-c0, c1-c3)   b23 = (c2+c3, c3-c2)
+__device__ __forceinline__ void w4_xform_b(f32x2 c01, f32x2 c23, f32x2& b01, f32x2& bx, f32x2& b23) {
+    asm("v_pk_add_f32 %0, %3, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %1, %4, %3 neg_lo:[0,1] neg_hi:[1,0]\n\t"
+        "v_pk_add_f32 %2, %4, %4 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"
+        "s_nop 1"
+        : "=&v"(b01), "=&v"(bx), "=&v"(b23) : "v"(c01), "v"(c23));
+}
+//   a01 = (g0+g1, g0-g1)   a23 = (g2+g3, g2-g3)
+__device__ __forceinline__ void w4_xform_a(f32x2 g01, f32x2 g23, f32x2& a01, f32x2& a23) {
+    asm("v_pk_add_f32 %0, %2, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %1, %3, %3 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
+        "s_nop 1"
+        : "=&v"(a01), "=&v"(a23) : "v"(g01), "v"(g23));
+}
+
+// (lo, hi) of two register pairs added / subtracted: the compiler splits a float2 add into two scalar ones.  PAD: the result may be an
+// MFMA operand right away (two wait states, see w3_xform_first)
+template <bool MINUS, bool PAD>
+__device__ __forceinline__ f32x2 w4_pk(f32x2 a, f32x2 b) {
+    f32x2 r;
+    if (MINUS) {
+        if (PAD) asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 1" : "=v"(r) : "v"(a), "v"(b));
+        else asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    } else {
+        if (PAD) asm("v_pk_add_f32 %0, %1, %2\n\ts_nop 1" : "=v"(r) : "v"(a), "v"(b));
+        else asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(512) void conv3x3_wgrad_wino2d_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                   float* __restrict__ slab, int N, int Cin, int H, int W, int Cout,
+                                                                   W3Geom geo, int segs_per_split) {
+    __shared__ __attribute__((aligned(256))) float lds[G4_LDS + G4_TAB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lk = lane >> 5;
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if ((gridDim.z & 7) == 0) {             // the (ci, co) tiles of a split on one XCD (see conv3x3_wgrad_kernel)
+        const int nxy = gridDim.x * gridDim.y;
+        const int b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int k = b & 7, slot = b >> 3;
+        bz = k + 8 * (slot / nxy);
+        const int xy = slot - (slot / nxy) * nxy;
+        bx = xy % gridDim.x;
+        by = xy / gridDim.x;
+    }
+    const int ci0 = bx * 64, co0 = by * 64, split = bz;
+    const int iHW = H * W, HP = geo.slots_img / geo.S;
+    // consumer role: transform point across rows, input-channel half
+    const int v = wave >> 1, cih = wave & 1;
+    // DMA role: channel group of the six planes; one extras instruction (which neighbour, x row)
+    const int pw = wave & 1, grp = wave;
+    const int e_which = wave >> 2, e_row = wave & 3;
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[s][q][r] = 0.f;
+
+    const int sbeg = split * segs_per_split;
+    const int send = min(geo.nseg, sbeg + segs_per_split);
+    const int nloc = send - sbeg;
+    const __amdgpu_buffer_rsrc_t dyrs = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)((long)N * Cout * iHW * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((long)N * Cin * iHW * 4), 0x00020000);
+    constexpr unsigned FAR = 0x80000000u;
+    const unsigned W4 = (unsigned)W * 4u;
+
+    // ---- slot table.  What a DMA needs of a stream slot - the byte offsets of its piece in the two dy rows and the four x rows of its
+    // row pair (FAR: outside the image or the stream) and whether it is a row's last piece - does not depend on the channel: it is
+    // computed ONCE per workgroup (one thread per (segment, slot): two divisions) into a ring of 64 segments in LDS, half a ring at a
+    // time, instead of by every lane of every wave for every segment (45 of a segment's 115 vector instructions per wave before).
+    int4* const tab = (int4*)(lds + G4_LDS);
+    auto fill = [&](int q0, int nq) __attribute__((always_inline)) {      // relative segments q0 .. q0 + nq - 1, nq * 8 <= 512
+        if (tid < nq * 8) {
+            const int q = q0 + (tid >> 3), slot = tid & 7;
+            const unsigned pos = (unsigned)(sbeg + q) * 8u + slot;
+            const int n = pos / (unsigned)geo.slots_img;
+            const int r = pos - n * geo.slots_img;
+            const int hp = r / geo.S, k = r - hp * geo.S;
+            const bool ok = k < geo.np && n < N;
+            const int row = 2 * hp;
+            const unsigned pix = (unsigned)(row * W + 4 * k);
+            const unsigned a0 = ok ? ((unsigned)(n * Cout * iHW) + pix) * 4u : FAR;
+            const unsigned b1 = ok ? ((unsigned)(n * Cin * iHW) + pix) * 4u : FAR;
+            int4 t0, t1;
+            t0.x = a0;
+            t0.y = (ok && row + 1 < H) ? a0 + W4 : FAR;
+            t0.z = (ok && row >= 1) ? b1 - W4 : FAR;
+            t0.w = b1;
+            t1.x = (ok && row + 1 < H) ? b1 + W4 : FAR;
+            t1.y = (ok && row + 2 < H) ? b1 + 2u * W4 : FAR;
+            t1.z = k == geo.np - 1 ? 1 : 0;
+            t1.w = 0;
+            tab[((q & 63) * 8 + slot) * 2] = t0;
+            tab[((q & 63) * 8 + slot) * 2 + 1] = t1;
+        }
+    };
+    const int my_ls = (lane & 7) ^ ((lane >> 4) | (4 * pw));
+    struct Entry { int4 t0, t1; };
+    auto entry = [&](int q) __attribute__((always_inline)) {
+        Entry e;
+        e.t0 = tab[((q & 63) * 8 + my_ls) * 2];
+        e.t1 = tab[((q & 63) * 8 + my_ls) * 2 + 1];
+        return e;
+    };
+    // the extras' slot (wave-uniform, scalar registers): slot -1 / slot 8 of the segment
+    struct Slot { int n, hp, k; };
+    auto decode = [&](int pos) __attribute__((always_inline)) {
+        Slot s;
+        if (pos < 0) { s.n = 0; s.hp = 0; s.k = pos; return s; }
+        s.n = pos / geo.slots_img;
+        const int r = pos - s.n * geo.slots_img;
+        s.hp = r / geo.S;
+        s.k = r - s.hp * geo.S;
+        return s;
+    };
+    auto advance = [&](Slot& s) __attribute__((always_inline)) {      // + 8 slots, branch-free (geo.adv = ceil(8 / S) carries)
+        s.k += 8;
+        for (int it = 0; it < geo.adv; ++it) {
+            const int c = s.k >= geo.S ? 1 : 0;
+            s.k -= c ? geo.S : 0;
+            s.hp += c;
+            const int d = s.hp >= HP ? 1 : 0;
+            s.hp -= d ? HP : 0;
+            s.n += d;
+        }
+    };
+    Slot es = decode(sbeg * 8 + (e_which ? 8 : -1));
+    unsigned offA, offB, offE;
+    {
+        const int co = co0 + 8 * grp + (lane >> 3), ci = ci0 + 8 * grp + (lane >> 3), cie = ci0 + lane;
+        offA = co < Cout ? (unsigned)(co * iHW) * 4u : FAR;
+        offB = ci < Cin ? (unsigned)(ci * iHW) * 4u : FAR;
+        offE = cie < Cin ? (unsigned)(cie * iHW) * 4u : FAR;
+    }
+    auto dma = [&](const __amdgpu_buffer_rsrc_t& rs, float* dst, unsigned vo) __attribute__((always_inline)) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, vo, 0, 0, 0);
+    };
+    auto issue = [&](int buf, const Entry& e) __attribute__((always_inline)) {
+        float* const bxm = lds + G4_X0 + buf * G4_BUF + grp * 256;
+        float* const bxe = lds + G4_XE0 + buf * G4_BUF + e_which * 1024 + e_row * 256;
+        float* const bdy = lds + G4_DY0 + buf * G4_BUF + grp * 256;
+        dma(dyrs, bdy, (unsigned)e.t0.x + offA);
+        dma(dyrs, bdy + G4_PLANE, (unsigned)e.t0.y + offA);
+        dma(xrs, bxm, (unsigned)e.t0.z + offB);
+        dma(xrs, bxm + G4_PLANE, (unsigned)e.t0.w + offB);
+        dma(xrs, bxm + 2 * G4_PLANE, (unsigned)e.t1.x + offB);
+        dma(xrs, bxm + 3 * G4_PLANE, (unsigned)e.t1.y + offB);
+        const int row = 2 * es.hp + e_row - 1;                         // wave-uniform
+        const bool eok = es.k >= 0 && es.k < geo.np && es.n < N && row >= 0 && row < H;
+        dma(xrs, bxe, (eok ? (unsigned)(es.n * Cin * iHW + row * W + 4 * es.k) * 4u : FAR) + offE);
+    };
+    // a row's last piece carries the next row's first columns when W % 4 != 0: zero them once the DMA has landed
+    auto patch = [&](int buf, int last_piece) __attribute__((always_inline)) {
+        if ((W & 3) == 0) return;
+        const int nv = W - 4 * (geo.np - 1);                            // valid elements of a row's last piece (1..3)
+        if (last_piece) {
+            float* const bxm = lds + G4_X0 + buf * G4_BUF + grp * 256 + lane * 4;
+            float* const bdy = lds + G4_DY0 + buf * G4_BUF + grp * 256 + lane * 4;
+#pragma unroll
+            for (int e = 1; e < 4; ++e)
+                if (e >= nv) {
+                    bdy[e] = 0.f; bdy[G4_PLANE + e] = 0.f;
+                    bxm[e] = 0.f; bxm[G4_PLANE + e] = 0.f; bxm[2 * G4_PLANE + e] = 0.f; bxm[3 * G4_PLANE + e] = 0.f;
+                }
+        }
+        if (es.k == geo.np - 1) {
+            float* o = lds + G4_XE0 + buf * G4_BUF + e_which * 1024 + e_row * 256 + lane * 4;
+#pragma unroll
+            for (int e = 1; e < 4; ++e)
+                if (e >= nv) o[e] = 0.f;
+        }
+    };
+
+    // ---- fragment addresses (bytes; kernel constants per lane)
+    const int cB = cih * 32 + li, swB = (cB >> 1) & 7;
+    const char* const ldsb = (const char*)lds;
+    int adA[2][4], adC[4], adP[4], adN[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = 2 * j + lk;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int cA = 32 * s + li, swA = (cA >> 1) & 7;
+            adA[s][j] = (G4_DY0 + cA * 32 + 4 * (m ^ swA)) * 4;
+        }
+        adC[j] = (G4_X0 + cB * 32 + 4 * (m ^ swB)) * 4;
+        adP[j] = (G4_X0 + cB * 32 + 4 * (((m - 1) & 7) ^ swB)) * 4;          // j = 0, lk = 0: not used (adP0 below)
+        adN[j] = (G4_X0 + cB * 32 + 4 * (((m + 1) & 7) ^ swB)) * 4;          // j = 3, lk = 1: not used (adN3 below)
+    }
+    auto ld = [&](int addr, int imm) __attribute__((always_inline)) { return *(const f32x4*)(ldsb + addr + imm); };
+
+    auto run = [&](auto v_tag) __attribute__((always_inline)) {
+        constexpr int V = decltype(v_tag)::value;
+        constexpr int RA = (V == 0 ? 0 : V == 1 ? 1 : V == 2 ? 2 : 3), RB = (V == 0 ? 2 : V == 1 ? 2 : 1);     // X_v = x[RA] +- x[RB]
+        constexpr bool PLUS = V == 1;
+        // the first slot's left neighbour / the last slot's right neighbour: extras for one lane half, the main plane for the other
+        const int adP0a = lk ? adP[0] + RA * 8192 : (G4_XE0 + RA * 256 + cB * 4) * 4;
+        const int adP0b = lk ? adP[0] + RB * 8192 : (G4_XE0 + RB * 256 + cB * 4) * 4;
+        const int adN3a = lk ? (G4_XE0 + 1024 + RA * 256 + cB * 4) * 4 : adN[3] + RA * 8192;
+        const int adN3b = lk ? (G4_XE0 + 1024 + RB * 256 + cB * 4) * 4 : adN[3] + RB * 8192;
+
+        auto segment = [&](auto cur_tag, int q, bool more) __attribute__((always_inline)) {
+            constexpr int OB = decltype(cur_tag)::value * G4_BUF * 4;
+            if (q > 0 && (q & 31) == 0) fill(q + 32, 32);      // the ring's other half: segments q + 32 .. q + 63 (first read in segment q + 30)
+            int last_piece = 0;
+            if (more) {
+                const Entry e = entry(q + 1);
+                advance(es);
+                issue(decltype(cur_tag)::value ^ 1, e);
+                last_piece = e.t1.z;
+            }
+            // raw fragments of one double-step: x rows RA / RB (piece, left neighbour, right neighbour), dy rows of the two co sub-tiles
+            struct Raw { f32x4 ca, cb, pa, pb, na, nb, g0[2], g1[2]; };
+            auto load = [&](int j, Raw& r) __attribute__((always_inline)) {
+                r.ca = ld(adC[j], OB + RA * 8192); r.cb = ld(adC[j], OB + RB * 8192);
+                r.pa = j == 0 ? ld(adP0a, OB) : ld(adP[j], OB + RA * 8192);
+                r.pb = j == 0 ? ld(adP0b, OB) : ld(adP[j], OB + RB * 8192);
+                r.na = j == 3 ? ld(adN3a, OB) : ld(adN[j], OB + RA * 8192);
+                r.nb = j == 3 ? ld(adN3b, OB) : ld(adN[j], OB + RB * 8192);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    if (V != 3) r.g0[s] = ld(adA[s][j], OB);
+                    if (V != 0) r.g1[s] = ld(adA[s][j], OB + 8192);
+                }
+            };
+            Raw cur, nxt;
+            load(0, cur);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j + 1 < 4) load(j + 1, nxt);
+                __builtin_amdgcn_sched_barrier(0);      // the next double-step's ds_reads stay above this one's MFMAs
+                // X_v = x[RA] +- x[RB]: the piece c0..c3 (columns 4k .. 4k+3), p = column 4k-1, n = column 4k+4
+                const f32x2 c01 = w4_pk<!PLUS, false>((f32x2){cur.ca[0], cur.ca[1]}, (f32x2){cur.cb[0], cur.cb[1]});
+                const f32x2 c23 = w4_pk<!PLUS, false>((f32x2){cur.ca[2], cur.ca[3]}, (f32x2){cur.cb[2], cur.cb[3]});
+                const float p = PLUS ? cur.pa[3] + cur.pb[3] : cur.pa[3] - cur.pb[3];
+                const float n = PLUS ? cur.na[0] + cur.nb[0] : cur.na[0] - cur.nb[0];
+                // row-wise transform: pair (4k, 4k+1): b = p-c1, c0+c1, c1-c0, c2-c0      pair (4k+2, 4k+3): b = c1-c3, c2+c3, c3-c2, n-c2
+                f32x2 b0, bx2, b1;
+                const float e0 = p - c01[1], e1 = n - c23[0];
+                w4_xform_b(c01, c23, b0, bx2, b1);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    // D_v, then the dy piece g0..g3: a = g0, g0+g1, g0-g1, g1 | g2, g2+g3, g2-g3, g3   (the 1/2 of a1, a2: output transform)
+                    f32x2 g01, g23;
+                    if (V == 0) { g01 = (f32x2){cur.g0[s][0], cur.g0[s][1]}; g23 = (f32x2){cur.g0[s][2], cur.g0[s][3]}; }
+                    else if (V == 3) { g01 = (f32x2){cur.g1[s][0], cur.g1[s][1]}; g23 = (f32x2){cur.g1[s][2], cur.g1[s][3]}; }
+                    else {
+                        g01 = w4_pk<V == 2, true>((f32x2){cur.g0[s][0], cur.g0[s][1]}, (f32x2){cur.g1[s][0], cur.g1[s][1]});
+                        g23 = w4_pk<V == 2, true>((f32x2){cur.g0[s][2], cur.g0[s][3]}, (f32x2){cur.g1[s][2], cur.g1[s][3]});
+                    }
+                    f32x2 a0, a1;
+                    w4_xform_a(g01, g23, a0, a1);
+                    acc[s][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g01[0], e0, acc[s][0], 0, 0, 0);
+                    acc[s][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[0], b0[0], acc[s][1], 0, 0, 0);
+                    acc[s][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[1], b0[1], acc[s][2], 0, 0, 0);
+                    acc[s][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(g01[1], bx2[0], acc[s][3], 0, 0, 0);
+                    acc[s][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g23[0], bx2[1], acc[s][0], 0, 0, 0);
+                    acc[s][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[0], b1[0], acc[s][1], 0, 0, 0);
+                    acc[s][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[1], b1[1], acc[s][2], 0, 0, 0);
+                    acc[s][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(g23[1], e1, acc[s][3], 0, 0, 0);
+                }
+                cur = nxt;
+            }
+            if (more) {
+                __builtin_amdgcn_s_waitcnt(0x0F70);     // the next segment's DMAs have landed
+                patch(decltype(cur_tag)::value ^ 1, last_piece);
+            }
+            __syncthreads();                            // next buffer complete, this one free
+        };
+        for (int q = 0; q < nloc; q += 2) {
+            segment(std::integral_constant<int, 0>{}, q, q + 1 < nloc);
+            if (q + 1 < nloc) segment(std::integral_constant<int, 1>{}, q + 1, q + 2 < nloc);
+        }
+    };
+
+    fill(0, 64);
+    __syncthreads();
+    if (nloc > 0) {
+        const Entry e = entry(0);
+        issue(0, e);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        patch(0, e.t1.z);
+    }
+    __syncthreads();
+    if (v == 0) run(std::integral_constant<int, 0>{});
+    else if (v == 1) run(std::integral_constant<int, 1>{});
+    else if (v == 2) run(std::integral_constant<int, 2>{});
+    else run(std::integral_constant<int, 3>{});
+    // row-wise output transform with the filter-side 1/2 (and the row-pair transform's 1/2 for V1, V2):
+    //   V(kw=0) = M0 + (M1+M2)/2   V(1) = (M1-M2)/2   V(2) = (M1+M2)/2 + M3
+    const long plane = (long)Cout * Cin;
+    const float sc = (v == 1 || v == 2) ? 0.5f : 1.0f;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + 32 * s + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            const int ci = ci0 + cB;
+            if (co < Cout && ci < Cin) {
+                const float m0 = sc * acc[s][0][r], m1 = 0.5f * sc * acc[s][1][r], m2 = 0.5f * sc * acc[s][2][r], m3 = sc * acc[s][3][r];
+                float* o = slab + ((long)split * 12 + v * 3) * plane + (long)co * Cin + ci;
+                o[0] = (m0 + m1) + m2;
+                o[plane] = m1 - m2;
+                o[2 * plane] = (m1 + m2) + m3;
+            }
+        }
+}
+
+// adds the splits of conv3x3_wgrad_wino2d_kernel's slab [split][v][kw][co][ci] in a fixed order and applies the row-pair output
+// transform: dw(kh=0) = V0 + (V1 + V2), dw(1) = V1 - V2, dw(2) = (V1 + V2) + V3 (the halves are already in V1, V2)
+template <int G>
+__global__ __launch_bounds__(64 * G) void wgrad_reduce2d_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cout, int Cin,
+                                                                int splits) {
+    __shared__ f32x4 red[G][4][64];
+    const long plane = (long)Cout * Cin;
+    const long per_kw = plane / 4;                  // float4s of a plane (Cout * Cin % 4 == 0: the caller checks)
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const long o = (long)blockIdx.x * 64 + lane;    // (kw, float4 of the plane)
+    const bool ok = o < 3 * per_kw;
+    const int kw = ok ? (int)(o / per_kw) : 0;
+    const long r4 = ok ? o - (long)kw * per_kw : 0;
+    f32x4 s[4];
+#pragma unroll
+    for (int vv = 0; vv < 4; ++vv) s[vv] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (ok)
+        for (int sp = g; sp < splits; sp += G)
+#pragma unroll
+            for (int vv = 0; vv < 4; ++vv) s[vv] += *(const f32x4*)(slab + ((long)sp * 12 + vv * 3 + kw) * plane + r4 * 4);
+#pragma unroll
+    for (int vv = 0; vv < 4; ++vv) red[g][vv][lane] = s[vv];
+    __syncthreads();
+    if (g == 0 && ok) {
+        f32x4 t[4];
+#pragma unroll
+        for (int vv = 0; vv < 4; ++vv) {
+            f32x4 u[G];
+#pragma unroll
+            for (int i = 0; i < G; ++i) u[i] = red[i][vv][lane];
+#pragma unroll
+            for (int w = 1; w < G; w *= 2)            // fixed balanced tree
+#pragma unroll
+                for (int i = 0; i + w < G; i += 2 * w) u[i] += u[i + w];
+            t[vv] = u[0];
+        }
+        const f32x4 s12 = t[1] + t[2];
+        const f32x4 k0 = t[0] + s12, k1 = t[1] - t[2], k2 = s12 + t[3];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float* d = dw + (r4 * 4 + e) * 9 + kw;
+            d[0] = k0[e];
+            d[3] = k1[e];
+            d[6] = k2[e];
+        }
+    }
+}
+
 
 const float* wino_zero_page_ptr() {
     static const float* zp[64] = {nullptr};
@@ -1906,7 +2297,24 @@ int wgrad_wino3_splits(int n, int cin, int h, int w, int cout, W3Geom* geo, int*
     *segs_per_split = sps;
     return (geo->nseg + sps - 1) / sps;
 }
-// VOCR_WGRAD_WINO_DMA: 2 (default) piece stream / twelve waves, 1 round 3's segment kernel with LDS-DMA, 0 its register-staged form
+// piece-stream geometry of conv3x3_wgrad_wino2d_kernel: row PAIRS, 8-slot segments
+int wgrad_wino2d_splits(int n, int cin, int h, int w, int cout, W3Geom* geo, int* segs_per_split) {
+    geo->np = vocr_cdiv(w, 4);
+    geo->S = geo->np + 1;
+    geo->slots_img = vocr_cdiv(h, 2) * geo->S;
+    const long nslot = (long)n * geo->slots_img;
+    geo->nseg = (int)((nslot + 7) / 8);
+    geo->adv = vocr_cdiv(8, geo->S);
+    const int tiles = vocr_cdiv(cin, 64) * vocr_cdiv(cout, 64);
+    long s = (256 + tiles - 1) / tiles;                      // one workgroup per CU
+    if (s > geo->nseg) s = geo->nseg;
+    if (s < 1) s = 1;
+    const int sps = (int)((geo->nseg + s - 1) / s);
+    *segs_per_split = sps;
+    return (geo->nseg + sps - 1) / sps;
+}
+// VOCR_WGRAD_WINO_DMA: 3 row pairs (F(3,2) across rows too) / eight waves, 2 (default) piece stream / twelve waves, 1 round 3's
+// segment kernel with LDS-DMA, 0 its register-staged form
 int wgrad_wino_mode() {
     static const int m = getenv("VOCR_WGRAD_WINO_DMA") ? atoi(getenv("VOCR_WGRAD_WINO_DMA")) : 2;
     return m;
@@ -1917,7 +2325,8 @@ extern "C" size_t vocr_conv3x3_wgrad_wino_workspace_bytes(int n, int cin, int h,
     if (n <= 0 || cin <= 0 || h <= 0 || w <= 0 || cout <= 0) return 0;
     int sps;
     W3Geom g3;
-    const int splits = wgrad_wino_mode() == 2 ? wgrad_wino3_splits(n, cin, h, w, cout, &g3, &sps) : wgrad_wino_splits(n, cin, h, w, cout, &sps);
+    if (wgrad_wino_mode() == 3 && (cout * cin) % 4 == 0) return (size_t)wgrad_wino2d_splits(n, cin, h, w, cout, &g3, &sps) * 12 * cout * cin * sizeof(float);
+    const int splits = wgrad_wino_mode() >= 2 ? wgrad_wino3_splits(n, cin, h, w, cout, &g3, &sps) : wgrad_wino_splits(n, cin, h, w, cout, &sps);
     return (size_t)splits * 9 * cout * cin * sizeof(float);
 }
 
@@ -1928,7 +2337,20 @@ extern "C" int vocr_conv3x3_wgrad_wino(const float* x, const float* dy, float* d
     VOCR_CHECK_ARG((long)n * (cin > cout ? cin : cout) * h * w < (1l << 29), "vocr_conv3x3_wgrad_wino: tensor exceeds 2^29 elements (32-bit byte offsets)");
     hipStream_t s = (hipStream_t)stream;
     int sps, splits;
-    if (wgrad_wino_mode() == 2) {
+    if (wgrad_wino_mode() == 3 && (cout * cin) % 4 == 0) {
+        W3Geom g4;
+        splits = wgrad_wino2d_splits(n, cin, h, w, cout, &g4, &sps);
+        dim3 grid(vocr_cdiv(cin, 64), vocr_cdiv(cout, 64), splits);
+        conv3x3_wgrad_wino2d_kernel<<<grid, 512, 0, s>>>(x, dy, (float*)workspace, n, cin, h, w, cout, g4, sps);
+        VOCR_CHECK_LAUNCH("vocr_conv3x3_wgrad_wino(row pairs)");
+        const long total4 = 3l * cout * cin / 4;
+        const int wgs = (int)((total4 + 63) / 64);
+        if (wgs < 64 && splits >= 64) wgrad_reduce2d_kernel<16><<<wgs, 1024, 0, s>>>((const float*)workspace, dw, cout, cin, splits);
+        else wgrad_reduce2d_kernel<4><<<wgs, 256, 0, s>>>((const float*)workspace, dw, cout, cin, splits);
+        VOCR_CHECK_LAUNCH("vocr_conv3x3_wgrad_wino(row pairs, reduce)");
+        return VOCR_OK;
+    }
+    if (wgrad_wino_mode() >= 2) {
         W3Geom g3;
         splits = wgrad_wino3_splits(n, cin, h, w, cout, &g3, &sps);
         dim3 grid(vocr_cdiv(cin, 64), vocr_cdiv(cout, 64), splits);
