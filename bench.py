@@ -139,16 +139,20 @@ def lstm_flops(args, first_dim_arg):
     return 2.0 * 2 * t * b * h * 4 * h           # both directions: [B, H] x [H, 4H] per time step
 
 
-# MFMA FLOPs a launch EXECUTES per algorithmic FLOP: the F(2,3) / F(3,2) kernels issue 4 multiplications where the direct form needs 6, the
+# MFMA FLOPs a launch EXECUTES per algorithmic FLOP: the F(2,3) kernels issue 4 multiplications where the direct form needs 6, the
 # F(4,3) kernel (forward / data-gradient launches with >= 128 output channels unless VOCR_CONV_WINO4=0) 6 where it needs 12
 _WINO4 = os.environ.get("VOCR_CONV_WINO4", "1") != "0"
+# the weight gradient (default VOCR_WGRAD_WINO_DMA=3) applies F(3,2) along the row AND across row pairs: 16 multiplications where the
+# direct form needs 36, times 2 ceil(H/2) / H (an odd height's last pair is half empty); modes <= 2: along the row only
+_WGRAD2D = os.environ.get("VOCR_WGRAD_WINO_DMA", "3") == "3"
 
 
 def executed_share(name, args):
     if name == "vocr_conv3x3_wino_fwd":
         return 0.5 if (_WINO4 and args[8] >= 128) else 2.0 / 3.0
     if name == "vocr_conv3x3_wgrad_wino":
-        return 2.0 / 3.0
+        h = args[6]
+        return (4.0 / 9.0) * (2.0 * ((h + 1) // 2) / h) if (_WGRAD2D and (args[5] * args[8]) % 4 == 0) else 2.0 / 3.0
     return 1.0
 FLOPS_OF = {"vocr_conv3x3_fwd": conv_flops, "vocr_conv3x3_wino_fwd": conv_flops, "vocr_conv3x3_wgrad": conv_flops,
             "vocr_conv3x3_wgrad_wino": conv_flops, "vocr_gemm": gemm_flops, "vocr_gemm_pair": gemm_pair_flops,
@@ -156,8 +160,8 @@ FLOPS_OF = {"vocr_conv3x3_fwd": conv_flops, "vocr_conv3x3_wino_fwd": conv_flops,
             "vocr_lstm_bwd_bias": lambda a: lstm_flops(a, 9)}
 FAMILY = {"vocr_conv3x3_fwd": "conv3x3 forward + data gradient (conv3x3_wino4 / conv3x3_wino2 kernels: F(4,3) / F(2,3) along the row)",
           "vocr_conv3x3_wino_fwd": "conv3x3 forward + data gradient (conv3x3_wino4 / conv3x3_wino2 kernels: F(4,3) / F(2,3) along the row)",
-          "vocr_conv3x3_wgrad": "conv3x3 weight gradient (conv3x3_wgrad_wino3_kernel: F(3,2), piece stream)",
-          "vocr_conv3x3_wgrad_wino": "conv3x3 weight gradient (conv3x3_wgrad_wino3_kernel: F(3,2), piece stream)",
+          "vocr_conv3x3_wgrad": "conv3x3 weight gradient (conv3x3_wgrad_wino2d_kernel: F(3,2) along the row and across row pairs, piece stream)",
+          "vocr_conv3x3_wgrad_wino": "conv3x3 weight gradient (conv3x3_wgrad_wino2d_kernel: F(3,2) along the row and across row pairs, piece stream)",
           "vocr_gemm": "dense GEMMs (gemm_dma_kernel / gemm_f32_kernel behind vocr_gemm and vocr_gemm_pair: bridge, LSTM projections, prob, their dX / dW)",
           "vocr_gemm_pair": "dense GEMMs (gemm_dma_kernel / gemm_f32_kernel behind vocr_gemm and vocr_gemm_pair: bridge, LSTM projections, prob, their dX / dW)",
           "vocr_lstm_fwd": "LSTM sweeps (lstm_fwd_chain4w / lstm_bwd_chain4w)", "vocr_lstm_fwd_range": "LSTM sweeps (lstm_fwd_chain4w / lstm_bwd_chain4w)",

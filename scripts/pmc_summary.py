@@ -84,7 +84,7 @@ def busy(paths):
 
 FAMILIES = (      # bench.py's FAMILY names -> kernel-name prefixes
     ("conv3x3 forward + data gradient (conv3x3_wino4 / conv3x3_wino2 kernels: F(4,3) / F(2,3) along the row)", ("conv3x3_wino_kernel", "conv3x3_wino2_kernel", "conv3x3_wino4", "conv3x3_wino8_kernel", "conv3x3_dma_kernel", "conv3x3_kernel", "conv3x3_tail")),
-    ("conv3x3 weight gradient (conv3x3_wgrad_wino3_kernel: F(3,2), piece stream)", ("conv3x3_wgrad",)),
+    ("conv3x3 weight gradient (conv3x3_wgrad_wino2d_kernel: F(3,2) along the row and across row pairs, piece stream)", ("conv3x3_wgrad",)),
     ("dense GEMMs (gemm_dma_kernel / gemm_f32_kernel behind vocr_gemm and vocr_gemm_pair: bridge, LSTM projections, prob, their dX / dW)", ("gemm_dma_kernel", "gemm_f32_kernel")),
     ("LSTM sweeps (lstm_fwd_chain4w / lstm_bwd_chain4w)", ("lstm_fwd_", "lstm_bwd_")),
 )

@@ -1781,13 +1781,28 @@ constexpr int G4_DY0 = 18432;
 constexpr int G4_LDS = 30720;                    // 120 KiB
 constexpr int G4_TAB = 64 * 8 * 8;               // + the slot table: [64 segments][8 slots][8 ints] = 16 KiB
 
-//   b01 = (c0+c1, c1-c0)   bx = (c2-c0, c1-c3)   b23 = (c2+c3, c3-c2)
-__device__ __forceinline__ void w4_xform_b(f32x2 c01, f32x2 c23, f32x2& b01, f32x2& bx, f32x2& b23) {
-    asm("v_pk_add_f32 %0, %3, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"
-        "v_pk_add_f32 %1, %4, %3 neg_lo:[0,1] neg_hi:[1,0]\n\t"
-        "v_pk_add_f32 %2, %4, %4 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"
-        "s_nop 1"
-        : "=&v"(b01), "=&v"(bx), "=&v"(b23) : "v"(c01), "v"(c23));
+// One block per operand and double-step: the row combination X_v = xa +- xb (D_v = da +- db) and the row-wise transform on top of it,
+// all packed adds; the block's results may be MFMA operands right away, so it ends in the two wait states (see w3_xform_first).
+//   c = ca +- cb      b01 = (c0+c1, c1-c0)   bx = (c2-c0, c1-c3)   b23 = (c2+c3, c3-c2)
+template <bool MINUS>
+__device__ __forceinline__ void w4_xform_b(f32x2 ca01, f32x2 ca23, f32x2 cb01, f32x2 cb23, f32x2& c01, f32x2& c23, f32x2& b01, f32x2& bx,
+                                           f32x2& b23) {
+    if (MINUS)
+        asm("v_pk_add_f32 %0, %5, %7 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %1, %6, %8 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %2, %0, %0 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %3, %1, %0 neg_lo:[0,1] neg_hi:[1,0]\n\t"
+            "v_pk_add_f32 %4, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"
+            "s_nop 1"
+            : "=&v"(c01), "=&v"(c23), "=&v"(b01), "=&v"(bx), "=&v"(b23) : "v"(ca01), "v"(ca23), "v"(cb01), "v"(cb23));
+    else
+        asm("v_pk_add_f32 %0, %5, %7\n\t"
+            "v_pk_add_f32 %1, %6, %8\n\t"
+            "v_pk_add_f32 %2, %0, %0 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %3, %1, %0 neg_lo:[0,1] neg_hi:[1,0]\n\t"
+            "v_pk_add_f32 %4, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"
+            "s_nop 1"
+            : "=&v"(c01), "=&v"(c23), "=&v"(b01), "=&v"(bx), "=&v"(b23) : "v"(ca01), "v"(ca23), "v"(cb01), "v"(cb23));
 }
 //   a01 = (g0+g1, g0-g1)   a23 = (g2+g3, g2-g3)
 __device__ __forceinline__ void w4_xform_a(f32x2 g01, f32x2 g23, f32x2& a01, f32x2& a23) {
@@ -1796,20 +1811,23 @@ __device__ __forceinline__ void w4_xform_a(f32x2 g01, f32x2 g23, f32x2& a01, f32
         "s_nop 1"
         : "=&v"(a01), "=&v"(a23) : "v"(g01), "v"(g23));
 }
-
-// (lo, hi) of two register pairs added / subtracted: the compiler splits a float2 add into two scalar ones.  PAD: the result may be an
-// MFMA operand right away (two wait states, see w3_xform_first)
-template <bool MINUS, bool PAD>
-__device__ __forceinline__ f32x2 w4_pk(f32x2 a, f32x2 b) {
-    f32x2 r;
-    if (MINUS) {
-        if (PAD) asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 1" : "=v"(r) : "v"(a), "v"(b));
-        else asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-    } else {
-        if (PAD) asm("v_pk_add_f32 %0, %1, %2\n\ts_nop 1" : "=v"(r) : "v"(a), "v"(b));
-        else asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    }
-    return r;
+//   g = ga +- gb, then the same
+template <bool MINUS>
+__device__ __forceinline__ void w4_xform_a2(f32x2 ga01, f32x2 ga23, f32x2 gb01, f32x2 gb23, f32x2& g01, f32x2& g23, f32x2& a01, f32x2& a23) {
+    if (MINUS)
+        asm("v_pk_add_f32 %0, %4, %6 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %1, %5, %7 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %2, %0, %0 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %3, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
+            "s_nop 1"
+            : "=&v"(g01), "=&v"(g23), "=&v"(a01), "=&v"(a23) : "v"(ga01), "v"(ga23), "v"(gb01), "v"(gb23));
+    else
+        asm("v_pk_add_f32 %0, %4, %6\n\t"
+            "v_pk_add_f32 %1, %5, %7\n\t"
+            "v_pk_add_f32 %2, %0, %0 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %3, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
+            "s_nop 1"
+            : "=&v"(g01), "=&v"(g23), "=&v"(a01), "=&v"(a23) : "v"(ga01), "v"(ga23), "v"(gb01), "v"(gb23));
 }
 
 __global__ __launch_bounds__(512) void conv3x3_wgrad_wino2d_kernel(const float* __restrict__ x, const float* __restrict__ dy,
@@ -1977,6 +1995,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_wino2d_kernel(const float* 
         adN[j] = (G4_X0 + cB * 32 + 4 * (((m + 1) & 7) ^ swB)) * 4;          // j = 3, lk = 1: not used (adN3 below)
     }
     auto ld = [&](int addr, int imm) __attribute__((always_inline)) { return *(const f32x4*)(ldsb + addr + imm); };
+    auto ldf = [&](int addr, int imm) __attribute__((always_inline)) { return *(const float*)(ldsb + addr + imm); };
 
     auto run = [&](auto v_tag) __attribute__((always_inline)) {
         constexpr int V = decltype(v_tag)::value;
@@ -1990,6 +2009,23 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_wino2d_kernel(const float* 
 
         auto segment = [&](auto cur_tag, int q, bool more) __attribute__((always_inline)) {
             constexpr int OB = decltype(cur_tag)::value * G4_BUF * 4;
+            // raw fragments of one double-step: x rows RA / RB (piece, left neighbour, right neighbour), dy rows of the two co sub-tiles
+            // (the neighbours' single elements as 4-byte reads: two lanes per bank, a quarter of a 16-byte read's LDS cycles and registers)
+            struct Raw { f32x4 ca, cb, g0[2], g1[2]; float pa, pb, na, nb; };
+            auto load = [&](int j, Raw& r) __attribute__((always_inline)) {
+                r.ca = ld(adC[j], OB + RA * 8192); r.cb = ld(adC[j], OB + RB * 8192);
+                r.pa = j == 0 ? ldf(adP0a, OB + 12) : ldf(adP[j], OB + RA * 8192 + 12);
+                r.pb = j == 0 ? ldf(adP0b, OB + 12) : ldf(adP[j], OB + RB * 8192 + 12);
+                r.na = j == 3 ? ldf(adN3a, OB) : ldf(adN[j], OB + RA * 8192);
+                r.nb = j == 3 ? ldf(adN3b, OB) : ldf(adN[j], OB + RB * 8192);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    if (V != 3) r.g0[s] = ld(adA[s][j], OB);
+                    if (V != 0) r.g1[s] = ld(adA[s][j], OB + 8192);
+                }
+            };
+            Raw cur, nxt;
+            load(0, cur);                               // first: their latency runs under the DMA issue below
             if (q > 0 && (q & 31) == 0) fill(q + 32, 32);      // the ring's other half: segments q + 32 .. q + 63 (first read in segment q + 30)
             int last_piece = 0;
             if (more) {
@@ -1998,47 +2034,30 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_wino2d_kernel(const float* 
                 issue(decltype(cur_tag)::value ^ 1, e);
                 last_piece = e.t1.z;
             }
-            // raw fragments of one double-step: x rows RA / RB (piece, left neighbour, right neighbour), dy rows of the two co sub-tiles
-            struct Raw { f32x4 ca, cb, pa, pb, na, nb, g0[2], g1[2]; };
-            auto load = [&](int j, Raw& r) __attribute__((always_inline)) {
-                r.ca = ld(adC[j], OB + RA * 8192); r.cb = ld(adC[j], OB + RB * 8192);
-                r.pa = j == 0 ? ld(adP0a, OB) : ld(adP[j], OB + RA * 8192);
-                r.pb = j == 0 ? ld(adP0b, OB) : ld(adP[j], OB + RB * 8192);
-                r.na = j == 3 ? ld(adN3a, OB) : ld(adN[j], OB + RA * 8192);
-                r.nb = j == 3 ? ld(adN3b, OB) : ld(adN[j], OB + RB * 8192);
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    if (V != 3) r.g0[s] = ld(adA[s][j], OB);
-                    if (V != 0) r.g1[s] = ld(adA[s][j], OB + 8192);
-                }
-            };
-            Raw cur, nxt;
-            load(0, cur);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (j + 1 < 4) load(j + 1, nxt);
                 __builtin_amdgcn_sched_barrier(0);      // the next double-step's ds_reads stay above this one's MFMAs
-                // X_v = x[RA] +- x[RB]: the piece c0..c3 (columns 4k .. 4k+3), p = column 4k-1, n = column 4k+4
-                const f32x2 c01 = w4_pk<!PLUS, false>((f32x2){cur.ca[0], cur.ca[1]}, (f32x2){cur.cb[0], cur.cb[1]});
-                const f32x2 c23 = w4_pk<!PLUS, false>((f32x2){cur.ca[2], cur.ca[3]}, (f32x2){cur.cb[2], cur.cb[3]});
-                const float p = PLUS ? cur.pa[3] + cur.pb[3] : cur.pa[3] - cur.pb[3];
-                const float n = PLUS ? cur.na[0] + cur.nb[0] : cur.na[0] - cur.nb[0];
-                // row-wise transform: pair (4k, 4k+1): b = p-c1, c0+c1, c1-c0, c2-c0      pair (4k+2, 4k+3): b = c1-c3, c2+c3, c3-c2, n-c2
-                f32x2 b0, bx2, b1;
+                // X_v = x[RA] +- x[RB]: the piece c0..c3 (columns 4k .. 4k+3), p = column 4k-1, n = column 4k+4; row-wise transform:
+                // pair (4k, 4k+1): b = p-c1, c0+c1, c1-c0, c2-c0      pair (4k+2, 4k+3): b = c1-c3, c2+c3, c3-c2, n-c2
+                f32x2 c01, c23, b0, bx2, b1;
+                w4_xform_b<!PLUS>((f32x2){cur.ca[0], cur.ca[1]}, (f32x2){cur.ca[2], cur.ca[3]}, (f32x2){cur.cb[0], cur.cb[1]},
+                                  (f32x2){cur.cb[2], cur.cb[3]}, c01, c23, b0, bx2, b1);
+                const float p = PLUS ? cur.pa + cur.pb : cur.pa - cur.pb;
+                const float n = PLUS ? cur.na + cur.nb : cur.na - cur.nb;
                 const float e0 = p - c01[1], e1 = n - c23[0];
-                w4_xform_b(c01, c23, b0, bx2, b1);
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     // D_v, then the dy piece g0..g3: a = g0, g0+g1, g0-g1, g1 | g2, g2+g3, g2-g3, g3   (the 1/2 of a1, a2: output transform)
-                    f32x2 g01, g23;
-                    if (V == 0) { g01 = (f32x2){cur.g0[s][0], cur.g0[s][1]}; g23 = (f32x2){cur.g0[s][2], cur.g0[s][3]}; }
-                    else if (V == 3) { g01 = (f32x2){cur.g1[s][0], cur.g1[s][1]}; g23 = (f32x2){cur.g1[s][2], cur.g1[s][3]}; }
-                    else {
-                        g01 = w4_pk<V == 2, true>((f32x2){cur.g0[s][0], cur.g0[s][1]}, (f32x2){cur.g1[s][0], cur.g1[s][1]});
-                        g23 = w4_pk<V == 2, true>((f32x2){cur.g0[s][2], cur.g0[s][3]}, (f32x2){cur.g1[s][2], cur.g1[s][3]});
+                    f32x2 g01, g23, a0, a1;
+                    if (V == 0 || V == 3) {
+                        const f32x4 g = V == 0 ? cur.g0[s] : cur.g1[s];
+                        g01 = (f32x2){g[0], g[1]}; g23 = (f32x2){g[2], g[3]};
+                        w4_xform_a(g01, g23, a0, a1);
+                    } else {
+                        w4_xform_a2<V == 2>((f32x2){cur.g0[s][0], cur.g0[s][1]}, (f32x2){cur.g0[s][2], cur.g0[s][3]},
+                                            (f32x2){cur.g1[s][0], cur.g1[s][1]}, (f32x2){cur.g1[s][2], cur.g1[s][3]}, g01, g23, a0, a1);
                     }
-                    f32x2 a0, a1;
-                    w4_xform_a(g01, g23, a0, a1);
                     acc[s][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g01[0], e0, acc[s][0], 0, 0, 0);
                     acc[s][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[0], b0[0], acc[s][1], 0, 0, 0);
                     acc[s][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[1], b0[1], acc[s][2], 0, 0, 0);
@@ -2313,10 +2332,10 @@ int wgrad_wino2d_splits(int n, int cin, int h, int w, int cout, W3Geom* geo, int
     *segs_per_split = sps;
     return (geo->nseg + sps - 1) / sps;
 }
-// VOCR_WGRAD_WINO_DMA: 3 row pairs (F(3,2) across rows too) / eight waves, 2 (default) piece stream / twelve waves, 1 round 3's
+// VOCR_WGRAD_WINO_DMA: 3 (default) row pairs (F(3,2) across rows too) / eight waves, 2 piece stream / twelve waves, 1 round 3's
 // segment kernel with LDS-DMA, 0 its register-staged form
 int wgrad_wino_mode() {
-    static const int m = getenv("VOCR_WGRAD_WINO_DMA") ? atoi(getenv("VOCR_WGRAD_WINO_DMA")) : 2;
+    static const int m = getenv("VOCR_WGRAD_WINO_DMA") ? atoi(getenv("VOCR_WGRAD_WINO_DMA")) : 3;
     return m;
 }
 }  // namespace
