@@ -74,6 +74,38 @@ def test_conv3x3_fwd_dgrad_wgrad(dev, n, cin, h, w, cout, form, monkeypatch):
     _close(db, dy.sum((0, 2, 3)), 1e-5, 1e-4, "channel_sum")
 
 
+# the row-pair weight-gradient kernel's geometry (conv3x3_wgrad_wino2d_kernel): one row and one column (a pair with one real row, a
+# one-piece row), two columns / three (pieces with 2 / 3 valid elements, four pairs per 8-slot segment), even and odd heights, rows of
+# exactly 7 and 8 slots, channel counts that leave most of a 64 x 64 tile empty, and Cin * Cout % 4 != 0 (falls back to the one-row kernel)
+@pytest.mark.parametrize("n,cin,h,w,cout", [(1, 4, 1, 1, 4), (3, 4, 2, 2, 8), (2, 8, 5, 3, 4), (2, 68, 9, 5, 12), (1, 8, 4, 24, 8),
+                                            (2, 8, 3, 28, 72), (1, 100, 8, 31, 36), (2, 5, 6, 17, 7), (4, 6, 7, 9, 6)])
+def test_conv3x3_wgrad_row_pairs_edge_shapes(dev, n, cin, h, w, cout):
+    from vistaocr_amd import ops
+    x = _rand((n, cin, h, w), 11)
+    dy = _rand((n, cout, h, w), 12)
+    ref = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, 3, 3), dy.double(), padding=1)
+    dw = ops.conv3x3_wgrad(x.to(dev), dy.to(dev))
+    _close(dw, ref, 1e-4, 2e-4 * math.sqrt(n * h * w), "conv wgrad (row pairs)")
+
+
+def test_conv3x3_wgrad_row_pairs_long_stream_matches_direct_kernel(dev):
+    """More than 96 segments per workgroup: the slot table's 64-segment ring in LDS is refilled (half a ring at a time) several times.
+    16 (ci, co) tiles -> 16 splits of 98 segments each; checked against the direct (non-transform) kernel of conv.hip on the GPU."""
+    from vistaocr_amd import ops, _lib
+    from vistaocr_amd._lib import call
+    lib = _lib.load()
+    n, cin, h, w, cout = 32, 256, 14, 220, 256
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand((n, cin, h, w), generator=g) * 2 - 1).to(dev)
+    dy = (torch.rand((n, cout, h, w), generator=g) * 2 - 1).to(dev)
+    dw = ops.conv3x3_wgrad(x, dy)
+    ref = torch.empty(cout, cin, 3, 3, dtype=torch.float32, device=dev)
+    ws = torch.empty(lib.vocr_conv3x3_wgrad_workspace_bytes(n, cin, h, w, cout) // 4 + 4, dtype=torch.float32, device=dev)
+    call("vocr_conv3x3_wgrad", x.data_ptr(), dy.data_ptr(), ref.data_ptr(), ws.data_ptr(), n, cin, h, w, cout, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    _close(dw, ref, 1e-4, 2e-4 * math.sqrt(n * h * w), "conv wgrad (row pairs, long stream)")
+
+
 @pytest.mark.parametrize("n,cin,h,w,cout", [(2, 1, 30, 70, 64), (2, 64, 15, 45, 128), (1, 128, 7, 33, 256), (1, 16, 9, 40, 64), (1, 24, 12, 31, 16)])
 def test_conv3x3_f16_operands(dev, n, cin, h, w, cout):
     """fp16-operand MFMA conv (config 5): products of fp16-rounded operands, fp32 accumulation — compared with the same
