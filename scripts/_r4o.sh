@@ -1,6 +1,3 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 run() { python bench.py --no-cpu-baseline --no-gemm-alone --event-every 0 --steps 60 --warmup 15 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1  %.3f ms  %.1f img/s  loss %s' % (d['ms_per_step'], d['value'], d['config'].get('final_loss')))"; }
-run default
-export VOCR_PROB_DW_OVERLAP=0; run prob_dw_main; unset VOCR_PROB_DW_OVERLAP
-run default
-export VOCR_PROB_DW_OVERLAP=0; run prob_dw_main; unset VOCR_PROB_DW_OVERLAP
+run packed; run packed; run packed

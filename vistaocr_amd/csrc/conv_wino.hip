@@ -536,6 +536,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino2_kernel_64(const float* _
 // segments are staged by that wave alone (no other wave reads them); the weights of a stage (4 input channels: 12 filter rows of
 // CO_T x 6 transformed values, as [row][co][4] + [row][co][2] so that a fragment is one 16-byte and one 8-byte read) arrive by
 // LDS-DMA for all four waves, two stages.
+#ifndef W43_PACKED         // 0: the scalar twelve-instruction input transform (A/B builds)
+#define W43_PACKED 1
+#endif
 constexpr int Q4_TS = 32;                   // quads per segment
 constexpr int Q4_PRW = 132;                 // floats per staged halo row: raw index r = 4 e + c <-> column 4 k_e - 1 + c, r < 130
 __global__ void wino4_pack_kernel(const float* __restrict__ w, float* __restrict__ pf, float* __restrict__ pd, int cout, int cin) {
@@ -562,6 +565,25 @@ __global__ void wino4_pack_kernel(const float* __restrict__ w, float* __restrict
         float* p2 = pd + (long)cout * 3 * cin * 4 + ((long)(co * 3 + (2 - kh)) * cin + ci) * 2;
         put(p4, p2, g[2], g[1], g[0]);
     }
+}
+
+// F(4,3) input transform of one quad's six raw columns e0..e5 as SIX packed instructions (the scalar form is twelve):
+//   (ta, tc) = e4 + (-4, -1) e2     (tb, td) = e3 + (-4, -1) e1     (v1, v2) = ta +- tb     (v3, v4) = tc +- 2 td
+//   (v0, v5) = (4 e0 + e4, 4 e1 + e5) - 5 (e2, e3)
+// op_sel / op_sel_hi pick the half of a register pair per result half, so no value is moved; ka = (-4, -1), kb = (2, -2), kc = (4, -5)
+// live in registers.  The results are MFMA operands right away: the block ends in the two wait states (see w3_xform_first).
+__device__ __forceinline__ void w43_input_xform(f32x2 e01, f32x2 e23, f32x2 e45, f32x2 ka, f32x2 kb, f32x2 kc, f32x2& v12, f32x2& v34,
+                                                f32x2& v05) {
+    f32x2 p2;                  // v05 first holds (4 e0 + e4, 4 e1 + e5), v34 first (ta, tc)
+    asm("v_pk_fma_f32 %2, %4, %9, %6 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %1, %5, %7, %6 op_sel:[0,0,0] op_sel_hi:[0,1,0]\n\t"
+        "v_pk_fma_f32 %3, %4, %7, %5 op_sel:[1,0,1] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %2, %5, %9, %2 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_add_f32 %0, %1, %3 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %1, %3, %8, %1 op_sel:[1,0,1] op_sel_hi:[1,1,1]\n\t"
+        "s_nop 1"
+        : "=&v"(v12), "=&v"(v34), "=&v"(v05), "=&v"(p2)
+        : "v"(e01), "v"(e23), "v"(e45), "v"(ka), "v"(kb), "v"(kc));
 }
 
 template <int CO_T, int NW, int CS>
@@ -700,6 +722,9 @@ __device__ __forceinline__ void conv3x3_wino4_body(const float* __restrict__ in,
     };
     // ---- K loop of one stage: 6 steps (channel pair cp: lanes 0-31 channel cp, lanes 32-63 channel cp + 2; filter row kh), each
     // 6 transform points x TM row blocks x TN segments MFMAs
+    // the packed input transform's constants: pinned in registers (as literals the compiler would re-materialise them per use)
+    f32x2 xka = {-4.f, -1.f}, xkb = {2.f, -2.f}, xkc = {4.f, -5.f};
+    asm volatile("" : "+v"(xka), "+v"(xkb), "+v"(xkc));
     auto kloop = [&](int buf) __attribute__((always_inline)) {
         const float* wa4 = Wt + buf * WBUF + ((lk * KS) * CO_T + wco + li) * 4;
         const float* wa2 = Wt + buf * WBUF + W4 + ((lk * KS) * CO_T + wco + li) * 2;
@@ -719,29 +744,37 @@ __device__ __forceinline__ void conv3x3_wino4_body(const float* __restrict__ in,
                 A2[i] = *(const f32x2*)(wa2 + (row * CO_T + 32 * i) * 2);
             }
         };
+        // one wave per SIMD: nobody else covers an LDS latency, so the fragments of step s + 1 are in flight under the MFMAs of step s;
+        // with two waves per SIMD (two workgroups per CU, or the 8-wave workgroup) the registers that costs are worth more than the prefetch
+        constexpr bool PF = NW == 4 && CS != 2;        // the 8-wave workgroup also has two waves per SIMD
         reads(0, a4, a2, d4, d2);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            // one wave per SIMD: nobody else covers an LDS latency, so the fragments of step s + 1 are in flight under the MFMAs of step s
             f32x4 nd4[TN], na4[TM];
             f32x2 nd2[TN], na2[TM];
 #pragma unroll
             for (int i = 0; i < TM; ++i) { na4[i] = a4[i]; na2[i] = a2[i]; }
 #pragma unroll
             for (int n = 0; n < TN; ++n) { nd4[n] = d4[n]; nd2[n] = d2[n]; }
-            if (s + 1 < KS) reads(s + 1, na4, na2, nd4, nd2);
+            if (PF && s + 1 < KS) reads(s + 1, na4, na2, nd4, nd2);
             float vv[TN][6];
 #pragma unroll
             for (int n = 0; n < TN; ++n) {
-                const float e0 = d4[n][0], e1 = d4[n][1], e2 = d4[n][2], e3 = d4[n][3], e4 = d2[n][0], e5 = d2[n][1];
-                const float ta = __builtin_fmaf(-4.f, e2, e4), tb = __builtin_fmaf(-4.f, e1, e3);
-                const float tc = e4 - e2, td = e3 - e1;
-                vv[n][0] = __builtin_fmaf(4.f, e0, __builtin_fmaf(-5.f, e2, e4));
-                vv[n][1] = ta + tb;
-                vv[n][2] = ta - tb;
-                vv[n][3] = __builtin_fmaf(2.f, td, tc);
-                vv[n][4] = __builtin_fmaf(-2.f, td, tc);
-                vv[n][5] = __builtin_fmaf(4.f, e1, __builtin_fmaf(-5.f, e3, e5));
+                if (W43_PACKED) {
+                    f32x2 v12, v34, v05;
+                    w43_input_xform((f32x2){d4[n][0], d4[n][1]}, (f32x2){d4[n][2], d4[n][3]}, d2[n], xka, xkb, xkc, v12, v34, v05);
+                    vv[n][0] = v05[0]; vv[n][1] = v12[0]; vv[n][2] = v12[1]; vv[n][3] = v34[0]; vv[n][4] = v34[1]; vv[n][5] = v05[1];
+                } else {
+                    const float e0 = d4[n][0], e1 = d4[n][1], e2 = d4[n][2], e3 = d4[n][3], e4 = d2[n][0], e5 = d2[n][1];
+                    const float ta = __builtin_fmaf(-4.f, e2, e4), tb = __builtin_fmaf(-4.f, e1, e3);
+                    const float tc = e4 - e2, td = e3 - e1;
+                    vv[n][0] = __builtin_fmaf(4.f, e0, __builtin_fmaf(-5.f, e2, e4));
+                    vv[n][1] = ta + tb;
+                    vv[n][2] = ta - tb;
+                    vv[n][3] = __builtin_fmaf(2.f, td, tc);
+                    vv[n][4] = __builtin_fmaf(-2.f, td, tc);
+                    vv[n][5] = __builtin_fmaf(4.f, e1, __builtin_fmaf(-5.f, e3, e5));
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -751,10 +784,14 @@ __device__ __forceinline__ void conv3x3_wino4_body(const float* __restrict__ in,
 #pragma unroll
                     for (int n = 0; n < TN; ++n)
                         acc[i][n][x] = __builtin_amdgcn_mfma_f32_32x32x2f32(x < 4 ? a4[i][x] : a2[i][x - 4], vv[n][x], acc[i][n][x], 0, 0, 0);
+            if (PF) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) { a4[i] = na4[i]; a2[i] = na2[i]; }
+                for (int i = 0; i < TM; ++i) { a4[i] = na4[i]; a2[i] = na2[i]; }
 #pragma unroll
-            for (int n = 0; n < TN; ++n) { d4[n] = nd4[n]; d2[n] = nd2[n]; }
+                for (int n = 0; n < TN; ++n) { d4[n] = nd4[n]; d2[n] = nd2[n]; }
+            } else if (s + 1 < KS) {
+                reads(s + 1, a4, a2, d4, d2);       // issued behind this step's MFMAs: the SIMD's other wave covers their latency
+            }
         }
     };
 
