@@ -1810,6 +1810,9 @@ __global__ __launch_bounds__(768) void conv3x3_wgrad_wino3_kernel(const float* _
 // 128 bytes apart) cover the 64 banks exactly once.  A DMA instruction fills 1 KiB = 8 channels x 8 positions; wave (wq, pw)
 // moves channel group 2 wq + pw of all six planes, so a lane only ever moves ONE logical slot, (lane & 7) ^ (lane >> 4 | 4 pw).
 // The slab holds [split][v][kw] planes; wgrad_reduce2d_kernel adds the splits and applies the row-pair output transform.
+#ifndef W4_CUT            // diagnostic builds: 1 no DMA in the loop (wrong results)
+#define W4_CUT 0
+#endif
 constexpr int G4_PLANE = 64 * 8 * 4;
 constexpr int G4_BUF = 8192;
 constexpr int G4_X0 = 0;
@@ -2065,7 +2068,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_wino2d_kernel(const float* 
             load(0, cur);                               // first: their latency runs under the DMA issue below
             if (q > 0 && (q & 31) == 0) fill(q + 32, 32);      // the ring's other half: segments q + 32 .. q + 63 (first read in segment q + 30)
             int last_piece = 0;
-            if (more) {
+            if (more && !(W4_CUT & 1)) {
                 const Entry e = entry(q + 1);
                 advance(es);
                 issue(decltype(cur_tag)::value ^ 1, e);
