@@ -76,8 +76,11 @@ size_t vocr_conv3x3_wino_pack_floats(int cout, int cin);
 int vocr_conv3x3_wino_pack_weights(const float* w, float* wpack_fwd, float* wpack_dgrad, int cout, int cin, void* stream);
 int vocr_conv3x3_wino_fwd(const float* x, const float* wpack, const float* bias, float* y,
                           int n, int cin, int h, int w, int cout, void* stream);
-/* Weight gradient with the transposed transform F(3,2) along the row (4 multiplications per column pair instead of 6): same
- * contract as vocr_conv3x3_wgrad (own workspace size), needs cin >= 4. */
+/* Weight gradient with the transposed minimal-filtering transform F(3,2) along the row and - when cin * cout is a multiple of 4 -
+ * across row pairs as well (16 multiplications per 2 x 2 block of gradient pixels and filter instead of 36; otherwise along the row
+ * only: 4 per column pair instead of 6): same contract as vocr_conv3x3_wgrad, needs cin >= 4; the workspace (ask
+ * vocr_conv3x3_wgrad_wino_workspace_bytes: it differs between the two forms) holds the split partial planes that a second kernel
+ * adds in a fixed order - the result is bitwise reproducible. */
 size_t vocr_conv3x3_wgrad_wino_workspace_bytes(int n, int cin, int h, int w, int cout);
 int vocr_conv3x3_wgrad_wino(const float* x, const float* dy, float* dw, void* workspace,
                             int n, int cin, int h, int w, int cout, void* stream);
