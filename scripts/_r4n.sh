@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-python scripts/sweep_corun.py 2>&1 | tail -30
+SWEEP_FIRST=1 python scripts/sweep_corun.py 2>&1 | tail -16

@@ -48,6 +48,29 @@ __device__ __forceinline__ void spin_body(float* out, int iters) {
             __builtin_amdgcn_s_sleep(4);      // 4 x 64 cycles
         }
         if (c0[0] + c1[3] == 123.456f) out[0] = c0[1];
+    } else if (KIND == 5) {   // 16x16x4 with the same pauses: 32 x 32 cycles, then 4 x 64 cycles free
+        f32x4 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c1, 0, 0, 0);
+                c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c2, 0, 0, 0);
+                c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c3, 0, 0, 0);
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        if (c0[0] + c1[3] + c2[1] + c3[2] == 123.456f) out[0] = c0[1];
+    } else if (KIND == 6) {   // 4x4x1 with the same pauses
+        f32x4 c[8] = {};
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int u = 0; u < 128; ++u) c[u & 7] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c[u & 7], 0, 0, 0);
+            __builtin_amdgcn_s_sleep(4);
+        }
+        float s = 0;
+        for (int u = 0; u < 8; ++u) s += c[u][0];
+        if (s == 123.456f) out[0] = s;
     } else {                  // 4x4x1 (16 blocks): 2 passes = 8 cycles
         f32x4 c[8] = {};
         for (int i = 0; i < iters; ++i) {
@@ -65,6 +88,8 @@ __global__ void spin1(float* out, int iters) { spin_body<1>(out, iters); }
 __global__ void spin2(float* out, int iters) { spin_body<2>(out, iters); }
 __global__ void spin3(float* out, int iters) { spin_body<3>(out, iters); }
 __global__ void spin4(float* out, int iters) { spin_body<4>(out, iters); }
+__global__ void spin5(float* out, int iters) { spin_body<5>(out, iters); }
+__global__ void spin6(float* out, int iters) { spin_body<6>(out, iters); }
 
 extern "C" int spin_launch(int kind, int blocks, int threads, int iters, float* out, void* stream) {
     hipStream_t s = (hipStream_t)stream;
@@ -72,6 +97,8 @@ extern "C" int spin_launch(int kind, int blocks, int threads, int iters, float* 
     else if (kind == 1) spin1<<<blocks, threads, 0, s>>>(out, iters);
     else if (kind == 3) spin3<<<blocks, threads, 0, s>>>(out, iters);
     else if (kind == 4) spin4<<<blocks, threads, 0, s>>>(out, iters);
+    else if (kind == 5) spin5<<<blocks, threads, 0, s>>>(out, iters);
+    else if (kind == 6) spin6<<<blocks, threads, 0, s>>>(out, iters);
     else spin2<<<blocks, threads, 0, s>>>(out, iters);
     return (int)hipGetLastError();
 }
