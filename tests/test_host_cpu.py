@@ -206,3 +206,24 @@ def test_optimizer_state_moves_between_flat_adam_and_torch_adam():
     # round-1 snapshots (flat moments) still load
     flat2.load_state_dict(dict(step=3, exp_avg=flat.exp_avg * 2, exp_avg_sq=flat.exp_avg_sq, param_groups=[dict(lr=5e-4)]))
     assert flat2.step_count == 3 and flat2.param_groups[0]["lr"] == 5e-4
+
+
+def test_bench_flop_accounting_of_the_minimal_filtering_kernels():
+    """bench.py's roofline leg: algorithmic FLOPs of a conv launch from its call arguments, and the share of them the kernel that the
+    library's dispatch picks actually executes (`achieved` is algorithmic, `executed_*` is reported beside it)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    args = lambda n, cin, h, w, cout: (0, 0, 0, 0, n, cin, h, w, cout, 0)
+    assert b.conv_flops(args(32, 256, 7, 294, 256)) == 2.0 * 32 * 7 * 294 * 256 * 256 * 9
+    # forward / data gradient: F(4,3) along the row from 128 output channels on (6 of 12 multiplications), F(2,3) below (4 of 6)
+    assert b.executed_share("vocr_conv3x3_wino_fwd", args(32, 128, 15, 420, 128)) == 0.5
+    assert b.executed_share("vocr_conv3x3_wino_fwd", args(32, 64, 30, 600, 64)) == pytest.approx(2.0 / 3.0)
+    # weight gradient: F(3,2) along the row and across row pairs: 16 of 36, times 2 ceil(H/2) / H for an odd height
+    assert b.executed_share("vocr_conv3x3_wgrad_wino", args(32, 64, 30, 600, 64)) == pytest.approx(4.0 / 9.0)
+    assert b.executed_share("vocr_conv3x3_wgrad_wino", args(32, 256, 7, 294, 256)) == pytest.approx(4.0 / 9.0 * 8.0 / 7.0)
+    assert b.executed_share("vocr_conv3x3_wgrad_wino", args(32, 5, 7, 294, 7)) == pytest.approx(2.0 / 3.0)      # Cin * Cout % 4 != 0: one-row kernel
+    assert b.executed_share("vocr_gemm", (0,) * 10) == 1.0
+    assert sorted(b.WORKLOADS) == ["c1", "c4", "c5"]
