@@ -1,10 +1,13 @@
-"""GPU box: bias_probe-style sweep timings with the in-tree library or an A/B build at scripts/_cut/libvocr.so (argv[1] == 'cut')."""
+"""GPU box: run another script of this directory with the in-tree library or with an A/B build at scripts/_cut/libvocr.so:
+python scripts/_lib_ab.py [cut] <script.py>"""
 import os, sys, runpy
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
 import vistaocr_amd._lib as L
-if len(sys.argv) > 1 and sys.argv[1] == "cut":
+args = sys.argv[1:]
+if args and args[0] == "cut":
     L.LIB_PATH = os.path.join(root, "scripts", "_cut", "libvocr.so")
+    args = args[1:]
 print("library:", L.LIB_PATH)
-sys.argv = [sys.argv[0]]
-runpy.run_path(os.path.join(root, "scripts", sys.argv[0] and "bias_probe.py"), run_name="__main__")
+sys.argv = [args[0]]
+runpy.run_path(os.path.join(root, "scripts", args[0]), run_name="__main__")

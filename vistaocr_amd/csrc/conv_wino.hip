@@ -536,6 +536,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino2_kernel_64(const float* _
 // segments are staged by that wave alone (no other wave reads them); the weights of a stage (4 input channels: 12 filter rows of
 // CO_T x 6 transformed values, as [row][co][4] + [row][co][2] so that a fragment is one 16-byte and one 8-byte read) arrive by
 // LDS-DMA for all four waves, two stages.
+#ifndef W43_CUT            // diagnostic builds: 1 no DMA / halo loads in the loop (wrong results)
+#define W43_CUT 0
+#endif
 #ifndef W43_PACKED         // 0: the scalar twelve-instruction input transform (A/B builds)
 #define W43_PACKED 1
 #endif
@@ -801,15 +804,13 @@ __device__ __forceinline__ void conv3x3_wino4_body(const float* __restrict__ in,
     store_patch(0);
     for (int h = 0; h < nh; h += 2) {
         __syncthreads();                            // buffer 0 complete (DMA drained: vmcnt(0)), buffer 1 free
-        dma_weights((h + 1) * CS, 1);
-        load_patch((h + 1) * CS, 1);
+        if (!(W43_CUT & 1)) { dma_weights((h + 1) * CS, 1); load_patch((h + 1) * CS, 1); }
         kloop(0);
-        store_patch(1);
+        if (!(W43_CUT & 1)) store_patch(1);
         __syncthreads();                            // buffer 1 complete, buffer 0 free
-        dma_weights((h + 2) * CS, 0);               // past the last channel: out of range / null resource, never used
-        load_patch((h + 2) * CS, 0);
+        if (!(W43_CUT & 1)) { dma_weights((h + 2) * CS, 0); load_patch((h + 2) * CS, 0); }      // past the last channel: out of range / null resource, never used
         kloop(1);
-        store_patch(0);
+        if (!(W43_CUT & 1)) store_patch(0);
     }
 
     // ---- output transform and stores: lane li = quad, 4 pixels 4k .. 4k+3
