@@ -29,6 +29,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 matrix peak (= vector peak)
+F16_MFMA_PEAK_TFLOPS = 2500.0    # same guide: BF16/F16 MFMA ~2.5 PF dense (never the 2:1-sparsity figure)
 HBM_PEAK_GBS = 8000.0
 
 HP = dict(num_in_channels=1, input_line_height=30, rds_line_height=30, lstm_input_dim=128, num_lstm_layers=3,
@@ -140,11 +141,12 @@ def lstm_flops(args, first_dim_arg):
 
 
 # MFMA FLOPs a launch EXECUTES per algorithmic FLOP: the F(2,3) kernels issue 4 multiplications where the direct form needs 6, the
-# F(4,3) kernel (forward / data-gradient launches with >= 128 output channels unless VOCR_CONV_WINO4=0) 6 where it needs 12
-_WINO4 = os.environ.get("VOCR_CONV_WINO4", "1") != "0"
-# the weight gradient (default VOCR_WGRAD_WINO_DMA=3) applies F(3,2) along the row AND across row pairs: 16 multiplications where the
-# direct form needs 36, times 2 ceil(H/2) / H (an odd height's last pair is half empty); modes <= 2: along the row only
-_WGRAD2D = os.environ.get("VOCR_WGRAD_WINO_DMA", "3") == "3"
+# F(4,3) kernel (forward / data-gradient launches with >= 128 output channels) 6 where it needs 12.  The shipped library has one code
+# path per shape (the kernel-variant switches exist only in -DVOCR_EXPERIMENTS builds), so these are constants of the product
+_WINO4 = True
+# the weight gradient applies F(3,2) along the row AND across row pairs: 16 multiplications where the direct form needs 36, times
+# 2 ceil(H/2) / H (an odd height's last pair is half empty)
+_WGRAD2D = True
 
 
 def executed_share(name, args):
@@ -154,18 +156,30 @@ def executed_share(name, args):
         h = args[6]
         return (4.0 / 9.0) * (2.0 * ((h + 1) // 2) / h) if (_WGRAD2D and (args[5] * args[8]) % 4 == 0) else 2.0 / 3.0
     return 1.0
+def lstm_packed_flops(args, h_arg):
+    h, rows = args[h_arg], args[h_arg + 1]       # packed rows (include/vocr.h): the frames the sweep computes, plus the zero groups
+    return 2.0 * 2 * rows * h * 4 * h
+
+
 FLOPS_OF = {"vocr_conv3x3_fwd": conv_flops, "vocr_conv3x3_wino_fwd": conv_flops, "vocr_conv3x3_wgrad": conv_flops,
-            "vocr_conv3x3_wgrad_wino": conv_flops, "vocr_gemm": gemm_flops, "vocr_gemm_pair": gemm_pair_flops,
+            "vocr_conv3x3_wgrad_wino": conv_flops, "vocr_conv3x3_f16_fwd": conv_flops, "vocr_conv3x3_wgrad_f16": conv_flops,
+            "vocr_gemm": gemm_flops, "vocr_gemm_pair": gemm_pair_flops,
             "vocr_lstm_fwd": lambda a: lstm_flops(a, 8), "vocr_lstm_fwd_range": lambda a: lstm_flops(a, 8),
-            "vocr_lstm_bwd_bias": lambda a: lstm_flops(a, 9)}
+            "vocr_lstm_bwd_bias": lambda a: lstm_flops(a, 9),
+            "vocr_lstm_fwd_packed": lambda a: lstm_packed_flops(a, 10), "vocr_lstm_bwd_packed": lambda a: lstm_packed_flops(a, 12)}
+_F16_CONV = "conv3x3 with fp16 operands, fp32 accumulate (conv3x3_f16_kernel forward + data gradient, conv3x3_wgrad_f16_kernel; v_mfma_f32_32x32x16_f16)"
+# a family's own roofline where it is not the f32 matrix pipe
+FAMILY_PEAK = {_F16_CONV: F16_MFMA_PEAK_TFLOPS}
 FAMILY = {"vocr_conv3x3_fwd": "conv3x3 forward + data gradient (conv3x3_wino4 / conv3x3_wino2 kernels: F(4,3) / F(2,3) along the row)",
           "vocr_conv3x3_wino_fwd": "conv3x3 forward + data gradient (conv3x3_wino4 / conv3x3_wino2 kernels: F(4,3) / F(2,3) along the row)",
           "vocr_conv3x3_wgrad": "conv3x3 weight gradient (conv3x3_wgrad_wino2d_kernel: F(3,2) along the row and across row pairs, piece stream)",
           "vocr_conv3x3_wgrad_wino": "conv3x3 weight gradient (conv3x3_wgrad_wino2d_kernel: F(3,2) along the row and across row pairs, piece stream)",
           "vocr_gemm": "dense GEMMs (gemm_dma_kernel / gemm_f32_kernel behind vocr_gemm and vocr_gemm_pair: bridge, LSTM projections, prob, their dX / dW)",
           "vocr_gemm_pair": "dense GEMMs (gemm_dma_kernel / gemm_f32_kernel behind vocr_gemm and vocr_gemm_pair: bridge, LSTM projections, prob, their dX / dW)",
+          "vocr_conv3x3_f16_fwd": _F16_CONV, "vocr_conv3x3_wgrad_f16": _F16_CONV,
           "vocr_lstm_fwd": "LSTM sweeps (lstm_fwd_chain4w / lstm_bwd_chain4w)", "vocr_lstm_fwd_range": "LSTM sweeps (lstm_fwd_chain4w / lstm_bwd_chain4w)",
-          "vocr_lstm_bwd_bias": "LSTM sweeps (lstm_fwd_chain4w / lstm_bwd_chain4w)"}
+          "vocr_lstm_bwd_bias": "LSTM sweeps (lstm_fwd_chain4w / lstm_bwd_chain4w)",
+          "vocr_lstm_fwd_packed": "LSTM sweeps (lstm_fwd_chain4w / lstm_bwd_chain4w)", "vocr_lstm_bwd_packed": "LSTM sweeps (lstm_fwd_chain4w / lstm_bwd_chain4w)"}
 
 
 def gemm_alone(hidden, din=128):
@@ -445,8 +459,11 @@ def run_rank(args):
             dist.barrier()
         torch.cuda.synchronize()
 
-    MFMA_NAMES = ["vocr_conv3x3_fwd", "vocr_conv3x3_wino_fwd", "vocr_conv3x3_wgrad", "vocr_conv3x3_wgrad_wino", "vocr_gemm", "vocr_gemm_pair",
-                  "vocr_lstm_fwd", "vocr_lstm_fwd_range", "vocr_lstm_bwd_bias"]
+    MFMA_NAMES = ["vocr_conv3x3_fwd", "vocr_conv3x3_wino_fwd", "vocr_conv3x3_wgrad", "vocr_conv3x3_wgrad_wino", "vocr_conv3x3_f16_fwd",
+                  "vocr_conv3x3_wgrad_f16", "vocr_gemm", "vocr_gemm_pair", "vocr_lstm_fwd", "vocr_lstm_fwd_range", "vocr_lstm_bwd_bias",
+                  "vocr_lstm_fwd_packed", "vocr_lstm_bwd_packed"]
+
+    rank_dt = [0.0, 0.0]          # [min, max] over ranks of the last timed loop's wall time
 
     def timed(batch, steps, event_every=None):
         barrier()
@@ -459,10 +476,13 @@ def run_rank(args):
             loss = va.train(batch, model, crit, opt)       # the function the reference calls; returns the loss float
         barrier()
         dt = time.perf_counter() - t0
+        rank_dt[0] = rank_dt[1] = dt
         if use_dist:
-            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            # the contract's number is the MAX over ranks; the MIN beside it makes a straggler visible in the one line the driver keeps
+            tt = torch.tensor([dt, -dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
+            dt = float(tt[0].item())
+            rank_dt[0], rank_dt[1] = -float(tt[1].item()), dt
         return dt, loss
 
     for _ in range(args.warmup):
@@ -490,7 +510,8 @@ def run_rank(args):
     opt.time_comm(False)
     names = MFMA_NAMES + ["vocr_bn_train_stats", "vocr_bn_relu_apply", "vocr_bn_relu_fracpool2x2_fwd", "vocr_bn_train_relu_apply",
                           "vocr_bn_train_relu_fracpool2x2_fwd", "vocr_bn_relu_bwd",
-                          "vocr_fracpool2x2_bwd", "vocr_bn_relu_fracpool2x2_bwd", "vocr_ctc_loss_grad", "vocr_clamp_adam", "vocr_bchw_to_wbch", "vocr_wbch_to_bchw"]
+                          "vocr_fracpool2x2_bwd", "vocr_bn_relu_fracpool2x2_bwd", "vocr_ctc_loss_grad", "vocr_clamp_adam", "vocr_bchw_to_wbch", "vocr_wbch_to_bchw",
+                          "vocr_relu_maxpool2_fwd", "vocr_relu_maxpool2_bwd", "vocr_gather_rows", "vocr_dropout_fwd", "vocr_mul"]
     _lib.enable_timing(names)
     for _ in range(PROFILE_STEPS):
         va.train(batch_dev, model, crit, opt)
@@ -534,10 +555,11 @@ def run_rank(args):
             for k, f in fam.items():
                 tf = f["flop"] / (f["ms"] * 1e-3) / 1e12 if f["ms"] > 0 else 0.0
                 xf = f["exe"] / (f["ms"] * 1e-3) / 1e12 if f["ms"] > 0 else 0.0
+                pk = FAMILY_PEAK.get(k, peak)
                 outf[k] = dict(ms_per_step=round(f["ms"] / per_step_div, 3), launches_per_step=f["n"] // per_step_div,
                                avg_launch_ms=round(f["ms"] / max(1, f["n"]), 4), launches_timed=f["n"],
-                               algorithmic_gflop_per_step=round(f["flop"] / per_step_div / 1e9, 1),
-                               achieved=round(tf, 2), frac=round(tf / peak, 4), executed_achieved=round(xf, 2), executed_frac=round(xf / peak, 4))
+                               algorithmic_gflop_per_step=round(f["flop"] / per_step_div / 1e9, 1), peak=pk,
+                               achieved=round(tf, 2), frac=round(tf / pk, 4), executed_achieved=round(xf, 2), executed_frac=round(xf / pk, 4))
             return outf
 
         fams = fam_stats(timed_recs, sampled_steps)
@@ -560,14 +582,21 @@ def run_rank(args):
         # whole step: algorithmic and executed MFMA FLOPs from the shapes of the calls the step made (un-timed profile pass)
         step_flop = sum(FLOPS_OF[n_](a) for n_ in MFMA_NAMES for a, _, _ in prof.get(n_, [])) / PROFILE_STEPS
         step_exe = sum(FLOPS_OF[n_](a) * executed_share(n_, a) for n_ in MFMA_NAMES for a, _, _ in prof.get(n_, [])) / PROFILE_STEPS
-        traffic = None
-        try:        # HBM-side bytes per launch from the committed PMC passes (cannot be collected live), keyed by kernel family
+        traffic, traffic_note = None, None
+        try:        # HBM-side bytes per launch from the committed PMC passes (cannot be collected live), keyed by kernel family AND tied to
+                    # the kernels they were measured on: the file carries the csrc tree hash of that run (vistaocr_amd.build.tree_hash)
+            from vistaocr_amd import build as _build
             tj = json.load(open(os.path.join(ROOT, "profiles", "kernel_traffic.json")))
             ent = tj.get(dom[0])
-            if ent:
+            if args.config != "c1":
+                traffic_note = "profiles/kernel_traffic.json was measured on configs[1]; not applicable to this workload"
+            elif tj.get("csrc_tree_hash") != _build.tree_hash():
+                traffic_note = ("traffic_stale: profiles/kernel_traffic.json was measured on csrc tree %s, this library is %s - rerun scripts/_prof.sh"
+                                % (str(tj.get("csrc_tree_hash"))[:12], _build.tree_hash()[:12]))
+            elif ent:
                 traffic = int((ent["fetch_KB_per_launch"] + ent["write_KB_per_launch"]) * 1024)
-        except Exception:
-            pass
+        except Exception as e:
+            traffic_note = "profiles/kernel_traffic.json unreadable: %s" % e
         breakdown = {}
         for name, lst in prof.items():
             if lst:
@@ -587,6 +616,8 @@ def run_rank(args):
                        "final_loss": round(float(final_loss), 3), "per_rank_rng": "seed 1234 + 1000*rank after an identical init"},
             "resident_input": {"value": round(B * world * args.steps / dt_res, 2), "ms_per_step": round(1000.0 * dt_res / args.steps, 3),
                                "what": "same K steps with the image batch already in HBM (no H2D inside train()); runs before the headline loop"},
+            "ms_per_step_ranks": {"min": round(1000.0 * rank_dt[0] / args.steps, 3), "max": round(1000.0 * rank_dt[1] / args.steps, 3),
+                                  "what": "slowest and fastest rank's wall time per step over the timed loop (ms_per_step is the max): a gap = a straggler"},
             "allreduce_ms_per_step": comm_ms,
             "host_enqueue_ms_per_step": {"mean": round(sum(enq) / len(enq), 3), "min": round(min(enq), 3), "share_of_step": round(sum(enq) / len(enq) / ms, 3),
                                          "what": "wall time of train_async() (enqueue only, no loss readback) on an idle queue, 4 steps, no profiler"},
@@ -595,8 +626,8 @@ def run_rank(args):
                                             "MFMA families in every %d-th timed step; families overlap on two streams, so their times add up to more "
                                             "than the step, and a side-stream launch's duration includes waiting for CUs that a persistent LSTM sweep holds: "
                                             "gemm_launches_alone has the same launches alone on the chip)" % max(1, args.event_every),
-                         "achieved": dom[1]["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": dom[1]["frac"],
-                         "executed_frac": dom[1]["executed_frac"], "traffic": traffic,
+                         "achieved": dom[1]["achieved"], "peak": dom[1].get("peak", peak), "unit": "TFLOP/s", "frac": dom[1]["frac"],
+                         "executed_frac": dom[1]["executed_frac"], "traffic": traffic, "traffic_note": traffic_note,
                          "avg_launch_ms": dom[1]["avg_launch_ms"], "launches_per_step": dom[1]["launches_per_step"],
                          "launches_timed": dom[1]["launches_timed"],
                          "dominant_by_time": dom[0], "families_in_step": fams, "conv_forward_alone": conv_fwd,
@@ -604,7 +635,9 @@ def run_rank(args):
                          "whole_step": {"flop": round(step_flop), "executed_flop": round(step_exe),
                                         "achieved": round(step_flop / (ms * 1e-3) / 1e12, 2), "frac": round(step_flop / (ms * 1e-3) / 1e12 / peak, 4),
                                         "executed_frac": round(step_exe / (ms * 1e-3) / 1e12 / peak, 4),
-                                        "what": "algorithmic / executed MFMA FLOPs of one step (from the shapes of the step's own calls) over ms_per_step"}},
+                                        "what": "algorithmic / executed MFMA FLOPs of one step (from the shapes of the step's own calls) over ms_per_step, against "
+                                                "the f32 matrix peak" + ("" if conv_dtype == "fp32" else " - the fp16-operand conv launches of this configuration run on "
+                                                "the 16x faster fp16 pipe, so this fraction mixes two rooflines: read families_in_step")}},
             "ms_per_step_by_entry_point": breakdown,
         }
         if want_cpu:

@@ -39,9 +39,10 @@ extern "C" {
 const char* vocr_last_error(void);
 /* The contract this header describes.  History: 2 = round 2 (caller-owned health word); 3 = round 3/4 (health words report-only and
  * cleared by the caller, LSTM workspace survives between the vocr_lstm_fwd_range calls of a sweep, larger vocr_gemm_workspace_bytes,
- * vocr_gemm_pair / vocr_lstm_bwd_parts / vocr_profile_range_*, x-fastest conv weight pack).  A binding compares vocr_abi_version()
+ * vocr_gemm_pair / vocr_lstm_bwd_parts / vocr_profile_range_*, x-fastest conv weight pack); 4 = round 5 (packed sequence rows:
+ * vocr_lstm_*_packed, vocr_seq_rowmap, vocr_gather_rows; VOCR_LSTM_SWEEP validated; experiment switches compiled out).  A binding compares vocr_abi_version()
  * with the VOCR_ABI_VERSION it was written against and refuses a library that answers anything else. */
-#define VOCR_ABI_VERSION 3
+#define VOCR_ABI_VERSION 4
 int  vocr_abi_version(void);
 /* Named ranges on the profiler's timeline (rocprofv3 --marker-trace), nested push / pop on the calling thread.  roctx is dlopen'ed on
  * first use; returns 0 when the range was recorded, 1 when roctx is not available (not an error), negative on a bad argument.  The
@@ -213,7 +214,11 @@ int vocr_dropout_fwd(const float* x, float* out, float* mask, size_t count, floa
  * a tile of a length-sorted batch is itself a valid packed batch - vistaocr_amd.CnnOcrModel does that).  For H in {64,128,256,512} a whole sweep is ONE persistent launch whose workgroups
  * hand h_t (forward) / partial sums (backward) to each other through memory: it needs its grid (<= two workgroups per CU)
  * co-resident, so do not run two sweeps concurrently on one device; a hand-off that times out (seconds) poisons the
- * output with NaN instead of hanging.  VOCR_LSTM_PERSISTENT=0 selects one launch per time step instead.
+ * output with NaN instead of hanging.  Environment: VOCR_LSTM_SWEEP=step selects one launch per time step instead (several processes
+ * sharing one GPU; VOCR_LSTM_PERSISTENT=0 is accepted as the old spelling), VOCR_LSTM_SWEEP=wide4|chain4|chain16 starts the kernel
+ * search at that kind (A/B, tests), an unknown value makes the call fail with VOCR_EINVAL; VOCR_LSTM_WRITE_THROUGH=1 forces the
+ * hand-off mode of a chain whose workgroups are spread over several XCDs.  These are the library's only runtime switches: the
+ * kernel-variant experiments of scripts/ exist only in -DVOCR_EXPERIMENTS builds.
  * `health` (may be NULL): see the note on health words at the top; the timeout flag the sweep itself tests lives in the workspace
  * (an implementation detail: callers watch `health`). */
 size_t vocr_lstm_workspace_bytes(int t, int b, int h);
@@ -245,6 +250,33 @@ int vocr_lstm_bwd_parts(const float* dy, const float* dy_mask, const float* whht
                         const float* gates, const float* cell, float* dgates, void* workspace, int t, int b, int h,
                         int32_t* health, void* stream);
 int vocr_lstm_bias_from_parts(float* dbias, const void* workspace, int t, int b, int h, void* stream);
+
+/* ---- the same recurrence without the padding: pack_padded_sequence's economy — src/models/cnnlstm.py:285-290 ---------- */
+/* The reference packs the length-sorted batch before nn.LSTM, so cuDNN never computes a padded frame.  Here the rows of every
+ * sequence-side tensor (bridge output, xproj, y, gates, cell, dy, dgates) can be kept in a PACKED, chain-major order instead of
+ * [T][B]: batch rows are taken in chains of 4 (4c .. 4c+3; sorted lengths make lens[4c] the chain's longest, L_c); a GROUP is one
+ * time step of one chain = 4 consecutive rows; the groups are [zero][chain 0: L_0 groups, t ascending][zero][chain 1: L_1]...[zero]:
+ *     rows = 4 * (sum_c L_c + chains + 1),      row(t, b) = 4 * (1 + c + sum_{c' < c} L_c' + t) + (b & 3)   for t < L_c, c = b >> 2.
+ * All GEMMs of the LSTM stack then run over `rows` rows instead of T*B, the recurrent weight gradient is still ONE product of
+ * row-shifted views (shift 4: the all-zero group in front of / behind a chain is its h_{-1} / h_{L_c}), and a chain's workgroups leave
+ * a sweep after their own L_c steps.  Contract: the caller zero-fills y before vocr_lstm_fwd_packed and dgates before
+ * vocr_lstm_bwd_packed (the zero groups, a last chain's rows >= B and nothing else stay untouched by the sweeps); rows of a chain past
+ * their own length are written as zeros like in the dense layout.  Results per frame are those of the dense entry points (same
+ * kernels, same summation orders).  Shapes: ask vocr_lstm_packed_supported (B <= 32, H in {256, 512} on a device that can hold the
+ * persistent sweep); otherwise use the dense entry points above.
+ * vocr_seq_rowmap builds both index maps on the device from lens: to_packed[T*B] (packed row of frame (t, b), -1: none) and
+ * to_dense[rows] (t*B + b of a packed row, -1: zero group / beyond B); either may be NULL.  vocr_gather_rows moves rows through such a
+ * map: dst[r][0..n) = src[map[r]][0..n), or fill[0..n) (NULL: zeros) where map[r] < 0 — packing (map = to_dense, nrows = rows) and
+ * unpacking (map = to_packed, nrows = T*B; fill = the output layer's bias reproduces the reference's logits of a padded frame). */
+int vocr_lstm_packed_supported(int b, int h);
+int vocr_seq_rowmap(const int32_t* lens, int t, int b, int rows, int32_t* to_packed, int32_t* to_dense, void* stream);
+int vocr_gather_rows(const float* src, float* dst, const int32_t* map, long nrows, int n, const float* fill, void* stream);
+int vocr_lstm_fwd_packed(const float* xproj, const float* whh_fwd, const float* whh_rev, const int32_t* lens, float* y,
+                         float* gates, float* cell, void* workspace, int t, int b, int h, int rows, int32_t* health, void* stream);
+/* dy_mask (may be NULL) as in vocr_lstm_bwd_parts; dbias (may be NULL) as in vocr_lstm_bwd_bias */
+int vocr_lstm_bwd_packed(const float* dy, const float* dy_mask, const float* whht_fwd, const float* whht_rev, const int32_t* lens,
+                         const float* gates, const float* cell, float* dgates, float* dbias, void* workspace, int t, int b, int h,
+                         int rows, int32_t* health, void* stream);
 
 /* ---- CTC: warpctc_pytorch.CTCLoss — src/train_cnn_lstm.py:358,138 ------------------------------------------ */
 /* logits[T][B][V] pre-softmax, blank = 0.  labels flat int32 (device), label_offsets[B], label_lens[B],

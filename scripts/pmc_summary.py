@@ -109,9 +109,15 @@ def traffic_json(fetch_csv, write_csv, out_path):
     res["_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py --steps 2 --warmup 1; fetch_KB_per_launch = 2 x FETCH_SIZE "
                     "(gfx950 reports 1/2 of streamed read bytes: MI355X_MICROARCH.md, calibrated here with scripts/fetch_calib.hip), WRITE_SIZE exact; "
                     "per launch, averaged over all launches of the family in the profiled steps")
+    # tie the numbers to the kernels they were measured on: bench.py reports traffic: null + a traffic_stale note when the library it
+    # runs was built from another csrc tree
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from vistaocr_amd import build as _build
+    res["csrc_tree_hash"] = _build.tree_hash()
     json.dump(res, open(out_path, "w"), indent=1)
     for fam, e in res.items():
-        if fam != "_note":
+        if isinstance(e, dict):
             print("%-60s fetch %9.1f KB (2 x %9.1f)  write %9.1f KB  per launch, n=%d" % (fam[:60], e["fetch_KB_per_launch"], e.get("fetch_KB_per_launch_reported", 0),
                                                                                           e["write_KB_per_launch"], e["launches_profiled"]))
 

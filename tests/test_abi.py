@@ -23,8 +23,8 @@ def test_library_builds_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "libvocr.so does not export %s" % name
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
-    assert lib.vocr_abi_version() == _lib.ABI_VERSION == 3
-    assert re.search(r"#define VOCR_ABI_VERSION\s+3\b", open(os.path.join(ROOT, "include", "vocr.h")).read())
+    assert lib.vocr_abi_version() == _lib.ABI_VERSION == 4
+    assert re.search(r"#define VOCR_ABI_VERSION\s+4\b", open(os.path.join(ROOT, "include", "vocr.h")).read())
 
 
 def test_stale_or_foreign_library_is_refused(monkeypatch):
@@ -45,16 +45,32 @@ def test_build_is_gated_by_a_hash_not_by_file_times(tmp_path, monkeypatch):
     import os as _os
     from vistaocr_amd import build
     build.build()
-    assert build._stale(build._tree_hash(build._hipcc())) is None
+    cid = build._compiler_id(build._hipcc())
+    assert build._stale(build._tree_hash(), cid) is None
     build.build()
     assert build.build_report()["built"] is False
     _os.utime(_os.path.join(build.CSRC, "misc.cpp"), None)                     # newer source file, same content: still up to date
-    assert build._stale(build._tree_hash(build._hipcc())) is None
-    assert build._stale("0" * 64) == "sources, flags or compiler changed"      # another tree hash: stale
+    assert build._stale(build._tree_hash(), cid) is None
+    assert build._stale("0" * 64, cid) == "sources or flags changed"           # another tree hash: stale
+    assert build._stale(build._tree_hash(), "0" * 64) == "compiler changed"    # another hipcc: stale
     stamp = json.load(open(build.STAMP))
     monkeypatch.setattr(build, "STAMP", str(tmp_path / "stamp.json"))
     json.dump(dict(stamp, lib="0" * 64), open(build.STAMP, "w"))
-    assert build._stale(stamp["tree"]) == "library is not the one the stamp describes"
+    assert build._stale(stamp["tree"], cid) == "library is not the one the stamp describes"
+
+
+def test_host_without_hipcc_accepts_the_shipped_library(monkeypatch):
+    """with no compiler on the host the hash could never equal the build box's stamp (the compiler's version string was
+    part of it) and build() raised 'hipcc not found' on an up-to-date tree.  Sources / flags and compiler are separate stamp fields now."""
+    from vistaocr_amd import build
+    build.build()
+    monkeypatch.setattr(build, "_hipcc", lambda: None)
+    assert build._stale(build._tree_hash(), None) is None
+    assert build.build() == build.LIB
+    assert build.build_report() == {"built": False, "reason": "no compiler here, shipped binary matches sources and flags"}
+    monkeypatch.setattr(build, "_tree_hash", lambda: "0" * 64)                 # sources really differ: only then is the compiler missed
+    with pytest.raises(RuntimeError, match="hipcc not found"):
+        build.build()
 
 
 def test_argument_validation_without_gpu():

@@ -1,0 +1,184 @@
+"""GPU: the packed sequence rows of include/vocr.h (pack_padded_sequence's economy, src/models/cnnlstm.py:285-290) against the dense
+time-major path of the same library - the dense path is what every oracle test holds to the reference; the config-4 oracle cases of
+tests/test_configs_gpu.py run packed by default and hold the packed path to the oracle directly.
+  * vocr_seq_rowmap against the layout's definition written out in Python (B not a multiple of 4, T above max(len), chains of equal length);
+  * vocr_gather_rows: packing and unpacking with and without a fill row;
+  * one BiLSTM layer, packed vs dense, on the 4-row sweeps of every shape class (wide members, 4-wave members at B <= 16 and at H = 256,
+    a partial last chain): y / dx on every real frame and all weight gradients;
+  * the whole model on a ragged batch: logits (padded frames = the output layer's bias, bit for bit), loss, greedy labels, every gradient."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _layout(lens, T, B):
+    """The definition (include/vocr.h): groups [zero][chain 0][zero][chain 1]...[zero], 4 rows per group."""
+    nch = (B + 3) // 4
+    to_packed = -np.ones(T * B, dtype=np.int64)
+    g = 1
+    rows = 4 * (sum(min(lens[4 * c], T) for c in range(nch)) + nch + 1)
+    to_dense = -np.ones(rows, dtype=np.int64)
+    for c in range(nch):
+        L = min(lens[4 * c], T)
+        for t in range(L):
+            for j in range(4):
+                b = 4 * c + j
+                if b < B:
+                    to_packed[t * B + b] = 4 * (g + t) + j
+                    to_dense[4 * (g + t) + j] = t * B + b
+        g += L + 1
+    return rows, to_packed, to_dense
+
+
+@pytest.mark.parametrize("lens,T", [([9, 9, 7, 7, 7, 3, 2, 2, 1], 9), ([5] * 8, 5), ([6, 5, 4, 3, 2, 1], 8), ([12], 12),
+                                    ([40, 40, 40, 39, 31, 31, 30, 22, 22, 22, 22, 21, 9, 9, 9, 8, 8, 8, 8, 8, 7, 7, 5, 5, 4, 4, 4, 3, 2, 2, 1, 1], 40)])
+def test_rowmap_is_the_documented_layout(dev, lens, T):
+    from vistaocr_amd import ops
+    B = len(lens)
+    lens_dev = torch.tensor(lens, dtype=torch.int32, device=dev)
+    maps = ops.SeqRowMaps(lens_dev, lens, T, B)
+    rows, tp, td = _layout(lens, T, B)
+    assert maps.rows == rows == ops.packed_row_count([min(v, T) for v in lens], B)
+    assert maps.to_packed.cpu().tolist() == tp.tolist()
+    assert maps.to_dense.cpu().tolist() == td.tolist()
+    # the two maps are inverse to each other on the frames that exist
+    live = tp >= 0
+    assert (td[tp[live]] == np.nonzero(live)[0]).all()
+
+
+@pytest.mark.parametrize("n", [128, 96, 7])
+def test_gather_rows_packs_and_unpacks(dev, n):
+    from vistaocr_amd import ops
+    lens, T = [11, 10, 10, 6, 6, 2], 11
+    B = len(lens)
+    maps = ops.SeqRowMaps(torch.tensor(lens, dtype=torch.int32, device=dev), lens, T, B)
+    x = torch.randn(T * B, n, device=dev)
+    fill = torch.randn(n, device=dev)
+    packed = ops.gather_rows(x, maps.to_dense, maps.rows)
+    _, tp, td = _layout(lens, T, B)
+    ref = torch.zeros(maps.rows, n)
+    ref[td >= 0] = x.cpu()[td[td >= 0]]
+    assert torch.equal(packed.cpu(), ref)
+    back = ops.gather_rows(packed, maps.to_packed, T * B, fill)
+    ref2 = fill.cpu().repeat(T * B, 1)
+    ref2[tp >= 0] = x.cpu()[tp >= 0]
+    assert torch.equal(back.cpu(), ref2)
+    # autograd: the backward of packing is unpacking with zeros
+    xg = x.clone().requires_grad_(True)
+    y = ops.GatherRowsFn.apply(xg, maps.to_dense, maps.to_packed, maps.rows)
+    g = torch.randn_like(y)
+    y.backward(g)
+    refg = torch.zeros(T * B, n)
+    refg[tp >= 0] = g.cpu()[tp[tp >= 0]]
+    assert torch.equal(xg.grad.cpu(), refg)
+
+
+def _layer_params(din, H, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    mk = lambda *s: ((torch.rand(*s, generator=g) - 0.5) * 0.16).to(dev).requires_grad_(True)
+    return [mk(4 * H, din), mk(4 * H, H), mk(4 * H), mk(4 * H), mk(4 * H, din), mk(4 * H, H), mk(4 * H), mk(4 * H)]
+
+
+@pytest.mark.parametrize("B,H,T,lens", [
+    (32, 512, 37, [37, 37, 36, 30, 30, 29, 29, 29, 22, 22, 21, 21, 20, 20, 20, 15, 15, 14, 12, 12, 11, 9, 9, 9, 6, 5, 5, 4, 3, 2, 2, 1]),   # wide members
+    (12, 512, 29, [29, 25, 25, 24, 17, 16, 16, 9, 8, 3, 2, 1]),                                                                    # 4-wave members
+    (30, 512, 21, [21] * 5 + [14] * 9 + [8] * 10 + [3] * 6),                                                                        # partial last chain
+    (7, 256, 18, [18, 18, 11, 10, 4, 4, 2]),                                                                                        # H = 256, partial chain
+    (20, 256, 16, [16, 16, 15, 15, 12, 12, 12, 11, 9, 9, 8, 8, 6, 5, 5, 4, 3, 3, 2, 1]),
+])
+def test_bilstm_layer_packed_matches_dense(dev, B, H, T, lens):
+    from vistaocr_amd import _lib, ops
+    assert _lib.load().vocr_lstm_packed_supported(B, H) == 1
+    din = 64
+    lens_dev = torch.tensor(lens, dtype=torch.int32, device=dev)
+    maps = ops.SeqRowMaps(lens_dev, lens, T, B)
+    g = torch.Generator().manual_seed(3)
+    x = ((torch.rand(T * B, din, generator=g) - 0.5) * 2).to(dev)
+    dy = ((torch.rand(T * B, 2 * H, generator=g) - 0.5) * 0.1).to(dev)
+    valid = (torch.arange(T).unsqueeze(1) < torch.tensor(lens).unsqueeze(0)).reshape(T * B).to(dev)
+    res = {}
+    for mode in ("dense", "packed"):
+        ps = _layer_params(din, H, 5, dev)
+        xg = x.clone().requires_grad_(True)
+        if mode == "dense":
+            y = ops.BiLstmLayerFn.apply(xg, lens_dev, T, B, *ps, None, False)
+        else:
+            xp = ops.GatherRowsFn.apply(xg, maps.to_dense, maps.to_packed, maps.rows)
+            yp = ops.BiLstmLayerFn.apply(xp, lens_dev, T, B, *ps, None, False, 0.0, 0, maps.rows)
+            y = ops.GatherRowsFn.apply(yp, maps.to_packed, maps.to_dense, T * B)
+        y.backward(dy)
+        torch.cuda.synchronize()
+        res[mode] = (y.detach(), xg.grad.detach(), [p.grad.detach() for p in ps])
+    yd, dxd, gd = res["dense"]
+    yp, dxp, gp = res["packed"]
+    assert float(yd[~valid].abs().max()) == 0.0 and float(yp[~valid].abs().max()) == 0.0        # zeros past a sequence's length, both layouts
+    # same kernels and summation orders per frame; only the x-projection / gradient GEMMs tile another row count
+    assert float((yd - yp).abs().max()) <= 2e-6 * float(yd.abs().max()) + 1e-7
+    assert float((dxd - dxp)[valid].abs().max()) <= 2e-5 * float(dxd.abs().max())
+    for nm, a, b in zip(("w_ih_f", "w_hh_f", "b_ih_f", "b_hh_f", "w_ih_r", "w_hh_r", "b_ih_r", "b_hh_r"), gd, gp):
+        rel = float((a - b).norm() / (a.norm() + 1e-30))
+        assert rel <= 2e-5, (nm, rel)
+
+
+@pytest.mark.parametrize("drop", [False, True])
+def test_model_packed_matches_dense_on_a_ragged_batch(dev, drop):
+    """Whole model, H = 512, 2 layers, widths 900 ... 40: the packed path (default for this batch: 55 % of the padded frames exist) against
+    pack_sequences = False.  Explicit dropout masks in the `drop` case: the packed path gathers them through the same map."""
+    import vistaocr_amd as va
+    from oracle import closed_form as cf
+    hp = dict(input_line_height=30, rds_line_height=30, lstm_input_dim=64, num_lstm_layers=2, num_lstm_hidden_units=512, p_lstm_dropout=0.5,
+              num_in_channels=1)
+    al = va.english_alphabet()
+    V = len(al)
+    widths = [900, 880, 640, 610, 600, 420, 400, 390, 380, 200, 180, 90, 60, 40]
+    B = len(widths)
+    lpl = [max(1, w // 40) for w in widths]
+    x, w, tgt, tl = cf.closed_form_batch(B, 1, 30, widths, V, lpl, seed=4)
+    s1, s2 = cf.closed_form_pool_samples(B)
+    sd_np = cf.closed_form_state(hp, V, lstm_scale=0.08, prob_scale=2.0)
+    out = {}
+    for packed in (False, True):
+        model = va.CnnOcrModel(alphabet=al, verbose=False, **hp)
+        sd = model.state_dict()
+        for k, v in sd_np.items():
+            sd[k] = torch.from_numpy(v)
+        model.load_state_dict(sd)
+        model.train()
+        model.pool_samples = [torch.from_numpy(s1), torch.from_numpy(s2)]
+        model.pack_sequences = packed
+        T = model.cnn_input_size_to_output_size((30, widths[0]))[1]
+        if drop:
+            r = np.random.RandomState(9)
+            model.dropout_masks = [torch.from_numpy((r.uniform(size=(T, B, 1024)) >= 0.5).astype(np.float32) * 2.0)]
+        else:
+            model.lstm.eval()
+        crit = va.CTCLoss()
+        logits, lens = model(torch.from_numpy(x), torch.from_numpy(w))
+        loss = crit(logits, torch.from_numpy(tgt), lens, torch.from_numpy(tl))
+        loss.backward()
+        torch.cuda.synchronize()
+        out[packed] = (logits.detach().cpu(), lens, float(loss.detach()), model.decode_labels(logits, lens),
+                       {k: p.grad.detach().cpu() for k, p in model.named_parameters()}, model)
+    ld, lens_d, loss_d, lab_d, gd, _ = out[False]
+    lp, lens_p, loss_p, lab_p, gp, mp = out[True]
+    from vistaocr_amd import ops
+    assert ops.packed_row_count(lens_p.tolist(), B) < 0.9 * ld.shape[0] * B          # this batch does take the packed path
+    assert lens_d.tolist() == lens_p.tolist()
+    T = ld.shape[0]
+    pad = ~(torch.arange(T).unsqueeze(1) < lens_p.to(torch.int64).unsqueeze(0))
+    bias = getattr(mp.prob_layer, "0").bias.detach().cpu()
+    assert torch.equal(lp[pad], bias.expand(int(pad.sum()), -1)) and torch.equal(ld[pad], lp[pad])     # padded frames: the bias, bit for bit
+    assert float((ld - lp).abs().max()) <= 2e-5 * float(ld.abs().max())
+    assert abs(loss_d - loss_p) <= 1e-5 * abs(loss_d)
+    assert lab_d == lab_p
+    for k in gd:
+        rel = float((gd[k] - gp[k]).norm() / (gd[k].norm() + 1e-30))
+        assert rel <= (2e-3 if k.startswith(("cnn.", "rapid_ds")) else 2e-4), (k, rel)

@@ -275,6 +275,7 @@ def test_dropout_inside_the_layer_op_equals_the_separate_op(T, B, H):
     res = []
     for fused in (True, "parts", False):
         os.environ["VOCR_LSTM_BWD_PARTS"] = "1" if fused == "parts" else "0"
+        os.environ["VOCR_EXPERIMENTS"] = "1"       # experiment switches are read only then (vistaocr_amd/ops.py:_exp)
         x = x0.clone().requires_grad_(True)
         ps = [p.clone().requires_grad_(True) for p in params0]
         if fused:
@@ -286,6 +287,7 @@ def test_dropout_inside_the_layer_op_equals_the_separate_op(T, B, H):
         torch.cuda.synchronize()
         res.append([out.detach().cpu(), x.grad.cpu()] + [p.grad.cpu() for p in ps])
     os.environ.pop("VOCR_LSTM_BWD_PARTS", None)
+    os.environ.pop("VOCR_EXPERIMENTS", None)
     ops.check_health_sync(dev)
     names = ["out", "dx", "dW_ih", "dW_hh", "db_ih", "db_hh", "dW_ih_r", "dW_hh_r", "db_ih_r", "db_hh_r"]
     for other in res[:2]:

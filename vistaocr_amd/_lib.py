@@ -69,6 +69,11 @@ SIGNATURES = {
     "vocr_lstm_bwd_parts_supported": (I, [I, I, I]),
     "vocr_lstm_bwd_parts": (I, [P, P, P, P, P, P, P, P, P, I, I, I, P, P]),
     "vocr_lstm_bias_from_parts": (I, [P, P, I, I, I, P]),
+    "vocr_lstm_packed_supported": (I, [I, I]),
+    "vocr_seq_rowmap": (I, [P, I, I, I, P, P, P]),
+    "vocr_gather_rows": (I, [P, P, P, ctypes.c_long, I, P, P]),
+    "vocr_lstm_fwd_packed": (I, [P, P, P, P, P, P, P, P, I, I, I, I, P, P]),
+    "vocr_lstm_bwd_packed": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P]),
     "vocr_ctc_workspace_bytes": (Z, [I, I, I, I]),
     "vocr_ctc_loss_grad": (I, [P, P, P, P, P, P, P, P, I, I, I, I, P]),
     "vocr_argmax_rows": (I, [P, P, P, I, I, P]),
@@ -81,7 +86,7 @@ SIGNATURES = {
     "vocr_comm_destroy": (I, [P]),
 }
 
-ABI_VERSION = 3          # include/vocr.h: VOCR_ABI_VERSION
+ABI_VERSION = 4          # include/vocr.h: VOCR_ABI_VERSION
 
 _lib = None
 

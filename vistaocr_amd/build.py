@@ -1,10 +1,12 @@
 """Build libvocr.so (HIP kernels + C-ABI) for gfx950 in-tree with hipcc.  No JIT cache: the .so sits next to
 the sources so it travels with the repo snapshot to the GPU box.
 
-The build is gated by a HASH, not by file times: the SHA-256 over every source and header, the compiler flags and hipcc's
-version string is written to csrc/build/libvocr.stamp next to the library.  A tree whose sources differ from what the
-library was built from (a fresh checkout with a shipped .so, a box with another ROCm) rebuilds; an unchanged tree does
-not.  `build_report()` says which of the two happened (the driver's "build exercised" question)."""
+The build is gated by a HASH, not by file times: csrc/build/libvocr.stamp holds the SHA-256 over every source, header and the
+compiler flags ("tree"), hipcc's version string ("compiler") and the library's own SHA-256 ("lib").  A tree whose sources differ
+from what the library was built from (a fresh checkout with a shipped .so) rebuilds, and so does a box with another ROCm; an
+unchanged tree does not.  On a host WITHOUT hipcc the shipped library is accepted when its sources / flags hash and its own
+hash match the stamp (the compiler cannot be compared there), and build() raises only when the sources really differ.
+`build_report()` says what happened (the driver's "build exercised" question)."""
 import hashlib
 import json
 import os
@@ -31,22 +33,33 @@ def _hipcc():
     return None
 
 
-def _tree_hash(hipcc):
+def _tree_hash():
+    """SHA-256 over every source, header and the compiler flags (no compiler: a host without hipcc can still compare it)."""
     h = hashlib.sha256()
     for path in [os.path.join(CSRC, s) for s in SOURCES] + HEADERS:
         h.update(os.path.basename(path).encode() + b"\0")
         with open(path, "rb") as f:
             h.update(f.read())
     h.update(" ".join(FLAGS).encode())
-    if hipcc:
-        try:
-            h.update(subprocess.run([hipcc, "--version"], capture_output=True, text=True, timeout=60).stdout.encode())
-        except Exception:
-            pass
     return h.hexdigest()
 
 
-def _stale(want):
+def tree_hash():
+    """Public name of the sources / flags hash: bench.py ties profiles/kernel_traffic.json to the kernels it was measured on."""
+    return _tree_hash()
+
+
+def _compiler_id(hipcc):
+    if not hipcc:
+        return None
+    try:
+        return hashlib.sha256(subprocess.run([hipcc, "--version"], capture_output=True, text=True, timeout=60).stdout.encode()).hexdigest()
+    except Exception:
+        return None
+
+
+def _stale(want, compiler):
+    """None when the shipped library is what `want` (sources + flags) and `compiler` (None: unknown here) would produce."""
     if not os.path.exists(LIB):
         return "no library"
     try:
@@ -54,7 +67,9 @@ def _stale(want):
     except Exception:
         return "no stamp"
     if st.get("tree") != want:
-        return "sources, flags or compiler changed"
+        return "sources or flags changed"
+    if compiler is not None and st.get("compiler") is not None and st.get("compiler") != compiler:
+        return "compiler changed"
     with open(LIB, "rb") as f:
         if hashlib.sha256(f.read()).hexdigest() != st.get("lib"):
             return "library is not the one the stamp describes"
@@ -68,10 +83,11 @@ def build_report():
 
 def build(force=False, verbose=False):
     hipcc = _hipcc()
-    want = _tree_hash(hipcc)
-    why = "forced" if force else _stale(want)
+    want, compiler = _tree_hash(), _compiler_id(hipcc)
+    why = "forced" if force and hipcc else _stale(want, compiler)
     if why is None:
-        _REPORT.update(built=False, reason="stamp matches sources, flags and compiler")
+        _REPORT.update(built=False, reason="stamp matches sources, flags and compiler" if compiler else
+                       "no compiler here, shipped binary matches sources and flags")
         return LIB
     if hipcc is None:
         raise RuntimeError("hipcc not found: libvocr.so cannot be built (%s)" % why)
@@ -95,7 +111,7 @@ def build(force=False, verbose=False):
         raise RuntimeError("link failed:\n" + r.stderr)
     with open(LIB, "rb") as f:
         libsum = hashlib.sha256(f.read()).hexdigest()
-    json.dump({"tree": want, "lib": libsum}, open(STAMP, "w"))
+    json.dump({"tree": want, "compiler": compiler, "lib": libsum}, open(STAMP, "w"))
     _REPORT.update(built=True, reason=why)
     return LIB
 

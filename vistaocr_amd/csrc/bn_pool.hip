@@ -905,7 +905,7 @@ extern "C" int vocr_fracpool2x2_bwd(const float* dout, const int32_t* idx, float
     VOCR_CHECK_ARG(dout && idx && dx && n > 0 && c > 0 && (long)n * c <= 65535, "vocr_fracpool2x2_bwd: bad argument");
     hipStream_t s = (hipStream_t)stream;
     const long in_plane = (long)h * w;
-    static const int use_lds = getenv("VOCR_POOL_LDS") ? atoi(getenv("VOCR_POOL_LDS")) : 1;      // experiments
+    static const int use_lds = VOCR_EXPERIMENT_INT("VOCR_POOL_LDS", 1);      // experiments
     if (use_lds && in_plane <= 8192) {
         pool_bwd_lds_kernel<8192><<<(unsigned)(n * c), 512, 0, s>>>(dout, idx, dx, (int)in_plane, oh * ow);
     } else if (use_lds && in_plane <= 18432) {

@@ -1276,7 +1276,7 @@ void launch_wgrad_reduce(const float* slab, float* dw, int cout, int cin, int sp
 // output channels per workgroup of the generic f32 kernel.  VOCR_WGRAD_TM=2 (experiment): 128, two dy fragments per wave -
 // measured 1117 vs 680 us on the 256->256 layer: 288 accumulator registers plus the staging registers spill.
 int wgrad_cot(int cin, int cout, bool f16 = false) {
-    static const int tm = getenv("VOCR_WGRAD_TM") ? atoi(getenv("VOCR_WGRAD_TM")) : 1;
+    static const int tm = VOCR_EXPERIMENT_INT("VOCR_WGRAD_TM", 1);
     return (!f16 && cin > 3 && cout >= 128 && tm == 2) ? 128 : 64;
 }
 
@@ -1340,10 +1340,10 @@ extern "C" int vocr_conv3x3_fwd(const float* x, const float* wpack, const float*
     // weight-gradient kernel the half-size ones win up to 9 per CU, +0.4 % on the step)
     const int co_tiles = cout > 64 ? vocr_cdiv(cout, 128) : 1;
     const long full_wgs = (long)vocr_cdiv(nseg, cout > 64 ? 4 : 8) * co_tiles;
-    static const int tile_mode = getenv("VOCR_CONV_TILE") ? atoi(getenv("VOCR_CONV_TILE")) : 0;     // experiments: 1 half, 2 full
+    static const int tile_mode = VOCR_EXPERIMENT_INT("VOCR_CONV_TILE", 0);     // experiments: 1 half, 2 full
     const bool small = tile_mode == 1 ? true : tile_mode == 2 ? false : full_wgs < 12l * 256;
     const bool tiny = tile_mode == 3;
-    static const int lds_pad = getenv("VOCR_CONV_LDS_PAD") ? atoi(getenv("VOCR_CONV_LDS_PAD")) : 0;   // experiments: extra LDS = fewer workgroups per CU        // experiments: 32 output channels per wave (one accumulator), half the tile again
+    static const int lds_pad = VOCR_EXPERIMENT_INT("VOCR_CONV_LDS_PAD", 0);   // experiments: extra LDS = fewer workgroups per CU        // experiments: 32 output channels per wave (one accumulator), half the tile again
 #define VOCR_CONV(CO_T, SPWV, NSEG, WCO)                                                                                     \
     do {                                                                                                                    \
         dim3 grid(vocr_cdiv(nseg, NSEG) * co_tiles);                                                                        \
@@ -1355,12 +1355,12 @@ extern "C" int vocr_conv3x3_fwd(const float* x, const float* wpack, const float*
     // vs 708 us on the 256->256 layer: with double buffering the loaders can only run one half-chunk ahead, so their
     // load -> land -> store latency (an LDS-DMA takes ~1.1 us from issue to landed) sits on the critical path of every
     // half-chunk instead of hiding behind the issuing wave's own MFMAs; a third buffer does not fit three workgroups per CU.)
-    static const int use_dma = getenv("VOCR_CONV_DMA") ? atoi(getenv("VOCR_CONV_DMA")) : 1;
+    static const int use_dma = VOCR_EXPERIMENT_INT("VOCR_CONV_DMA", 1);
     // VOCR_CONV_TAIL: 1 (default) the last partial round of tiles is cut into pieces that lead the same launch, 3 the pieces
     // run as conv3x3_tail_kernel behind the launch, 0 one launch of whole tiles as before; any other value = 1.  (The
     // upper-bound experiment that dropped the partial round - wrong results, -8.7 % on the forward stack - is no longer in
     // the shipped library.)
-    static const int tail_env = getenv("VOCR_CONV_TAIL") ? atoi(getenv("VOCR_CONV_TAIL")) : 1;
+    static const int tail_env = VOCR_EXPERIMENT_INT("VOCR_CONV_TAIL", 1);
     static const int tail_mode = (tail_env == 0 || tail_env == 3) ? tail_env : 1;
     const int ncu = conv_cu_count();
     if (use_dma && vec && !tiny) {
@@ -1416,7 +1416,7 @@ extern "C" int vocr_conv3x3_wgrad(const float* x, const float* dy, float* dw, vo
     } else {
         const int cot = wgrad_cot(cin, cout);
         dim3 grid(vocr_cdiv(cin, 64), vocr_cdiv(cout, cot), splits);
-        static const int mode = getenv("VOCR_WGRAD_MODE") ? atoi(getenv("VOCR_WGRAD_MODE")) : 2;
+        static const int mode = VOCR_EXPERIMENT_INT("VOCR_WGRAD_MODE", 2);
         if (cot == 128) conv3x3_wgrad_kernel<0, 2><<<grid, 256, 0, s>>>(x, dy, (float*)workspace, zp, n, cin, h, w, cout, seg_geom(n, h, w), sps);
         else if (mode == 2) conv3x3_wgrad_kernel<2><<<grid, 512, 0, s>>>(x, dy, (float*)workspace, zp, n, cin, h, w, cout, seg_geom(n, h, w), sps);
         else if (mode == 1) conv3x3_wgrad_kernel<1><<<grid, 256, 0, s>>>(x, dy, (float*)workspace, zp, n, cin, h, w, cout, seg_geom(n, h, w), sps);

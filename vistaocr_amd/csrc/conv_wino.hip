@@ -66,24 +66,24 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
 // VOCR_CONV_WINO2 (default 1): conv3x3_wino2_body, which reads the x-fastest pack; 0: round 3's kernels (VOCR_CONV_PACK4 then picks the
 // pack for the VOCR_CONV_WINO8=1 experiments)
 static int wino2_mode() {
-    static const int v = getenv("VOCR_CONV_WINO2") ? atoi(getenv("VOCR_CONV_WINO2")) : 1;
+    static const int v = VOCR_EXPERIMENT_INT("VOCR_CONV_WINO2", 1);
     return v;
 }
 // VOCR_CONV_WINO4 (default 1): F(4,3) along the row (conv3x3_wino4_body) for the forward / data-gradient launches with >= 128 output
 // channels: own pack (18 transformed + 9 direct rows per channel); 0: F(2,3) everywhere (round 3 / early round 4)
 static int wino4_mode() {
-    static const int v = getenv("VOCR_CONV_WINO4") ? atoi(getenv("VOCR_CONV_WINO4")) : 1;
+    static const int v = VOCR_EXPERIMENT_INT("VOCR_CONV_WINO4", 1);
     return v;
 }
 // which packs / launches take the F(4,3) kernel: convolutions with at least 128 OUTPUT channels (the forward of a layer with Cout >= 128, the
 // data gradient of a layer with Cin >= 128); measured slower than F(2,3) with 64 (eight segments per workgroup)
 static int wino4_min_cout() {
-    static const int v = getenv("VOCR_CONV_WINO4_MINCO") ? atoi(getenv("VOCR_CONV_WINO4_MINCO")) : 128;      // experiments: 64
+    static const int v = VOCR_EXPERIMENT_INT("VOCR_CONV_WINO4_MINCO", 128);      // experiments: 64
     return v;
 }
 static bool wino4_for(int cout) { return wino4_mode() != 0 && cout >= wino4_min_cout() && cout % 4 == 0; }
 static int wino_pack_x4() {
-    static const int v = wino2_mode() ? 1 : (getenv("VOCR_CONV_PACK4") ? atoi(getenv("VOCR_CONV_PACK4")) : 0);
+    static const int v = wino2_mode() ? 1 : (VOCR_EXPERIMENT_INT("VOCR_CONV_PACK4", 0));
     return v;
 }
 
@@ -2261,7 +2261,7 @@ extern "C" int vocr_conv3x3_wino_fwd(const float* x, const float* wpack, const f
     hipStream_t s = (hipStream_t)stream;
     const float* wdirect = wpack + (size_t)cin * (f43 ? 18 : 12) * cout;
     // VOCR_CONV_TAIL: 1 (default) the last partial round of tiles is cut into direct-form pieces that lead the launch, 0 whole tiles only
-    static const int tail_mode = getenv("VOCR_CONV_TAIL") ? atoi(getenv("VOCR_CONV_TAIL")) : 1;
+    static const int tail_mode = VOCR_EXPERIMENT_INT("VOCR_CONV_TAIL", 1);
     int ncu = 256;
     {
         int dev = 0;
@@ -2279,7 +2279,7 @@ extern "C" int vocr_conv3x3_wino_fwd(const float* x, const float* wpack, const f
     } while (0)
     // VOCR_CONV_WINO8=1: one 8-wave workgroup per CU with a three-stage ring (measured no faster, see the kernel); default: the
     // two-stage 4-wave kernel, two workgroups per CU
-    static const int wino8 = getenv("VOCR_CONV_WINO8") ? atoi(getenv("VOCR_CONV_WINO8")) : 0;
+    static const int wino8 = VOCR_EXPERIMENT_INT("VOCR_CONV_WINO8", 0);
     const int wino2 = wino2_mode();
     if (f43) {
         // one 4-wave workgroup per CU; a piece of the tail is 1/(CO_T/32 * 4 NSEG) of a tile
@@ -2378,7 +2378,7 @@ int wgrad_wino2d_splits(int n, int cin, int h, int w, int cout, W3Geom* geo, int
 // VOCR_WGRAD_WINO_DMA: 3 (default) row pairs (F(3,2) across rows too) / eight waves, 2 piece stream / twelve waves, 1 round 3's
 // segment kernel with LDS-DMA, 0 its register-staged form
 int wgrad_wino_mode() {
-    static const int m = getenv("VOCR_WGRAD_WINO_DMA") ? atoi(getenv("VOCR_WGRAD_WINO_DMA")) : 3;
+    static const int m = VOCR_EXPERIMENT_INT("VOCR_WGRAD_WINO_DMA", 3);
     return m;
 }
 }  // namespace

@@ -382,7 +382,7 @@ extern "C" int vocr_ctc_loss_grad(const float* logits, const int32_t* labels, co
     log_softmax_rows_kernel<<<vocr_cdiv(rows, 4), 256, 0, s>>>(logits, lp, rows, v);
     VOCR_CHECK_LAUNCH("vocr_ctc_loss_grad(log_softmax)");
     const size_t smem = (size_t)(2 * (sp + 4) + sp) * sizeof(float);
-    static const int generic_only = getenv("VOCR_CTC_GENERIC") ? atoi(getenv("VOCR_CTC_GENERIC")) : 0;      // tests: compare the two kernels
+    static const int generic_only = VOCR_EXPERIMENT_INT("VOCR_CTC_GENERIC", 0);      // tests: compare the two kernels
     if (sp == 64 && !generic_only) ctc_alpha_beta64_kernel<<<2 * b, 64, 0, s>>>(lp, labels, label_offsets, label_lens, act_lens, ab, nll, t, b, v);
     else ctc_alpha_beta_kernel<<<2 * b, 64, smem, s>>>(lp, labels, label_offsets, label_lens, act_lens, ab, nll, t, b, v, sp);
     VOCR_CHECK_LAUNCH("vocr_ctc_loss_grad(alpha_beta)");

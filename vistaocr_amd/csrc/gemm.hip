@@ -427,7 +427,7 @@ GemmPlan gemm_plan(int m, int n, int k, bool has_epilogue, long max_pieces_128, 
     // ... unless K is long and the last partial round can be cut into K pieces (below): whole 128x128 tiles + tail pieces measured
     // 390 vs 411 us on the 9408x2048x1024 projection and 354 vs 378 us on its data gradient (scripts/gemm_bench.py); with
     // K = 128 the half-size tiles stay ahead (73 vs 80 us)
-    static const int half_mode = getenv("VOCR_GEMM_HALF") ? atoi(getenv("VOCR_GEMM_HALF")) : -1;      // experiments: 0 never, 1 always as above
+    static const int half_mode = VOCR_EXPERIMENT_INT("VOCR_GEMM_HALF", -1);      // experiments: 0 never, 1 always as above
     if (half_mode == 0 || (half_mode < 0 && allow_tail_fill && max_pieces_128 > 1 && k >= 512 && tiles128 >= 2l * gemm_cu_count())) p.half = false;
     p.bm = p.big ? 128 : 64;
     p.bn = p.big ? (p.half ? 64 : 128) : 64;
@@ -473,7 +473,7 @@ GemmPlan gemm_plan(int m, int n, int k, bool has_epilogue, long max_pieces_128, 
 bool gemm_tail_fill_enabled() {
     // (with half-size tiles the K pieces bought nothing - 9 tiles per CU balance the last round by themselves; they pay with whole
     // 128x128 tiles, see gemm_plan)
-    static const int on = getenv("VOCR_GEMM_TAILFILL") ? atoi(getenv("VOCR_GEMM_TAILFILL")) : 1;
+    static const int on = VOCR_EXPERIMENT_INT("VOCR_GEMM_TAILFILL", 1);
     return on != 0;
 }
 }  // namespace

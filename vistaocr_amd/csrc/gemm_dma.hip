@@ -370,7 +370,7 @@ static int cu_count() {
 // column panels and enough rows per workgroup to amortise the weight panel, buffers below 2 GiB.
 Plan plan(int transa, int transb, int m, int n, int k, int lda, int ldb, int ldc, int nprob, int nseg, bool no_split) {
     Plan p = {false, 0, 0, 1, 0, 0};
-    static const int on = getenv("VOCR_GEMM_DMA") ? atoi(getenv("VOCR_GEMM_DMA")) : 1;
+    static const int on = VOCR_EXPERIMENT_INT("VOCR_GEMM_DMA", 1);
     if (!on) return p;
     if (m < 256 || n < 128 || k < 64) return p;
     if ((lda | ldb | ldc | k | n) & 3) return p;

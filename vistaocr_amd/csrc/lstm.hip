@@ -549,197 +549,41 @@ __global__ __launch_bounds__(256) void lstm_fwd_chain(const float* __restrict__ 
     }
 }
 
-__device__ __forceinline__ int wave_of(unsigned tid) { return (int)(tid >> 6); }
-
-// Forward chain sweep on 8-row chains (see lstm_bwd_kowner8 for why): 8 chains fill all 8 XCDs at a batch of 32 and
-// v_mfma_f32_4x4x1_16b_f32 keeps the MFMA rate with only 8 batch rows.  One instruction = 2 row-groups x 8 column-groups
-// = 8 rows x 32 gate columns x one k; the workgroup's 64 gate columns take two instructions per k, K = H is split
-// over the 8 waves (64 k each: 16 16-byte loads of h per lane, W_hh slice in 128 VGPRs), the eight partial tiles are
-// reduced through LDS in a fixed order.  Hand-off, placement check, x-projection prefetch and step ranges as in
-// lstm_fwd_chain.  H = 64*KQ4 with KQ4 % 8 == 0.
-template <int KQ4>
-__global__ __launch_bounds__(512) void lstm_fwd_chain8(const float* __restrict__ xproj, const float* __restrict__ whh_f,
-                                                       const float* __restrict__ whh_r, const int32_t* __restrict__ lens,
-                                                       float* y, float* __restrict__ gates, float* __restrict__ cell,
-                                                       unsigned* flags, unsigned* ids, unsigned* status, unsigned* health, int T, int B, int NT8, int force_wt,
-                                                       int s0, int s1) {
-    constexpr int H = 64 * KQ4;
-    constexpr int members = H >> 4;
-    constexpr int KW = H / 8;                         // k per wave
-    constexpr int NL = KW / 4;                        // 16-byte loads per lane per step
-    constexpr int HP = KW + 4;                        // staging row pitch: 16-byte reads of 8 rows hit distinct banks
-    __shared__ float lds[8 * 8 * 65 + 4 + 8 * 8 * HP + 8 * 64];
-    float (*red)[8][65] = (float (*)[8][65])lds;
-    float* hst = lds + 8 * 8 * 65 + 4 + wave_of(threadIdx.x) * 8 * HP;      // this wave's h_{t-1}[8 rows][its KW k]
-    float (*actb)[64] = (float (*)[64])(lds + 8 * 8 * 65 + 4 + 8 * 8 * HP);  // activated gates [row][gate*16 + unit]
-    const int chain = blockIdx.x & 7, member = blockIdx.x >> 3;
-    if (chain >= 2 * NT8) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int dir = chain / NT8, bt = chain % NT8;
-    const int unit0 = member * 16, b0 = bt * 8;
-    const int nrows = min(B - b0, 8);
-    const int blk = lane >> 2, li = lane & 3, cg = blk >> 1, rg = blk & 1;
-    const int kbase = wave * KW;
-    const float* whh = dir ? whh_r : whh_f;
-    unsigned* cflags = flags + chain * 32;
-    const bool local = chain_is_xcd_local(ids + chain * 32, members, member, status, health, (unsigned*)(lds + 8 * 8 * 65)) && !force_wt;
-
-    // resident B operand: column 32*I + 4*cg + li = (gate, local unit) = (col >> 4, col & 15)
-    f32x4 wv[2][NL];
-#pragma unroll
-    for (int I = 0; I < 2; ++I) {
-        const int col = 32 * I + 4 * cg + li;
-        const f32x4* wp = (const f32x4*)(whh + ((long)(col >> 4) * H + unit0 + (col & 15)) * H + kbase);
-#pragma unroll
-        for (int i = 0; i < NL; ++i) wv[I][i] = wp[i];
+// Row layout of the sequence-side tensors (xproj, y, gates, cell, dy, dgates) as the 4-row chain sweeps address them.
+//   dense  (packed_rows == 0): the reference's padded time-major order, row(t, b) = t*B + b; every chain runs all T steps and a row
+//          past its length computes zeros.
+//   packed (packed_rows  > 0): what pack_padded_sequence buys the reference (src/models/cnnlstm.py:288-290: cuDNN never touches a
+//          padded frame).  The batch is sorted by length, so chain c (batch rows 4c .. 4c+3) needs L_c = lens[4c] steps and no more.
+//          Rows come in GROUPS of 4 (one time step of one chain), chain-major: [zero group][chain 0: L_0 groups][zero group][chain 1:
+//          L_1 groups] ... [zero group]; group(c, t) = 1 + c + sum_{c' < c} L_c' + t, row = 4*group + (b & 3), packed_rows =
+//          4 * (sum L_c + chains + 1).  Inside a chain consecutive steps are 4 rows apart, and the all-zero group on either side
+//          stands for h_{-1} / h_{L} = 0, so the recurrent weight gradient stays ONE product of row-shifted views (dgates rows
+//          [4, R) against y rows [0, R - 4) forward, the other way round reverse), exactly as in the dense layout with a shift of B.
+//          Every GEMM of the LSTM stack runs over the packed rows only; the zero groups (and a last chain's rows >= B) are zeroed by the
+//          caller (vocr_lstm_fwd_packed / vocr_lstm_bwd_packed document it).  The reverse direction of a chain starts at its own last
+//          frame t = L_c - 1; a row shorter than its chain is masked until t < len exactly as in the dense layout.
+struct SeqRows {
+    int base;        // row of (t = 0, first row of the chain)
+    int stride;      // rows between consecutive time steps of the chain
+    int steps;       // time steps this chain runs
+    long total;      // rows of one direction's plane (T*B or packed_rows)
+};
+__device__ __forceinline__ SeqRows seq_rows(const int32_t* __restrict__ lens, int T, int B, int bt, int packed_rows) {
+    SeqRows r;
+    if (packed_rows == 0) {
+        r.base = 4 * bt;
+        r.stride = B;
+        r.steps = T;
+        r.total = (long)T * B;
+    } else {
+        int g = 1 + bt;
+        for (int c = 0; c < bt; ++c) g += lens[4 * c];
+        r.base = 4 * g;
+        r.stride = 4;
+        r.steps = min(lens[4 * bt], T);
+        r.total = packed_rows;
     }
-    // epilogue in two phases: (A) every thread reduces and activates ONE pre-activation - wave w takes gate w & 3 of rows
-    // 4*(w >> 2) .. +3, so a wave evaluates a single activation function on all 64 lanes - and leaves it in LDS; (B) the
-    // 128 cell threads (waves 0, 1: row = tid >> 4, unit = tid & 15) pick up their four gates and do the cell update.
-    // (Two waves doing reduction + five activations per thread took 0.5 of the 2.8 us step with six waves waiting.)
-    const int egate = __builtin_amdgcn_readfirstlane(wave) & 3;             // scalar: the activation below is a uniform branch
-    const int erow = 4 * (wave >> 2) + (lane >> 4), ecol = egate * 16 + (lane & 15);
-    const bool erowok = erow < nrows;
-    const int bl = (tid >> 4) & 7, cu = tid & 15, cb_ = b0 + bl, unit = unit0 + cu;
-    const bool cellthr = tid < 128 && bl < nrows;
-    const int len_b = cellthr ? lens[cb_] : 0;
-    float cstate = 0.f;
-    if (s0 > 0 && cellthr) {
-        const int tp0 = dir == 0 ? s0 - 1 : T - s0;
-        cstate = cell[(((long)dir * T + tp0) * B + cb_) * H + unit];
-    }
-    bool timed_out = false;
-    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, T * B * 2 * H * 4, 0x00020000);
-    // h_{t-1} is fetched in whole lines (lane = 16-byte piece p of the wave's [8 rows][KW] slice: rows clamped, never
-    // masked - A row r only reaches output row r) and broadcast to the 8 column-group lanes through LDS; having every
-    // lane load its own row's 64 k directly asked L2 for each line 8 times (5.0 vs 3.9 us per step).
-    constexpr int PPR = KW / 4;                       // pieces per row
-    constexpr int NP = 8 * PPR / 64;                  // pieces per lane
-    int poff[NP], pdst[NP];
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        const int p = lane + 64 * j, prow = p / PPR, pc = p % PPR;
-        const int grow = b0 + prow < B ? b0 + prow : b0;
-        poff[j] = (grow * 2 * H + dir * H + kbase + 4 * pc) * 4;
-        pdst[j] = prow * HP + 4 * pc;
-    }
-    const float* hrd = hst + (4 * rg + li) * HP;
-
-    const int xb = erowok ? b0 + erow : b0;
-    auto x_load = [&](int st) {
-        const int tt = dir == 0 ? st : T - 1 - st;
-        return xproj[(((long)dir * T + tt) * B + xb) * 4 * H + (long)egate * H + unit0 + (lane & 15)];
-    };
-    float xn = x_load(s0);
-
-    LSTM_STAMP_DECL;
-    for (int step = s0; step < s1; ++step) {
-        const int t = dir == 0 ? step : T - 1 - step;
-        LSTM_STAMP(7);
-        const int tprev = dir == 0 ? t - 1 : t + 1;
-        const float xp = xn;
-        if (step == 0) xn = x_load(T > 1 ? 1 : 0);
-        f32x4 acc[2];
-        acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (step > 0) {
-            if (wave == 7 && !timed_out && step > s0) {
-                unsigned spins = 0;
-                for (;;) {
-                    unsigned f0 = (unsigned)step;
-                    if (lane < members) f0 = __hip_atomic_load(cflags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (__all(f0 >= (unsigned)step)) break;
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1u << 22)) {
-                        if (lane == 0) raise_timeout(status, health);
-                        timed_out = true;
-                        break;
-                    }
-                }
-            }
-            LSTM_STAMP(0);          // poll (wave 7) 
-            __syncthreads();
-            LSTM_STAMP(1);
-            const int toff = tprev * B * 2 * H * 4;
-            u32x4_t pv[NP];
-            if (local) {            // one XCD: plain loads of the L2-resident hand-off (see lstm_fwd_chain)
-#pragma unroll
-                for (int j = 0; j < NP; ++j) pv[j] = __builtin_amdgcn_raw_buffer_load_b128(yrsrc, toff + poff[j], 0, 0);
-            } else {
-#pragma unroll
-                for (int j = 0; j < NP; ++j) pv[j] = __builtin_amdgcn_raw_buffer_load_b128(yrsrc, toff + poff[j], 0, 16);      // aux 16 = sc1
-            }
-            xn = x_load(step + 1 < T ? step + 1 : step);
-#pragma unroll
-            for (int j = 0; j < NP; ++j) *(u32x4_t*)(hst + pdst[j]) = pv[j];
-#ifdef VOCR_LSTM_STAMPS
-            __builtin_amdgcn_s_waitcnt(0x0F70);
-            LSTM_STAMP(2);          // h loads landed
-#endif
-            // same wave writes and reads its staging rows: the LDS counter orders them, no barrier
-            f32x4 hv[NL];
-#pragma unroll
-            for (int i = 0; i < NL; ++i) hv[i] = *(const f32x4*)(hrd + 4 * i);
-#pragma unroll
-            for (int i = 0; i < NL; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int I = 0; I < 2; ++I)
-                        acc[I] = __builtin_amdgcn_mfma_f32_4x4x1f32(hv[i][e], wv[I][i][e], acc[I], 0, 0, 0);
-        }
-        // acc[I][r] = partial of (row 4*rg + r, column 32*I + 4*cg + li)
-#pragma unroll
-        for (int I = 0; I < 2; ++I)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) red[wave][4 * rg + r][32 * I + 4 * cg + li] = acc[I][r];
-        LSTM_STAMP(3);              // LDS stage + MFMA + partial tile to LDS
-        __syncthreads();
-        LSTM_STAMP(4);
-
-        {
-            const float pre = (((red[0][erow][ecol] + red[1][erow][ecol]) + (red[2][erow][ecol] + red[3][erow][ecol])) +
-                               ((red[4][erow][ecol] + red[5][erow][ecol]) + (red[6][erow][ecol] + red[7][erow][ecol]))) + xp;
-            actb[erow][ecol] = egate == 2 ? tanhf(pre) : sigmoidf_(pre);           // wave-uniform choice
-        }
-        __syncthreads();
-        if (cellthr) {
-            const bool active = t < len_b;
-            const long sidx = (((long)dir * T + t) * B + cb_) * H + unit;
-            float* yo = y + ((long)t * B + cb_) * 2 * H + dir * H + unit;
-            f32x4* go = (f32x4*)(gates + sidx * 4);
-            float h = 0.f;
-            if (active) {
-                const float ig = actb[bl][cu], fg = actb[bl][16 + cu], gg = actb[bl][32 + cu], og = actb[bl][48 + cu];
-                const float c = fg * cstate + ig * gg;
-                h = og * tanhf(c);
-                *go = (f32x4){ig, fg, gg, og};
-                cell[sidx] = c;
-                cstate = c;
-            } else {
-                *go = (f32x4){0.f, 0.f, 0.f, 0.f};
-                cell[sidx] = 0.f;
-                cstate = 0.f;
-            }
-            if (step == s1 - 1 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u)
-                h = __uint_as_float(0x7FC00000u);                                        // a hand-off timed out: fail loudly
-            if (local) __hip_atomic_store(yo, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // stays in this XCD's L2
-            else __hip_atomic_store(yo, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                // write-through (sc1)
-        }
-        LSTM_STAMP(5);              // reduce + cell update + stores issued (waves 0, 1)
-        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): every storing wave drains before the flag
-        LSTM_STAMP(6);
-        __syncthreads();
-        if (tid == 0) {
-            if (local) __hip_atomic_store(cflags + member, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            else __hip_atomic_store(cflags + member, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-#ifdef VOCR_LSTM_STAMPS
-    if (lane == 0 && (wave == 0 || wave == 7) && g_lstm_stamp_out) {
-        unsigned long long* o = g_lstm_stamp_out + ((size_t)blockIdx.x * 2 + (wave == 7)) * 8;
-        for (int k = 0; k < 8; ++k) o[k] = st_acc[k];
-    }
-#endif
+    return r;
 }
 
 template <int N, int I = 0, typename F>
@@ -752,7 +596,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // Self-validating hand-off: the host fills the hand-off buffer with this bit pattern before a sweep (a NaN no arithmetic here
 // produces: h is stored canonicalised); a consumer wave re-issues ITS OWN loads until no dword holds the pattern, a producer only
-// stores.  Against the flag protocol of lstm_fwd_chain8 (flag poll and h loads = two L2 round trips in series, plus a store drain
+// stores.  Against the flag protocol of lstm_fwd_chain (flag poll and h loads = two L2 round trips in series, plus a store drain
 // + barrier + flag store on the producing side): no flags, no drain, two barriers per step instead of four, and a wave starts its
 // MFMAs as soon as its own k-slice has arrived.
 // cache policy of a polling load: sc1 (never served from the CU's vector L1, which may hold the line from an earlier look or
@@ -781,7 +625,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_chain4v(const float* __restrict_
                                                         const float* __restrict__ whh_r, const int32_t* __restrict__ lens,
                                                         float* y, float* __restrict__ gates, float* __restrict__ cell,
                                                         float* hx, unsigned* ids, unsigned* status, unsigned* health, int T, int B, int NT4,
-                                                        int force_wt, int s0, int s1) {
+                                                        int force_wt, int s0, int s1, int packed_rows) {
     constexpr int H = 64 * KQ4;
     constexpr int members = H >> 4;
     constexpr int KW = H / 4;                         // k per wave
@@ -816,10 +660,15 @@ __global__ __launch_bounds__(256) void lstm_fwd_chain4v(const float* __restrict_
     const int bl = lane >> 4, cu = lane & 15, cb_ = b0 + bl, unit = unit0 + cu;
     const bool cellthr = tid < 64 && bl < nrows;
     const int len_b = cellthr ? lens[cb_] : 0;
+    const SeqRows sr = seq_rows(lens, T, B, bt, packed_rows);
+    const int Tc = sr.steps;
+    s1 = min(s1, Tc);
+    // the cell thread's own element of step t: plane-local row = sr.base + sr.stride*t + bl
+    const long crow0 = (long)dir * sr.total + sr.base + bl;
     float cstate = 0.f;
     if (s0 > 0 && cellthr) {
-        const int tp0 = dir == 0 ? s0 - 1 : T - s0;
-        cstate = cell[(((long)dir * T + tp0) * B + cb_) * H + unit];
+        const int tp0 = dir == 0 ? s0 - 1 : Tc - s0;
+        cstate = cell[(crow0 + (long)sr.stride * tp0) * H + unit];
     }
     bool timed_out = false;
     // hand-off ring hx[step & 3][chain][member][4 rows][16 units]: a member's block of a step is 256 contiguous bytes = two whole
@@ -847,12 +696,13 @@ __global__ __launch_bounds__(256) void lstm_fwd_chain4v(const float* __restrict_
         }
     }
 
-    const int xb = erowok ? b0 + erow : b0;
+    const float* xrowp = xproj + ((long)dir * sr.total + sr.base + (erowok ? erow : 0)) * 4 * H + (long)egate * H + unit0 + (lane & 15);
+    const long xstep = (long)sr.stride * 4 * H;
     auto x_load = [&](int st) {
-        const int tt = dir == 0 ? st : T - 1 - st;
-        return xproj[(((long)dir * T + tt) * B + xb) * 4 * H + (long)egate * H + unit0 + (lane & 15)];
+        const int tt = dir == 0 ? st : Tc - 1 - st;
+        return xrowp[tt * xstep];
     };
-    float xn = x_load(s0);
+    float xn = s0 < s1 ? x_load(s0) : 0.f;
     // the resident operand is complete before the loop (otherwise every iteration carries the first one's vmcnt waits, which
     // then also wait for whatever else is in flight)
 #pragma unroll
@@ -860,9 +710,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_chain4v(const float* __restrict_
 
     LSTM_STAMP_DECL;
     for (int step = s0; step < s1; ++step) {
-        const int t = dir == 0 ? step : T - 1 - step;
+        const int t = dir == 0 ? step : Tc - 1 - step;
         LSTM_STAMP(7);
-        const int tprev = dir == 0 ? t - 1 : t + 1;
         const float xp = xn;
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};      // even / odd 4-k pieces: two independent MFMA chains
         u32x4_t pv[NP];
@@ -886,7 +735,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_chain4v(const float* __restrict_
             }
         }
         LSTM_STAMP(0);              // own slice of h_{t-1} arrived (polls)
-        xn = x_load(step + 1 < T ? step + 1 : step);           // behind the polls: loads return in order
+        xn = x_load(step + 1 < Tc ? step + 1 : step);          // behind the polls: loads return in order
         if (step > 0) {
             {
 #pragma unroll
@@ -921,8 +770,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_chain4v(const float* __restrict_
         LSTM_STAMP(4);
         if (cellthr) {
             const bool active = t < len_b;
-            const long sidx = (((long)dir * T + t) * B + cb_) * H + unit;
-            float* yo = y + ((long)t * B + cb_) * 2 * H + dir * H + unit;
+            const long sidx = (crow0 + (long)sr.stride * t) * H + unit;
+            float* yo = y + (sr.base + bl + (long)sr.stride * t) * 2 * H + dir * H + unit;
             f32x4* go = (f32x4*)(gates + sidx * 4);
             float h = 0.f, c = 0.f;
             f32x4 gv = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -972,7 +821,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_chain4w(const float* __restrict_
                                                         const float* __restrict__ whh_r, const int32_t* __restrict__ lens,
                                                         float* y, float* __restrict__ gates, float* __restrict__ cell,
                                                         float* hx, unsigned* ids, unsigned* status, unsigned* health, int T, int B, int NT4,
-                                                        int force_wt, int s0, int s1, int nap) {
+                                                        int force_wt, int s0, int s1, int nap, int packed_rows) {
     constexpr int H = 64 * KQ4;
     constexpr int members = H >> 5;                   // 32 units each
     constexpr int KW = H / 8;                         // k per wave
@@ -1009,10 +858,15 @@ __global__ __launch_bounds__(512) void lstm_fwd_chain4w(const float* __restrict_
     const int crow = tid >> 5, cu = tid & 31, cb_ = b0 + crow, unit = unit0 + cu;       // cell threads: waves 0, 1
     const bool cellthr = tid < 128 && crow < nrows;
     const int len_b = cellthr ? lens[cb_] : 0;
+    const SeqRows sr = seq_rows(lens, T, B, bt, packed_rows);
+    const int Tc = sr.steps;
+    s1 = min(s1, Tc);
+    // the cell thread's own element of step t: plane-local row = sr.base + sr.stride*t + crow
+    const long crow0 = (long)dir * sr.total + sr.base + crow;
     float cstate = 0.f;
     if (s0 > 0 && cellthr) {
-        const int tp0 = dir == 0 ? s0 - 1 : T - s0;
-        cstate = cell[(((long)dir * T + tp0) * B + cb_) * H + unit];
+        const int tp0 = dir == 0 ? s0 - 1 : Tc - s0;
+        cstate = cell[(crow0 + (long)sr.stride * tp0) * H + unit];
     }
     bool timed_out = false;
     if (tid < 2) sig[tid] = s0;                       // read by the other waves from step s0 + 1 on: behind step s0's barriers
@@ -1024,12 +878,13 @@ __global__ __launch_bounds__(512) void lstm_fwd_chain4w(const float* __restrict_
         const int kk = kbase + 4 * (lane >> 2);
         poff = (((kk >> 5) * 4 + prow) * 32 + (kk & 31)) * 4;
     }
-    const int xb = erowok ? b0 + erow : b0;
+    const float* xrowp = xproj + ((long)dir * sr.total + sr.base + (erowok ? erow : 0)) * 4 * H + (long)egate * H + unit0 + eu;
+    const long xstep = (long)sr.stride * 4 * H;
     auto x_load = [&](int st) {
-        const int tt = dir == 0 ? st : T - 1 - st;
-        return xproj[(((long)dir * T + tt) * B + xb) * 4 * H + (long)egate * H + unit0 + eu];
+        const int tt = dir == 0 ? st : Tc - 1 - st;
+        return xrowp[tt * xstep];
     };
-    float xn = x_load(s0);
+    float xn = s0 < s1 ? x_load(s0) : 0.f;
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -1037,7 +892,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_chain4w(const float* __restrict_
 
     LSTM_STAMP_DECL;
     for (int step = s0; step < s1; ++step) {
-        const int t = dir == 0 ? step : T - 1 - step;
+        const int t = dir == 0 ? step : Tc - 1 - step;
         LSTM_STAMP(7);
         const float xp = xn;
         f32x4 acc[2];
@@ -1068,7 +923,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_chain4w(const float* __restrict_
             }
         }
         LSTM_STAMP(0);              // own slice of h_{t-1} arrived (polls)
-        xn = x_load(step + 1 < T ? step + 1 : step);           // behind the polls: loads return in order
+        xn = x_load(step + 1 < Tc ? step + 1 : step);          // behind the polls: loads return in order
         if (step > 0) {
             static_for<NL>([&](auto bc) {
                 constexpr int b = decltype(bc)::value;
@@ -1098,8 +953,8 @@ __global__ __launch_bounds__(512) void lstm_fwd_chain4w(const float* __restrict_
         LSTM_STAMP(4);
         if (cellthr) {
             const bool active = t < len_b;
-            const long sidx = (((long)dir * T + t) * B + cb_) * H + unit;
-            float* yo = y + ((long)t * B + cb_) * 2 * H + dir * H + unit;
+            const long sidx = (crow0 + (long)sr.stride * t) * H + unit;
+            float* yo = y + (sr.base + crow + (long)sr.stride * t) * 2 * H + dir * H + unit;
             f32x4* go = (f32x4*)(gates + sidx * 4);
             float h = 0.f, c = 0.f;
             f32x4 gv = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1398,195 +1253,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kowner(const float* __restrict__
     }
 }
 
-// K-owner backward sweep on 8-row chains ("kowner8").  With 16-row chains a batch of 32 makes only 4 chains = 4 XCDs,
-// and the 1.7 us MFMA phase (the chain's 32 CUs multiplying 16 rows) is the largest piece of a step.  8-row chains fill
-// all 8 XCDs, but v_mfma_f32_16x16x4_f32 would idle half its rows, so this kernel uses v_mfma_f32_4x4x1_16b_f32: 16
-// independent 4x4 outer products per instruction at the same FLOP rate, laid out as 8 unit-groups x 2 row-groups, i.e.
-// 32 units x 8 rows x one k per instruction (probed layout, scripts/mfma4x4_probe.hip: lane 4b+j, register r holds
-// A[4b+r] * B[4b+j]).  An outer product needs one A and one B value per lane per k, four times the operand registers of
-// the 16x16 form, hence 8 waves: wave w keeps W_hh^T for units [64w, 64w+64) x its 64 (gate, unit) rows in 128 VGPRs.
-// Everything else is lstm_bwd_kowner: own dgates from LDS, 512-byte partial blocks per (consumer, producer), 32
-// coalesced dword loads summed in a fixed order.
-template <int NCH>
-__global__ __launch_bounds__(512) void lstm_bwd_kowner8(const float* __restrict__ dy, const float* __restrict__ whht_f,
-                                                        const float* __restrict__ whht_r, const int32_t* __restrict__ lens,
-                                                        const float* __restrict__ gates, const float* __restrict__ cell,
-                                                        float* __restrict__ dgates, float* partials, unsigned* flags, unsigned* ids,
-                                                        unsigned* status, unsigned* health, float* bias_part, int T, int B, int NT8, int force_wt) {
-    constexpr int H = 128 * NCH;
-    constexpr int members = H / 16;
-    constexpr int NG = H / 32 / 8;                    // 32-unit output groups per wave (2 at H = 512)
-    constexpr int DP = 68;
-    __shared__ float dgl[8 * DP + 4];                 // own dgates [row][gate][local unit] (+ one scratch word)
-    const int chain = blockIdx.x & 7, member = blockIdx.x >> 3;
-    if (chain >= 2 * NT8) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int dir = chain / NT8, bt = chain % NT8, unit0 = member * 16;
-    const int blk = lane >> 2, li = lane & 3, ug = blk >> 1, rg = blk & 1;
-    unsigned* cflags = flags + chain * 32;
-    const bool local = chain_is_xcd_local(ids + chain * 32, members, member, status, health, (unsigned*)(dgl + 8 * DP)) && !force_wt;
-
-    // resident A operand: aw[g][gate][i][e] = W_hh[gate*H + unit0 + 4i + e][n] = whht[n][gate*H + unit0 + 4i + e],
-    // n = 32*(wave*NG + g) + 4*ug + li
-    f32x4 aw[NG][4][4];
-    {
-        const float* whht = dir ? whht_r : whht_f;
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const int n = 32 * (wave * NG + g) + 4 * ug + li;
-#pragma unroll
-            for (int gate = 0; gate < 4; ++gate) {
-                const f32x4* wp = (const f32x4*)(whht + (long)n * 4 * H + gate * H + unit0);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) aw[g][gate][i] = wp[i];
-            }
-        }
-    }
-    const int b0 = bt * 8;
-    const bool cellw = tid < 128;                     // waves 0-1: one cell (row, unit) per thread
-    const int eb = b0 + ((tid >> 4) & 7), ej = tid & 15, eunit = unit0 + ej;
-    const bool ev = cellw && eb < B;
-    const int ebs = eb < B ? eb : b0;
-    const int len = lens[ebs];
-    float dcar = 0.f;
-    float bs[4] = {0.f, 0.f, 0.f, 0.f};               // this cell's share of the bias gradient: sum of its dgates over time
-    bool timed_out = false;
-    const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc((void*)partials, 0, 2 * 8 * 32 * 32 * 128 * 4, 0x00020000);
-
-    LSTM_STAMP_DECL;
-    for (int step = 0; step < T; ++step) {
-        const int t = dir == 0 ? T - 1 - step : step;
-        LSTM_STAMP(7);
-        const bool act = ev && t < len;
-        float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, c = 0.f, cprev = 0.f, dyv = 0.f;
-        if (act) {
-            const long sidx = (((long)dir * T + t) * B + ebs) * H + eunit;
-            const f32x4 gv = *(const f32x4*)(gates + sidx * 4);
-            ig = gv[0];
-            fg = gv[1];
-            gg = gv[2];
-            og = gv[3];
-            c = cell[sidx];
-            const int tp = dir == 0 ? t - 1 : t + 1;
-            cprev = (tp >= 0 && tp < len) ? cell[(((long)dir * T + tp) * B + ebs) * H + eunit] : 0.f;
-            dyv = dy[((long)t * B + ebs) * 2 * H + dir * H + eunit];
-        }
-        float rs = 0.f;
-        if (step > 0) {
-            if (wave == 7 && !timed_out) {
-                unsigned spins = 0;
-                for (;;) {
-                    unsigned f0 = (unsigned)step;
-                    if (lane < members) f0 = __hip_atomic_load(cflags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (__all(f0 >= (unsigned)step)) break;
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1u << 22)) {
-                        if (lane == 0) raise_timeout(status, health);
-                        timed_out = true;
-                        break;
-                    }
-                }
-            }
-            LSTM_STAMP(0);          // gate/cell loads issued + poll (wave 7)
-            __syncthreads();
-            LSTM_STAMP(1);
-            if (cellw) {
-                // this workgroup's block of every member's partials of the previous step: [member m][row][unit]
-                const int pbase = (((((step - 1) & 1) * 8 + chain) * 32 + member) * 32 * 128 + tid) * 4;
-                float pv[members];
-#pragma unroll
-                for (int m = 0; m < members; ++m) pv[m] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(prsrc, pbase + m * 512, 0, 16));   // sc1
-#pragma unroll
-                for (int m = 0; m < members; ++m) rs += pv[m];
-            }
-        }
-        LSTM_STAMP(2);              // 32 partial loads + sum (waves 0, 1)
-        if (cellw) {
-            float dg[4] = {0.f, 0.f, 0.f, 0.f};
-            if (act) dcar = lstm_cell_grad(dyv + rs, dcar, ig, fg, gg, og, c, cprev, dg);
-            else dcar = 0.f;
-            if (step == T - 1 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u)
-                dg[0] = dg[1] = dg[2] = dg[3] = __uint_as_float(0x7FC00000u);        // a hand-off timed out: fail loudly
-            if (ev) {
-                const long gbase = (((long)dir * T + t) * B + eb) * 4 * H + eunit;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    dgates[gbase + (long)g * H] = dg[g];     // for the weight/input-gradient GEMMs: plain stores
-                    bs[g] += dg[g];
-                }
-            }
-            if (step + 1 < T) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) dgl[(tid >> 4) * DP + g * 16 + ej] = dg[g];
-            }
-        }
-        LSTM_STAMP(3);              // cell gradient + dgates stores + LDS (waves 0, 1)
-        if (step + 1 < T) {
-            __syncthreads();
-            LSTM_STAMP(4);
-            // B operand: own dgates of row 4*rg + li, all 64 (gate, unit) values
-            f32x4 bv[4][4];
-#pragma unroll
-            for (int gate = 0; gate < 4; ++gate)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) bv[gate][i] = *(const f32x4*)&dgl[(4 * rg + li) * DP + gate * 16 + 4 * i];
-            f32x4 acc[NG];
-#pragma unroll
-            for (int g = 0; g < NG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int gate = 0; gate < 4; ++gate)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int g = 0; g < NG; ++g)
-                            acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(aw[g][gate][i][e], bv[gate][i][e], acc[g], 0, 0, 0);
-            // acc[g][r] = partial of (unit 32*(wave*NG+g) + 4*ug + r, row 4*rg + li): 4 consecutive units of one row
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                u32x4_t raw;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) raw[e] = __float_as_uint(acc[g][e]);
-                const int cons = 2 * (wave * NG + g) + (ug >> 2);
-                const int soff = ((((((step & 1) * 8 + chain) * 32 + cons) * 32 + member) * 8 + 4 * rg + li) * 16 + 4 * (ug & 3)) * 4;
-                if (local) __builtin_amdgcn_raw_buffer_store_b128(raw, prsrc, soff, 0, 1);        // sc0: stays in this XCD's L2
-                else __builtin_amdgcn_raw_buffer_store_b128(raw, prsrc, soff, 0, 16);            // write-through (sc1), 16 B
-            }
-            LSTM_STAMP(5);          // MFMA + partial stores issued
-            __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): every storing wave drains before the flag
-            LSTM_STAMP(6);
-        }
-        __syncthreads();                                     // also: dgl is free for the next step
-        if (tid == 0) {
-            if (local) __hip_atomic_store(cflags + member, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            else __hip_atomic_store(cflags + member, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-#ifdef VOCR_LSTM_STAMPS
-    if (lane == 0 && (wave == 0 || wave == 7) && g_lstm_stamp_out) {
-        unsigned long long* o = g_lstm_stamp_out + ((size_t)(256 + blockIdx.x) * 2 + (wave == 7)) * 8;
-        for (int k = 0; k < 8; ++k) o[k] = st_acc[k];
-    }
-#endif
-    // bias gradient of this chain's rows: sum the 8 rows in a fixed order -> bias_part[chain][gate*H + unit]
-    if (bias_part) {
-        if (cellw) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) dgl[(tid >> 4) * DP + g * 16 + ej] = bs[g];
-        }
-        __syncthreads();
-        if (tid < 64) {
-            const int g = tid >> 4, u = tid & 15;
-            float v = 0.f;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) v += dgl[r * DP + g * 16 + u];
-            bias_part[(long)chain * 4 * H + g * H + unit0 + u] = v;
-        }
-    }
-}
-
-// Backward sweep on 4-row chains with a self-validating hand-off ("bwd chain4v"): the K-owner form of lstm_bwd_kowner8
+// Backward sweep on 4-row chains with a self-validating hand-off ("bwd chain4v"): the K-owner form of lstm_bwd_kowner
 // (a workgroup multiplies its OWN 64 gate gradients into partial dh for all H units and every consumer sums the 32 partial
 // blocks of its 16 units in a fixed order) on the geometry of lstm_fwd_chain4v: 2*ceil(B/4) <= 16 chains, workgroups of 4
 // waves, two per CU above 8 chains.
@@ -1607,7 +1274,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_chain4v(const float* __restrict_
                                                         const float* __restrict__ whht_r, const int32_t* __restrict__ lens,
                                                         const float* __restrict__ gates, const float* __restrict__ cell,
                                                         const float* __restrict__ dy_mask, float* __restrict__ dgates, float* ring, unsigned* ids, unsigned* status,
-                                                        unsigned* health, float* bias_part, int T, int B, int NT4, int force_wt) {
+                                                        unsigned* health, float* bias_part, int T, int B, int NT4, int force_wt, int packed_rows) {
     constexpr int H = 128 * NCH;
     constexpr int members = H / 16;
     constexpr int UW = H / 4;                         // units per wave
@@ -1648,6 +1315,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_chain4v(const float* __restrict_
     const bool ev = cellw && eb < B;
     const int ebs = eb < B ? eb : b0;
     const int len = lens[ebs];
+    const SeqRows sr = seq_rows(lens, T, B, bt, packed_rows);
+    const int Tc = sr.steps;
+    const long prow0 = (long)dir * sr.total + sr.base + (ebs - b0);       // plane-local row of the lane's cell at t = 0
+    const long yrow0 = sr.base + (ebs - b0);
     float dcar = 0.f;
     float bs[4] = {0.f, 0.f, 0.f, 0.f};
     bool timed_out = false;
@@ -1659,24 +1330,24 @@ __global__ __launch_bounds__(256) void lstm_bwd_chain4v(const float* __restrict_
     f32x4 gv_n = (f32x4){0.f, 0.f, 0.f, 0.f};
     float c_n = 0.f, cprev_n = 0.f, dy_n = 0.f;
     auto fetch = [&](int st) {
-        const int tt = dir == 0 ? T - 1 - st : st;
+        const int tt = dir == 0 ? Tc - 1 - st : st;
         gv_n = (f32x4){0.f, 0.f, 0.f, 0.f};
         c_n = cprev_n = dy_n = 0.f;
         if (ev && tt < len) {
-            const long sidx = (((long)dir * T + tt) * B + ebs) * H + eunit;
+            const long sidx = (prow0 + (long)sr.stride * tt) * H + eunit;
             gv_n = *(const f32x4*)(gates + sidx * 4);
             c_n = cell[sidx];
             const int tp = dir == 0 ? tt - 1 : tt + 1;
-            if (tp >= 0 && tp < len) cprev_n = cell[(((long)dir * T + tp) * B + ebs) * H + eunit];
-            const long di = ((long)tt * B + ebs) * 2 * H + dir * H + eunit;
+            if (tp >= 0 && tp < len) cprev_n = cell[(prow0 + (long)sr.stride * tp) * H + eunit];
+            const long di = (yrow0 + (long)sr.stride * tt) * 2 * H + dir * H + eunit;
             dy_n = dy[di];
             if (dy_mask) dy_n *= dy_mask[di];         // the inter-layer dropout's backward, fused into the read
         }
     };
-    if (cellw) fetch(0);
+    if (cellw && Tc > 0) fetch(0);
 
-    for (int step = 0; step < T; ++step) {
-        const int t = dir == 0 ? T - 1 - step : step;
+    for (int step = 0; step < Tc; ++step) {
+        const int t = dir == 0 ? Tc - 1 - step : step;
         float* dgw = dgl + (step & 1) * 4 * DP;
         float dg[4] = {0.f, 0.f, 0.f, 0.f};
         if (cellw) {
@@ -1735,7 +1406,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_chain4v(const float* __restrict_
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 if (dg[g] != dg[g]) dg[g] = __uint_as_float(0x7FC00000u);              // never the hand-off pattern
-            if (step == T - 1 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u)
+            if (step == Tc - 1 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u)
                 dg[0] = dg[1] = dg[2] = dg[3] = __uint_as_float(0x7FC00000u);        // a hand-off timed out: fail loudly
 #pragma unroll
             for (int g = 0; g < 4; ++g) dgw[erow * DP + g * 16 + ej] = dg[g];
@@ -1745,9 +1416,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_chain4v(const float* __restrict_
         __syncthreads();
         if (cellw) {
             // off the critical path (the other waves are already multiplying): next step's records, this step's dgates for the GEMMs
-            if (step + 1 < T) fetch(step + 1);
+            if (step + 1 < Tc) fetch(step + 1);
             if (ev) {
-                const long gbase = (((long)dir * T + t) * B + eb) * 4 * H + eunit;
+                const long gbase = (prow0 + (long)sr.stride * t) * 4 * H + eunit;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     dgates[gbase + (long)g * H] = dg[g];
@@ -1755,7 +1426,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_chain4v(const float* __restrict_
                 }
             }
         }
-        if (step + 1 < T) {
+        if (step + 1 < Tc) {
             // B operand: lane = (16-lane group g, .., row j = lane & 3): bv[q][e] = dgates[row j][k = 16q + 4g + e]
             f32x4 bv[4];
 #pragma unroll
@@ -1827,7 +1498,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_chain4w(const float* __restrict_
                                                         const float* __restrict__ whht_r, const int32_t* __restrict__ lens,
                                                         const float* __restrict__ gates, const float* __restrict__ cell,
                                                         const float* __restrict__ dy_mask, float* __restrict__ dgates, float* ring, unsigned* ids, unsigned* status,
-                                                        unsigned* health, float* bias_part, int T, int B, int NT4, int force_wt) {
+                                                        unsigned* health, float* bias_part, int T, int B, int NT4, int force_wt, int packed_rows) {
     constexpr int H = 128 * NCH;
     static_assert(H == 512, "8 waves x 64 units");
     constexpr int members = H / 32;
@@ -1861,6 +1532,10 @@ __global__ __launch_bounds__(512) void lstm_bwd_chain4w(const float* __restrict_
     const bool ev = cellw && eb < B;
     const int ebs = eb < B ? eb : b0;
     const int len = lens[cellw ? ebs : b0];
+    const SeqRows sr = seq_rows(lens, T, B, bt, packed_rows);
+    const int Tc = sr.steps;
+    const long prow0 = (long)dir * sr.total + sr.base + (cellw ? ebs - b0 : 0);      // plane-local row of the thread's cell at t = 0
+    const long yrow0 = sr.base + (cellw ? ebs - b0 : 0);
     float dcar = 0.f;
     float bs[4] = {0.f, 0.f, 0.f, 0.f};
     bool timed_out = false;
@@ -1871,28 +1546,28 @@ __global__ __launch_bounds__(512) void lstm_bwd_chain4w(const float* __restrict_
     f32x4 gv_n = (f32x4){0.f, 0.f, 0.f, 0.f};
     float c_n = 0.f, cprev_n = 0.f, dy_n = 0.f;
     auto fetch = [&](int st) {
-        const int tt = dir == 0 ? T - 1 - st : st;
+        const int tt = dir == 0 ? Tc - 1 - st : st;
         gv_n = (f32x4){0.f, 0.f, 0.f, 0.f};
         c_n = cprev_n = dy_n = 0.f;
         if (ev && tt < len) {
-            const long sidx = (((long)dir * T + tt) * B + ebs) * H + eunit;
+            const long sidx = (prow0 + (long)sr.stride * tt) * H + eunit;
             // The records of a step are read once and the gate gradients written once: streamed with the non-temporal policy, so that
             // they do not push the partial-block ring (1 MB per XCD, rewritten every four steps) out of L2 - evicted ring lines were
             // 460 MB of HBM writes per sweep beside the 154 MB of gate gradients.
             gv_n = __builtin_nontemporal_load((const f32x4*)(gates + sidx * 4));
             c_n = __builtin_nontemporal_load(cell + sidx);
             const int tp = dir == 0 ? tt - 1 : tt + 1;
-            if (tp >= 0 && tp < len) cprev_n = __builtin_nontemporal_load(cell + (((long)dir * T + tp) * B + ebs) * H + eunit);
-            const long di = ((long)tt * B + ebs) * 2 * H + dir * H + eunit;
+            if (tp >= 0 && tp < len) cprev_n = __builtin_nontemporal_load(cell + (prow0 + (long)sr.stride * tp) * H + eunit);
+            const long di = (yrow0 + (long)sr.stride * tt) * 2 * H + dir * H + eunit;
             dy_n = __builtin_nontemporal_load(dy + di);
             if (dy_mask) dy_n *= __builtin_nontemporal_load(dy_mask + di);         // the inter-layer dropout's backward, fused into the read
         }
     };
-    if (cellw) fetch(0);
+    if (cellw && Tc > 0) fetch(0);
 
     LSTM_STAMP_DECL;
-    for (int step = 0; step < T; ++step) {
-        const int t = dir == 0 ? T - 1 - step : step;
+    for (int step = 0; step < Tc; ++step) {
+        const int t = dir == 0 ? Tc - 1 - step : step;
         float* dgw = dgl + (step & 1) * 4 * DP;
         LSTM_STAMP(7);
         float dg[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1953,7 +1628,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_chain4w(const float* __restrict_
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 if (dg[g] != dg[g]) dg[g] = __uint_as_float(0x7FC00000u);              // never the hand-off pattern
-            if (step == T - 1 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u)
+            if (step == Tc - 1 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u)
                 dg[0] = dg[1] = dg[2] = dg[3] = __uint_as_float(0x7FC00000u);        // a hand-off timed out: fail loudly
 #pragma unroll
             for (int g = 0; g < 4; ++g) dgw[erow * DP + g * 32 + ej] = dg[g];
@@ -1964,9 +1639,9 @@ __global__ __launch_bounds__(512) void lstm_bwd_chain4w(const float* __restrict_
         __syncthreads();
         if (cellw) {
             // off the critical path (the other waves are already multiplying): next step's records, this step's dgates for the GEMMs
-            if (step + 1 < T) fetch(step + 1);
+            if (step + 1 < Tc) fetch(step + 1);
             if (ev) {
-                const long gbase = (((long)dir * T + t) * B + eb) * 4 * H + eunit;
+                const long gbase = (prow0 + (long)sr.stride * t) * 4 * H + eunit;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     __builtin_nontemporal_store(dg[g], dgates + gbase + (long)g * H);
@@ -1975,7 +1650,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_chain4w(const float* __restrict_
             }
         }
         LSTM_STAMP(2);
-        if (step + 1 < T) {
+        if (step + 1 < Tc) {
             // B operand: lane = (16-lane group g, row j = lane & 3): bv[q][e] = dgates[row j][k = 16q + 4g + e], q < 8
             f32x4 bv[8];
 #pragma unroll
@@ -2081,33 +1756,43 @@ int resident_workgroup_capacity() {
 
 }  // namespace
 
-// ---- which sweep a shape runs on.  Five generations of kernels, newest first; a shape takes the first one it fits:
+// ---- which sweep a shape runs on.  Newest first; a shape takes the first one it fits:
 //   wide4    lstm_fwd_chain4w / lstm_bwd_chain4w   16 < B <= 32, H = 512: 4-row chains of 16 wide members, one 8-wave workgroup per CU,
-//                                                  self-validating hand-off (round 3; the BASELINE configuration)
-//   chain4   lstm_fwd_chain4v / lstm_bwd_chain4v   B <= 32, H in {256, 512}: 4-row chains, self-validating hand-off (round 3)
-//   chain8   lstm_fwd_chain8 / lstm_bwd_kowner8    B <= 32, H in {256, 512}: 8-row chains, arrival flags (round 2)
-//   chain16  lstm_fwd_chain / lstm_bwd_kowner      B <= 64, H in {64 (forward only), 128, 256, 512}: 16-row chains, arrival flags (round 1)
+//                                                  self-validating hand-off (the BASELINE configuration)
+//   chain4   lstm_fwd_chain4v / lstm_bwd_chain4v   B <= 32, H in {256, 512}: 4-row chains, self-validating hand-off
+//   chain16  lstm_fwd_chain / lstm_bwd_kowner      B <= 64, H in {64 (forward only), 128, 256, 512}: 16-row chains, arrival flags
 //   step     lstm_*_step_fast / lstm_*_step_kernel one launch per time step (any shape; also when the grid cannot be co-resident)
-// VOCR_LSTM_SWEEP=<name> starts the search at that generation for both directions (A/B of the generations, tests), VOCR_LSTM_SWEEP_FWD /
-// VOCR_LSTM_SWEEP_BWD for one direction; VOCR_LSTM_WRITE_THROUGH=1 forces the hand-off mode of a chain spread over several XCDs.
-enum SweepKind { SWEEP_WIDE4 = 0, SWEEP_CHAIN4 = 1, SWEEP_CHAIN8 = 2, SWEEP_CHAIN16 = 3, SWEEP_STEP = 4 };
+// (Round 2's 8-row flag chains were no shape's default since round 3 and are gone.)
+// Runtime knobs (include/vocr.h): VOCR_LSTM_SWEEP=<name> starts the search at that kind for both directions - `step` is the one an
+// operator needs: several processes sharing one GPU, whose persistent sweeps would wait for each other's CUs - VOCR_LSTM_SWEEP_FWD /
+// VOCR_LSTM_SWEEP_BWD for one direction; VOCR_LSTM_PERSISTENT=0 is accepted as the old spelling of VOCR_LSTM_SWEEP=step; an unknown
+// value is an error of the call (VOCR_EINVAL), not a silent default.  VOCR_LSTM_WRITE_THROUGH=1 forces the hand-off mode of a chain
+// spread over several XCDs.
+enum SweepKind { SWEEP_WIDE4 = 0, SWEEP_CHAIN4 = 1, SWEEP_CHAIN16 = 2, SWEEP_STEP = 3, SWEEP_BAD = -1 };
 
 static SweepKind sweep_floor(bool backward) {
-    static int cache[2] = {-1, -1};
-    if (cache[backward] < 0) {
+    static int cache[2] = {-2, -2};
+    if (cache[backward] == -2) {
         const char* v = getenv(backward ? "VOCR_LSTM_SWEEP_BWD" : "VOCR_LSTM_SWEEP_FWD");
         if (!v) v = getenv("VOCR_LSTM_SWEEP");
         int k = SWEEP_WIDE4;
         if (v) {
-            if (!strcmp(v, "chain4")) k = SWEEP_CHAIN4;
-            else if (!strcmp(v, "chain8")) k = SWEEP_CHAIN8;
+            if (!strcmp(v, "wide4") || !*v) k = SWEEP_WIDE4;
+            else if (!strcmp(v, "chain4")) k = SWEEP_CHAIN4;
             else if (!strcmp(v, "chain16")) k = SWEEP_CHAIN16;
             else if (!strcmp(v, "step")) k = SWEEP_STEP;
+            else k = SWEEP_BAD;
+        } else {
+            const char* p = getenv("VOCR_LSTM_PERSISTENT");
+            if (p && !strcmp(p, "0")) k = SWEEP_STEP;
         }
         cache[backward] = k;
     }
     return (SweepKind)cache[backward];
 }
+
+#define VOCR_CHECK_SWEEP_ENV(backward) \
+    VOCR_CHECK_ARG(sweep_floor(backward) != SWEEP_BAD, "VOCR_LSTM_SWEEP%s: unknown sweep kind (wide4, chain4, chain16, step)", "")
 
 static bool sweep_write_through() {
     static const int v = getenv("VOCR_LSTM_WRITE_THROUGH") ? atoi(getenv("VOCR_LSTM_WRITE_THROUGH")) : 0;
@@ -2117,13 +1802,12 @@ static bool sweep_write_through() {
 // `persistent_ok`: the shape and its buffers allow a persistent sweep at all (fast path, alignment, 32-bit offsets, co-residency)
 static SweepKind lstm_sweep_kind(bool backward, int b, int h, bool persistent_ok) {
     const SweepKind floor_ = sweep_floor(backward);
-    if (!persistent_ok || floor_ == SWEEP_STEP || b <= 0) return SWEEP_STEP;
+    if (!persistent_ok || floor_ == SWEEP_STEP || floor_ == SWEEP_BAD || b <= 0) return SWEEP_STEP;
     const int cap = resident_workgroup_capacity();
-    const int nt4 = (b + 3) / 4, nt8 = (b + 7) / 8;
+    const int nt4 = (b + 3) / 4;
     const bool h45 = h == 512 || h == 256;
     if (floor_ <= SWEEP_WIDE4 && h == 512 && nt4 > 4 && nt4 <= 8 && 256 <= cap) return SWEEP_WIDE4;
     if (floor_ <= SWEEP_CHAIN4 && 2 * nt4 <= 16 && h45 && (2 * nt4 > 8 ? 16 : 8) * (h / 16) <= 2 * cap) return SWEEP_CHAIN4;
-    if (floor_ <= SWEEP_CHAIN8 && 2 * nt8 <= 8 && h45) return SWEEP_CHAIN8;
     return SWEEP_CHAIN16;
 }
 
@@ -2155,12 +1839,15 @@ extern "C" size_t vocr_lstm_workspace_bytes(int t, int b, int h) {
     return lstm_ws_handoff_offset(b, h) + 4096 + (size_t)4 * 16 * 4 * h * sizeof(float);
 }
 
-extern "C" int vocr_lstm_fwd_range(const float* xproj, const float* whh_fwd, const float* whh_rev, const int32_t* lens, float* y,
-                                   float* gates, float* cell, void* workspace, int t, int b, int h, int step_begin, int step_end,
-                                   int32_t* health, void* stream) {
+static bool lstm_packed_kind_ok(int b, int h);
+
+static int lstm_fwd_impl(const float* xproj, const float* whh_fwd, const float* whh_rev, const int32_t* lens, float* y,
+                         float* gates, float* cell, void* workspace, int t, int b, int h, int step_begin, int step_end,
+                         int packed_rows, int32_t* health, void* stream) {
     VOCR_CHECK_ARG(xproj && whh_fwd && whh_rev && lens && y && gates && cell && workspace, "vocr_lstm_fwd: null pointer");
     VOCR_CHECK_ARG(t > 0 && b > 0 && b <= 64 && h > 0 && h % 16 == 0, "vocr_lstm_fwd: need 1<=B<=64 and H%%16==0 (B=%d H=%d)", b, h);
     VOCR_CHECK_ARG(0 <= step_begin && step_begin < step_end && step_end <= t, "vocr_lstm_fwd: bad step range [%d, %d) of %d", step_begin, step_end, t);
+    VOCR_CHECK_SWEEP_ENV(false);
         hipStream_t s = (hipStream_t)stream;
     const int rt = (b + 15) / 16;
     const bool fast = (h == 64 || h == 128 || h == 256 || h == 512) && aligned16(whh_fwd) && aligned16(whh_rev) && aligned16(y) &&
@@ -2168,8 +1855,13 @@ extern "C" int vocr_lstm_fwd_range(const float* xproj, const float* whh_fwd, con
     VOCR_CHECK_ARG(aligned16(gates), "vocr_lstm_fwd: gates must be 16-byte aligned");
     const dim3 grid(2 * (h / 4));
     // the chain kernels address y through a buffer descriptor with 32-bit byte offsets
-    const bool fits32 = (long)t * b * 2 * h * 4 < (1l << 31);
+    const bool fits32 = (packed_rows ? (long)packed_rows : (long)t * b) * 2 * h * 4 < (1l << 31);
     const SweepKind kind = lstm_sweep_kind(false, b, h, fast && fits32 && 8 * (h / 16) <= resident_workgroup_capacity());
+    if (packed_rows) {
+        VOCR_CHECK_ARG(lstm_packed_kind_ok(b, h) && (kind == SWEEP_WIDE4 || kind == SWEEP_CHAIN4) && step_begin == 0 && step_end == t,
+                       "vocr_lstm_fwd_packed: the packed row layout needs a 4-row chain sweep (ask vocr_lstm_packed_supported; B=%d H=%d)", b, h);
+        VOCR_CHECK_ARG(packed_rows % 4 == 0 && packed_rows >= 4 * (1 + 2 * ((b + 3) / 4)), "vocr_lstm_fwd_packed: bad row count %d", packed_rows);
+    }
     if (kind != SWEEP_STEP) {
         // arrival flags: [chain <= 8][32 workgroups] at [0..255], XCC ids at [256..511]; status words at [512..]
         unsigned* flags = (unsigned*)workspace;
@@ -2177,19 +1869,20 @@ extern "C" int vocr_lstm_fwd_range(const float* xproj, const float* whh_fwd, con
         unsigned* hword = (unsigned*)health;
         const dim3 cg(8 * (h / 16));
         const int fwt = sweep_write_through() ? 1 : 0;
-        const int nt8 = (b + 7) / 8, nt4 = (b + 3) / 4;
+        const int nt4 = (b + 3) / 4;
         if (kind == SWEEP_WIDE4 || kind == SWEEP_CHAIN4) {
             // self-validating hand-off: the ring starts as the "not written yet" pattern (first range of a sweep only)
             unsigned* blk = (unsigned*)((char*)workspace + lstm_ws_handoff_offset(b, h));
             float* hx = (float*)(blk + 1024);
             if (lstm_fwd_selfval_prep(blk, (size_t)4 * 2 * nt4 * 4 * h * sizeof(float), step_begin == 0, s) != VOCR_OK) return VOCR_ELAUNCH;
             if (kind == SWEEP_WIDE4) {
-                static const int nap4w = getenv("VOCR_LSTM_NAP") ? atoi(getenv("VOCR_LSTM_NAP")) : 0;      // -1: polls start at once (experiments)
-                lstm_fwd_chain4w<8><<<256, 512, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, hx, blk, blk + 512, hword, t, b, nt4, fwt, step_begin, step_end, nap4w);
+                static const int nap4w = VOCR_EXPERIMENT_INT("VOCR_LSTM_NAP", 0);      // -1: polls start at once (experiments)
+                lstm_fwd_chain4w<8><<<256, 512, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, hx, blk, blk + 512, hword, t, b, nt4, fwt, step_begin, step_end, nap4w,
+                                                        packed_rows);
             } else {
                 const dim3 cg4((2 * nt4 > 8 ? 16 : 8) * (h / 16));
-                if (h == 512) lstm_fwd_chain4v<8><<<cg4, 256, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, hx, blk, blk + 512, hword, t, b, nt4, fwt, step_begin, step_end);
-                else lstm_fwd_chain4v<4><<<cg4, 256, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, hx, blk, blk + 512, hword, t, b, nt4, fwt, step_begin, step_end);
+                if (h == 512) lstm_fwd_chain4v<8><<<cg4, 256, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, hx, blk, blk + 512, hword, t, b, nt4, fwt, step_begin, step_end, packed_rows);
+                else lstm_fwd_chain4v<4><<<cg4, 256, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, hx, blk, blk + 512, hword, t, b, nt4, fwt, step_begin, step_end, packed_rows);
             }
             VOCR_CHECK_LAUNCH("vocr_lstm_fwd(4-row chains, self-validating)");
             return VOCR_OK;
@@ -2197,16 +1890,6 @@ extern "C" int vocr_lstm_fwd_range(const float* xproj, const float* whh_fwd, con
         if (hipMemsetAsync(flags, 0, 520 * sizeof(unsigned), s) != hipSuccess) {
             vocr_set_error("vocr_lstm_fwd: memset failed");
             return VOCR_ELAUNCH;
-        }
-        if (kind == SWEEP_CHAIN8) {      // 8-row chains on all 8 XCDs, 4x4x1 MFMA
-            if (h == 512)
-                lstm_fwd_chain8<8><<<cg, 512, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, flags, flags + 256, status, hword, t, b, nt8, fwt,
-                                                      step_begin, step_end);
-            else
-                lstm_fwd_chain8<4><<<cg, 512, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, flags, flags + 256, status, hword, t, b, nt8, fwt,
-                                                      step_begin, step_end);
-            VOCR_CHECK_LAUNCH("vocr_lstm_fwd(chain, 8-row)");
-            return VOCR_OK;
         }
 #define VOCR_CHAIN(KQ4) lstm_fwd_chain<KQ4><<<cg, 256, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, flags, flags + 256, status, hword, t, b, rt, fwt, step_begin, step_end)
         if (h == 64) VOCR_CHAIN(1); else if (h == 128) VOCR_CHAIN(2); else if (h == 256) VOCR_CHAIN(4); else VOCR_CHAIN(8);
@@ -2230,9 +1913,103 @@ extern "C" int vocr_lstm_fwd_range(const float* xproj, const float* whh_fwd, con
     return VOCR_OK;
 }
 
+extern "C" int vocr_lstm_fwd_range(const float* xproj, const float* whh_fwd, const float* whh_rev, const int32_t* lens, float* y,
+                                   float* gates, float* cell, void* workspace, int t, int b, int h, int step_begin, int step_end,
+                                   int32_t* health, void* stream) {
+    return lstm_fwd_impl(xproj, whh_fwd, whh_rev, lens, y, gates, cell, workspace, t, b, h, step_begin, step_end, 0, health, stream);
+}
+
 extern "C" int vocr_lstm_fwd(const float* xproj, const float* whh_fwd, const float* whh_rev, const int32_t* lens, float* y,
                              float* gates, float* cell, void* workspace, int t, int b, int h, int32_t* health, void* stream) {
-    return vocr_lstm_fwd_range(xproj, whh_fwd, whh_rev, lens, y, gates, cell, workspace, t, b, h, 0, t, health, stream);
+    return lstm_fwd_impl(xproj, whh_fwd, whh_rev, lens, y, gates, cell, workspace, t, b, h, 0, t, 0, health, stream);
+}
+
+// ---- packed row layout (struct SeqRows above; include/vocr.h)
+static bool lstm_packed_kind_ok(int b, int h) {
+    const SweepKind kf = lstm_sweep_kind(false, b, h, true), kb = lstm_sweep_kind(true, b, h, true);
+    return (kf == SWEEP_WIDE4 || kf == SWEEP_CHAIN4) && (kb == SWEEP_WIDE4 || kb == SWEEP_CHAIN4);
+}
+
+extern "C" int vocr_lstm_packed_supported(int b, int h) {
+    if (b <= 0 || b > 32 || (h != 256 && h != 512)) return 0;
+    return lstm_packed_kind_ok(b, h) ? 1 : 0;
+}
+
+extern "C" int vocr_lstm_fwd_packed(const float* xproj, const float* whh_fwd, const float* whh_rev, const int32_t* lens, float* y,
+                                    float* gates, float* cell, void* workspace, int t, int b, int h, int rows, int32_t* health,
+                                    void* stream) {
+    VOCR_CHECK_ARG(rows > 0, "vocr_lstm_fwd_packed: rows must be positive");
+    return lstm_fwd_impl(xproj, whh_fwd, whh_rev, lens, y, gates, cell, workspace, t, b, h, 0, t, rows, health, stream);
+}
+
+// to_packed[t*B + b] = packed row of frame (t, b), or -1 where the packed layout has none (t >= the length of b's chain);
+// to_dense[r] = t*B + b of packed row r, or -1 for the all-zero groups and a last chain's rows >= B
+__global__ void seq_rowmap_kernel(const int32_t* __restrict__ lens, int T, int B, int rows, int32_t* __restrict__ to_packed,
+                                  int32_t* __restrict__ to_dense) {
+    __shared__ int gbase[17];          // first group of chain c (its t = 0); [nch] = the trailing zero group
+    const int nch = (B + 3) / 4;
+    if (threadIdx.x == 0) {
+        int g = 1;
+        for (int c = 0; c < nch; ++c) {
+            gbase[c] = g;
+            g += min(lens[4 * c], T) + 1;
+        }
+        gbase[nch] = g - 1;
+    }
+    __syncthreads();
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (to_packed && i < (long)T * B) {
+        const int t = (int)(i / B), b = (int)(i % B), c = b >> 2;
+        to_packed[i] = t < min(lens[4 * c], T) ? 4 * (gbase[c] + t) + (b & 3) : -1;
+    }
+    if (to_dense && i < rows) {
+        const int g = (int)(i >> 2), j = (int)(i & 3);
+        int v = -1;
+        for (int c = 0; c < nch; ++c) {
+            const int L = min(lens[4 * c], T);
+            if (g >= gbase[c] && g < gbase[c] + L && 4 * c + j < B) v = (g - gbase[c]) * B + 4 * c + j;
+        }
+        to_dense[i] = v;
+    }
+}
+
+extern "C" int vocr_seq_rowmap(const int32_t* lens, int t, int b, int rows, int32_t* to_packed, int32_t* to_dense, void* stream) {
+    VOCR_CHECK_ARG(lens && (to_packed || to_dense), "vocr_seq_rowmap: null pointer");
+    VOCR_CHECK_ARG(t > 0 && b > 0 && b <= 64 && rows > 0 && rows % 4 == 0, "vocr_seq_rowmap: bad shape (T=%d B=%d rows=%d)", t, b, rows);
+    const long n = (long)t * b > rows ? (long)t * b : rows;
+    seq_rowmap_kernel<<<vocr_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(lens, t, b, rows, to_packed, to_dense);
+    VOCR_CHECK_LAUNCH("vocr_seq_rowmap");
+    return VOCR_OK;
+}
+
+// dst[r][:] = src[map[r]][:] (map[r] >= 0) or fill[:] / 0 (map[r] < 0): one wave per row, 16-byte pieces when n % 4 == 0
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, const int32_t* __restrict__ map,
+                                                          long nrows, int n, const float* __restrict__ fill) {
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= nrows) return;
+    const int lane = threadIdx.x & 63;
+    const int m = map[r];
+    float* d = dst + r * n;
+    if ((n & 3) == 0) {
+        const f32x4* s4 = m >= 0 ? (const f32x4*)(src + (long)m * n) : nullptr;
+        for (int i = lane; i < (n >> 2); i += 64) {
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (s4) v = __builtin_nontemporal_load(s4 + i);
+            else if (fill) v = ((const f32x4*)fill)[i];
+            ((f32x4*)d)[i] = v;
+        }
+    } else {
+        for (int i = lane; i < n; i += 64) d[i] = m >= 0 ? src[(long)m * n + i] : (fill ? fill[i] : 0.f);
+    }
+}
+
+extern "C" int vocr_gather_rows(const float* src, float* dst, const int32_t* map, long nrows, int n, const float* fill, void* stream) {
+    VOCR_CHECK_ARG(src && dst && map, "vocr_gather_rows: null pointer");
+    VOCR_CHECK_ARG(nrows > 0 && n > 0, "vocr_gather_rows: bad shape (%ld x %d)", nrows, n);
+    VOCR_CHECK_ARG((n & 3) != 0 || ((((uintptr_t)src | (uintptr_t)dst | (uintptr_t)fill) & 15) == 0), "vocr_gather_rows: 16-byte alignment");
+    gather_rows_kernel<<<vocr_cdiv(nrows, 4), 256, 0, (hipStream_t)stream>>>(src, dst, map, nrows, n, fill);
+    VOCR_CHECK_LAUNCH("vocr_gather_rows");
+    return VOCR_OK;
 }
 
 extern "C" int vocr_colsum(const float* x, float* out, int m, int n, void* workspace, void* stream);
@@ -2263,7 +2040,7 @@ static int lstm_bwd_selfval_kind(int b, int h) {
 
 static int lstm_bwd_impl(const float* dy, const float* dy_mask, const float* whht_fwd, const float* whht_rev, const int32_t* lens,
                          const float* gates, const float* cell, float* dgates, float* dbias, bool combine, void* workspace, int t,
-                         int b, int h, int32_t* health, void* stream);
+                         int b, int h, int32_t* health, void* stream, int packed_rows = 0);
 
 extern "C" int vocr_lstm_bwd_bias(const float* dy, const float* whht_fwd, const float* whht_rev, const int32_t* lens,
                                   const float* gates, const float* cell, float* dgates, float* dbias, void* workspace, int t,
@@ -2292,18 +2069,29 @@ extern "C" int vocr_lstm_bias_from_parts(float* dbias, const void* workspace, in
     return VOCR_OK;
 }
 
+extern "C" int vocr_lstm_bwd_packed(const float* dy, const float* dy_mask, const float* whht_fwd, const float* whht_rev, const int32_t* lens,
+                                    const float* gates, const float* cell, float* dgates, float* dbias, void* workspace, int t, int b,
+                                    int h, int rows, int32_t* health, void* stream) {
+    VOCR_CHECK_ARG(rows > 0 && rows % 4 == 0 && vocr_lstm_packed_supported(b, h),
+                   "vocr_lstm_bwd_packed: the packed row layout needs a 4-row chain sweep (ask vocr_lstm_packed_supported; B=%d H=%d rows=%d)", b, h, rows);
+    VOCR_CHECK_ARG(aligned16(whht_fwd) && aligned16(whht_rev) && aligned16(dgates) && aligned16(gates), "vocr_lstm_bwd_packed: 16-byte alignment");
+    return lstm_bwd_impl(dy, dy_mask, whht_fwd, whht_rev, lens, gates, cell, dgates, dbias, true, workspace, t, b, h, health, stream, rows);
+}
+
 static int lstm_bwd_impl(const float* dy, const float* dy_mask, const float* whht_fwd, const float* whht_rev, const int32_t* lens,
                          const float* gates, const float* cell, float* dgates, float* dbias, bool combine, void* workspace, int t,
-                         int b, int h, int32_t* health, void* stream) {
+                         int b, int h, int32_t* health, void* stream, int packed_rows) {
     const float* whh_fwd = whht_fwd;
     const float* whh_rev = whht_rev;
     VOCR_CHECK_ARG(dy && whh_fwd && whh_rev && lens && gates && cell && dgates && workspace, "vocr_lstm_bwd: null pointer");
     VOCR_CHECK_ARG(t > 0 && b > 0 && b <= 64 && h > 0 && h % 16 == 0, "vocr_lstm_bwd: need 1<=B<=64 and H%%16==0 (B=%d H=%d)", b, h);
+    VOCR_CHECK_SWEEP_ENV(true);
     hipStream_t s = (hipStream_t)stream;
     float* dcb = (float*)workspace;
     const int rt = (b + 15) / 16;
     const bool fast = (h == 128 || h == 256 || h == 512) && aligned16(whh_fwd) && aligned16(whh_rev) && aligned16(dgates);
     const SweepKind kind = lstm_sweep_kind(true, b, h, fast && 8 * (h / 16) <= resident_workgroup_capacity() && aligned16(gates));
+    VOCR_CHECK_ARG(!packed_rows || kind == SWEEP_WIDE4 || kind == SWEEP_CHAIN4, "vocr_lstm_bwd_packed: no 4-row chain sweep for B=%d H=%d", b, h);
     if (kind != SWEEP_STEP) {
         // arrival flags: [chain <= 8][32 workgroups] at [0..255]; status words at [512..]
         unsigned* flags = (unsigned*)workspace;
@@ -2312,7 +2100,7 @@ static int lstm_bwd_impl(const float* dy, const float* dy_mask, const float* whh
         const dim3 g(8 * (h / 16));
         // K-owner form: partial sums [parity][chain][consumer][producer][16 x 16] behind the flags/status words
         float* partials = (float*)((char*)workspace + 4096);
-        const int nt8 = (b + 7) / 8, nt4 = (b + 3) / 4;
+        const int nt4 = (b + 3) / 4;
         const int fwt = sweep_write_through() ? 1 : 0;
         float* bpart = dbias ? (float*)((char*)workspace + 4096 + ((size_t)16 << 20)) : nullptr;     // [chain][4H]
         if (kind == SWEEP_WIDE4 || kind == SWEEP_CHAIN4) {
@@ -2324,13 +2112,13 @@ static int lstm_bwd_impl(const float* dy, const float* dy_mask, const float* whh
                 return VOCR_ELAUNCH;
             }
             if (kind == SWEEP_WIDE4) {
-                lstm_bwd_chain4w<4><<<256, 512, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dy_mask, dgates, partials, flags, status, hword, bpart, t, b, nt4, fwt);
+                lstm_bwd_chain4w<4><<<256, 512, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dy_mask, dgates, partials, flags, status, hword, bpart, t, b, nt4, fwt, packed_rows);
             } else {
                 const dim3 g4((nch > 8 ? 16 : 8) * (h / 16));
                 if (h == 512)
-                    lstm_bwd_chain4v<4><<<g4, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dy_mask, dgates, partials, flags, status, hword, bpart, t, b, nt4, fwt);
+                    lstm_bwd_chain4v<4><<<g4, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dy_mask, dgates, partials, flags, status, hword, bpart, t, b, nt4, fwt, packed_rows);
                 else
-                    lstm_bwd_chain4v<2><<<g4, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dy_mask, dgates, partials, flags, status, hword, bpart, t, b, nt4, fwt);
+                    lstm_bwd_chain4v<2><<<g4, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dy_mask, dgates, partials, flags, status, hword, bpart, t, b, nt4, fwt, packed_rows);
             }
             VOCR_CHECK_LAUNCH("vocr_lstm_bwd(k-owner, 4-row chains, self-validating)");
             if (dbias && combine) {
@@ -2342,18 +2130,6 @@ static int lstm_bwd_impl(const float* dy, const float* dy_mask, const float* whh
         if (hipMemsetAsync(flags, 0, 520 * sizeof(unsigned), s) != hipSuccess) {
             vocr_set_error("vocr_lstm_bwd: memset failed");
             return VOCR_ELAUNCH;
-        }
-        if (kind == SWEEP_CHAIN8) {      // 8-row chains on all 8 XCDs, 4x4x1 MFMA
-            if (h == 512)
-                lstm_bwd_kowner8<4><<<g, 512, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, hword, bpart, t, b, nt8, fwt);
-            else
-                lstm_bwd_kowner8<2><<<g, 512, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, hword, bpart, t, b, nt8, fwt);
-            VOCR_CHECK_LAUNCH("vocr_lstm_bwd(k-owner, 8-row chains)");
-            if (dbias) {
-                lstm_bias_combine_kernel<<<dim3(vocr_cdiv(4 * h, 256), 2), 256, 0, s>>>(bpart, dbias, 4 * h, nt8);
-                VOCR_CHECK_LAUNCH("vocr_lstm_bwd(bias combine)");
-            }
-            return VOCR_OK;
         }
         if (h == 128) lstm_bwd_kowner<1><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, hword, t, b, rt, fwt);
         else if (h == 256) lstm_bwd_kowner<2><<<g, 256, 0, s>>>(dy, whh_fwd, whh_rev, lens, gates, cell, dgates, partials, flags, flags + 256, status, hword, t, b, rt, fwt);

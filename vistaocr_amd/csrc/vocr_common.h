@@ -10,6 +10,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define VOCR_WAVE 64
 
+// Experiment switches (A/B of kernel variants, tile shapes, launch plans).  The shipped library has ONE code path per shape: every
+// switch is its default, a compile-time constant.  A `-DVOCR_EXPERIMENTS` build (scripts/_lib_ab.py) reads them from the environment.
+// The two runtime knobs an operator may need stay outside this macro and are documented in include/vocr.h: VOCR_LSTM_SWEEP=step
+// (one launch per time step: several processes sharing one GPU) and VOCR_LSTM_WRITE_THROUGH=1.
+#ifdef VOCR_EXPERIMENTS
+#include <stdlib.h>
+#define VOCR_EXPERIMENT_INT(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#else
+#define VOCR_EXPERIMENT_INT(name, dflt) (dflt)
+#endif
+
 void vocr_set_error(const char* fmt, ...);
 
 #define VOCR_CHECK_ARG(cond, ...)                 \

@@ -10,7 +10,7 @@ import math
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import _lib, ops
 from ._lib import prof_range
 from .decoder import decode_greedy, greedy_label_sequences
 
@@ -178,6 +178,10 @@ class CnnOcrModel(nn.Module):
         self.dropout_masks = None         # list of [T,B,2H] pre-scaled masks or None -> drawn on device
         self._dropout_calls = 0
         self.dropout_seed = 0x5EED
+        # packed sequence rows (forward(): "pack_padded_sequence's economy"): on by default for a batch whose packed row count is at
+        # most `pack_threshold` of T*B (below that the two row gathers cost more than the GEMM rows they save)
+        self.pack_sequences = True
+        self.pack_threshold = 0.9
         # backward milestones of THIS model (train.make_optimizer registers the data-parallel bucket start here)
         self._vocr_hooks = {"sequence_grads_ready": []}
 
@@ -281,6 +285,16 @@ class CnnOcrModel(nn.Module):
         lens_dev = lens_cpu.to(dev, non_blocking=True)
 
         hseq = lstm_in[: T * b]
+        # pack_padded_sequence's economy (cnnlstm.py:285-290): when enough of the padded [T, b] frames are padding, the whole LSTM stack
+        # runs on the packed chain-major rows of include/vocr.h - every projection / gradient GEMM over the packed rows only, a chain's
+        # workgroups leaving the sweeps after their own longest row - and the logits are unpacked at the end (a padded frame's logits are
+        # the output layer's bias, exactly what the dense path computes from its all-zero LSTM output).  A uniform batch stays dense.
+        maps = None
+        if self.pack_sequences and b <= 32 and ops.packed_row_count(out_w, b) <= self.pack_threshold * T * b \
+                and _lib.load().vocr_lstm_packed_supported(b, self.num_lstm_hidden_units):
+            maps = ops.SeqRowMaps(lens_dev, out_w, T, b)
+            hseq = ops.GatherRowsFn.apply(hseq, maps.to_dense, maps.to_packed, maps.rows)
+        rows = maps.rows if maps is not None else 0
         drop = self.lstm.training and self.p_lstm_dropout > 0      # nn.LSTM reads its own .training flag
         for l in range(self.num_lstm_layers):
             f = self.lstm.layer(l, "")
@@ -292,26 +306,31 @@ class CnnOcrModel(nn.Module):
                 self._dropout_calls += 1
             with prof_range("model.lstm.l%d" % l):
                 hseq = self._bilstm_layer(hseq, lens_dev, out_w, T, b, f, r, prep,
-                                          (self.p_lstm_dropout, self.dropout_seed + self._dropout_calls) if fused else None)
+                                          (self.p_lstm_dropout, self.dropout_seed + self._dropout_calls) if fused else None, rows)
             if l < self.num_lstm_layers - 1:
                 if self.dropout_masks is not None:
-                    hseq = ops.MulMaskFn.apply(hseq, self.dropout_masks[l].to(dev).reshape(T * b, -1))
+                    mk = self.dropout_masks[l].to(dev).reshape(T * b, -1)
+                    if maps is not None:
+                        mk = ops.gather_rows(mk, maps.to_dense, maps.rows)
+                    hseq = ops.MulMaskFn.apply(hseq, mk)
                 elif draw and not fused:
                     hseq = ops.DropoutFn.apply(hseq, self.p_lstm_dropout, self.dropout_seed + self._dropout_calls)
         pr = getattr(self.prob_layer, "0")
         with prof_range("model.prob"):
-            prob_output = ops.LinearFn.apply(hseq, pr.weight, pr.bias, False).view(T, b, -1)
+            prob_output = ops.LinearFn.apply(hseq, pr.weight, pr.bias, False)
+            if maps is not None:
+                prob_output = ops.GatherRowsFn.apply(prob_output, maps.to_packed, maps.to_dense, T * b, pr.bias)
+            prob_output = prob_output.view(T, b, -1)
         return prob_output, lens_cpu
 
-    def _bilstm_layer(self, hseq, lens_dev, out_w, T, b, f, r, prep, drop=None):
+    def _bilstm_layer(self, hseq, lens_dev, out_w, T, b, f, r, prep, drop=None, rows=0):
         """One bidirectional layer.  The sweep kernels take up to 64 batch rows per call (include/vocr.h); the reference's --batch-size is
         free (src/train_cnn_lstm.py:155), so a larger batch runs as tiles of <= 64 rows: the recurrence never couples batch rows, the
         widths are sorted, so a tile is itself a valid packed batch and only sweeps its own longest sequence.  A tile's weight
         gradients go through autograd (which adds the tiles' contributions) instead of the direct sinks."""
         if b <= 64:
-            if drop is not None:
-                return ops.BiLstmLayerFn.apply(hseq, lens_dev, T, b, f[0], f[1], f[2], f[3], r[0], r[1], r[2], r[3], prep, True, drop[0], drop[1])
-            return ops.BiLstmLayerFn.apply(hseq, lens_dev, T, b, f[0], f[1], f[2], f[3], r[0], r[1], r[2], r[3], prep)
+            dp, ds = drop if drop is not None else (0.0, 0)
+            return ops.BiLstmLayerFn.apply(hseq, lens_dev, T, b, f[0], f[1], f[2], f[3], r[0], r[1], r[2], r[3], prep, True, dp, ds, rows)
         ntile = (b + 63) // 64
         rows = (b + ntile - 1) // ntile
         h3 = hseq.view(T, b, -1)

@@ -48,12 +48,22 @@ def _f32c(t):
 
 # ---- side stream: weight-gradient GEMMs of an LSTM layer run concurrently with the next (latency-bound) sweep
 import os as _os
+
+
+def _exp(name, default):
+    """An experiment switch (A/B of launch plans and kernel variants): its default unless the process runs with VOCR_EXPERIMENTS=1.
+    A user's environment cannot change which kernels the product runs; tests and scripts/ opt in explicitly."""
+    if _os.environ.get("VOCR_EXPERIMENTS", "0") != "1":
+        return default
+    return _os.environ.get(name, default)
+
+
 # Measured on MI355X (bench.py): with one launch per LSTM step the overlap bought nothing (the GEMM delayed every step
 # launch as much as it hid); with the persistent chain sweeps it is worth +4 % (1102 -> 1146 img/s).  A persistent sweep
 # never waits on these GEMMs, so co-scheduling cannot deadlock it.
 # One low-priority side stream per DEVICE (like the allocator's pools): it carries no model state, only "work was queued
 # on it since the last join".
-_SIDE_ENABLED = _os.environ.get("VOCR_SIDE_STREAM", "1") == "1"
+_SIDE_ENABLED = _exp("VOCR_SIDE_STREAM", "1") == "1"
 _SIDE = {}
 
 
@@ -65,7 +75,7 @@ def _side(device=None):
     if st is None:
         lo, hi = torch.cuda.Stream.priority_range()        # (lowest priority value, highest priority value)
         with torch.cuda.device(idx):
-            stream = torch.cuda.Stream(priority=lo) if _os.environ.get("VOCR_SIDE_LOWPRIO", "1") == "1" else torch.cuda.Stream()
+            stream = torch.cuda.Stream(priority=lo) if _exp("VOCR_SIDE_LOWPRIO", "1") == "1" else torch.cuda.Stream()
         st = _SIDE[idx] = {"stream": stream, "pending": False}
     return st
 
@@ -79,80 +89,14 @@ def mark_side_pending(device=None):
 
 
 def join_side_stream(device=None):
-    """Make the current stream wait for every weight-gradient kernel issued on this device's side streams (deferred work is launched
-    first)."""
+    """Make the current stream wait for every weight-gradient kernel issued on this device's side stream."""
     if not torch.cuda.is_available():
         return
     idx = torch.cuda.current_device() if device is None else torch.device(device).index
-    flush_deferred(idx)
     st = _SIDE.get(idx)
     if st is not None and st["pending"]:
         torch.cuda.current_stream(idx).wait_stream(st["stream"])
         st["pending"] = False
-    d = _DEFER.get(idx)
-    if d is not None and d["pending"]:
-        torch.cuda.current_stream(idx).wait_stream(d["stream"])
-        d["pending"] = False
-
-
-# ---- deferred weight gradients (opt-in, VOCR_LSTM_DW_DEFER=1; MEASURED SLOWER: 18.82 vs 18.50 ms per step).  The idea: the LSTM
-# layers' dW GEMMs (2.3 ms of MFMA work per step, off the critical path) are not launched during the LSTM backward - the persistent
-# sweeps and the panel GEMM cannot share a CU (registers, LDS), so there they only take turns with the sweeps and the data-gradient
-# GEMMs - but when the backward reaches the CNN, on a third low-priority stream, to fill the matrix pipe while the HBM-bound
-# BatchNorm / pooling passes stream.  What happened: the sweeps do run alone then (3 x 0.83 instead of 3 x 1.23 ms), but the CNN
-# backward's own MFMA kernels (data + weight gradient on two streams) already cover its HBM passes, so the deferred GEMMs just
-# lengthen that window by more than the LSTM window shrinks.  Each entry: (event where the operands became ready, closure).
-_DEFER = {}
-_DEFER_ON = _os.environ.get("VOCR_LSTM_DW_DEFER", "0") == "1"
-
-
-def _defer(device=None):
-    idx = torch.cuda.current_device() if device is None else torch.device(device).index
-    if idx is None:
-        idx = torch.cuda.current_device()
-    d = _DEFER.get(idx)
-    if d is None:
-        lo, _hi = torch.cuda.Stream.priority_range()
-        with torch.cuda.device(idx):
-            d = _DEFER[idx] = {"stream": torch.cuda.Stream(priority=lo), "pending": False, "work": []}
-    return d
-
-
-def defer_stream(device=None):
-    return _defer(device)["stream"]
-
-
-def deferred_stream_if_used(device=None):
-    """The deferred stream if work has been launched on it since the last join, else None (never creates the stream: every extra
-    stream competes for the GPU's hardware queues, see vistaocr_amd/__init__.py)."""
-    idx = torch.cuda.current_device() if device is None else torch.device(device).index
-    d = _DEFER.get(idx)
-    return d["stream"] if d is not None and d["pending"] else None
-
-
-def defer_work(fn, device=None):
-    """Queue `fn` (a closure that issues kernels on the CURRENT stream) for flush_deferred(); its operands are ready at this point of the
-    current stream."""
-    d = _defer(device)
-    ev = torch.cuda.Event()
-    ev.record()
-    d["work"].append((ev, fn))
-
-
-def flush_deferred(device=None):
-    """Launch everything queued by defer_work() on the deferred stream (called when the backward reaches the CNN, and by every join)."""
-    idx = torch.cuda.current_device() if device is None else (device if isinstance(device, int) else torch.device(device).index)
-    d = _DEFER.get(idx)
-    if d is None or not d["work"]:
-        return
-    work, d["work"] = d["work"], []
-    # Behind the CURRENT point of the main stream, not merely behind the operands' events: the host runs milliseconds ahead of the
-    # device, so kernels that only waited for their operands would start in the middle of the LSTM backward after all.
-    d["stream"].wait_stream(torch.cuda.current_stream(idx))
-    with torch.cuda.stream(d["stream"]):
-        for ev, fn in work:
-            fn()
-    d["pending"] = True
 
 
 # ---- health words (include/vocr.h): one int32[2] per device, report-only.  [0]: a persistent LSTM sweep's hand-off timed
@@ -259,7 +203,7 @@ class ForwardPrep(object):
 
 def forward_prep(conv_weights, lstm_layers, with_transposes):
     """conv_weights: 4-D fp32 weights to pack; lstm_layers: [(w_hh_f, b_ih_f, b_hh_f, w_hh_r, b_ih_r, b_hh_r), ...]."""
-    if not _SIDE_ENABLED or _os.environ.get("VOCR_FWD_PREP", "1") != "1":
+    if not _SIDE_ENABLED or _exp("VOCR_FWD_PREP", "1") != "1":
         return None
     prep = ForwardPrep()
     main = torch.cuda.current_stream()
@@ -289,12 +233,12 @@ def forward_prep(conv_weights, lstm_layers, with_transposes):
 
 
 # ------------------------------------------------------------------------------------------------ conv + BN + ReLU
-_BN_FUSED_FINAL = _os.environ.get("VOCR_BN_FUSED_FINAL", "1") == "1"
-_WINO = _os.environ.get("VOCR_CONV_WINO", "1") == "1"
-_WINO_WGRAD = _os.environ.get("VOCR_WGRAD_WINO", "1") == "1"
+_BN_FUSED_FINAL = _exp("VOCR_BN_FUSED_FINAL", "1") == "1"
+_WINO = _exp("VOCR_CONV_WINO", "1") == "1"
+_WINO_WGRAD = _exp("VOCR_WGRAD_WINO", "1") == "1"
 
 
-_WINO_MIN_CIN = int(_os.environ.get("VOCR_CONV_WINO_MIN_CIN", "1"))
+_WINO_MIN_CIN = int(_exp("VOCR_CONV_WINO_MIN_CIN", "1"))
 
 
 def _wino_ok(cin, cout):
@@ -458,7 +402,7 @@ class ConvBnReluFn(torch.autograd.Function):
             # gradient as a pass of its own that materialises the full plane).  Alone on the chip it always beat the three passes
             # (139 vs 167 us per layer); in the step it was neutral in round 2 (starved beside the weight-gradient kernel) and is
             # worth -0.15 ms since the round-3 GEMMs (same-box A/B 18.96 -> 18.81 ms).  Bit-identical results either way.
-            fused_pool_bwd = bool(lib.vocr_bn_relu_fracpool2x2_bwd_supported(h, w, oh, ow)) and _os.environ.get("VOCR_POOL_BWD_FUSED", "1") == "1"
+            fused_pool_bwd = bool(lib.vocr_bn_relu_fracpool2x2_bwd_supported(h, w, oh, ow)) and _exp("VOCR_POOL_BWD_FUSED", "1") == "1"
             if not fused_pool_bwd:          # gradient of the fused pooling first: back to the full plane
                 dfull = torch.empty(n, cout, h, w, dtype=torch.float32, device=da.device)
                 call("vocr_fracpool2x2_bwd", _p(da), _p(idx), _p(dfull), n, cout, h, w, oh, ow, _stream())
@@ -483,7 +427,7 @@ class ConvBnReluFn(torch.autograd.Function):
         else:
             call("vocr_bn_relu_bwd", _p(da), _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(xhat_sum), _p(dy), _p(dgamma),
                  _p(dbeta), _p(dbias), n, cout, h * w, _p(ws), _stream())
-        if sinks is not None and _SIDE_ENABLED and ctx.needs_input_grad[0] and _os.environ.get("VOCR_CONV_OVERLAP", "1") == "1":
+        if sinks is not None and _SIDE_ENABLED and ctx.needs_input_grad[0] and _exp("VOCR_CONV_OVERLAP", "1") == "1":
             # weight gradient (off the critical path, written straight into the optimiser's buffer) on the low-priority side
             # stream beside the data gradient: each kernel's last partial round of workgroups is filled by the other's
             side = side_stream()
@@ -633,9 +577,7 @@ class PermuteBchwToWbchFn(torch.autograd.Function):
     def backward(ctx, dout):
         b, c, h, w = ctx.shape
         dout = _f32c(dout)
-        # everything above the CNN (bridge, LSTM, prob) has produced its gradients by now - or is about to: the deferred LSTM weight
-        # gradients start here, beside the CNN backward
-        flush_deferred()
+        # everything above the CNN (bridge, LSTM, prob) has produced its gradients by now
         _fire(ctx.hooks, "sequence_grads_ready")
         dx = torch.empty(b, c, h, w, dtype=torch.float32, device=dout.device)
         call("vocr_wbch_to_bchw", _p(dout), _p(dx), b, c, h, w, _stream())
@@ -677,7 +619,7 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             gemm(0, 0, m, k, n, dz, n, weight, k, dx, k)            # dx[m,k] = dz[m,n] W[n,k]
-        if sinks is not None and _SIDE_ENABLED and ctx.needs_input_grad[0] and _os.environ.get("VOCR_LINEAR_DW_OVERLAP", "1") == "1":
+        if sinks is not None and _SIDE_ENABLED and ctx.needs_input_grad[0] and _exp("VOCR_LINEAR_DW_OVERLAP", "1") == "1":
             # parameter gradients go straight into the optimiser's buffers: nothing downstream of this node reads them, so they run on
             # the low-priority side stream (joined before the optimiser step like every other weight gradient)
             side = side_stream()
@@ -740,14 +682,58 @@ class DropoutFn(torch.autograd.Function):
         return dx, None, None
 
 
+# ------------------------------------------------------------------------------------------------ packed sequence rows
+def packed_row_count(lens, b):
+    """Rows of the packed (chain-major) layout of include/vocr.h for a length-sorted batch: 4 * (sum_c L_c + chains + 1), L_c = lens[4c]."""
+    nch = (b + 3) // 4
+    return 4 * (sum(int(lens[4 * c]) for c in range(nch)) + nch + 1)
+
+
+class SeqRowMaps(object):
+    """Both index maps of a batch's packed layout (vocr_seq_rowmap), built once per forward on the device."""
+
+    def __init__(self, lens_dev, lens_host, T, B):
+        self.T, self.B = T, B
+        self.rows = packed_row_count(lens_host, B)
+        self.to_packed = torch.empty(T * B, dtype=torch.int32, device=lens_dev.device)
+        self.to_dense = torch.empty(self.rows, dtype=torch.int32, device=lens_dev.device)
+        call("vocr_seq_rowmap", _p(lens_dev), T, B, self.rows, _p(self.to_packed), _p(self.to_dense), _stream())
+
+
+def gather_rows(src, row_map, nrows, fill=None):
+    src = _f32c(src)
+    n = src.shape[1]
+    out = torch.empty(nrows, n, dtype=torch.float32, device=src.device)
+    call("vocr_gather_rows", _p(src), _p(out), _p(row_map), nrows, n, _p(fill), _stream())
+    return out
+
+
+class GatherRowsFn(torch.autograd.Function):
+    """Rows through an index map and back (packing: dense [T*B] -> packed rows; unpacking: the inverse, optionally with a fill row -
+    the output layer's bias - where the packed layout has no frame).  The two maps are inverse to each other on the frames that
+    exist, so the backward of one direction is the other direction with zeros for the rest."""
+
+    @staticmethod
+    def forward(ctx, x, fwd_map, bwd_map, nrows_out, fill=None):
+        _need_gpu(x)
+        ctx.bwd = (bwd_map, x.shape[0])
+        return gather_rows(x, fwd_map, nrows_out, fill)
+
+    @staticmethod
+    def backward(ctx, dout):
+        bwd_map, nrows_in = ctx.bwd
+        return gather_rows(dout, bwd_map, nrows_in), None, None, None, None
+
+
 # ------------------------------------------------------------------------------------------------ LSTM layer
 class BiLstmLayerFn(torch.autograd.Function):
     """One bidirectional nn.LSTM layer on a packed batch (src/models/cnnlstm.py:148-149,288-290).
-    x: [T*B, Din] time-major; returns y: [T*B, 2H] with zeros past each sequence's length."""
+    x: [T*B, Din] time-major; returns y: [T*B, 2H] with zeros past each sequence's length.
+    rows > 0: x and y are [rows, .] in the packed chain-major layout of include/vocr.h (no row for a padded frame of a whole chain)."""
 
     @staticmethod
     def forward(ctx, x, lens_dev, T, B, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r, prep=None, direct_grads=True,
-                drop_p=0.0, drop_seed=0):
+                drop_p=0.0, drop_seed=0, rows=0):
         """drop_p > 0: nn.LSTM's inter-layer dropout on this layer's OUTPUT (counter-based mask of vocr_dropout_fwd, as DropoutFn) -
         here so that its backward can ride on the backward sweep's read of dy instead of being a pass of its own."""
         _need_gpu(x, lens_dev, w_ih_f, w_hh_f, w_ih_r, w_hh_r)
@@ -756,7 +742,9 @@ class BiLstmLayerFn(torch.autograd.Function):
         din = x.shape[1]
         H = w_hh_f.shape[1]
         dev = x.device
-        xproj = torch.empty(2, T * B, 4 * H, dtype=torch.float32, device=dev)
+        R = int(rows) if rows else T * B              # rows of every sequence-side matrix of this layer
+        assert x.shape[0] == R, (x.shape, R)
+        xproj = torch.empty(2, R, 4 * H, dtype=torch.float32, device=dev)
         ctx.wt = None
         if prep is not None and w_hh_f.data_ptr() in prep.lstm:
             prep.wait()
@@ -767,41 +755,22 @@ class BiLstmLayerFn(torch.autograd.Function):
             bsum = torch.empty(2, 4 * H, dtype=torch.float32, device=dev)
             call("vocr_add", _p(b_ih_f), _p(b_hh_f), _p(bsum[0]), 4 * H, _stream())
             call("vocr_add", _p(b_ih_r), _p(b_hh_r), _p(bsum[1]), 4 * H, _stream())
-        y = torch.empty(T * B, 2 * H, dtype=torch.float32, device=dev)
-        gates = torch.empty(2, T * B, 4 * H, dtype=torch.float32, device=dev)
-        cell = torch.empty(2, T * B, H, dtype=torch.float32, device=dev)
+        # packed rows: the sweeps leave the zero groups (and a last chain's rows >= B) alone - they must read as zeros downstream
+        y = (torch.zeros if rows else torch.empty)(R, 2 * H, dtype=torch.float32, device=dev)
+        gates = torch.empty(2, R, 4 * H, dtype=torch.float32, device=dev)
+        cell = torch.empty(2, R, H, dtype=torch.float32, device=dev)
         ws = _ws(lib.vocr_lstm_workspace_bytes(T, B, H), dev)
         G = 4 * H
 
-        def xgemm(d, r0, r1):                       # x-projection of time-major rows [r0, r1) for direction d
-            gemm(0, 1, r1 - r0, G, din, x[r0:r1], din, w_ih_r if d else w_ih_f, din, xproj[d][r0:r1], G, bias=bsum[d])
-
-        Th = T // 2
-        if _SIDE_ENABLED and Th >= 16 and Th * B * din >= (1 << 20) and _os.environ.get("VOCR_XPROJ_SPLIT", "0") == "1":
-            # Opt-in (VOCR_XPROJ_SPLIT=1): only the x-projection of the rows the sweep's first half needs (forward
-            # direction: t < Th; reverse direction: t >= T - Th) runs ahead of it; the other halves run on the side
-            # stream under steps [0, Th) and steps [Th, T) start when they are done (vocr_lstm_fwd_range).  Worth
-            # +0.6 % while the 16-row sweeps left half the chip idle; with the 8-row sweeps on all 8 XCDs the
-            # co-running GEMM costs the sweep more than it hides (same-box A/B 1370 vs 1422 img/s), so it is off.
-            side = side_stream()
-            for t_ in (x, xproj, bsum, w_ih_f, w_ih_r):
-                t_.record_stream(side)
-            xgemm(0, 0, Th * B)
-            xgemm(1, (T - Th) * B, T * B)
-            side.wait_stream(torch.cuda.current_stream())      # behind the first halves: they must not share the chip
-            with torch.cuda.stream(side):
-                xgemm(0, Th * B, T * B)
-                xgemm(1, 0, (T - Th) * B)
-            args = (_p(xproj), _p(w_hh_f), _p(w_hh_r), _p(lens_dev), _p(y), _p(gates), _p(cell), _p(ws), T, B, H)
-            call("vocr_lstm_fwd_range", *args, 0, Th, _p(health(dev)), _stream())
-            torch.cuda.current_stream().wait_stream(side)
-            call("vocr_lstm_fwd_range", *args, Th, T, _p(health(dev)), _stream())
+        # both directions' x-projections in one launch: 2 x (columns / 128) panels x row groups == the CU count
+        gemm_pair(0, 0, 1, R, G, din, x, x, din, w_ih_f, w_ih_r, din, xproj[0], xproj[1], G, bias0=bsum[0], bias1=bsum[1])
+        if rows:
+            call("vocr_lstm_fwd_packed", _p(xproj), _p(w_hh_f), _p(w_hh_r), _p(lens_dev), _p(y), _p(gates), _p(cell), _p(ws), T, B, H, R,
+                 _p(health(dev)), _stream())
         else:
-            # both directions' x-projections in one launch: 2 x (columns / 128) panels x row groups == the CU count
-            gemm_pair(0, 0, 1, T * B, G, din, x, x, din, w_ih_f, w_ih_r, din, xproj[0], xproj[1], G, bias0=bsum[0], bias1=bsum[1])
             call("vocr_lstm_fwd", _p(xproj), _p(w_hh_f), _p(w_hh_r), _p(lens_dev), _p(y), _p(gates), _p(cell), _p(ws), T, B, H,
                  _p(health(dev)), _stream())
-        ctx.dims = (T, B, H, din)
+        ctx.dims = (T, B, H, din, int(rows))
         ctx.direct_grads = bool(direct_grads)       # False: the layer runs as several batch tiles, autograd adds their weight gradients
         ctx.b_refs = (b_ih_f, b_hh_f, b_ih_r, b_hh_r)
         mask = None
@@ -818,11 +787,12 @@ class BiLstmLayerFn(torch.autograd.Function):
     @_ranged("bwd.bilstm")
     def backward(ctx, dy):
         x, lens_dev, y, gates, cell, w_ih_f, w_hh_f, w_ih_r, w_hh_r, mask = ctx.saved_tensors
-        T, B, H, din = ctx.dims
+        T, B, H, din, rows = ctx.dims
+        R = rows if rows else T * B
         dy = _f32c(dy)
         lib = _lib.load()
         dev = x.device
-        dg = torch.empty(2, T * B, 4 * H, dtype=torch.float32, device=dev)
+        dg = (torch.zeros if rows else torch.empty)(2, R, 4 * H, dtype=torch.float32, device=dev)
         ws = _ws(lib.vocr_lstm_workspace_bytes(T, B, H), dev)
         if ctx.wt is not None:
             wt_f, wt_r = ctx.wt                                          # transposed at forward time on the side stream
@@ -833,10 +803,13 @@ class BiLstmLayerFn(torch.autograd.Function):
         # sweep's read of dy and the bias gradient's last reduction is left to the weight-gradient work on the side stream, so two
         # small kernels leave the critical path.  The sweeps then reach the chip ahead of the previous layer's weight-gradient GEMMs
         # (the LSTM-backward window ends 0.2 ms earlier), which pushes those GEMMs into the CNN backward, where a third MFMA kernel
-        # beside the data- and weight-gradient convolutions costs 0.4 ms - the same arithmetic as VOCR_LSTM_DW_DEFER.  Bit-identical
-        # results either way (tests/test_round3_gpu.py).
-        parts = bool(lib.vocr_lstm_bwd_parts_supported(T, B, H)) and _os.environ.get("VOCR_LSTM_BWD_PARTS", "0") == "1"
-        if parts:
+        # beside the data- and weight-gradient convolutions costs 0.4 ms.  Bit-identical results either way (tests/test_round3_gpu.py).
+        parts = not rows and bool(lib.vocr_lstm_bwd_parts_supported(T, B, H)) and _exp("VOCR_LSTM_BWD_PARTS", "0") == "1"
+        if rows:
+            # packed rows: the dropout mask rides on the sweep's read of dy (no pass of its own)
+            call("vocr_lstm_bwd_packed", _p(dy), _p(mask), _p(wt_f), _p(wt_r), _p(lens_dev), _p(gates), _p(cell), _p(dg), _p(dbias), _p(ws),
+                 T, B, H, R, _p(health(dev)), _stream())
+        elif parts:
             call("vocr_lstm_bwd_parts", _p(dy), _p(mask), _p(wt_f), _p(wt_r), _p(lens_dev), _p(gates), _p(cell), _p(dg), _p(ws),
                  T, B, H, _p(health(dev)), _stream())
         else:
@@ -852,7 +825,7 @@ class BiLstmLayerFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             # dx = dg_fwd W_ih_fwd + dg_rev W_ih_rev as ONE product whose K runs through both pairs (no accumulating second pass)
-            gemm_pair(1, 0, 0, T * B, din, G, dg[0], dg[1], G, w_ih_f, w_ih_r, din, dx, None, din)
+            gemm_pair(1, 0, 0, R, din, G, dg[0], dg[1], G, w_ih_f, w_ih_r, din, dx, None, din)
 
         # weight gradients: if every parameter already owns a gradient buffer (FlatClampAdam aliases them into one
         # flat buffer), write them there from the side stream so they overlap the next layer's sweep; otherwise
@@ -865,11 +838,13 @@ class BiLstmLayerFn(torch.autograd.Function):
             dwi_f, dwh_f, dbi_f, dbh_f, dwi_r, dwh_r, dbi_r, dbh_r = outs
             if parts:
                 call("vocr_lstm_bias_from_parts", _p(dbias), _p(ws), T, B, H, _stream())
-            gemm_pair(co, 1, 0, G, din, T * B, dg[0], dg[1], G, x, x, din, dwi_f, dwi_r, din)
+            gemm_pair(co, 1, 0, G, din, R, dg[0], dg[1], G, x, x, din, dwi_f, dwi_r, din)
             if T > 1:
-                # forward dir: h_{t-1} = y[t-1, :, :H];   reverse dir: h_{t+1} = y[t+1, :, H:]  (zero past the length)
-                m = (T - 1) * B
-                gemm_pair(co, 1, 0, G, H, m, dg[0][B:], dg[1], G, y, y[B:, H:], 2 * H, dwh_f, dwh_r, H)
+                # forward dir: h_{t-1} = y[t-1, :, :H];   reverse dir: h_{t+1} = y[t+1, :, H:]  (zero past the length).  Dense rows:
+                # consecutive time steps are B rows apart; packed rows: 4 (the chain's groups), with an all-zero group on either side
+                sh = 4 if rows else B
+                m = R - sh
+                gemm_pair(co, 1, 0, G, H, m, dg[0][sh:], dg[1], G, y, y[sh:, H:], 2 * H, dwh_f, dwh_r, H)
             else:
                 dwh_f.zero_()
                 dwh_r.zero_()
@@ -878,28 +853,21 @@ class BiLstmLayerFn(torch.autograd.Function):
             dbh_f.copy_(dbias[0])
             dbh_r.copy_(dbias[1])
 
-        if direct and _SIDE_ENABLED and _DEFER_ON:
-            for t_ in (dg, x, y, dbias, ws):
-                t_.record_stream(defer_stream())
-            defer_work(lambda: weight_grads(sinks))
-            return (dx, None, None, None) + (None,) * 12
-        if direct and _SIDE_ENABLED and _os.environ.get("VOCR_LSTM_DW_OVERLAP", "1") == "1":
+        if direct and _SIDE_ENABLED and _exp("VOCR_LSTM_DW_OVERLAP", "1") == "1":
             side = side_stream()
             side.wait_stream(torch.cuda.current_stream())
             for t_ in (dg, x, y, dbias, ws):
                 t_.record_stream(side)
             with torch.cuda.stream(side):
-                # under the next layer's persistent sweep: VOCR_DW_TILES=1 asks for the tile kernel, whose workgroups fit on a CU beside a
-                # sweep workgroup (the panel kernel's do not: 144 KB of LDS and 340 registers per lane)
-                weight_grads(sinks, co=4 if _os.environ.get("VOCR_DW_TILES", "0") == "1" else 0)
+                weight_grads(sinks)                 # under the next layer's persistent sweep
             mark_side_pending()
-            return (dx, None, None, None) + (None,) * 12
+            return (dx, None, None, None) + (None,) * 13
         if direct:
             weight_grads(sinks)
-            return (dx, None, None, None) + (None,) * 12
+            return (dx, None, None, None) + (None,) * 13
         outs = [torch.empty_like(p) for p in params]
         weight_grads(outs)
-        return (dx, None, None, None) + tuple(outs) + (None, None, None, None)
+        return (dx, None, None, None) + tuple(outs) + (None, None, None, None, None)
 
 
 # ------------------------------------------------------------------------------------------------ CTC

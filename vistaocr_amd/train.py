@@ -140,9 +140,6 @@ class FlatClampAdam(object):
                     self._comm_stream = torch.cuda.Stream(device=dev)
                 self._comm_stream.wait_stream(torch.cuda.current_stream(dev))
                 self._comm_stream.wait_stream(ops.side_stream(dev))
-                dstream = ops.deferred_stream_if_used(dev)                 # the deferred LSTM weight gradients (opt-in), launched just before this hook
-                if dstream is not None:
-                    self._comm_stream.wait_stream(dstream)
                 with torch.cuda.stream(self._comm_stream):
                     if self._time_comm:
                         e0 = torch.cuda.Event(enable_timing=True)
