@@ -257,7 +257,12 @@ def cpu_baseline_worker(parity_file, config, budget_s):
         for hyp, ref in zip(strs_h, strs_o):
             c, _ = compute_cer_wer(hyp, ref) if ref.strip() != "" else ((0.0 if hyp.strip() == "" else 1.0), 0.0)
             cer += c / len(strs_o)
+        # per-frame argmax agreement on the frames whose oracle decision is at least 1e-3 away from flipping: the label-level bar of the
+        # fp16-operand configuration (tests/test_configs_gpu.py holds the same quantity to >= 0.97); 1.0 by construction on the fp32 path
+        safe = valid & ((top2.values[:, :, 0] - top2.values[:, :, 1]) > 1e-3)
+        agree = float((blob["argmax"].to(torch.int64)[safe] == top2.indices[:, :, 0][safe]).float().mean()) if "argmax" in blob else None
         out["parity"] = dict(loss_rel_err=abs(loss_h - loss_o) / abs(loss_o), label_mismatches=sum(int(a != b) for a, b in zip(labels_h, labels_o)),
+                             frame_argmax_agreement_on_safe_frames=agree, safe_frames=int(safe.sum()),
                              lines=len(labels_o), labels_emitted=sum(len(l) for l in labels_o), cer=cer, hip_loss=loss_h, oracle_loss=loss_o,
                              lens_equal=bool(ln.tolist() == list(blob["lens"])), oracle_decode_margin=margin,
                              oracle_forward_s=round(time.time() - t0, 1),
@@ -445,7 +450,8 @@ def run_rank(args):
         model.load_state_dict(init_state)               # back to the uniform(-0.08, 0.08) init the timed steps start from
         fd, parity_file = tempfile.mkstemp(suffix=".pt", prefix="vocr_parity_")
         os.close(fd)
-        torch.save(dict(hidden=args.hidden, loss=ploss, labels=plabels, strings=pstr, lens=lens.tolist()), parity_file)
+        torch.save(dict(hidden=args.hidden, loss=ploss, labels=plabels, strings=pstr, lens=lens.tolist(),
+                        argmax=lg.argmax(2).to(torch.int16).cpu()), parity_file)
         del init_state, lg, psd
     model.train()
     opt = va.make_optimizer(model, lr=1e-3)          # flat Adam; all-reduce in two buckets, the big one under the CNN backward
@@ -647,8 +653,11 @@ def run_rank(args):
                 if conv_dtype == "fp32":        # north_star's bar: greedy labels bit-exact, CTC loss within 1e-3
                     bad = par["label_mismatches"] > 0 or par["loss_rel_err"] > 1e-3 or not par["lens_equal"] or par["labels_emitted"] < 10 * B
                 else:                           # fp16 conv operands against the fp32 oracle: the loss bar of tests/test_round2_gpu.py (1e-2); labels are reported
-                    bad = par["loss_rel_err"] > 1e-2 or not par["lens_equal"]
-                    par["what"] += "; fp16 conv operands: loss held to 1e-2, label agreement reported, not required"
+                    agree = par.get("frame_argmax_agreement_on_safe_frames")
+                    bad = par["loss_rel_err"] > 1e-2 or not par["lens_equal"] or agree is None or agree < 0.97
+                    par["what"] += ("; fp16 conv operands against the fp32 oracle: loss held to 1e-2 and the per-frame argmax to >= 0.97 agreement on the "
+                                    "frames whose oracle decision is >= 1e-3 from flipping (the bars of tests/test_configs_gpu.py::test_config5_fp16); "
+                                    "whole-line label equality is reported (label_mismatches), not required - one flipped near-tie frame changes a line")
                 if bad:
                     parity_failed = "parity leg failed: %s" % json.dumps(par)
     if parity_file and os.path.exists(parity_file):

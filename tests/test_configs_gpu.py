@@ -136,7 +136,7 @@ def _run_pair(name):
     lo_loss.backward()
     assert lens.tolist() == ln.tolist()
     rel = abs(float(loss.detach()) - float(lo_loss.detach())) / abs(float(lo_loss.detach()))
-    assert rel <= case.get("loss_rtol", 1e-3), (float(loss), float(lo_loss))
+    assert rel <= case.get("loss_rtol", 1e-3), (float(loss.detach()), float(lo_loss.detach()))
     lg = logits.detach().cpu()
     T = lg.shape[0]
     valid = torch.arange(T).unsqueeze(1) < ln.unsqueeze(0)

@@ -83,7 +83,7 @@ def test_fit_control_flow_and_checkpoint_schema(tmp_path):
         marks.append((w, float(next(model.parameters()).flatten()[0])))
         return 1.0, w / 2, w
     prefix = os.path.join(tmp_path, "run")
-    w0 = float(next(m.parameters()).flatten()[0])
+    w0 = float(next(m.parameters()).detach().flatten()[0])
     hist = fit(m, None, opt, [None] * 40, None, fake_train, prefix, batch_size=32, n_epochs=1, snapshot_every_n_iterations=4,
                patience=1, min_lr=1e-4, validate_fn=fake_val)
     assert [round(l, 3) for l in hist["loss"][:2]] == [2.0, 2.0]

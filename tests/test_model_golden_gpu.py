@@ -163,7 +163,7 @@ def test_against_on_box_oracle_with_dropout_mask():
     loss = va.CTCLoss()(lg, torch.from_numpy(tgt), lens, torch.from_numpy(tl))
     loss.backward()
     assert lens.tolist() == ln.tolist()
-    assert abs(float(loss) - float(loss_o)) <= LOSS_RTOL * abs(float(loss_o))
+    assert abs(float(loss.detach()) - float(loss_o.detach())) <= LOSS_RTOL * abs(float(loss_o.detach()))
     assert model.decode_labels(lg, lens) == vo.greedy_decode(lo.detach(), ln, al.idx_to_char, uxxxx=True)[1]
     for k, p in model.named_parameters():
         ref = sd[k].grad
@@ -203,8 +203,8 @@ def test_full_size_properties():
     crit = va.CTCLoss()
     loss = crit(logits, tgt, lens, tl)
     assert torch.isfinite(loss).all()
-    per = sum(float(crit(logits[:, b:b + 1].contiguous(), tgt[20 * b:20 * b + 20], lens[b:b + 1], tl[b:b + 1])) for b in range(B))
-    assert abs(per - float(loss)) <= 1e-4 * abs(per)
+    per = sum(float(crit(logits[:, b:b + 1].contiguous(), tgt[20 * b:20 * b + 20], lens[b:b + 1], tl[b:b + 1]).detach()) for b in range(B))
+    assert abs(per - float(loss.detach())) <= 1e-4 * abs(per)
     lg = logits.detach().clone().requires_grad_(True)
     crit(lg, tgt, lens, tl).backward()
     assert float(lg.grad[int(lens[-1]):, -1].abs().max()) == 0.0

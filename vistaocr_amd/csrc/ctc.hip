@@ -209,6 +209,121 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta64_kernel(const float* __res
     }
 }
 
+// The same for 64 < S <= 128 (32 <= L <= 63: the long lines of BASELINE configs[3], ~1200 px with W / 30 labels): TWO extended-label
+// positions per lane (s = lane and s = lane + 64), the seam between the halves crossed with two broadcasts per step.  The generic
+// kernel took 622 us for T = 576 (1.08 us per frame, chip otherwise idle: the backward waits for it).  Same expressions in the same
+// order per element: bit-identical to ctc_alpha_beta_kernel.
+__global__ __launch_bounds__(64) void ctc_alpha_beta128_kernel(const float* __restrict__ lp, const int32_t* __restrict__ labels,
+                                                               const int32_t* __restrict__ label_offsets,
+                                                               const int32_t* __restrict__ label_lens,
+                                                               const int32_t* __restrict__ act_lens, float* __restrict__ ab,
+                                                               float* __restrict__ nll, int T, int B, int V) {
+    constexpr int SP = 128, PF = 8;
+    const int b = blockIdx.x >> 1, dirn = blockIdx.x & 1;
+    const int lane = threadIdx.x;
+    const int L = label_lens[b], S = 2 * L + 1, Tb = act_lens[b];
+    const int32_t* lab = labels + label_offsets[b];
+    float* out = ab + ((long)(b * 2 + dirn) * T) * SP;
+    if (Tb <= 0) {
+        if (dirn == 0 && lane == 0) nll[b] = (S == 1) ? 0.f : INFINITY;
+        return;
+    }
+    const int s0 = lane, s1 = lane + 64;
+    const bool in0 = s0 < S, in1 = s1 < S;
+    auto ext = [&](int s_) { return (s_ >= 0 && s_ < S && (s_ & 1)) ? lab[s_ >> 1] : 0; };
+    const int e0 = ext(s0), e1 = ext(s1);
+    const float* col0 = lp + (long)b * V + e0;             // lp[t][b][e] = col[t * B * V]
+    const float* col1 = lp + (long)b * V + e1;
+    const long tstride = (long)B * V;
+    float buf0[PF], buf1[PF];
+    if (dirn == 0) {
+        const bool skip0 = s0 >= 2 && e0 != 0 && e0 != ext(s0 - 2);
+        const bool skip1 = e1 != 0 && e1 != ext(s1 - 2);
+        float v0 = NEG_INF, v1 = NEG_INF;
+        if (lane == 0) v0 = lp[(long)b * V];
+        else if (lane == 1 && S > 1) v0 = col0[0];
+        out[s0] = v0;
+        out[s1] = v1;
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            buf0[k] = col0[(long)min(1 + k, Tb - 1) * tstride];
+            buf1[k] = col1[(long)min(1 + k, Tb - 1) * tstride];
+        }
+        for (int t0 = 1; t0 < Tb; t0 += PF) {
+#pragma unroll
+            for (int k = 0; k < PF; ++k) {
+                const int t = t0 + k;
+                if (t < Tb) {                                   // wave-uniform
+                    const float lpe0 = buf0[k], lpe1 = buf1[k];
+                    buf0[k] = col0[(long)min(t + PF, Tb - 1) * tstride];
+                    buf1[k] = col1[(long)min(t + PF, Tb - 1) * tstride];
+                    const float w63 = __shfl(v0, 63, 64), w62 = __shfl(v0, 62, 64);
+                    float a2 = __shfl_up(v0, 1, 64), a3 = __shfl_up(v0, 2, 64);
+                    float c2 = __shfl_up(v1, 1, 64), c3 = __shfl_up(v1, 2, 64);
+                    if (lane < 1) { a2 = NEG_INF; c2 = w63; }
+                    if (lane == 0) c3 = w62;
+                    if (lane == 1) c3 = w63;
+                    if (!skip0) a3 = NEG_INF;
+                    if (!skip1) c3 = NEG_INF;
+                    const float l0 = lse3(v0, a2, a3), l1 = lse3(v1, c2, c3);
+                    v0 = (in0 && l0 != NEG_INF) ? l0 + lpe0 : NEG_INF;
+                    v1 = (in1 && l1 != NEG_INF) ? l1 + lpe1 : NEG_INF;
+                    out[(long)t * SP + s0] = v0;
+                    out[(long)t * SP + s1] = v1;
+                }
+            }
+        }
+        // alpha[S-1], alpha[S-2] (a short line of a batch with long ones keeps both in the first half)
+        const float a = S - 1 >= 64 ? __shfl(v1, S - 1 - 64, 64) : __shfl(v0, S - 1, 64);
+        const float c = S < 2 ? NEG_INF : S - 2 >= 64 ? __shfl(v1, S - 2 - 64, 64) : __shfl(v0, S - 2, 64);
+        if (lane == 0) {
+            const float m = fmaxf(a, c);
+            nll[b] = (m == NEG_INF) ? INFINITY : -(logf(expf(a - m) + expf(c - m)) + m);
+        }
+    } else {
+        const bool skip0 = s0 + 2 < S && e0 != 0 && e0 != ext(s0 + 2);
+        const bool skip1 = s1 + 2 < S && e1 != 0 && e1 != ext(s1 + 2);
+        float v0 = NEG_INF, v1 = NEG_INF;
+        {
+            const float last = lp[((long)(Tb - 1) * B + b) * V];
+            if (s0 == S - 1) v0 = last;
+            else if (s0 == S - 2 && S > 1) v0 = col0[(long)(Tb - 1) * tstride];
+            if (s1 == S - 1) v1 = last;
+            else if (s1 == S - 2 && S > 1) v1 = col1[(long)(Tb - 1) * tstride];
+        }
+        out[(long)(Tb - 1) * SP + s0] = v0;
+        out[(long)(Tb - 1) * SP + s1] = v1;
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            buf0[k] = col0[(long)max(Tb - 2 - k, 0) * tstride];
+            buf1[k] = col1[(long)max(Tb - 2 - k, 0) * tstride];
+        }
+        for (int t0 = Tb - 2; t0 >= 0; t0 -= PF) {
+#pragma unroll
+            for (int k = 0; k < PF; ++k) {
+                const int t = t0 - k;
+                if (t >= 0) {
+                    const float lpe0 = buf0[k], lpe1 = buf1[k];
+                    buf0[k] = col0[(long)max(t - PF, 0) * tstride];
+                    buf1[k] = col1[(long)max(t - PF, 0) * tstride];
+                    const float u0 = __shfl(v1, 0, 64), u1 = __shfl(v1, 1, 64);
+                    float b2 = __shfl_down(v0, 1, 64), b3 = __shfl_down(v0, 2, 64);
+                    float d2 = __shfl_down(v1, 1, 64), d3 = __shfl_down(v1, 2, 64);
+                    if (lane == 63) { b2 = u0; b3 = u1; d2 = NEG_INF; }
+                    if (lane == 62) b3 = u0;
+                    if (!skip0) b3 = NEG_INF;
+                    if (!skip1) d3 = NEG_INF;
+                    const float l0 = lse3(v0, b2, b3), l1 = lse3(v1, d2, d3);
+                    v0 = (in0 && l0 != NEG_INF) ? l0 + lpe0 : NEG_INF;
+                    v1 = (in1 && l1 != NEG_INF) ? l1 + lpe1 : NEG_INF;
+                    out[(long)t * SP + s0] = v0;
+                    out[(long)t * SP + s1] = v1;
+                }
+            }
+        }
+    }
+}
+
 // one wave per (t,b): grad[v] = exp(lp[v]) - exp(lse_{s: l'_s = v}(alpha+beta) + nll - lp[v]); zero for t >= act_len
 __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__ lp, const int32_t* __restrict__ labels,
                                                        const int32_t* __restrict__ label_offsets,
@@ -384,6 +499,7 @@ extern "C" int vocr_ctc_loss_grad(const float* logits, const int32_t* labels, co
     const size_t smem = (size_t)(2 * (sp + 4) + sp) * sizeof(float);
     static const int generic_only = VOCR_EXPERIMENT_INT("VOCR_CTC_GENERIC", 0);      // tests: compare the two kernels
     if (sp == 64 && !generic_only) ctc_alpha_beta64_kernel<<<2 * b, 64, 0, s>>>(lp, labels, label_offsets, label_lens, act_lens, ab, nll, t, b, v);
+    else if (sp == 128 && !generic_only) ctc_alpha_beta128_kernel<<<2 * b, 64, 0, s>>>(lp, labels, label_offsets, label_lens, act_lens, ab, nll, t, b, v);
     else ctc_alpha_beta_kernel<<<2 * b, 64, smem, s>>>(lp, labels, label_offsets, label_lens, act_lens, ab, nll, t, b, v, sp);
     VOCR_CHECK_LAUNCH("vocr_ctc_loss_grad(alpha_beta)");
     if (dlogits) {
