@@ -163,11 +163,13 @@ def lstm_packed_flops(args, h_arg):
 
 FLOPS_OF = {"vocr_conv3x3_fwd": conv_flops, "vocr_conv3x3_wino_fwd": conv_flops, "vocr_conv3x3_wgrad": conv_flops,
             "vocr_conv3x3_wgrad_wino": conv_flops, "vocr_conv3x3_f16_fwd": conv_flops, "vocr_conv3x3_wgrad_f16": conv_flops,
+            "vocr_conv3x3_h16_fwd": conv_flops, "vocr_conv3x3_wgrad_h16": conv_flops,
             "vocr_gemm": gemm_flops, "vocr_gemm_pair": gemm_pair_flops,
             "vocr_lstm_fwd": lambda a: lstm_flops(a, 8), "vocr_lstm_fwd_range": lambda a: lstm_flops(a, 8),
             "vocr_lstm_bwd_bias": lambda a: lstm_flops(a, 9),
             "vocr_lstm_fwd_packed": lambda a: lstm_packed_flops(a, 10), "vocr_lstm_bwd_packed": lambda a: lstm_packed_flops(a, 12)}
-_F16_CONV = "conv3x3 with fp16 operands, fp32 accumulate (conv3x3_f16_kernel forward + data gradient, conv3x3_wgrad_f16_kernel; v_mfma_f32_32x32x16_f16)"
+_F16_CONV = ("conv3x3 with fp16 operands, fp32 accumulate (conv3x3_h16_kernel on NHWC fp16 activations: forward + data gradient; conv3x3_wgrad_h16_kernel on "
+             "channel-major fp16 copies: weight gradient; the register-staged kernels where the channel counts do not fit; v_mfma_f32_32x32x16_f16)")
 # a family's own roofline where it is not the f32 matrix pipe
 FAMILY_PEAK = {_F16_CONV: F16_MFMA_PEAK_TFLOPS}
 FAMILY = {"vocr_conv3x3_fwd": "conv3x3 forward + data gradient (conv3x3_wino4 / conv3x3_wino2 kernels: F(4,3) / F(2,3) along the row)",
@@ -176,7 +178,7 @@ FAMILY = {"vocr_conv3x3_fwd": "conv3x3 forward + data gradient (conv3x3_wino4 / 
           "vocr_conv3x3_wgrad_wino": "conv3x3 weight gradient (conv3x3_wgrad_wino2d_kernel: F(3,2) along the row and across row pairs, piece stream)",
           "vocr_gemm": "dense GEMMs (gemm_dma_kernel / gemm_f32_kernel behind vocr_gemm and vocr_gemm_pair: bridge, LSTM projections, prob, their dX / dW)",
           "vocr_gemm_pair": "dense GEMMs (gemm_dma_kernel / gemm_f32_kernel behind vocr_gemm and vocr_gemm_pair: bridge, LSTM projections, prob, their dX / dW)",
-          "vocr_conv3x3_f16_fwd": _F16_CONV, "vocr_conv3x3_wgrad_f16": _F16_CONV,
+          "vocr_conv3x3_f16_fwd": _F16_CONV, "vocr_conv3x3_wgrad_f16": _F16_CONV, "vocr_conv3x3_h16_fwd": _F16_CONV, "vocr_conv3x3_wgrad_h16": _F16_CONV,
           "vocr_lstm_fwd": "LSTM sweeps (lstm_fwd_chain4w / lstm_bwd_chain4w)", "vocr_lstm_fwd_range": "LSTM sweeps (lstm_fwd_chain4w / lstm_bwd_chain4w)",
           "vocr_lstm_bwd_bias": "LSTM sweeps (lstm_fwd_chain4w / lstm_bwd_chain4w)",
           "vocr_lstm_fwd_packed": "LSTM sweeps (lstm_fwd_chain4w / lstm_bwd_chain4w)", "vocr_lstm_bwd_packed": "LSTM sweeps (lstm_fwd_chain4w / lstm_bwd_chain4w)"}
@@ -466,7 +468,7 @@ def run_rank(args):
         torch.cuda.synchronize()
 
     MFMA_NAMES = ["vocr_conv3x3_fwd", "vocr_conv3x3_wino_fwd", "vocr_conv3x3_wgrad", "vocr_conv3x3_wgrad_wino", "vocr_conv3x3_f16_fwd",
-                  "vocr_conv3x3_wgrad_f16", "vocr_gemm", "vocr_gemm_pair", "vocr_lstm_fwd", "vocr_lstm_fwd_range", "vocr_lstm_bwd_bias",
+                  "vocr_conv3x3_wgrad_f16", "vocr_conv3x3_h16_fwd", "vocr_conv3x3_wgrad_h16", "vocr_gemm", "vocr_gemm_pair", "vocr_lstm_fwd", "vocr_lstm_fwd_range", "vocr_lstm_bwd_bias",
                   "vocr_lstm_fwd_packed", "vocr_lstm_bwd_packed"]
 
     rank_dt = [0.0, 0.0]          # [min, max] over ranks of the last timed loop's wall time
@@ -517,7 +519,7 @@ def run_rank(args):
     names = MFMA_NAMES + ["vocr_bn_train_stats", "vocr_bn_relu_apply", "vocr_bn_relu_fracpool2x2_fwd", "vocr_bn_train_relu_apply",
                           "vocr_bn_train_relu_fracpool2x2_fwd", "vocr_bn_relu_bwd",
                           "vocr_fracpool2x2_bwd", "vocr_bn_relu_fracpool2x2_bwd", "vocr_ctc_loss_grad", "vocr_clamp_adam", "vocr_bchw_to_wbch", "vocr_wbch_to_bchw",
-                          "vocr_relu_maxpool2_fwd", "vocr_relu_maxpool2_bwd", "vocr_gather_rows", "vocr_dropout_fwd", "vocr_mul"]
+                          "vocr_relu_maxpool2_fwd", "vocr_relu_maxpool2_bwd", "vocr_gather_rows", "vocr_dropout_fwd", "vocr_mul", "vocr_nchw_to_nhwc_f16", "vocr_f32_to_f16_layouts"]
     _lib.enable_timing(names)
     for _ in range(PROFILE_STEPS):
         va.train(batch_dev, model, crit, opt)

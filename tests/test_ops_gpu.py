@@ -106,7 +106,9 @@ def test_conv3x3_wgrad_row_pairs_long_stream_matches_direct_kernel(dev):
     _close(dw, ref, 1e-4, 2e-4 * math.sqrt(n * h * w), "conv wgrad (row pairs, long stream)")
 
 
-@pytest.mark.parametrize("n,cin,h,w,cout", [(2, 1, 30, 70, 64), (2, 64, 15, 45, 128), (1, 128, 7, 33, 256), (1, 16, 9, 40, 64), (1, 24, 12, 31, 16)])
+@pytest.mark.parametrize("n,cin,h,w,cout", [(2, 1, 30, 70, 64), (2, 64, 15, 45, 128), (1, 128, 7, 33, 256), (1, 16, 9, 40, 64), (1, 24, 12, 31, 16),
+                                            # the NHWC-fp16 kernel (Cin % 16 == 0) at sizes with several workgroups, partial segments and both channel tilings
+                                            (3, 64, 30, 131, 64), (2, 256, 7, 294, 256), (4, 128, 15, 97, 128), (2, 16, 30, 100, 64), (1, 48, 5, 33, 80)])
 def test_conv3x3_f16_operands(dev, n, cin, h, w, cout):
     """fp16-operand MFMA conv (config 5): products of fp16-rounded operands, fp32 accumulation — compared with the same
     rounding done on the CPU, so the only difference left is the summation order."""
@@ -124,9 +126,28 @@ def test_conv3x3_f16_operands(dev, n, cin, h, w, cout):
     dx = ops.conv3x3_forward_f16(dy.to(dev), pd, None, cin)
     _close(dx, dxr, 1e-5, 2e-5 * (cout * 9) ** 0.5, "conv f16 dgrad")
     if cin > 3:
+        # the fp16-operand weight-gradient kernel (the C entry point) against the same rounding on the CPU ...
+        from vistaocr_amd import _lib
+        from vistaocr_amd._lib import call
+        lib = _lib.load()
         dwr = torch.nn.grad.conv2d_weight(xh, wt.shape, dyh, padding=1)
-        dw = ops.conv3x3_wgrad(x.to(dev), dy.to(dev), f16=True)
+        dw = torch.empty(cout, cin, 3, 3, device=dev)
+        ws = torch.empty(lib.vocr_conv3x3_wgrad_workspace_bytes(n, cin, h, w, cout) // 4 + 4, device=dev)
+        xd, dyd = x.to(dev), dy.to(dev)
+        call("vocr_conv3x3_wgrad_f16", xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), ws.data_ptr(), n, cin, h, w, cout, torch.cuda.current_stream().cuda_stream)
         _close(dw, dwr, 1e-4, 2e-4 * math.sqrt(n * h * w), "conv f16 wgrad")
+        # ... what the fp16 configuration runs without the channel-major copies: the fp32 row-pair kernel on the exact operands ...
+        dw32 = ops.conv3x3_wgrad(xd, dyd, f16=True)
+        _close(dw32, torch.nn.grad.conv2d_weight(x, wt.shape, dy, padding=1), 1e-4, 2e-4 * math.sqrt(n * h * w), "conv wgrad in the fp16 configuration")
+        # ... and with them (round 5): the all-DMA fp16 kernel on [N][C][H][WP] copies with zero-padded rows
+        if ops.wgrad_f16_layouts_ok(cin, cout):
+            x16p, dy16p = ops.f16_layouts(xd, False, True)[1], ops.f16_layouts(dyd, False, True)[1]
+            wp = x16p.shape[3]
+            assert wp % 8 == 0 and wp >= w + 8 and float(x16p[..., w:].abs().max()) == 0.0 and torch.equal(x16p[..., :w].float().cpu(), xh)
+            dwh = ops.conv3x3_wgrad(xd, dyd, f16=True, x16p=x16p, dy16p=dy16p)
+            _close(dwh, dwr, 1e-4, 2e-4 * math.sqrt(n * h * w), "conv f16 wgrad (channel-major copies)")
+            dwh2 = ops.conv3x3_wgrad(xd, dyd, f16=True, x16p=x16p, dy16p=dy16p)
+            assert torch.equal(dwh, dwh2), "fixed-order slab sum: bitwise reproducible"
     # and it really is fp16 rounding: it differs from the fp32 conv by about 2^-11 relative, not more
     y32 = F.conv2d(x, wt, bias, padding=1)
     rel = float((y.cpu() - y32).abs().max() / y32.abs().max())

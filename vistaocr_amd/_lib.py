@@ -32,6 +32,14 @@ SIGNATURES = {
     "vocr_conv3x3_f16_pack_weights": (I, [P, P, P, I, I, P]),
     "vocr_conv3x3_f16_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
     "vocr_conv3x3_wgrad_f16": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "vocr_conv3x3_h16_supported": (I, [I, I]),
+    "vocr_nchw_to_nhwc_f16": (I, [P, P, I, I, I, I, P]),
+    "vocr_conv3x3_h16_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "vocr_f16_padded_row": (I, [I]),
+    "vocr_f32_to_f16_layouts": (I, [P, P, P, I, I, I, I, P]),
+    "vocr_conv3x3_wgrad_h16_supported": (I, [I, I]),
+    "vocr_conv3x3_wgrad_h16_workspace_bytes": (Z, [I, I, I, I, I]),
+    "vocr_conv3x3_wgrad_h16": (I, [P, P, P, P, I, I, I, I, I, P]),
     "vocr_channel_sum_workspace_bytes": (Z, [I, I, I]),
     "vocr_channel_sum": (I, [P, P, I, I, I, P, P]),
     "vocr_bn_workspace_bytes": (Z, [I, I, I]),

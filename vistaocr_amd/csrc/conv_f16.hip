@@ -220,3 +220,522 @@ extern "C" int vocr_conv3x3_f16_fwd(const float* x, const void* wpack, const flo
     VOCR_CHECK_LAUNCH("vocr_conv3x3_f16_fwd");
     return VOCR_OK;
 }
+
+// =====================================================================================================================
+// Round 5: the fp16-operand convolution on NHWC fp16 activations ("h16").  The kernel above gathers fp32 NCHW columns through
+// registers (48 dword loads and 24 conversions per lane and 16-channel chunk) and is staging-bound at 250-330 TFLOP/s - slower than
+// the fp32 minimal-filtering kernels it was meant to beat.  Here the activation is converted ONCE per use into [N][H][W][C] fp16
+// (vocr_nchw_to_nhwc_f16: 4 B read + 2 B written per element, HBM-bound), where the 8 channels a lane half of
+// v_mfma_f32_32x32x16_f16 needs for one pixel are 16 contiguous bytes: every operand then reaches LDS by DMA
+// (buffer_load_dwordx4 ... lds) with a per-lane source address computed once per launch, the channel chunk as the instruction's
+// scalar offset and out-of-image pieces as out-of-range offsets that deliver zeros - no register staging, no conversion, no VALU
+// in the loop beside the MFMAs and their fragment reads.
+//   workgroup = 4 waves; wave tile = 64 output channels x 4 segments of 32 pixels (8 accumulator tiles, 128 registers);
+//   WCO = 2: 128 channels x 8 segments per workgroup, WCO = 1 (64-channel layers): 64 x 16.
+//   LDS stage (one 16-channel chunk = one MFMA k-step per tap), two stages:
+//     weights [tap][half][co][8 halfs]           (the existing fp16 pack: A fragment = one conflict-free ds_read_b128)
+//     input   [seg][kh][half][36 pixels][8]      (B fragment of tap (kh, kw) = piece li + kw: 16 consecutive lanes = 256 contiguous bytes)
+//   one barrier per chunk (72 MFMAs of 32 cycles per wave between barriers); the DMAs of chunk c + 1 fly under the MFMAs of chunk c.
+// Output: fp32 NCHW (+ bias), a row of 32 pixels per channel = one 128-byte store, as before.  Forward and data gradient share the
+// kernel (the data-gradient pack has the taps flipped and the channel roles swapped).
+
+namespace {
+
+#define LDS16(p) ((__attribute__((address_space(3))) void*)(p))
+
+// (a __device__ template behind plain kernels: a device builtin inside a TEMPLATE __global__ makes the host pass drop the launch stub)
+// WCO = waves along the output channels (2: 128 channels per workgroup, 1: 64), SPW = segments per wave (2 or 3).  Eight waves = two per
+// SIMD: one wave's fragment reads and DMA issues are covered by the other's MFMAs.
+template <int WCO, int SPW>
+__device__ __forceinline__ void conv3x3_h16_body(const _Float16* __restrict__ x16, const _Float16* __restrict__ wpack,
+                                                 const float* __restrict__ bias, float* __restrict__ out, int N, int Cin, int H,
+                                                 int W, int Cout, int SW, int nseg_total, unsigned x_bytes, unsigned w_bytes) {
+    constexpr int CO_T = 64 * WCO;
+    constexpr int WSG = 8 / WCO;                      // waves along the segments
+    constexpr int NSEG = SPW * WSG;
+    constexpr int WP = 9 * 2 * CO_T;                  // 16-byte pieces of a stage's weights
+    constexpr int PP = 36;                            // pieces per patch row: 34 pixels + 2 never-read ones
+    constexpr int IP = NSEG * 3 * 2 * PP;             // ... and of its input patches
+    constexpr int IPA = (IP + 63) / 64 * 64;          // ... rounded up to whole waves of pieces (a DMA instruction writes 64)
+    constexpr int SP = WP + IPA;
+    constexpr int NQ = (WP + 511) / 512, NJ = (IPA + 511) / 512;
+    constexpr unsigned OOB = 0x80000000u;
+    static_assert(WP % 64 == 0, "whole waves of DMA pieces");
+    static_assert(2 * SP * 16 <= 160 * 1024, "two stages in LDS");
+    __shared__ __attribute__((aligned(16))) _Float16 lds[2 * SP * 8];
+    __shared__ SegInfo16 segs[NSEG];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lk = lane >> 5;
+    const int co0 = blockIdx.y * CO_T;
+    const int seg0 = blockIdx.x * NSEG;
+    const long HW = (long)H * W;
+    if (tid < NSEG) {
+        const int g = seg0 + tid;
+        SegInfo16 s;
+        s.valid = g < nseg_total;
+        const int gg = s.valid ? g : 0;
+        const int n = gg / (H * SW), rem = gg % (H * SW);
+        s.h = rem / SW;
+        s.w0 = (rem % SW) * SEGW;
+        s.base = n;                                   // image index (the NHWC offset is formed below, the NCHW one in the epilogue)
+        segs[tid] = s;
+    }
+    __syncthreads();
+
+    // ---- DMA source offsets, once per launch.  Piece P = tid + 512 j of a stage lands at LDS byte 16 P (the DMA writes a wave's 64
+    // pieces contiguously); a chunk advances every source by a scalar offset
+    unsigned wo[NQ], xo[NJ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const int p = tid + 512 * j;
+        const int th = p / CO_T, co = p % CO_T;       // th = tap*2 + half
+        wo[j] = (p < WP && co0 + co < Cout) ? (unsigned)(((long)th * Cout + co0 + co) * 16) : OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int p = tid + 512 * j;
+        unsigned o = OOB;
+        if (p < IP) {
+            const int sg = p / (6 * PP), r = p % (6 * PP);
+            const int kh = r / (2 * PP), r2 = r % (2 * PP);
+            const int half = r2 / PP, px = r2 % PP;
+            const SegInfo16 s = segs[sg];
+            const int hh = s.h + kh - 1, ww = s.w0 - 1 + px;
+            if (s.valid && px < PROW && hh >= 0 && hh < H && ww >= 0 && ww < W)
+                o = (unsigned)((((long)s.base * H + hh) * W + ww) * Cin * 2 + half * 16);
+        }
+        xo[j] = o;
+    }
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x16, 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wpack, 0, w_bytes, 0x00020000);
+    const int wchunk_bytes = 9 * 2 * Cout * 16;
+
+    // DMA d (0 .. NQ + NJ - 1) of a stage's fill; issued one per tap between the MFMAs of the chunk before
+    auto issue_one = [&](int d, int chunk, int stage) {
+        _Float16* base = lds + (long)stage * SP * 8;
+        if (d < NQ) {
+            if (512 * d + 64 * wave < WP)             // wave-uniform: whole 64-piece groups only
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS16(base + (long)(512 * d + 64 * wave) * 8), 16, wo[d < NQ ? d : 0], chunk * wchunk_bytes, 0, 0);
+        } else {
+            const int j = d - NQ;
+            if (512 * j + 64 * wave < IPA)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS16(base + (long)(WP + 512 * j + 64 * wave) * 8), 16, xo[j < NJ ? j : 0], chunk * 32, 0, 0);
+        }
+    };
+    constexpr int ND = NQ + NJ;
+    static_assert(ND <= 18, "at most two DMAs per tap");
+
+    const int wco = (wave / WSG) * 64, wsg = (wave % WSG) * SPW;
+    f32x16 acc[2][SPW];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < SPW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nchunks = Cin / CI_C;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) issue_one(d, 0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0)
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const bool more = c + 1 < nchunks;
+        const _Float16* wl = lds + (long)(c & 1) * SP * 8;
+        const _Float16* il = wl + (long)WP * 8;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int kh = tap / 3, kw = tap % 3;
+            half8 a[2], b[SPW];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = *(const half8*)(wl + ((tap * 2 + lk) * CO_T + wco + 32 * i + li) * 8);
+#pragma unroll
+            for (int j = 0; j < SPW; ++j) b[j] = *(const half8*)(il + ((((wsg + j) * 3 + kh) * 2 + lk) * PP + li + kw) * 8);
+            if (more) {                               // this chunk's share of the next stage's fill, spread over the taps
+                if (2 * tap < ND) issue_one(2 * tap, c + 1, (c + 1) & 1);
+                if (2 * tap + 1 < ND) issue_one(2 * tap + 1, c + 1, (c + 1) & 1);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < SPW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);           // this wave's DMAs of chunk c + 1 have landed ...
+        __syncthreads();                              // ... everybody's have, and everybody is done reading stage c & 1
+    }
+#pragma unroll
+    for (int j = 0; j < SPW; ++j) {
+        const SegInfo16 s = segs[wsg + j];
+        const int wx = s.w0 + li;
+        if (!s.valid || wx >= W) continue;
+        const long obase = (long)s.base * Cout * HW + (long)s.h * W + wx;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wco + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (co < Cout) out[obase + (long)co * HW] = acc[i][j][r] + (bias ? bias[co] : 0.f);
+            }
+    }
+}
+
+#define VOCR_H16_KERNEL(NAME, WCO, SPW)                                                                                                   \
+    __global__ __launch_bounds__(512) void NAME(const _Float16* __restrict__ x16, const _Float16* __restrict__ wpack,                     \
+                                                const float* __restrict__ bias, float* __restrict__ out, int N, int Cin, int H, int W,    \
+                                                int Cout, int SW, int nseg_total, unsigned x_bytes, unsigned w_bytes) {                   \
+        conv3x3_h16_body<WCO, SPW>(x16, wpack, bias, out, N, Cin, H, W, Cout, SW, nseg_total, x_bytes, w_bytes);                           \
+    }
+VOCR_H16_KERNEL(conv3x3_h16_kernel_128x2, 2, 2)       // 128 channels x  8 segments
+VOCR_H16_KERNEL(conv3x3_h16_kernel_128x3, 2, 3)       // 128 channels x 12 segments
+VOCR_H16_KERNEL(conv3x3_h16_kernel_64x2, 1, 2)        //  64 channels x 16 segments
+#undef VOCR_H16_KERNEL
+
+// fp32 [N][C][H][W] -> fp16 [N][H][W][C] (C % 8 == 0): one workgroup = one image row x 64 pixels x 64 channels through LDS;
+// reads are 256-byte channel rows, writes 16-byte pieces that are contiguous across a pixel's channels and across pixels
+__global__ __launch_bounds__(256) void nchw_to_nhwc_f16_kernel(const float* __restrict__ x, _Float16* __restrict__ y, int C, int H, int W) {
+    __shared__ float t[64][65];
+    const int tid = threadIdx.x;
+    const int w0 = blockIdx.x * 64, nh = blockIdx.y, c0 = blockIdx.z * 64;
+    const int n = nh / H, h = nh % H;
+    const int px = tid & 63, cs = tid >> 6;
+    const float* src = x + (((long)n * C + c0) * H + h) * W + w0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int c = cs + 4 * k;
+        t[c][px] = (c0 + c < C && w0 + px < W) ? src[(long)c * H * W + px] : 0.f;
+    }
+    __syncthreads();
+    const int cpw = min(64, C - c0) >> 3;             // 16-byte pieces per pixel in this channel tile
+    for (int p = tid; p < 64 * cpw; p += 256) {
+        const int q = p / cpw, cp = p % cpw;
+        if (w0 + q >= W) continue;
+        half8 v;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (_Float16)t[cp * 8 + k][q];
+        *(half8*)(y + (((long)n * H + h) * W + w0 + q) * C + c0 + cp * 8) = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int vocr_conv3x3_h16_supported(int cin, int cout) { return cin > 0 && cout > 0 && cin % 16 == 0 ? 1 : 0; }
+
+extern "C" int vocr_nchw_to_nhwc_f16(const float* x, void* x16, int n, int c, int h, int w, void* stream) {
+    VOCR_CHECK_ARG(x && x16 && n > 0 && c > 0 && h > 0 && w > 0, "vocr_nchw_to_nhwc_f16: bad argument");
+    VOCR_CHECK_ARG(c % 8 == 0 && (((uintptr_t)x16) & 15) == 0, "vocr_nchw_to_nhwc_f16: C %% 8 == 0 and a 16-byte aligned output");
+    VOCR_CHECK_ARG((long)n * h <= 65535 && vocr_cdiv(c, 64) <= 65535, "vocr_nchw_to_nhwc_f16: too many rows");
+    nchw_to_nhwc_f16_kernel<<<dim3(vocr_cdiv(w, 64), n * h, vocr_cdiv(c, 64)), 256, 0, (hipStream_t)stream>>>(x, (_Float16*)x16, c, h, w);
+    VOCR_CHECK_LAUNCH("vocr_nchw_to_nhwc_f16");
+    return VOCR_OK;
+}
+
+extern "C" int vocr_conv3x3_h16_fwd(const void* x16, const void* wpack, const float* bias, float* y, int n, int cin, int h, int w,
+                                    int cout, void* stream) {
+    VOCR_CHECK_ARG(x16 && wpack && y, "vocr_conv3x3_h16_fwd: null pointer");
+    VOCR_CHECK_ARG(n > 0 && cin > 0 && h > 0 && w > 0 && cout > 0 && cin % 16 == 0, "vocr_conv3x3_h16_fwd: bad shape (Cin %% 16 == 0)");
+    VOCR_CHECK_ARG(((((uintptr_t)wpack) | ((uintptr_t)x16)) & 15) == 0, "vocr_conv3x3_h16_fwd: 16-byte alignment");
+    const long xb = (long)n * h * w * cin * 2, wb = 9l * cin * cout * 2;
+    VOCR_CHECK_ARG(xb < (1l << 31) && wb < (1l << 31), "vocr_conv3x3_h16_fwd: tensor too large for 32-bit buffer offsets");
+    const int SW = vocr_cdiv(w, SEGW);
+    const long nseg = (long)n * h * SW;
+    VOCR_CHECK_ARG(nseg < (1l << 30), "vocr_conv3x3_h16_fwd: too many segments");
+    hipStream_t s = (hipStream_t)stream;
+    const _Float16* xp = (const _Float16*)x16;
+    const _Float16* wp = (const _Float16*)wpack;
+    if (cout > 64) {
+        // 8 or 12 segments per workgroup: whichever needs less time in whole rounds of one workgroup per CU
+        int ncu = 256;
+        {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+        }
+        const int ct = vocr_cdiv(cout, 128);
+        const long r2 = (long)vocr_cdiv((long)vocr_cdiv(nseg, 8) * ct, ncu) * 2, r3 = (long)vocr_cdiv((long)vocr_cdiv(nseg, 12) * ct, ncu) * 3;
+        if (r3 < r2) conv3x3_h16_kernel_128x3<<<dim3(vocr_cdiv(nseg, 12), ct), 512, 0, s>>>(xp, wp, bias, y, n, cin, h, w, cout, SW, (int)nseg, (unsigned)xb, (unsigned)wb);
+        else conv3x3_h16_kernel_128x2<<<dim3(vocr_cdiv(nseg, 8), ct), 512, 0, s>>>(xp, wp, bias, y, n, cin, h, w, cout, SW, (int)nseg, (unsigned)xb, (unsigned)wb);
+    } else {
+        conv3x3_h16_kernel_64x2<<<dim3(vocr_cdiv(nseg, 16), 1), 512, 0, s>>>(xp, wp, bias, y, n, cin, h, w, cout, SW, (int)nseg, (unsigned)xb, (unsigned)wb);
+    }
+    VOCR_CHECK_LAUNCH("vocr_conv3x3_h16_fwd");
+    return VOCR_OK;
+}
+
+// =====================================================================================================================
+// Round 5: the fp16-operand WEIGHT GRADIENT.  dW[co][ci][kh][kw] = sum over pixels of dy[co][p] x[ci][p + (kh-1, kw-1)]: M = co,
+// N = ci, K = pixels, one accumulator tile per tap (9 x 16 registers per 32 x 32 block of (co, ci)).  v_mfma_f32_32x32x16_f16 wants 8
+// CONSECUTIVE k per lane half, i.e. 8 consecutive pixels of one channel: both operands are read from channel-major fp16 copies
+// [N][C][H][WP] whose rows are padded to WP = ceil8(W) + 8 with zeros (vocr_f32_to_f16_layouts writes them in the same pass as the NHWC
+// copy).  The zero tail makes every 16-byte piece that sticks out of a row read zeros from memory (the left halo of a row start is the
+// previous row's tail), so all operands reach LDS by DMA with nothing to patch; rows above / below the image are out-of-range offsets.
+//   The kw = 1 fragment of x is an aligned 16-byte read; kw = 0 / 2 start one pixel (2 bytes) earlier / later: the wave reads the two
+//   neighbouring dwords as well and funnel-shifts (5 v_alignbit_b32 per row of taps - free beside 32-cycle MFMAs).
+//   workgroup = 8 waves = (co tiles of 32) x (ci tiles of 32) x (k subsets) over a tile of min(Cout, 128) x min(Cin, 64); a work UNIT is
+//   64 pixels of one image row (<= 4 k-steps of 16 pixels); the units are cut into as many contiguous ranges ("splits") as there are
+//   CUs per tile; every wave writes its 9 accumulator tiles to a slab and wgrad_h16_reduce_kernel adds the slabs in a fixed order
+//   (bitwise reproducible, no atomics).
+namespace {
+
+typedef unsigned u32x4h __attribute__((ext_vector_type(4)));
+
+struct WgH16Args {
+    const _Float16* dy;            // [N][Co][H][WP]
+    const _Float16* x;             // [N][Ci][H][WP]
+    float* slab;                   // [tile][split][ksub][tap][CTco][CTci]
+    int N, Ci, Co, H, W, WP;
+    int spr;                       // 64-pixel slabs per row
+    int units;                     // N * H * spr
+    int splits;
+    unsigned dy_bytes, x_bytes;
+};
+
+template <int CW, int IW>
+__device__ __forceinline__ void wgrad_h16_body(const WgH16Args g) {
+    constexpr int KS = 8 / (CW * IW);
+    constexpr int CTco = 32 * CW, CTci = 32 * IW;
+    constexpr int DYP = CTco * 9;                     // dy pieces of a stage: [co][8 data + 1 pad]
+    constexpr int XP = CTci * 33;                     // x pieces: [ci][kh][10 data + 1 pad]
+    constexpr int DYPA = (DYP + 63) / 64 * 64, XPA = (XP + 63) / 64 * 64;
+    constexpr int SP = DYPA + XPA;
+    constexpr int NDY = (DYPA + 511) / 512, NX = (XPA + 511) / 512;
+    constexpr unsigned OOB = 0x80000000u;
+    __shared__ __attribute__((aligned(16))) _Float16 lds[2 * SP * 8];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lk = lane >> 5;
+    const int ks = wave % KS, iw = (wave / KS) % IW, cw = wave / (KS * IW);
+    const int tiles_ci = g.Ci / CTci;
+    const int tile = blockIdx.x / g.splits, split = blockIdx.x % g.splits;
+    const int co0 = (tile / tiles_ci) * CTco, ci0 = (tile % tiles_ci) * CTci;
+    const int u0 = (int)((long)g.units * split / g.splits), u1 = (int)((long)g.units * (split + 1) / g.splits);
+    const long rowb = (long)g.WP * 2;                 // bytes per row
+
+    // per-lane constant parts of the DMA sources (unit-independent): dy piece -> (co row, piece q), x piece -> (ci, kh, piece q)
+    unsigned dyo[NDY], xo[NX];
+    int xkh[NX], xq[NX];
+#pragma unroll
+    for (int j = 0; j < NDY; ++j) {
+        const int p = tid + 512 * j;
+        const int row = p / 9, q = p % 9;
+        dyo[j] = (p < DYP && q < 8) ? (unsigned)(((long)(co0 + row) * g.H) * rowb + q * 16) : OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+        const int p = tid + 512 * j;
+        const int ci = p / 33, r = p % 33;
+        xkh[j] = r / 11;
+        xq[j] = r % 11;
+        // relative to a base one row and one piece IN FRONT of the tensor (the buffer's range check looks at this per-lane part alone, so
+        // it has to be non-negative; the unit's part below is the instruction's scalar offset)
+        xo[j] = (p < XP && xq[j] < 10) ? (unsigned)(((long)(ci0 + ci) * g.H + xkh[j]) * rowb + xq[j] * 16) : OOB;
+    }
+    const unsigned xpad = (unsigned)(rowb + 16);
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)g.dy, 0, g.dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)g.x - xpad), 0, g.x_bytes + xpad, 0x00020000);
+
+    auto issue = [&](int u, int stage) {
+        const int r = u / g.spr, sx = u % g.spr;      // image row index n*H + h, slab in the row
+        const int n = r / g.H, h = r % g.H;
+        _Float16* base = lds + (long)stage * SP * 8;
+        // scalar parts: dy (n*Co*H + h) rows + 64 sx pixels; x (n*Ci*H + h) rows + 64 sx pixels
+        const unsigned sdy = (unsigned)(((long)n * g.Co * g.H + h) * rowb + sx * 128);
+        const unsigned sxx = (unsigned)(((long)n * g.Ci * g.H + h) * rowb + sx * 128);
+#pragma unroll
+        for (int j = 0; j < NDY; ++j)
+            if (512 * j + 64 * wave < DYPA)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, LDS16(base + (long)(512 * j + 64 * wave) * 8), 16, dyo[j], sdy, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NX; ++j)
+            if (512 * j + 64 * wave < XPA) {
+                // rows above / below the image and pieces that start at or behind the row's padded end deliver zeros
+                // (and the left halo of the tensor's very first row, which would lie in front of the allocation)
+                const bool dead = (xkh[j] == 0 && h == 0) || (xkh[j] == 2 && h == g.H - 1) || (64 * sx + 8 * (xq[j] - 1) >= g.WP) ||
+                                  (xo[j] != OOB && xo[j] + sxx < xpad);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS16(base + (long)(DYPA + 512 * j + 64 * wave) * 8), 16, dead ? OOB : xo[j], sxx, 0, 0);
+            }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    if (u0 < u1) issue(u0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    for (int u = u0; u < u1; ++u) {
+        const int st = (u - u0) & 1;
+        if (u + 1 < u1) issue(u + 1, st ^ 1);
+        const _Float16* dl = lds + (long)st * SP * 8;
+        const _Float16* xl = dl + (long)DYPA * 8;
+        const int sx = u % g.spr;
+        const int nk = min(4, (g.W - 64 * sx + 15) >> 4);          // 16-pixel k-steps with a real pixel in this slab
+        for (int s = ks; s < nk; s += KS) {
+            const half8 a = *(const half8*)(dl + ((cw * 32 + li) * 9 + 2 * s + lk) * 8);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const unsigned* row = (const unsigned*)(xl + (((iw * 32 + li) * 3 + kh) * 11) * 8);
+                const int q = 1 + 2 * s + lk;             // the aligned piece: pixels 64 sx + 16 s + 8 lk .. + 7
+                const u32x4h d = *(const u32x4h*)(row + 4 * q);
+                const unsigned d0 = row[4 * q - 1], d5 = row[4 * q + 4];
+                const unsigned a01 = __builtin_amdgcn_alignbit(d[0], d0, 16), a12 = __builtin_amdgcn_alignbit(d[1], d[0], 16),
+                               a23 = __builtin_amdgcn_alignbit(d[2], d[1], 16), a34 = __builtin_amdgcn_alignbit(d[3], d[2], 16),
+                               a45 = __builtin_amdgcn_alignbit(d5, d[3], 16);
+                const u32x4h b0 = {a01, a12, a23, a34}, b2 = {a12, a23, a34, a45};
+                acc[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, b0), acc[kh * 3 + 0], 0, 0, 0);
+                acc[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, d), acc[kh * 3 + 1], 0, 0, 0);
+                acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, b2), acc[kh * 3 + 2], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+    }
+    // slab[tile][split][ks][tap][co in tile][ci in tile]
+    float* sl = g.slab + ((((long)tile * g.splits + split) * KS + ks) * 9) * CTco * CTci;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = cw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            sl[((long)t * CTco + co) * CTci + iw * 32 + li] = acc[t][r];
+        }
+}
+
+
+__global__ __launch_bounds__(512) void conv3x3_wgrad_h16_kernel_128x64(const WgH16Args g) { wgrad_h16_body<4, 2>(g); }
+__global__ __launch_bounds__(512) void conv3x3_wgrad_h16_kernel_64x64(const WgH16Args g) { wgrad_h16_body<2, 2>(g); }
+
+// dw[co][ci][tap] = sum over (split, ksub) of slab[tile][split][ksub][tap][co'][ci'], in that fixed order
+__global__ __launch_bounds__(256) void wgrad_h16_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Co, int Ci, int CTco,
+                                                               int CTci, int parts) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;             // (tap, co, ci), ci fastest
+    if (i >= 9l * Co * Ci) return;
+    const int ci = (int)(i % Ci), co = (int)((i / Ci) % Co), tap = (int)(i / ((long)Ci * Co));
+    const int tile = (co / CTco) * (Ci / CTci) + ci / CTci;
+    const float* p = slab + (((long)tile * parts) * 9 + tap) * CTco * CTci + (long)(co % CTco) * CTci + ci % CTci;
+    const long stride = 9l * CTco * CTci;
+    float v = 0.f;
+    for (int k = 0; k < parts; ++k) v += p[k * stride];
+    dw[((long)co * Ci + ci) * 9 + tap] = v;
+}
+
+// fp32 [N][C][H][W] -> fp16 [N][H][W][C] (nhwc, may be NULL) and / or fp16 [N][C][H][WP] with zero-padded rows (nchwp, may be NULL;
+// WP = ceil8(W) + 8) in one pass over the input: one workgroup = one image row x 64 pixels x 64 channels through LDS
+__global__ __launch_bounds__(256) void f32_to_f16_layouts_kernel(const float* __restrict__ x, _Float16* __restrict__ nhwc, _Float16* __restrict__ nchwp,
+                                                                 int C, int H, int W, int WP) {
+    __shared__ float t[64][65];
+    const int tid = threadIdx.x;
+    const int w0 = blockIdx.x * 64, nh = blockIdx.y, c0 = blockIdx.z * 64;
+    const int n = nh / H, h = nh % H;
+    const int px = tid & 63, cs = tid >> 6;
+    const float* src = x + (((long)n * C + c0) * H + h) * W + w0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int c = cs + 4 * k;
+        t[c][px] = (c0 + c < C && w0 + px < W) ? src[(long)c * H * W + px] : 0.f;
+    }
+    __syncthreads();
+    if (nhwc) {
+        const int cpw = min(64, C - c0) >> 3;         // 16-byte pieces per pixel in this channel tile
+        for (int p = tid; p < 64 * cpw; p += 256) {
+            const int q = p / cpw, cp = p % cpw;
+            if (w0 + q >= W) continue;
+            half8 v;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = (_Float16)t[cp * 8 + k][q];
+            *(half8*)(nhwc + (((long)n * H + h) * W + w0 + q) * C + c0 + cp * 8) = v;
+        }
+    }
+    if (nchwp) {
+        // thread = (channel, 16-pixel group): two 16-byte pieces of the channel's padded row; pixels >= W are zeros (loaded as such)
+        const int c = tid >> 2, gq = tid & 3;
+        if (c0 + c < C) {
+            _Float16* dst = nchwp + (((long)n * C + c0 + c) * H + h) * WP + w0 + 16 * gq;
+#pragma unroll
+            for (int hpc = 0; hpc < 2; ++hpc) {
+                if (w0 + 16 * gq + 8 * hpc >= WP) continue;
+                half8 v;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = (_Float16)t[c][16 * gq + 8 * hpc + k];
+                *(half8*)(dst + 8 * hpc) = v;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+static inline int h16_wp(int w) { return (w + 7) / 8 * 8 + 8; }
+
+extern "C" int vocr_f16_padded_row(int w) { return w > 0 ? h16_wp(w) : 0; }
+
+extern "C" int vocr_f32_to_f16_layouts(const float* x, void* nhwc, void* nchwp, int n, int c, int h, int w, void* stream) {
+    VOCR_CHECK_ARG(x && (nhwc || nchwp) && n > 0 && c > 0 && h > 0 && w > 0, "vocr_f32_to_f16_layouts: bad argument");
+    VOCR_CHECK_ARG(c % 8 == 0 && ((((uintptr_t)nhwc) | ((uintptr_t)nchwp)) & 15) == 0, "vocr_f32_to_f16_layouts: C %% 8 == 0 and 16-byte aligned outputs");
+    VOCR_CHECK_ARG((long)n * h <= 65535 && vocr_cdiv(c, 64) <= 65535, "vocr_f32_to_f16_layouts: too many rows");
+    const int wp = h16_wp(w);
+    f32_to_f16_layouts_kernel<<<dim3(vocr_cdiv(nchwp ? wp : w, 64), n * h, vocr_cdiv(c, 64)), 256, 0, (hipStream_t)stream>>>(
+        x, (_Float16*)nhwc, (_Float16*)nchwp, c, h, w, wp);
+    VOCR_CHECK_LAUNCH("vocr_f32_to_f16_layouts");
+    return VOCR_OK;
+}
+
+namespace {
+struct WgH16Plan { bool ok; int ctco, ctci, tiles, splits, parts; };
+WgH16Plan wgrad_h16_plan(int n, int cin, int h, int w, int cout) {
+    WgH16Plan p = {false, 0, 0, 0, 0, 0};
+    if (cin % 64 != 0 || cout % 64 != 0 || (cout > 64 && cout % 128 != 0)) return p;
+    p.ctco = cout >= 128 ? 128 : 64;
+    p.ctci = 64;
+    p.tiles = (cout / p.ctco) * (cin / p.ctci);
+    int ncu = 256;
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+    }
+    const long units = (long)n * h * vocr_cdiv(w, 64);
+    long s = ncu / p.tiles;
+    if (s < 1) s = 1;
+    if (s > units) s = units;
+    p.splits = (int)s;
+    p.parts = p.splits * (8 / ((p.ctco / 32) * (p.ctci / 32)));
+    p.ok = true;
+    return p;
+}
+}  // namespace
+
+extern "C" int vocr_conv3x3_wgrad_h16_supported(int cin, int cout) { return wgrad_h16_plan(1, cin, 1, 64, cout).ok ? 1 : 0; }
+
+extern "C" size_t vocr_conv3x3_wgrad_h16_workspace_bytes(int n, int cin, int h, int w, int cout) {
+    if (n <= 0 || h <= 0 || w <= 0) return 0;
+    const WgH16Plan p = wgrad_h16_plan(n, cin, h, w, cout);
+    return p.ok ? (size_t)p.tiles * p.parts * 9 * p.ctco * p.ctci * sizeof(float) : 0;
+}
+
+extern "C" int vocr_conv3x3_wgrad_h16(const void* x16p, const void* dy16p, float* dw, void* workspace, int n, int cin, int h, int w, int cout,
+                                      void* stream) {
+    VOCR_CHECK_ARG(x16p && dy16p && dw && workspace && n > 0 && h > 0 && w > 0, "vocr_conv3x3_wgrad_h16: bad argument");
+    const WgH16Plan p = wgrad_h16_plan(n, cin, h, w, cout);
+    VOCR_CHECK_ARG(p.ok, "vocr_conv3x3_wgrad_h16: Cin %% 64 == 0 and Cout in {64, multiples of 128} (ask vocr_conv3x3_wgrad_h16_supported)");
+    VOCR_CHECK_ARG(((((uintptr_t)x16p) | ((uintptr_t)dy16p)) & 15) == 0, "vocr_conv3x3_wgrad_h16: 16-byte alignment");
+    const int wp = h16_wp(w);
+    const long xb = (long)n * cin * h * wp * 2, db = (long)n * cout * h * wp * 2;
+    VOCR_CHECK_ARG(xb < (1l << 31) && db < (1l << 31), "vocr_conv3x3_wgrad_h16: tensor too large for 32-bit buffer offsets");
+    WgH16Args g;
+    g.dy = (const _Float16*)dy16p; g.x = (const _Float16*)x16p; g.slab = (float*)workspace;
+    g.N = n; g.Ci = cin; g.Co = cout; g.H = h; g.W = w; g.WP = wp;
+    g.spr = vocr_cdiv(w, 64);
+    g.units = n * h * g.spr;
+    g.splits = p.splits;
+    g.dy_bytes = (unsigned)db; g.x_bytes = (unsigned)xb;
+    hipStream_t s = (hipStream_t)stream;
+    if (p.ctco == 128) conv3x3_wgrad_h16_kernel_128x64<<<p.tiles * p.splits, 512, 0, s>>>(g);
+    else conv3x3_wgrad_h16_kernel_64x64<<<p.tiles * p.splits, 512, 0, s>>>(g);
+    VOCR_CHECK_LAUNCH("vocr_conv3x3_wgrad_h16");
+    wgrad_h16_reduce_kernel<<<vocr_cdiv(9l * cout * cin, 256), 256, 0, s>>>((const float*)workspace, dw, cout, cin, p.ctco, p.ctci, p.parts);
+    VOCR_CHECK_LAUNCH("vocr_conv3x3_wgrad_h16(reduce)");
+    return VOCR_OK;
+}

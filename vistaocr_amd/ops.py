@@ -277,11 +277,34 @@ def conv3x3_pack_f16(weight):
     return pf, pd
 
 
-def conv3x3_forward_f16(x, wpack16, bias, cout):
+def f16_layouts(x, want_nhwc=True, want_nchwp=False):
+    """fp32 [N,C,H,W] -> the fp16 operand copies of the fp16-operand conv kernels, one pass over x (vocr_f32_to_f16_layouts):
+    nhwc  [N,H,W,C]   forward / data gradient: the 8 channels of a lane half are 16 contiguous bytes;
+    nchwp [N,C,H,WP]  weight gradient: 8 consecutive pixels of a channel, rows zero-padded to WP = ceil8(W) + 8."""
+    n, c, h, w = x.shape
+    nhwc = torch.empty(n, h, w, c, dtype=torch.float16, device=x.device) if want_nhwc else None
+    nchwp = torch.empty(n, c, h, _lib.load().vocr_f16_padded_row(w), dtype=torch.float16, device=x.device) if want_nchwp else None
+    call("vocr_f32_to_f16_layouts", _p(x), _p(nhwc), _p(nchwp), n, c, h, w, _stream())
+    return nhwc, nchwp
+
+
+def conv3x3_forward_f16(x, wpack16, bias, cout, x_nhwc=None):
+    """fp16 operands, fp32 accumulate, fp32 NCHW in and out (BASELINE configs[4]).  Cin % 16 == 0: the all-DMA kernel on an NHWC fp16
+    copy of x (`x_nhwc`, made here unless the caller has it); otherwise (the rapid_ds stage's Cin = 1) the register-staged kernel."""
     n, cin, h, w = x.shape
     y = torch.empty(n, cout, h, w, dtype=torch.float32, device=x.device)
-    call("vocr_conv3x3_f16_fwd", _p(x), _p(wpack16), _p(bias), _p(y), n, cin, h, w, cout, _stream())
+    if _lib.load().vocr_conv3x3_h16_supported(cin, cout):
+        if x_nhwc is None:
+            x_nhwc = f16_layouts(x)[0]
+        call("vocr_conv3x3_h16_fwd", _p(x_nhwc), _p(wpack16), _p(bias), _p(y), n, cin, h, w, cout, _stream())
+    else:
+        call("vocr_conv3x3_f16_fwd", _p(x), _p(wpack16), _p(bias), _p(y), n, cin, h, w, cout, _stream())
     return y
+
+
+def wgrad_f16_layouts_ok(cin, cout):
+    """The fp16 weight-gradient kernel on the channel-major padded copies takes this layer (Cin % 64 == 0, Cout 64 or a multiple of 128)."""
+    return bool(_lib.load().vocr_conv3x3_wgrad_h16_supported(cin, cout))
 
 
 def conv3x3_forward(x, wpack, bias, cout):
@@ -296,12 +319,20 @@ def conv3x3_forward(x, wpack, bias, cout):
     return y
 
 
-def conv3x3_wgrad(x, dy, out=None, f16=False):
+def conv3x3_wgrad(x, dy, out=None, f16=False, x16p=None, dy16p=None):
     n, cin, h, w = x.shape
     cout = dy.shape[1]
     lib = _lib.load()
     dw = out if out is not None else torch.empty(cout, cin, 3, 3, dtype=torch.float32, device=x.device)
-    if not f16 and _WINO_WGRAD and cin >= 4 and n * max(cin, cout) * h * w < (1 << 29):
+    if f16 and x16p is not None and dy16p is not None:
+        # fp16 operands from the channel-major padded copies (conv3x3_wgrad_h16_kernel): all-DMA staging, 9 tap accumulators per wave
+        ws = _ws(lib.vocr_conv3x3_wgrad_h16_workspace_bytes(n, cin, h, w, cout), x.device)
+        call("vocr_conv3x3_wgrad_h16", _p(x16p), _p(dy16p), _p(dw), _p(ws), n, cin, h, w, cout, _stream())
+        return dw
+    # Without those copies the fp16 configuration takes the fp32 row-pair kernel wherever it applies: it issues 4/9 of the direct form's
+    # multiplications and measured FASTER than the register-staged fp16 weight-gradient kernel (2.8 vs 3.8 ms per step in the round-5
+    # bench), on exact fp32 operands; `f16` then only decides the kernel of the layers that kernel does not take (Cin < 4)
+    if _WINO_WGRAD and cin >= 4 and n * max(cin, cout) * h * w < (1 << 29):
         ws = _ws(lib.vocr_conv3x3_wgrad_wino_workspace_bytes(n, cin, h, w, cout), x.device)
         call("vocr_conv3x3_wgrad_wino", _p(x), _p(dy), _p(dw), _p(ws), n, cin, h, w, cout, _stream())
         return dw
@@ -333,9 +364,14 @@ class ConvBnReluFn(torch.autograd.Function):
         cout = weight.shape[0]
         lib = _lib.load()
         ctx.f16 = bool(f16)
+        x16p = None
         if ctx.f16:
             pf, pd = conv3x3_pack_f16(weight)
-            y = conv3x3_forward_f16(x, pf, bias, cout)
+            x_nhwc = None
+            if lib.vocr_conv3x3_h16_supported(cin, cout):
+                # one pass over x: the forward operand and (training) the weight gradient's channel-major copy, kept for the backward
+                x_nhwc, x16p = f16_layouts(x, True, bool(training) and wgrad_f16_layouts_ok(cin, cout))
+            y = conv3x3_forward_f16(x, pf, bias, cout, x_nhwc)
         else:
             if prep is not None and weight.data_ptr() in prep.packs:
                 prep.wait_packs()
@@ -382,7 +418,7 @@ class ConvBnReluFn(torch.autograd.Function):
                 call("vocr_bn_relu_apply", _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(out), n, cout, h * w, _stream())
         ctx.training = training
         ctx.prefs = (weight, bias, gamma, beta)
-        ctx.save_for_backward(x, y, mean, invstd, gamma, beta, pd, idx, samples, xhat_sum)
+        ctx.save_for_backward(x, y, mean, invstd, gamma, beta, pd, idx, samples, xhat_sum, x16p)
         return out
 
     @staticmethod
@@ -390,7 +426,7 @@ class ConvBnReluFn(torch.autograd.Function):
     def backward(ctx, da):
         if not ctx.training:
             raise RuntimeError("vistaocr_amd: backward through eval-mode BatchNorm is not part of the reference path")
-        x, y, mean, invstd, gamma, beta, pd, idx, samples, xhat_sum = ctx.saved_tensors
+        x, y, mean, invstd, gamma, beta, pd, idx, samples, xhat_sum, x16p = ctx.saved_tensors
         da = _f32c(da)
         n, cin, h, w = x.shape
         cout = y.shape[1]
@@ -427,21 +463,28 @@ class ConvBnReluFn(torch.autograd.Function):
         else:
             call("vocr_bn_relu_bwd", _p(da), _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(xhat_sum), _p(dy), _p(dgamma),
                  _p(dbeta), _p(dbias), n, cout, h * w, _p(ws), _stream())
+        dy_nhwc = dy16p = None
+        if ctx.f16:
+            # one pass over dy: the data gradient's NHWC operand and the weight gradient's channel-major padded one
+            want_nhwc = bool(ctx.needs_input_grad[0]) and bool(lib.vocr_conv3x3_h16_supported(cout, cin))
+            if want_nhwc or x16p is not None:
+                dy_nhwc, dy16p = f16_layouts(dy, want_nhwc, x16p is not None)
         if sinks is not None and _SIDE_ENABLED and ctx.needs_input_grad[0] and _exp("VOCR_CONV_OVERLAP", "1") == "1":
             # weight gradient (off the critical path, written straight into the optimiser's buffer) on the low-priority side
             # stream beside the data gradient: each kernel's last partial round of workgroups is filled by the other's
             side = side_stream()
             side.wait_stream(torch.cuda.current_stream())
-            for t_ in (x, dy):
-                t_.record_stream(side)
+            for t_ in (x, dy, x16p, dy16p):
+                if t_ is not None:
+                    t_.record_stream(side)
             with torch.cuda.stream(side):
-                conv3x3_wgrad(x, dy, out=dw, f16=ctx.f16)
+                conv3x3_wgrad(x, dy, out=dw, f16=ctx.f16, x16p=x16p, dy16p=dy16p)
             mark_side_pending()
         else:
-            dw = conv3x3_wgrad(x, dy, out=dw, f16=ctx.f16)
+            dw = conv3x3_wgrad(x, dy, out=dw, f16=ctx.f16, x16p=x16p, dy16p=dy16p)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = conv3x3_forward_f16(dy, pd, None, cin) if ctx.f16 else conv3x3_forward(dy, pd, None, cin)
+            dx = conv3x3_forward_f16(dy, pd, None, cin, dy_nhwc) if ctx.f16 else conv3x3_forward(dy, pd, None, cin)
         if sinks is not None:
             return (dx,) + (None,) * 15
         return (dx, dw, dbias, dgamma, dbeta) + (None,) * 11
