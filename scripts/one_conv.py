@@ -20,4 +20,26 @@ dx = torch.empty(9408, 1024, device=dev)
 for _ in range(5): ops.gemm_pair(1, 0, 0, 9408, 1024, 2048, dg0, dg1, 2048, w0, w1, 1024, dx, None, 1024)
 dw0 = torch.empty(2048, 1024, device=dev); dw1 = torch.empty(2048, 1024, device=dev)
 for _ in range(5): ops.gemm_pair(0, 1, 0, 2048, 1024, 9408, dg0, dg1, 2048, a, a, 1024, dw0, dw1, 1024)
+# round 5: the fp16-operand kernels (configs[4]) and one LSTM layer's two sweeps at the bench shape
+x_nhwc, x16p = ops.f16_layouts(x, True, True)
+dy16p = ops.f16_layouts(dy, False, True)[1]
+p16 = ops.conv3x3_pack_f16(wt)[0]
+for _ in range(5): y16 = ops.conv3x3_forward_f16(x, p16, None, cout, x_nhwc)
+for _ in range(5): dw16 = ops.conv3x3_wgrad(x, dy, f16=True, x16p=x16p, dy16p=dy16p)
+from vistaocr_amd import _lib
+from vistaocr_amd._lib import call
+lib = _lib.load()
+T, B, H = 294, 32, 512
+xp = (torch.rand(2, T * B, 4 * H, device=dev) - 0.5) * 0.6
+wf = (torch.rand(4 * H, H, device=dev) - 0.5) * 0.2; wr = (torch.rand(4 * H, H, device=dev) - 0.5) * 0.2
+lens = torch.full((B,), T, dtype=torch.int32, device=dev)
+yl = torch.empty(T * B, 2 * H, device=dev); gt = torch.empty(2, T * B, 4 * H, device=dev); cl = torch.empty(2, T * B, H, device=dev)
+ws = torch.zeros(lib.vocr_lstm_workspace_bytes(T, B, H) // 4 + 16, device=dev)
+dyl = (torch.rand(T * B, 2 * H, device=dev) - 0.5) * 0.02; dgl = torch.empty(2, T * B, 4 * H, device=dev); dbl = torch.empty(2, 4 * H, device=dev)
+hw = torch.zeros(4, dtype=torch.int32, device=dev)
+wtf, wtr = ops.transpose2d(wf), ops.transpose2d(wr)
+st = torch.cuda.current_stream().cuda_stream
+for _ in range(4):
+    call("vocr_lstm_fwd", xp.data_ptr(), wf.data_ptr(), wr.data_ptr(), lens.data_ptr(), yl.data_ptr(), gt.data_ptr(), cl.data_ptr(), ws.data_ptr(), T, B, H, hw.data_ptr(), st)
+    call("vocr_lstm_bwd_bias", dyl.data_ptr(), wtf.data_ptr(), wtr.data_ptr(), lens.data_ptr(), gt.data_ptr(), cl.data_ptr(), dgl.data_ptr(), dbl.data_ptr(), ws.data_ptr(), T, B, H, hw.data_ptr(), st)
 torch.cuda.synchronize()

@@ -54,6 +54,9 @@ def busy(paths):
             k = short(r["Kernel_Name"])
             key = "conv forward (%s)" % k.split("<")[0] if (k.startswith("conv3x3_dma_kernel") or k.startswith("conv3x3_wino_kernel") or k.startswith("conv3x3_wino2_kernel") or k.startswith("conv3x3_wino4")) \
                 else "conv weight gradient (%s)" % k.split("<")[0] if (k.startswith("conv3x3_wgrad_kernel") or k.startswith("conv3x3_wgrad_wino")) \
+                else "fp16-operand conv forward (%s)" % k.split("<")[0] if k.startswith("conv3x3_h16_kernel") \
+                else "fp16-operand conv weight gradient (%s)" % k.split("<")[0] if k.startswith("conv3x3_wgrad_h16_kernel") \
+                else "LSTM sweep (%s)" % k.split("<")[0] if (k.startswith("lstm_fwd_chain4w") or k.startswith("lstm_bwd_chain4w")) \
                 else "GEMM tile kernel (%s)" % k[:60] if k.startswith("gemm_f32_kernel") \
                 else "GEMM panel kernel (%s)" % k[:60] if k.startswith("gemm_dma_kernel") else None
             if key is None:
@@ -84,9 +87,12 @@ def busy(paths):
 
 FAMILIES = (      # bench.py's FAMILY names -> kernel-name prefixes
     ("conv3x3 forward + data gradient (conv3x3_wino4 / conv3x3_wino2 kernels: F(4,3) / F(2,3) along the row)", ("conv3x3_wino_kernel", "conv3x3_wino2_kernel", "conv3x3_wino4", "conv3x3_wino8_kernel", "conv3x3_dma_kernel", "conv3x3_kernel", "conv3x3_tail")),
-    ("conv3x3 weight gradient (conv3x3_wgrad_wino2d_kernel: F(3,2) along the row and across row pairs, piece stream)", ("conv3x3_wgrad",)),
+    ("conv3x3 weight gradient (conv3x3_wgrad_wino2d_kernel: F(3,2) along the row and across row pairs, piece stream)", ("conv3x3_wgrad_wino", "conv3x3_wgrad_kernel", "conv3x3_wgrad_smallcin")),
     ("dense GEMMs (gemm_dma_kernel / gemm_f32_kernel behind vocr_gemm and vocr_gemm_pair: bridge, LSTM projections, prob, their dX / dW)", ("gemm_dma_kernel", "gemm_f32_kernel")),
     ("LSTM sweeps (lstm_fwd_chain4w / lstm_bwd_chain4w)", ("lstm_fwd_", "lstm_bwd_")),
+    ("conv3x3 with fp16 operands, fp32 accumulate (conv3x3_h16_kernel on NHWC fp16 activations: forward + data gradient; conv3x3_wgrad_h16_kernel on "
+     "channel-major fp16 copies: weight gradient; the register-staged kernels where the channel counts do not fit; v_mfma_f32_32x32x16_f16)",
+     ("conv3x3_h16_kernel", "conv3x3_wgrad_h16_kernel", "conv3x3_f16_kernel", "conv3x3_wgrad_f16_kernel")),
 )
 
 

@@ -91,7 +91,7 @@ def test_config1_full_size_vs_oracle():
     emitted = sum(len(l) for l in olabels)
     print("full-size configs[1] (batch seed %d): loss %.4f vs oracle %.4f (rel %.2e); max |dlogit| %.2e at scale %.1f; oracle decode "
           "margin %.2e; labels emitted %d; label sequences differing: %d of %d"
-          % (seed, float(loss), float(lo_loss), rel, err, float(lo.detach().abs().max()), margin, emitted, mism, B))
+          % (seed, float(loss.detach()), float(lo_loss.detach()), rel, err, float(lo.detach().abs().max()), margin, emitted, mism, B))
     assert rel <= 1e-3
     assert emitted >= 10 * B, "the label comparison would be vacuous"
     assert err <= margin / 4, "logit error %.2e is not small against the decode margin %.2e" % (err, margin)
