@@ -96,20 +96,21 @@ int vocr_conv3x3_f16_fwd(const float* x, const void* wpack, const float* bias, f
                          int n, int cin, int h, int w, int cout, void* stream);
 int vocr_conv3x3_wgrad_f16(const float* x, const float* dy, float* dw, void* workspace,
                            int n, int cin, int h, int w, int cout, void* stream);
-/* Round 5: the same fp16-operand convolution on an NHWC fp16 copy of the activation (cin % 16 == 0; ask vocr_conv3x3_h16_supported).
- * vocr_nchw_to_nhwc_f16: fp32 [n][c][h][w] -> fp16 [n][h][w][c] (c % 8 == 0, x16 16-byte aligned) - one HBM-bound pass per use;
- * vocr_conv3x3_h16_fwd: x16 in that layout, the weight packs of vocr_conv3x3_f16_pack_weights, y fp32 [n][cout][h][w] (+ bias):
- * every operand reaches LDS by DMA and the loop holds nothing but MFMAs and their fragment reads.  Results equal
- * vocr_conv3x3_f16_fwd's up to the fp32 summation order (both round the same operands to fp16 and accumulate in fp32).
+/* Round 5: the same fp16-operand convolution on a channel-blocked fp16 copy of the activation, x16 = [n][cin/16][h][w][16] (cin % 16 == 0;
+ * ask vocr_conv3x3_h16_supported): the 16 channels of a block are 32 contiguous bytes per pixel and consecutive pixels follow each
+ * other, so the kernel's 16-byte LDS-DMA pieces use whole cache lines.  vocr_f32_to_f16_layouts (below) writes the copy in one HBM-bound
+ * pass per use.  vocr_conv3x3_h16_fwd: x16 in that layout, the weight packs of vocr_conv3x3_f16_pack_weights, y fp32 [n][cout][h][w]
+ * (+ bias): every operand reaches LDS by DMA and the loop holds nothing but MFMAs and their fragment reads.  Results equal
+ * vocr_conv3x3_f16_fwd's bit for bit (same operand rounding, same summation order per output).
  * dgrad = vocr_conv3x3_h16_fwd(dy16, wpack_dgrad, NULL, dx, n, cout, h, w, cin). */
 int vocr_conv3x3_h16_supported(int cin, int cout);
-int vocr_nchw_to_nhwc_f16(const float* x, void* x16, int n, int c, int h, int w, void* stream);
 int vocr_conv3x3_h16_fwd(const void* x16, const void* wpack, const float* bias, float* y,
                          int n, int cin, int h, int w, int cout, void* stream);
 /* Round 5, weight gradient with fp16 operands: both operands as channel-major fp16 copies [n][c][h][WP] whose rows are zero-padded to
  * WP = vocr_f16_padded_row(w) = ceil8(w) + 8 (8 consecutive pixels of a channel = 16 bytes = what a lane half of the MFMA needs when the
  * contraction runs over pixels; the zero tail is every row's right AND the next row's left halo).  vocr_f32_to_f16_layouts writes the
- * NHWC copy (nhwc, may be NULL) and / or the padded channel-major one (nchwp, may be NULL) in ONE pass over the fp32 tensor (c % 8 == 0).
+ * channel-blocked copy [n][c/16][h][w][16] (`nhwc`, may be NULL; needs c % 16 == 0) and / or the padded channel-major one (`nchwp`, may
+ * be NULL) in ONE pass over the fp32 tensor (c % 8 == 0).
  * vocr_conv3x3_wgrad_h16: x16p [n][cin][h][WP], dy16p [n][cout][h][WP] -> dw[cout][cin][3][3] fp32; cin % 64 == 0 and cout 64 or a
  * multiple of 128 (ask vocr_conv3x3_wgrad_h16_supported); workspace = split slabs added in a fixed order (bitwise reproducible).
  * Same arithmetic as vocr_conv3x3_wgrad_f16 (operands rounded to fp16, fp32 accumulate), another summation order. */

@@ -20,8 +20,8 @@ for (cin, cout, h, w) in [(16, 64, 30, 600), (64, 64, 30, 600), (64, 128, 15, 42
     n = 32
     x = torch.randn(n, cin, h, w, device=dev); wt = torch.randn(cout, cin, 3, 3, device=dev) * 0.05; b = torch.randn(cout, device=dev)
     pf, pd = ops.conv3x3_pack_f16(wt)
-    y = torch.empty(n, cout, h, w, device=dev); x16 = torch.empty(n, h, w, cin, dtype=torch.float16, device=dev)
-    t_c = timeit(lambda: call("vocr_nchw_to_nhwc_f16", x.data_ptr(), x16.data_ptr(), n, cin, h, w, s()))
+    y = torch.empty(n, cout, h, w, device=dev); x16 = torch.empty(n, cin // 16, h, w, 16, dtype=torch.float16, device=dev)
+    t_c = timeit(lambda: call("vocr_f32_to_f16_layouts", x.data_ptr(), x16.data_ptr(), None, n, cin, h, w, s()))
     t_h = timeit(lambda: call("vocr_conv3x3_h16_fwd", x16.data_ptr(), pf.data_ptr(), b.data_ptr(), y.data_ptr(), n, cin, h, w, cout, s()))
     y1 = y.clone()
     t_f = timeit(lambda: call("vocr_conv3x3_f16_fwd", x.data_ptr(), pf.data_ptr(), b.data_ptr(), y.data_ptr(), n, cin, h, w, cout, s()))

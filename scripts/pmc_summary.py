@@ -2,10 +2,15 @@
   python scripts/pmc_summary.py traffic <FETCH csv> <WRITE csv>   -> per-kernel KB per dispatch; conv forward / data-gradient split
   python scripts/pmc_summary.py busy <csv> [<csv> ...]             -> MFMA-busy / wait shares for conv forward, wgrad, GEMM
 The matching *_kernel_trace.csv (same directory) supplies the dispatch durations."""
-import collections, csv, glob, os, sys
+import collections, csv, glob, os, re, sys
 
 
 def short(k):
+    # names with _Float16 parameters stay mangled in rocprofv3's CSVs: _ZN12_GLOBAL__N_1<len><name>E...
+    m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", k)
+    if m:
+        n = int(m.group(1))
+        return k[m.end():m.end() + n]
     return k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
 
 

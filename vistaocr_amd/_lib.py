@@ -33,7 +33,6 @@ SIGNATURES = {
     "vocr_conv3x3_f16_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
     "vocr_conv3x3_wgrad_f16": (I, [P, P, P, P, I, I, I, I, I, P]),
     "vocr_conv3x3_h16_supported": (I, [I, I]),
-    "vocr_nchw_to_nhwc_f16": (I, [P, P, I, I, I, I, P]),
     "vocr_conv3x3_h16_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
     "vocr_f16_padded_row": (I, [I]),
     "vocr_f32_to_f16_layouts": (I, [P, P, P, I, I, I, I, P]),

@@ -222,10 +222,10 @@ extern "C" int vocr_conv3x3_f16_fwd(const float* x, const void* wpack, const flo
 }
 
 // =====================================================================================================================
-// Round 5: the fp16-operand convolution on NHWC fp16 activations ("h16").  The kernel above gathers fp32 NCHW columns through
+// Round 5: the fp16-operand convolution on channel-blocked NHWC fp16 activations ("h16").  The kernel above gathers fp32 NCHW columns through
 // registers (48 dword loads and 24 conversions per lane and 16-channel chunk) and is staging-bound at 250-330 TFLOP/s - slower than
-// the fp32 minimal-filtering kernels it was meant to beat.  Here the activation is converted ONCE per use into [N][H][W][C] fp16
-// (vocr_nchw_to_nhwc_f16: 4 B read + 2 B written per element, HBM-bound), where the 8 channels a lane half of
+// the fp32 minimal-filtering kernels it was meant to beat.  Here the activation is converted ONCE per use into a channel-blocked fp16
+// copy [N][C/16][H][W][16] (vocr_f32_to_f16_layouts: 4 B read + 2 B written per element, HBM-bound), where the 8 channels a lane half of
 // v_mfma_f32_32x32x16_f16 needs for one pixel are 16 contiguous bytes: every operand then reaches LDS by DMA
 // (buffer_load_dwordx4 ... lds) with a per-lane source address computed once per launch, the channel chunk as the instruction's
 // scalar offset and out-of-image pieces as out-of-range offsets that deliver zeros - no register staging, no conversion, no VALU
@@ -235,6 +235,8 @@ extern "C" int vocr_conv3x3_f16_fwd(const float* x, const void* wpack, const flo
 //   LDS stage (one 16-channel chunk = one MFMA k-step per tap), two stages:
 //     weights [tap][half][co][8 halfs]           (the existing fp16 pack: A fragment = one conflict-free ds_read_b128)
 //     input   [seg][kh][half][36 pixels][8]      (B fragment of tap (kh, kw) = piece li + kw: 16 consecutive lanes = 256 contiguous bytes)
+//   Source layout: with plain [N][H][W][C] a DMA instruction's 64 pieces touched 64 different 128-byte lines and used 16 bytes of each
+//   (fill-bound at 600 TFLOP/s on 256 -> 256, 236 on 64 -> 64); channel-blocked, a patch row of a chunk is one contiguous run: 645 / 341.
 //   one barrier per chunk (72 MFMAs of 32 cycles per wave between barriers); the DMAs of chunk c + 1 fly under the MFMAs of chunk c.
 // Output: fp32 NCHW (+ bias), a row of 32 pixels per channel = one 128-byte store, as before.  Forward and data gradient share the
 // kernel (the data-gradient pack has the taps flipped and the channel roles swapped).
@@ -303,13 +305,14 @@ __device__ __forceinline__ void conv3x3_h16_body(const _Float16* __restrict__ x1
             const SegInfo16 s = segs[sg];
             const int hh = s.h + kh - 1, ww = s.w0 - 1 + px;
             if (s.valid && px < PROW && hh >= 0 && hh < H && ww >= 0 && ww < W)
-                o = (unsigned)((((long)s.base * H + hh) * W + ww) * Cin * 2 + half * 16);
+                o = (unsigned)(((((long)s.base * (Cin / CI_C)) * H + hh) * W + ww) * 32 + half * 16);     // [N][C/16][H][W][16]: chunk 0
         }
         xo[j] = o;
     }
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x16, 0, x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wpack, 0, w_bytes, 0x00020000);
     const int wchunk_bytes = 9 * 2 * Cout * 16;
+    const int xchunk_bytes = H * W * 32;              // one 16-channel block of one image
 
     // DMA d (0 .. NQ + NJ - 1) of a stage's fill; issued one per tap between the MFMAs of the chunk before
     auto issue_one = [&](int d, int chunk, int stage) {
@@ -320,11 +323,13 @@ __device__ __forceinline__ void conv3x3_h16_body(const _Float16* __restrict__ x1
         } else {
             const int j = d - NQ;
             if (512 * j + 64 * wave < IPA)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS16(base + (long)(WP + 512 * j + 64 * wave) * 8), 16, xo[j < NJ ? j : 0], chunk * 32, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS16(base + (long)(WP + 512 * j + 64 * wave) * 8), 16, xo[j < NJ ? j : 0], chunk * xchunk_bytes, 0, 0);
         }
     };
     constexpr int ND = NQ + NJ;
-    static_assert(ND <= 18, "at most two DMAs per tap");
+#ifndef H16_SPREAD
+#define H16_SPREAD 5
+#endif
 
     const int wco = (wave / WSG) * 64, wsg = (wave % WSG) * SPW;
     f32x16 acc[2][SPW];
@@ -344,22 +349,31 @@ __device__ __forceinline__ void conv3x3_h16_body(const _Float16* __restrict__ x1
         const bool more = c + 1 < nchunks;
         const _Float16* wl = lds + (long)(c & 1) * SP * 8;
         const _Float16* il = wl + (long)WP * 8;
+        // fragments of tap t + 1 are read while the MFMAs of tap t run (two register sets): with the reads in front of their own MFMAs a
+        // tap was LDS latency + 4-6 MFMAs per wave and the two waves of a SIMD could not cover each other (30 % MFMA-busy)
+        half8 fa[2][2], fb[2][SPW];
+        auto load_frags = [&](int tap, int set) {
+            const int kh = tap / 3, kw = tap % 3;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[set][i] = *(const half8*)(wl + ((tap * 2 + lk) * CO_T + wco + 32 * i + li) * 8);
+#pragma unroll
+            for (int j = 0; j < SPW; ++j) fb[set][j] = *(const half8*)(il + ((((wsg + j) * 3 + kh) * 2 + lk) * PP + li + kw) * 8);
+        };
+        load_frags(0, 0);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const int kh = tap / 3, kw = tap % 3;
-            half8 a[2], b[SPW];
+            if (tap + 1 < 9) load_frags(tap + 1, (tap + 1) & 1);
+            if (more && tap < H16_SPREAD) {           // the next stage's fill: H16_SPREAD taps share its DMAs
+                constexpr int PER = (ND + H16_SPREAD - 1) / H16_SPREAD;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = *(const half8*)(wl + ((tap * 2 + lk) * CO_T + wco + 32 * i + li) * 8);
-#pragma unroll
-            for (int j = 0; j < SPW; ++j) b[j] = *(const half8*)(il + ((((wsg + j) * 3 + kh) * 2 + lk) * PP + li + kw) * 8);
-            if (more) {                               // this chunk's share of the next stage's fill, spread over the taps
-                if (2 * tap < ND) issue_one(2 * tap, c + 1, (c + 1) & 1);
-                if (2 * tap + 1 < ND) issue_one(2 * tap + 1, c + 1, (c + 1) & 1);
+                for (int d = 0; d < PER; ++d)
+                    if (tap * PER + d < ND) issue_one(tap * PER + d, c + 1, (c + 1) & 1);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < SPW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < SPW; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[tap & 1][i], fb[tap & 1][j], acc[i][j], 0, 0, 0);
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);           // this wave's DMAs of chunk c + 1 have landed ...
         __syncthreads();                              // ... everybody's have, and everybody is done reading stage c & 1
@@ -391,44 +405,9 @@ VOCR_H16_KERNEL(conv3x3_h16_kernel_128x3, 2, 3)       // 128 channels x 12 segme
 VOCR_H16_KERNEL(conv3x3_h16_kernel_64x2, 1, 2)        //  64 channels x 16 segments
 #undef VOCR_H16_KERNEL
 
-// fp32 [N][C][H][W] -> fp16 [N][H][W][C] (C % 8 == 0): one workgroup = one image row x 64 pixels x 64 channels through LDS;
-// reads are 256-byte channel rows, writes 16-byte pieces that are contiguous across a pixel's channels and across pixels
-__global__ __launch_bounds__(256) void nchw_to_nhwc_f16_kernel(const float* __restrict__ x, _Float16* __restrict__ y, int C, int H, int W) {
-    __shared__ float t[64][65];
-    const int tid = threadIdx.x;
-    const int w0 = blockIdx.x * 64, nh = blockIdx.y, c0 = blockIdx.z * 64;
-    const int n = nh / H, h = nh % H;
-    const int px = tid & 63, cs = tid >> 6;
-    const float* src = x + (((long)n * C + c0) * H + h) * W + w0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int c = cs + 4 * k;
-        t[c][px] = (c0 + c < C && w0 + px < W) ? src[(long)c * H * W + px] : 0.f;
-    }
-    __syncthreads();
-    const int cpw = min(64, C - c0) >> 3;             // 16-byte pieces per pixel in this channel tile
-    for (int p = tid; p < 64 * cpw; p += 256) {
-        const int q = p / cpw, cp = p % cpw;
-        if (w0 + q >= W) continue;
-        half8 v;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = (_Float16)t[cp * 8 + k][q];
-        *(half8*)(y + (((long)n * H + h) * W + w0 + q) * C + c0 + cp * 8) = v;
-    }
-}
-
 }  // namespace
 
 extern "C" int vocr_conv3x3_h16_supported(int cin, int cout) { return cin > 0 && cout > 0 && cin % 16 == 0 ? 1 : 0; }
-
-extern "C" int vocr_nchw_to_nhwc_f16(const float* x, void* x16, int n, int c, int h, int w, void* stream) {
-    VOCR_CHECK_ARG(x && x16 && n > 0 && c > 0 && h > 0 && w > 0, "vocr_nchw_to_nhwc_f16: bad argument");
-    VOCR_CHECK_ARG(c % 8 == 0 && (((uintptr_t)x16) & 15) == 0, "vocr_nchw_to_nhwc_f16: C %% 8 == 0 and a 16-byte aligned output");
-    VOCR_CHECK_ARG((long)n * h <= 65535 && vocr_cdiv(c, 64) <= 65535, "vocr_nchw_to_nhwc_f16: too many rows");
-    nchw_to_nhwc_f16_kernel<<<dim3(vocr_cdiv(w, 64), n * h, vocr_cdiv(c, 64)), 256, 0, (hipStream_t)stream>>>(x, (_Float16*)x16, c, h, w);
-    VOCR_CHECK_LAUNCH("vocr_nchw_to_nhwc_f16");
-    return VOCR_OK;
-}
 
 extern "C" int vocr_conv3x3_h16_fwd(const void* x16, const void* wpack, const float* bias, float* y, int n, int cin, int h, int w,
                                     int cout, void* stream) {
@@ -638,14 +617,17 @@ __global__ __launch_bounds__(256) void f32_to_f16_layouts_kernel(const float* __
     }
     __syncthreads();
     if (nhwc) {
-        const int cpw = min(64, C - c0) >> 3;         // 16-byte pieces per pixel in this channel tile
-        for (int p = tid; p < 64 * cpw; p += 256) {
-            const int q = p / cpw, cp = p % cpw;
+        // channel-blocked "NHWC": [N][C/16][H][W][16] - a pixel's 16 channels of one block are 32 contiguous bytes and consecutive
+        // pixels follow each other, so the conv kernel's 16-byte DMA pieces use whole cache lines (plain [N][H][W][C] left 16 of every
+        // 128 bytes of a line per instruction: the forward kernel ran at 600 TFLOP/s, fill-bound)
+        const int cbn = min(64, C - c0) >> 4;         // 16-channel blocks in this channel tile
+        for (int p = tid; p < cbn * 128; p += 256) {
+            const int cb = p >> 7, q = (p >> 1) & 63, half = p & 1;
             if (w0 + q >= W) continue;
             half8 v;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = (_Float16)t[cp * 8 + k][q];
-            *(half8*)(nhwc + (((long)n * H + h) * W + w0 + q) * C + c0 + cp * 8) = v;
+            for (int k = 0; k < 8; ++k) v[k] = (_Float16)t[cb * 16 + half * 8 + k][q];
+            *(half8*)(nhwc + ((((long)n * (C >> 4) + (c0 >> 4) + cb) * H + h) * W + w0 + q) * 16 + half * 8) = v;
         }
     }
     if (nchwp) {
@@ -673,7 +655,8 @@ extern "C" int vocr_f16_padded_row(int w) { return w > 0 ? h16_wp(w) : 0; }
 
 extern "C" int vocr_f32_to_f16_layouts(const float* x, void* nhwc, void* nchwp, int n, int c, int h, int w, void* stream) {
     VOCR_CHECK_ARG(x && (nhwc || nchwp) && n > 0 && c > 0 && h > 0 && w > 0, "vocr_f32_to_f16_layouts: bad argument");
-    VOCR_CHECK_ARG(c % 8 == 0 && ((((uintptr_t)nhwc) | ((uintptr_t)nchwp)) & 15) == 0, "vocr_f32_to_f16_layouts: C %% 8 == 0 and 16-byte aligned outputs");
+    VOCR_CHECK_ARG(c % 8 == 0 && (!nhwc || c % 16 == 0) && ((((uintptr_t)nhwc) | ((uintptr_t)nchwp)) & 15) == 0,
+                   "vocr_f32_to_f16_layouts: C %% 8 == 0 (%% 16 for the channel-blocked copy) and 16-byte aligned outputs");
     VOCR_CHECK_ARG((long)n * h <= 65535 && vocr_cdiv(c, 64) <= 65535, "vocr_f32_to_f16_layouts: too many rows");
     const int wp = h16_wp(w);
     f32_to_f16_layouts_kernel<<<dim3(vocr_cdiv(nchwp ? wp : w, 64), n * h, vocr_cdiv(c, 64)), 256, 0, (hipStream_t)stream>>>(

@@ -279,10 +279,11 @@ def conv3x3_pack_f16(weight):
 
 def f16_layouts(x, want_nhwc=True, want_nchwp=False):
     """fp32 [N,C,H,W] -> the fp16 operand copies of the fp16-operand conv kernels, one pass over x (vocr_f32_to_f16_layouts):
-    nhwc  [N,H,W,C]   forward / data gradient: the 8 channels of a lane half are 16 contiguous bytes;
+    nhwc  [N,C/16,H,W,16]  forward / data gradient (channel-blocked NHWC): the 8 channels of a lane half are 16 contiguous bytes and a
+                           row segment of a 16-channel block is one contiguous run, so the kernel's DMA pieces use whole cache lines;
     nchwp [N,C,H,WP]  weight gradient: 8 consecutive pixels of a channel, rows zero-padded to WP = ceil8(W) + 8."""
     n, c, h, w = x.shape
-    nhwc = torch.empty(n, h, w, c, dtype=torch.float16, device=x.device) if want_nhwc else None
+    nhwc = torch.empty(n, c // 16, h, w, 16, dtype=torch.float16, device=x.device) if want_nhwc else None
     nchwp = torch.empty(n, c, h, _lib.load().vocr_f16_padded_row(w), dtype=torch.float16, device=x.device) if want_nchwp else None
     call("vocr_f32_to_f16_layouts", _p(x), _p(nhwc), _p(nchwp), n, c, h, w, _stream())
     return nhwc, nchwp
