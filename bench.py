@@ -519,7 +519,7 @@ def run_rank(args):
     names = MFMA_NAMES + ["vocr_bn_train_stats", "vocr_bn_relu_apply", "vocr_bn_relu_fracpool2x2_fwd", "vocr_bn_train_relu_apply",
                           "vocr_bn_train_relu_fracpool2x2_fwd", "vocr_bn_relu_bwd",
                           "vocr_fracpool2x2_bwd", "vocr_bn_relu_fracpool2x2_bwd", "vocr_ctc_loss_grad", "vocr_clamp_adam", "vocr_bchw_to_wbch", "vocr_wbch_to_bchw",
-                          "vocr_relu_maxpool2_fwd", "vocr_relu_maxpool2_bwd", "vocr_gather_rows", "vocr_dropout_fwd", "vocr_mul", "vocr_f32_to_f16_layouts"]
+                          "vocr_relu_maxpool2_fwd", "vocr_relu_maxpool2_bwd", "vocr_gather_rows", "vocr_dropout_fwd", "vocr_mul", "vocr_f32_to_f16_layouts", "vocr_conv3x3_c1_fwd", "vocr_conv3x3_c1_wgrad"]
     _lib.enable_timing(names)
     for _ in range(PROFILE_STEPS):
         va.train(batch_dev, model, crit, opt)

@@ -85,6 +85,15 @@ int vocr_conv3x3_wino_fwd(const float* x, const float* wpack, const float* bias,
 size_t vocr_conv3x3_wgrad_wino_workspace_bytes(int n, int cin, int h, int w, int cout);
 int vocr_conv3x3_wgrad_wino(const float* x, const float* dy, float* dw, void* workspace,
                             int n, int cin, int h, int w, int cout, void* stream);
+/* Round 5: one input channel (the first layer of a grey-line model, configs[4]'s rapid_ds stage) as plain vector arithmetic - the layer is
+ * bound by writing its output once, not by 576 FLOP per pixel.  w = the layer's own weight [cout][1][3][3] (no pack), y fp32
+ * [n][cout][h][wd] (+ bias); round_f16 != 0 rounds x and w to fp16 first (the fp16-operand configuration's arithmetic; fp32 accumulate
+ * either way).  vocr_conv3x3_c1_wgrad: dw[cout][1][3][3] from x [n][1][h][wd] and dy [n][cout][h][wd], exact fp32, split partial sums
+ * added in a fixed order (workspace: vocr_conv3x3_c1_wgrad_workspace_bytes). */
+int vocr_conv3x3_c1_fwd(const float* x, const float* w, const float* bias, float* y, int n, int h, int wd, int cout, int round_f16,
+                        void* stream);
+size_t vocr_conv3x3_c1_wgrad_workspace_bytes(int n, int h, int cout);
+int vocr_conv3x3_c1_wgrad(const float* x, const float* dy, float* dw, void* workspace, int n, int h, int wd, int cout, void* stream);
 /* fp16-operand variant (BASELINE config 5: "fp16 conv MFMA", fp32 accumulate): tensors stay fp32 in HBM, operands are
  * rounded to fp16 on the way into the matrix cores (v_mfma_f32_32x32x16_f16).  Weight packs are fp16:
  * fwd  [ceil(cin/16)][9][2][cout][8],  dgrad [ceil(cout/16)][9][2][cin][8] (taps flipped); sizes from *_pack_bytes.

@@ -106,6 +106,45 @@ def test_conv3x3_wgrad_row_pairs_long_stream_matches_direct_kernel(dev):
     _close(dw, ref, 1e-4, 2e-4 * math.sqrt(n * h * w), "conv wgrad (row pairs, long stream)")
 
 
+@pytest.mark.parametrize("n,h,w,cout", [(2, 30, 70, 64), (3, 30, 601, 64), (2, 60, 257, 16), (1, 5, 3, 7), (4, 7, 1024, 32)])
+def test_conv3x3_one_input_channel_kernels(dev, n, h, w, cout):
+    """Round 5: the vector-arithmetic kernels of the one-input-channel layers (the first layer of a grey-line model, configs[4]'s rapid_ds
+    stage) against F.conv2d / conv2d_weight on the CPU: forward in fp32 and with fp16-rounded operands, weight gradient exact fp32 and
+    bitwise reproducible; widths that are not a multiple of 4, rows shorter than a quad, many rows per split."""
+    from vistaocr_amd import ops
+    x = _rand((n, 1, h, w), 1)
+    wt = _rand((cout, 1, 3, 3), 2, 0.3)
+    bias = _rand((cout,), 3)
+    dy = _rand((n, cout, h, w), 4)
+    y = ops.conv3x3_c1_forward(x.to(dev), wt.to(dev), bias.to(dev))
+    _close(y, F.conv2d(x, wt, bias, padding=1), 1e-5, 2e-5, "conv Cin=1 fwd")
+    yh = ops.conv3x3_c1_forward(x.to(dev), wt.to(dev), bias.to(dev), f16=True)
+    _close(yh, F.conv2d(x.half().float(), wt.half().float(), bias, padding=1), 1e-5, 2e-5, "conv Cin=1 fwd, fp16-rounded operands")
+    from vistaocr_amd import _lib
+    from vistaocr_amd._lib import call
+    lib = _lib.load()
+
+    def c1_wgrad():          # the C entry point directly (ops.conv3x3_wgrad picks it for fewer than 32 output channels only)
+        dw_ = torch.empty(cout, 1, 3, 3, device=dev)
+        ws = torch.empty(lib.vocr_conv3x3_c1_wgrad_workspace_bytes(n, h, cout) // 4 + 4, device=dev)
+        call("vocr_conv3x3_c1_wgrad", xd.data_ptr(), dyd.data_ptr(), dw_.data_ptr(), ws.data_ptr(), n, h, w, cout, torch.cuda.current_stream().cuda_stream)
+        return dw_
+    xd, dyd = x.to(dev), dy.to(dev)
+    dw = c1_wgrad()
+    _close(dw, torch.nn.grad.conv2d_weight(x, wt.shape, dy, padding=1), 1e-4, 2e-4 * math.sqrt(n * h * w), "conv Cin=1 wgrad")
+    assert torch.equal(dw, c1_wgrad())
+    _close(ops.conv3x3_wgrad(xd, dyd), dw.cpu(), 1e-4, 2e-4 * math.sqrt(n * h * w), "conv Cin=1 wgrad through ops")
+    # the layer op takes these kernels when nothing flows back into the image, the packed kernels when the input needs a gradient
+    g = [t.clone().to(dev).requires_grad_(True) for t in (wt, bias)]
+    gam, bet = torch.ones(cout, device=dev, requires_grad=True), torch.zeros(cout, device=dev, requires_grad=True)
+    rm, rv = torch.zeros(cout, device=dev), torch.ones(cout, device=dev)
+    outs = []
+    for xin in (x.to(dev), x.to(dev).requires_grad_(True)):
+        a = ops.ConvBnReluFn.apply(xin, g[0], g[1], gam, bet, rm.clone(), rv.clone(), True, 1e-5, 0.1)
+        outs.append(a.detach())
+    _close(outs[0], outs[1].cpu(), 1e-4, 1e-4, "Cin=1 layer: vector kernel vs packed kernel")
+
+
 @pytest.mark.parametrize("n,cin,h,w,cout", [(2, 1, 30, 70, 64), (2, 64, 15, 45, 128), (1, 128, 7, 33, 256), (1, 16, 9, 40, 64), (1, 24, 12, 31, 16),
                                             # the NHWC-fp16 kernel (Cin % 16 == 0) at sizes with several workgroups, partial segments and both channel tilings
                                             (3, 64, 30, 131, 64), (2, 256, 7, 294, 256), (4, 128, 15, 97, 128), (2, 16, 30, 100, 64), (1, 48, 5, 33, 80)])

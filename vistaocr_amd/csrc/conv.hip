@@ -1471,3 +1471,194 @@ extern "C" int vocr_channel_sum(const float* x, float* out, int n, int c, int hw
     }
     return VOCR_OK;
 }
+
+// =====================================================================================================================
+// Round 5: the ONE-input-channel convolution (the first layer of every grey-line configuration, and configs[4]'s rapid_ds stage) as
+// plain vector arithmetic.  576 FLOP per output pixel against 256 bytes written: the layer is bound by streaming its OUTPUT once
+// (147 MB at batch 32 = ~30 us at HBM speed); the MFMA kernels spent 78 us (Cin padded to 4 in the F(2,3) kernel) and 375 us (Cin
+// padded to 16 in the fp16 kernel) on it.  A thread owns 4 consecutive pixels: its 3 x 6 input window stays in registers, the filter
+// taps are wave-uniform (scalar loads), one 16-byte store per output channel = 1 KB contiguous per wave.
+// round_f16: operands rounded to fp16 first (the fp16-operand configuration's arithmetic), fp32 accumulation either way.
+namespace {
+
+__global__ __launch_bounds__(256) void conv3x3_c1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ y, int H, int W, int Cout,
+                                                             int round_f16) {
+    // a thread's 4 pixels never cross a row: quads are counted per row (QW = ceil(W / 4)) and flattened over the image's rows, so a
+    // 600-pixel row does not leave 106 of 256 threads idle
+    const int n = blockIdx.y;
+    const int QW = (W + 3) >> 2;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= H * QW) return;
+    const int h = q / QW, w0 = (q % QW) * 4;
+    const float* xi = x + (long)n * H * W;
+    float win[3][6];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int hh = h + kh - 1;
+        const bool rok = hh >= 0 && hh < H;
+        const float* row = xi + (long)(rok ? hh : 0) * W;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int ww = w0 - 1 + j;
+            float v = (rok && ww >= 0 && ww < W) ? row[ww] : 0.f;
+            if (round_f16) v = (float)(_Float16)v;
+            win[kh][j] = v;
+        }
+    }
+    float* yo = y + ((long)n * Cout * H + h) * W + w0;
+    const long cstride = (long)H * W;
+    const bool full = w0 + 3 < W && ((((uintptr_t)yo) | ((uintptr_t)(cstride * 4))) & 15) == 0;
+    for (int co = 0; co < Cout; ++co) {
+        float k[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            k[t] = w[co * 9 + t];                     // wave-uniform: scalar loads
+            if (round_f16) k[t] = (float)(_Float16)k[t];
+        }
+        const float b = bias ? bias[co] : 0.f;
+        float o[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            float a = 0.f;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) a = __builtin_fmaf(win[kh][p + kw], k[kh * 3 + kw], a);
+            o[p] = a + b;
+        }
+        float* d = yo + co * cstride;
+        if (full) {
+            *(f32x4*)d = (f32x4){o[0], o[1], o[2], o[3]};
+        } else {
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                if (w0 + p < W) d[p] = o[p];
+        }
+    }
+}
+
+// dw[co][tap] = sum over (n, h, w) of dy[n][co][h][w] x[n][h + kh - 1][w + kw - 1].  Workgroup = (group of 4 output channels, split of
+// the image rows); a thread keeps 4 x 9 accumulators over its pixel lane of every row of the split, dy streams through once (one
+// coalesced load per channel and row strip), the nine x neighbours come from the cache; block tree in LDS, then the splits are added
+// in a fixed order by the second kernel (bitwise reproducible).
+__global__ __launch_bounds__(256) void conv3x3_c1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                               float* __restrict__ part, int N, int H, int W, int Cout, int rows_per_split) {
+    __shared__ float red[36][257];
+    const int tid = threadIdx.x;
+    const int cg = blockIdx.x, split = blockIdx.y;
+    const int co0 = cg * 4;
+    const int nco = min(4, Cout - co0);
+    const long HW = (long)H * W;
+    const int r0 = split * rows_per_split, r1 = min(N * H, r0 + rows_per_split);
+    float acc[4][9];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[c][t] = 0.f;
+    // the split's pixels as one flat range of QUADS (4 consecutive pixels of a row; rows hold QW = ceil(W / 4) of them): a thread reads
+    // its 3 x 6 input window with three 16-byte loads + the two edge columns, and one 16-byte load of dy per channel
+    const int QW = (W + 3) >> 2;
+    const bool vec = (W & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)dy)) & 15) == 0;
+    for (long q = (long)r0 * QW + tid; q < (long)r1 * QW; q += 256) {
+        const int r = (int)(q / QW), w0 = (int)(q % QW) * 4;
+        const int n = r / H, h = r % H;
+        const float* xi = x + (long)n * HW;
+        const float* dyb = dy + ((long)n * Cout + co0) * HW + (long)h * W + w0;
+        float win[3][6];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int hh = h + kh - 1;
+            const bool rok = hh >= 0 && hh < H;
+            const float* row = xi + (long)(rok ? hh : 0) * W;
+            if (vec) {
+                const f32x4 v = rok ? *(const f32x4*)(row + w0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                win[kh][1] = v[0]; win[kh][2] = v[1]; win[kh][3] = v[2]; win[kh][4] = v[3];
+                win[kh][0] = (rok && w0 > 0) ? row[w0 - 1] : 0.f;
+                win[kh][5] = (rok && w0 + 4 < W) ? row[w0 + 4] : 0.f;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const int ww = w0 - 1 + j;
+                    win[kh][j] = (rok && ww >= 0 && ww < W) ? row[ww] : 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c < nco) {
+                float g[4];
+                if (vec) {
+                    const f32x4 v = __builtin_nontemporal_load((const f32x4*)(dyb + c * HW));
+                    g[0] = v[0]; g[1] = v[1]; g[2] = v[2]; g[3] = v[3];
+                } else {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) g[p] = w0 + p < W ? dyb[c * HW + p] : 0.f;
+                }
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) acc[c][kh * 3 + kw] = __builtin_fmaf(g[p], win[kh][p + kw], acc[c][kh * 3 + kw]);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) red[c * 9 + t][tid] = acc[c][t];
+    __syncthreads();
+    // 36 rows of 256 partial sums: wave w reduces rows w, w + 4, ... with a fixed shuffle tree (a shuffle tree per accumulator in every
+    // wave and twice as many, shorter splits measured 100 / 188 us against 69 / 116)
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int row = wave; row < 36; row += 4) {
+        float v = (red[row][lane] + red[row][lane + 64]) + (red[row][lane + 128] + red[row][lane + 192]);
+        v = wave_sum(v);
+        const int c = row / 9, t = row % 9;
+        if (lane == 0 && c < nco) part[((long)split * Cout + co0 + c) * 9 + t] = v;
+    }
+}
+
+__global__ void conv3x3_c1_wgrad_final_kernel(const float* __restrict__ part, float* __restrict__ dw, int n_out, int splits) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    float v = 0.f;
+    for (int s = 0; s < splits; ++s) v += part[(long)s * n_out + i];
+    dw[i] = v;
+}
+
+inline int c1_wgrad_splits(int n, int h, int cout) {
+    const int groups = (cout + 3) / 4;
+    int s = (4 * 256 + groups - 1) / groups;          // ~4 workgroups per CU in total
+    if (s > n * h) s = n * h;
+    return s < 1 ? 1 : s;
+}
+
+}  // namespace
+
+extern "C" int vocr_conv3x3_c1_fwd(const float* x, const float* w, const float* bias, float* y, int n, int h, int wd, int cout, int round_f16,
+                                   void* stream) {
+    VOCR_CHECK_ARG(x && w && y && n > 0 && h > 0 && wd > 0 && cout > 0, "vocr_conv3x3_c1_fwd: bad argument");
+    VOCR_CHECK_ARG(n <= 65535, "vocr_conv3x3_c1_fwd: grid too large");
+    conv3x3_c1_fwd_kernel<<<dim3(vocr_cdiv((long)h * ((wd + 3) / 4), 256), n), 256, 0, (hipStream_t)stream>>>(x, w, bias, y, h, wd, cout, round_f16);
+    VOCR_CHECK_LAUNCH("vocr_conv3x3_c1_fwd");
+    return VOCR_OK;
+}
+
+extern "C" size_t vocr_conv3x3_c1_wgrad_workspace_bytes(int n, int h, int cout) {
+    if (n <= 0 || h <= 0 || cout <= 0) return 0;
+    return (size_t)c1_wgrad_splits(n, h, cout) * cout * 9 * sizeof(float);
+}
+
+extern "C" int vocr_conv3x3_c1_wgrad(const float* x, const float* dy, float* dw, void* workspace, int n, int h, int wd, int cout, void* stream) {
+    VOCR_CHECK_ARG(x && dy && dw && workspace && n > 0 && h > 0 && wd > 0 && cout > 0, "vocr_conv3x3_c1_wgrad: bad argument");
+    const int splits = c1_wgrad_splits(n, h, cout);
+    const int rps = vocr_cdiv((long)n * h, splits);
+    hipStream_t s = (hipStream_t)stream;
+    conv3x3_c1_wgrad_kernel<<<dim3(vocr_cdiv(cout, 4), splits), 256, 0, s>>>(x, dy, (float*)workspace, n, h, wd, cout, rps);
+    VOCR_CHECK_LAUNCH("vocr_conv3x3_c1_wgrad");
+    conv3x3_c1_wgrad_final_kernel<<<vocr_cdiv(cout * 9, 64), 64, 0, s>>>((const float*)workspace, dw, cout * 9, splits);
+    VOCR_CHECK_LAUNCH("vocr_conv3x3_c1_wgrad(final)");
+    return VOCR_OK;
+}

@@ -320,11 +320,28 @@ def conv3x3_forward(x, wpack, bias, cout):
     return y
 
 
+def conv3x3_c1_forward(x, weight, bias, f16=False):
+    """One input channel: the vector-arithmetic kernel straight on the layer's weight (no pack); f16 rounds the operands like the
+    fp16-operand kernels do."""
+    n, _, h, w = x.shape
+    cout = weight.shape[0]
+    y = torch.empty(n, cout, h, w, dtype=torch.float32, device=x.device)
+    call("vocr_conv3x3_c1_fwd", _p(x), _p(weight), _p(bias), _p(y), n, h, w, cout, int(bool(f16)), _stream())
+    return y
+
+
 def conv3x3_wgrad(x, dy, out=None, f16=False, x16p=None, dy16p=None):
     n, cin, h, w = x.shape
     cout = dy.shape[1]
     lib = _lib.load()
     dw = out if out is not None else torch.empty(cout, cin, 3, 3, dtype=torch.float32, device=x.device)
+    if cin == 1 and cout < 32:
+        # one input channel and few output channels (configs[4]'s rapid_ds stage, 1 -> 16): stream dy once, exact fp32 in either
+        # configuration (116 us against 200 on the MFMA kernel below, whose 64-channel tile is three quarters empty there; with 64
+        # output channels that kernel stays ahead, 52 against 69 us)
+        ws = _ws(lib.vocr_conv3x3_c1_wgrad_workspace_bytes(n, h, cout), x.device)
+        call("vocr_conv3x3_c1_wgrad", _p(x), _p(dy), _p(dw), _p(ws), n, h, w, cout, _stream())
+        return dw
     if f16 and x16p is not None and dy16p is not None:
         # fp16 operands from the channel-major padded copies (conv3x3_wgrad_h16_kernel): all-DMA staging, 9 tap accumulators per wave
         ws = _ws(lib.vocr_conv3x3_wgrad_h16_workspace_bytes(n, cin, h, w, cout), x.device)
@@ -366,7 +383,11 @@ class ConvBnReluFn(torch.autograd.Function):
         lib = _lib.load()
         ctx.f16 = bool(f16)
         x16p = None
-        if ctx.f16:
+        if cin == 1 and not ctx.needs_input_grad[0]:
+            # grey lines' first layer: bound by its output stream, not by arithmetic (no pack; nothing flows back into the image)
+            pf = pd = None
+            y = conv3x3_c1_forward(x, weight, bias, ctx.f16)
+        elif ctx.f16:
             pf, pd = conv3x3_pack_f16(weight)
             x_nhwc = None
             if lib.vocr_conv3x3_h16_supported(cin, cout):
@@ -501,7 +522,10 @@ class ConvReluPoolFn(torch.autograd.Function):
         n, cin, h, w = x.shape
         cout = weight.shape[0]
         ctx.f16 = bool(f16)
-        if ctx.f16:
+        if cin == 1 and not ctx.needs_input_grad[0]:
+            pf = pd = None
+            y = conv3x3_c1_forward(x, weight, bias, ctx.f16)
+        elif ctx.f16:
             pf, pd = conv3x3_pack_f16(weight)
             y = conv3x3_forward_f16(x, pf, bias, cout)
         else:
