@@ -116,5 +116,32 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_experiments(out_dir=None, extra_flags=()):
+    """An A/B library with the experiment switches compiled IN (-DVOCR_EXPERIMENTS: the VOCR_* kernel-variant environment variables of
+    scripts/ are read again), written to scripts/_cut/libvocr.so - never the library the product loads (scripts/_lib_ab.py points a
+    probe at it)."""
+    hipcc = _hipcc()
+    if hipcc is None:
+        raise RuntimeError("hipcc not found")
+    out_dir = out_dir or os.path.join(os.path.dirname(CSRC), "..", "scripts", "_cut")
+    os.makedirs(out_dir, exist_ok=True)
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(out_dir, os.path.splitext(src)[0] + ".o")
+        cmd = [hipcc] + FLAGS + ["-DVOCR_EXPERIMENTS"] + list(extra_flags) + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (src, r.stderr))
+        objs.append(obj)
+    lib = os.path.join(out_dir, "libvocr.so")
+    r = subprocess.run([hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", lib] + objs + ["-ldl"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stderr)
+    return lib
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True), build_report())
+    if "--experiments" in sys.argv:
+        print(build_experiments())
+    else:
+        print(build(force="--force" in sys.argv, verbose=True), build_report())
