@@ -106,6 +106,35 @@ def test_conv3x3_wgrad_row_pairs_long_stream_matches_direct_kernel(dev):
     _close(dw, ref, 1e-4, 2e-4 * math.sqrt(n * h * w), "conv wgrad (row pairs, long stream)")
 
 
+def test_conv3x3_pack_is_validated_and_huge_tensors_take_the_direct_rows(dev):
+    """Advisor, round 4: (1) conv3x3_forward accepted any 21- or 27-row pack whatever format the library assumes for this channel count (an
+    out-of-bounds device read instead of an error); (2) the F(4,3) launches hard-failed for tensors of 2^29 elements or more.  Now the row
+    count is checked against the library's own answer, and a tensor beyond the minimal-filtering kernels' 32-bit offsets runs the direct
+    kernel on the direct-form rows that trail every transformed pack - checked here against the normal path on one image of the batch."""
+    from vistaocr_amd import ops, _lib
+    lib = _lib.load()
+    cin, cout = 16, 128
+    wt = _rand((cout, cin, 3, 3), 2, 0.2).to(dev)
+    bias = _rand((cout,), 3).to(dev)
+    pf, _ = ops.conv3x3_pack(wt)
+    rows = lib.vocr_conv3x3_wino_pack_floats(cout, cin) // (cout * cin)
+    assert pf.shape[0] == rows * cin and rows in (21, 27)
+    other = 21 if rows == 27 else 27
+    xs = _rand((1, cin, 6, 40), 1).to(dev)
+    with pytest.raises(ValueError, match="weight pack"):
+        ops.conv3x3_forward(xs, torch.zeros(other * cin, cout, device=dev), bias, cout)
+    n, h, w = 8, 30, 17500                                   # n * cout * h * w = 5.4e8 >= 2^29
+    assert n * cout * h * w >= (1 << 29)
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand(n, cin, h, w, generator=g) - 0.5).to(dev)
+    y = ops.conv3x3_forward(x, pf, bias, cout)               # direct kernel on the trailing rows
+    y3 = ops.conv3x3_forward(x[3:4].contiguous(), pf, bias, cout)      # minimal-filtering kernel
+    d = float((y[3:4] - y3).abs().max())
+    assert d <= 1e-4 * float(y3.abs().max()), d
+    del x, y, y3
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("n,h,w,cout", [(2, 30, 70, 64), (3, 30, 601, 64), (2, 60, 257, 16), (1, 5, 3, 7), (4, 7, 1024, 32)])
 def test_conv3x3_one_input_channel_kernels(dev, n, h, w, cout):
     """Round 5: the vector-arithmetic kernels of the one-input-channel layers (the first layer of a grey-line model, configs[4]'s rapid_ds

@@ -863,259 +863,6 @@ VOCR_WINO4_KERNEL(conv3x3_wino4x2_kernel_128, 128, 4, 2, 2)
 VOCR_WINO4_KERNEL(conv3x3_wino4x2_kernel_64, 64, 4, 2, 2)
 #undef VOCR_WINO4_KERNEL
 
-// The same contraction with ONE workgroup of EIGHT waves per CU and a ring of THREE half-chunk stages (round 3; VOCR_CONV_WINO8=1).
-// What changes against conv3x3_wino_kernel (two 4-wave workgroups per CU, two stages):
-//   * the weights of a half-chunk are shared by 8 waves instead of 4 (CO_T = 128: two channel halves x FOUR segments; CO_T = 64:
-//     EIGHT segments), so half as many weight bytes are DMA'd per MFMA;
-//   * the weight DMA of half-chunk h+2 is issued at the head of half-chunk h and first waited for at the end of half-chunk h+1: it
-//     has more than a whole k-loop to land (the two-stage kernel waited ~1500 of a half-chunk's ~4800 cycles for it);
-//   * the halo rows of half-chunk h+2 are loaded to registers at the head of half-chunk h (in front of the DMAs, so that waiting
-//     for them leaves the DMAs in flight) and stored to LDS behind its k-loop;
-//   * one BARE barrier per half-chunk (`s_barrier` without the workgroup-scope release of __syncthreads(), which the compiler
-//     implements by draining every outstanding LDS-DMA).  What it orders: every wave's stores of stage h (made two half-chunks ago,
-//     LDS counter drained), every wave's DMAs of stage h (waited for at the end of half-chunk h-1), and that every wave is done
-//     reading stage h-1, whose slot is refilled next;
-//   * two waves per SIMD: a wave at the barrier or waiting for its loads is covered by its partner's MFMAs;
-//   * the 32 bias values of a lane are fetched up front.
-// MEASURED: no faster than the two-stage kernel on the 128- and 256-channel layers (480 vs 477 us on 256 -> 256: the DMA wait and
-// the barriers it removes were already covered by the second workgroup of the CU) and slower on the 64-channel ones (eight
-// segments per workgroup: 397 vs 297 us), so it is NOT the default; kept as the A/B that shows the k-loop itself - 12 LDS reads
-// per 8 MFMAs - is what bounds these kernels.
-template <int CO_T, bool PK4>
-__global__ __launch_bounds__(512) void conv3x3_wino8_kernel(const float* __restrict__ in, const float* __restrict__ wpack,
-                                                            const float* __restrict__ bias, float* __restrict__ out,
-                                                            const float* __restrict__ zero_page, int N, int Cin, int H, int W,
-                                                            int Cout, WGeom geo, int co_tiles, const float* __restrict__ wdirect,
-                                                            int n_tail, int first_tail_tile) {
-    constexpr int WAVES_CO = CO_T / 64;                      // a wave owns 64 output channels (two MFMA row blocks) ...
-    constexpr int NSEG = 8 / WAVES_CO;                       // ... of one segment
-    constexpr int TM = 2;
-    constexpr int WBUF = WR * CO_T;                          // floats per weight stage
-    constexpr int PBUF = NSEG * PSEG;                        // floats per halo stage
-    constexpr int SBUF = WBUF + PBUF;
-    constexpr int NST = 3;
-    constexpr int ROWS_W = NSEG * 12 / 8;                    // halo rows a wave stages per half-chunk (6 or 12)
-    constexpr int LPR = CO_T / 4;                            // lanes per weight row in one DMA
-    constexpr int RPI = 64 / LPR;                            // weight rows per DMA instruction (2 or 4)
-    constexpr int NDMA = WR / RPI;                           // DMA instructions per half-chunk (24 or 12)
-    constexpr int DPW = (NDMA + 7) / 8;                      // ... per wave (3 or 2; CO_T = 64: waves 4-7 pad with one dummy)
-    // ONE LDS object: NST x { Wt[48][CO_T] | P[NSEG][4][3][68] } | 256 floats DMA dummy | 64 floats store dummy
-    __shared__ __attribute__((aligned(16))) float lds[NST * SBUF + 256 + 64];
-    constexpr int DMA_DUMMY = NST * SBUF, ST_DUMMY = NST * SBUF + 256;
-
-    if ((int)blockIdx.x < n_tail) {
-        // the last partial round of workgroup tiles, cut into 32-channel x 32-pixel pieces computed by the DIRECT form straight
-        // from global memory (conv_tail.h; conv.hip explains why): a tile is (CO_T/32) channel blocks x 2*NSEG pixel blocks
-        constexpr int COSUB = CO_T / 32, PPW = COSUB * 2 * NSEG;
-        const int piece = blockIdx.x, vt = first_tail_tile + piece / PPW, sub = piece % PPW;
-        const int pb = sub / COSUB, q0 = ((vt / co_tiles) * NSEG + pb / 2) * TS + (pb & 1) * 16;
-        const int pli = threadIdx.x & 31;
-        const WSlot ps = wslot(q0 + (pli >> 1), geo);
-        const int pcol = 2 * ps.k + (pli & 1);
-        conv3x3_tail_piece_px<8>(lds, ps.n, ps.h, pcol, ps.valid && ps.k < geo.T && pcol < W, q0 < geo.nslot,
-                                 (vt % co_tiles) * CO_T + (sub % COSUB) * 32, in, wdirect, bias, out, zero_page, Cin, H, W, Cout);
-        return;
-    }
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31, lk = lane >> 5;
-    const int v = xcd_slice_order(blockIdx.x - n_tail, gridDim.x - n_tail);
-    const int co0 = (v % co_tiles) * CO_T;
-    const int seg0 = (v / co_tiles) * NSEG;
-    const long HW = (long)H * W;
-
-    const int wco = (wave / NSEG) * 64;
-    const int wsg = wave % NSEG;
-    f32x16 acc[TM][4];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int x = 0; x < 4; ++x)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][x][r] = 0.f;
-
-    // ---- halo loader: this wave stages rows [wave*ROWS_W, (wave+1)*ROWS_W) of the (segment, c, kh) rows of a half-chunk (one
-    // segment per wave or per wave pair); a row is 66 columns w0-1 .. w0+64: lanes 0..63 take the first 64, the last two of all the
-    // wave's rows share one load
-    constexpr int RPS = 12;                                  // rows per segment and half-chunk
-    int r_c[ROWS_W], r_kh[ROWS_W];
-#pragma unroll
-    for (int j = 0; j < ROWS_W; ++j) {
-        const int r = wave * ROWS_W + j;
-        r_c[j] = (r % RPS) / 3; r_kh[j] = r % 3;
-    }
-    const int st_seg = (wave * ROWS_W) / RPS;
-    const WSlot ms = wslot((seg0 + st_seg) * TS + (lane >> 1), geo);
-    const int mcol = 2 * ms.k - 1 + (lane & 1);
-    const float m_ok = (ms.valid && mcol >= 0 && mcol < W) ? 1.f : 0.f;
-    const int m_base = ms.n * Cin * (int)HW + min(max(mcol, 0), W - 1);
-    int m_row[3];
-    float m_rok[3];
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-        const int hh = ms.h + kh - 1;
-        m_row[kh] = min(max(hh, 0), H - 1) * W;
-        m_rok[kh] = (hh >= 0 && hh < H) ? m_ok : 0.f;
-    }
-    const int m_lds = (lane & 1) * POFF + (lane >> 1);                         // even raw index -> E, odd -> O
-    const int hj = min(lane >> 1, ROWS_W - 1);
-    const bool h_lane = lane < 2 * ROWS_W;
-    const WSlot hs = wslot((seg0 + st_seg) * TS + 32, geo);
-    const int hcol = 2 * hs.k - 1 + (lane & 1);
-    const int h_c = ((wave * ROWS_W + hj) % RPS) / 3, h_kh = (wave * ROWS_W + hj) % 3;
-    const int h_hh = hs.h + h_kh - 1;
-    const float h_okc = (hs.valid && h_lane && hcol >= 0 && hcol < W && h_hh >= 0 && h_hh < H) ? 1.f : 0.f;
-    const int h_off = hs.n * Cin * (int)HW + min(max(h_hh, 0), H - 1) * W + min(max(hcol, 0), W - 1);
-    const int h_lds = h_lane ? (st_seg * PSEG + h_c * 3 * PRW + h_kh * PRW + (lane & 1) * POFF + 32) : -1;
-    float rp[ROWS_W + 1];
-    auto load_patch = [&](int ci0) {
-#pragma unroll
-        for (int j = 0; j < ROWS_W; ++j) {
-            const float* cb = in + (long)min(ci0 + r_c[j], Cin - 1) * HW;                          // wave-uniform
-            rp[j] = cb[m_base + m_row[r_kh[j]]];
-        }
-        rp[ROWS_W] = in[(long)min(ci0 + h_c, Cin - 1) * HW + h_off];
-    };
-    auto store_patch = [&](int ci0, int slot) {
-        float* const P = lds + slot * SBUF + WBUF;
-#pragma unroll
-        for (int j = 0; j < ROWS_W; ++j) {
-            const float rm = (ci0 + r_c[j]) < Cin ? 1.f : 0.f;                                       // wave-uniform
-            P[st_seg * PSEG + r_c[j] * 3 * PRW + r_kh[j] * PRW + m_lds] = rp[j] * (m_rok[r_kh[j]] * rm);
-        }
-        float* const hd = h_lane ? P + h_lds : lds + ST_DUMMY + lane;
-        *hd = rp[ROWS_W] * ((ci0 + h_c) < Cin ? h_okc : 0.f);
-    };
-    // ---- weight DMA: instruction q of a half-chunk moves rows [q*RPI, (q+1)*RPI) x CO_T floats = 1 KiB; every wave issues exactly DPW
-    // (the wait counts are constants): an instruction past the stage reads the zero page into a dummy KiB
-    const int Ktot = Cin * 12;
-    const int drow = lane / LPR, dcol = (lane % LPR) * 4;
-    const bool dcol_ok = co0 + dcol < Cout;
-    auto dma_weights = [&](int ci0, int slot) {
-#pragma unroll
-        for (int d = 0; d < DPW; ++d) {
-            const int q = wave + 8 * d;                                               // wave-uniform
-            const bool real = q < NDMA;
-            const float* src;
-            if (PK4) {
-                // pack [(ci*3 + kh)][co][4]: a stage row is CO_T x 4 floats = CO_T / 64 instructions, lane = one output channel
-                constexpr int IPR = CO_T / 64;
-                const int row = q / IPR, co = co0 + (q % IPR) * 64 + lane;
-                const int grow = ci0 * 3 + row;
-                src = (real && grow < Cin * 3 && co < Cout) ? wpack + ((long)grow * Cout + co) * 4 : zero_page;
-            } else {
-                const int gk = ci0 * 12 + q * RPI + drow;
-                src = (real && gk < Ktot && dcol_ok) ? wpack + (long)gk * Cout + co0 + dcol : zero_page;
-            }
-            float* const dst = real ? lds + slot * SBUF + q * 256 : lds + DMA_DUMMY;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        }
-    };
-    // ---- K loop of one half-chunk: 6 steps (channel pair cp: lanes 0-31 take channel cp, lanes 32-63 channel cp + 2; row kh),
-    // each 4 transform points x TM row blocks = 8 MFMAs
-    auto kloop = [&](int slot) {
-        const float* wa = lds + slot * SBUF + wco + li + lk * (2 * 12) * CO_T;
-        const float* wa4 = lds + slot * SBUF + (wco + li) * 4 + lk * (2 * 3) * CO_T * 4;       // PK4: [(c*3 + kh)][co][4]
-        const float* pb = lds + slot * SBUF + WBUF + wsg * PSEG + li + lk * 2 * 3 * PRW;
-        float a[4][TM], e0, e1, o0, o1;
-        auto reads = [&](int s, float (&aa)[4][TM], float& E0, float& E1, float& O0, float& O1) {
-            const int cp = s / 3, kh = s % 3;                                            // compile-time after unrolling
-            const float* pr = pb + (cp * 3 + kh) * PRW;
-            E0 = pr[0]; E1 = pr[1]; O0 = pr[POFF]; O1 = pr[POFF + 1];
-            if (PK4) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const f32x4 q4 = *(const f32x4*)(wa4 + ((cp * 3 + kh) * CO_T + 32 * i) * 4);
-#pragma unroll
-                    for (int x = 0; x < 4; ++x) aa[x][i] = q4[x];
-                }
-            } else {
-#pragma unroll
-                for (int x = 0; x < 4; ++x)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) aa[x][i] = wa[((cp * 3 + kh) * 4 + x) * CO_T + 32 * i];
-            }
-        };
-        reads(0, a, e0, e1, o0, o1);
-#pragma unroll
-        for (int s = 0; s < 6; ++s) {
-            float an[4][TM], ne0 = 0.f, ne1 = 0.f, no0 = 0.f, no1 = 0.f;
-#pragma unroll
-            for (int x = 0; x < 4; ++x)
-#pragma unroll
-                for (int i = 0; i < TM; ++i) an[x][i] = 0.f;
-            if (s + 1 < 6) reads(s + 1, an, ne0, ne1, no0, no1);
-            const float vv[4] = {e0 - e1, o0 + e1, e1 - o0, o0 - o1};
-            __builtin_amdgcn_sched_barrier(0);      // next step's ds_reads are issued BEFORE this step's MFMAs
-#pragma unroll
-            for (int x = 0; x < 4; ++x)
-#pragma unroll
-                for (int i = 0; i < TM; ++i) acc[i][x] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x][i], vv[x], acc[i][x], 0, 0, 0);
-#pragma unroll
-            for (int x = 0; x < 4; ++x)
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a[x][i] = an[x][i];
-            e0 = ne0; e1 = ne1; o0 = no0; o1 = no1;
-        }
-    };
-
-    // the 32 bias values of this lane's output channels, fetched now (read one by one in the epilogue, every load was a round trip to
-    // memory with the wave stalled)
-    float bvals[TM][16];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co0 + wco + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            bvals[i][r] = (bias && co < Cout) ? bias[co] : 0.f;
-        }
-    const int nh = (Cin + CI_H - 1) / CI_H;                 // half-chunks
-    // vmcnt(DPW): everything but this wave's youngest DPW vector-memory operations (= the DMAs just issued) is done
-    constexpr int VM_KEEP_DMA = 0x0F70 | (DPW & 15);
-    // prologue: stages 0 and 1.  Order inside a stage: halo loads first, DMAs behind them.
-    load_patch(0);
-    dma_weights(0, 0);
-    __builtin_amdgcn_s_waitcnt(VM_KEEP_DMA);
-    store_patch(0, 0);
-    load_patch(CI_H);
-    dma_weights(CI_H, 1);
-    __builtin_amdgcn_s_waitcnt(VM_KEEP_DMA);                // the halo rows of stage 1 - and with them the DMAs of stage 0 - have arrived
-    store_patch(CI_H, 1);
-    int slot = 0;
-    for (int h = 0; h < nh; ++h) {
-        __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0): this wave's halo stores are in LDS
-        asm volatile("s_barrier" ::: "memory");             // stage h complete for every wave; every wave is done with stage h-1
-        const int s2 = slot == 0 ? 2 : slot - 1;            // (h + 2) % 3 == (h - 1) % 3
-        load_patch((h + 2) * CI_H);                         // past the last channel: clamped addresses, zero weights, never used
-        dma_weights((h + 2) * CI_H, s2);
-        kloop(slot);
-        __builtin_amdgcn_s_waitcnt(VM_KEEP_DMA);            // halo rows of stage h+2 (and the DMAs of stage h+1, which are older) are in
-        store_patch((h + 2) * CI_H, s2);
-        slot = slot == 2 ? 0 : slot + 1;
-    }
-
-    // ---- output transform and stores: lane li = column pair, y(2t) = m0 + m1 + m2, y(2t+1) = m1 - m2 - m3
-    const WSlot os = wslot((seg0 + wsg) * TS + li, geo);
-    const int px = 2 * os.k;
-    if (!os.valid || os.k >= geo.T || px >= W) return;
-    const bool two = px + 1 < W;
-    float* obase = out + (long)os.n * Cout * HW + (long)os.h * W + px;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co0 + wco + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            if (co < Cout) {
-                const float b = bvals[i][r];
-                const float m0 = acc[i][0][r], m1 = acc[i][1][r], m2 = acc[i][2][r], m3 = acc[i][3][r];
-                float* o = obase + (long)co * HW;
-                o[0] = ((m0 + m1) + m2) + b;
-                if (two) o[1] = ((m1 - m2) - m3) + b;
-            }
-        }
-}
-
 // ---------------------------------------------------------------- weight gradient, F(3,2) along the row
 // dw[co][ci][kh][kw] = sum over pixels of dy[co][h][w] * x[ci][h+kh-1][w+kw-1].  For a column PAIR (2p, 2p+1) the three taps kw
 // are the outputs of a 2-tap filter g = (dy[2p], dy[2p+1]) over d0..d3 = x columns 2p-1 .. 2p+2 - the transposed form of the
@@ -2277,9 +2024,6 @@ extern "C" int vocr_conv3x3_wino_fwd(const float* x, const float* wpack, const f
         const int n_main = cut ? tiles - rem : tiles, n_tail = cut ? rem * (CO_T / 32) * 2 * NSEG : 0;                      \
         KERNEL<<<dim3(n_tail + n_main), THREADS, 0, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, geo, (CO_TILES), wdirect, n_tail, n_main); \
     } while (0)
-    // VOCR_CONV_WINO8=1: one 8-wave workgroup per CU with a three-stage ring (measured no faster, see the kernel); default: the
-    // two-stage 4-wave kernel, two workgroups per CU
-    static const int wino8 = VOCR_EXPERIMENT_INT("VOCR_CONV_WINO8", 0);
     const int wino2 = wino2_mode();
     if (f43) {
         // one 4-wave workgroup per CU; a piece of the tail is 1/(CO_T/32 * 4 NSEG) of a tile
@@ -2296,7 +2040,9 @@ extern "C" int vocr_conv3x3_wino_fwd(const float* x, const float* wpack, const f
         const int rem4 = tiles4 % slots4;
         const bool cut4 = tail_mode == 1 && tiles4 > slots4 && rem4 > 0 && rem4 <= slots4 / 2;
         const int n_main4 = cut4 ? tiles4 - rem4 : tiles4;
-        const int n_tail4 = cut4 ? rem4 * 4 * 4 * nw : 0;                      // (CO_T / 32) x 4 NSEG pieces per tile: 16 nw either way
+        // pieces per tile as conv3x3_wino4_body decodes them: COSUB x 4 x NSEG = 4 x 4 x nw/2 (128 channels) = 2 x 4 x nw (64) = 8 nw
+        // (round 4 launched 16 nw: the second half mapped beyond the tiles and returned at once, each holding 61 - 126 KB of LDS)
+        const int n_tail4 = cut4 ? rem4 * 8 * nw : 0;
         if (cout > 64) {
             if (x2) conv3x3_wino4x2_kernel_128<<<dim3(n_tail4 + n_main4), 256, 0, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, geo, vocr_cdiv(cout, 128), wdirect, n_tail4, n_main4);
             else if (nw == 8) conv3x3_wino4w8_kernel_128<<<dim3(n_tail4 + n_main4), 512, 0, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, geo, vocr_cdiv(cout, 128), wdirect, n_tail4, n_main4);
@@ -2306,12 +2052,6 @@ extern "C" int vocr_conv3x3_wino_fwd(const float* x, const float* wpack, const f
             else if (nw == 8) conv3x3_wino4w8_kernel_64<<<dim3(n_tail4 + n_main4), 512, 0, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, geo, 1, wdirect, n_tail4, n_main4);
             else conv3x3_wino4_kernel_64<<<dim3(n_tail4 + n_main4), 256, 0, s>>>(x, wpack, bias, y, zp, n, cin, h, w, cout, geo, 1, wdirect, n_tail4, n_main4);
         }
-    } else if (wino8 && wino_pack_x4()) {
-        if (cout > 64) VOCR_WINO_LAUNCH((conv3x3_wino8_kernel<128, true>), 512, 128, 4, vocr_cdiv(cout, 128));
-        else VOCR_WINO_LAUNCH((conv3x3_wino8_kernel<64, true>), 512, 64, 8, 1);
-    } else if (wino8) {
-        if (cout > 64) VOCR_WINO_LAUNCH((conv3x3_wino8_kernel<128, false>), 512, 128, 4, vocr_cdiv(cout, 128));
-        else VOCR_WINO_LAUNCH((conv3x3_wino8_kernel<64, false>), 512, 64, 8, 1);
     } else if (wino2 && (long)n * (cin > cout ? cin : cout) * h * w < (1l << 29)) {
         if (cout > 64) VOCR_WINO_LAUNCH(conv3x3_wino2_kernel_128, 256, 128, 2, vocr_cdiv(cout, 128));
         else VOCR_WINO_LAUNCH(conv3x3_wino2_kernel_64, 256, 64, 4, 1);

@@ -311,11 +311,21 @@ def wgrad_f16_layouts_ok(cin, cout):
 def conv3x3_forward(x, wpack, bias, cout):
     n, cin, h, w = x.shape
     y = torch.empty(n, cout, h, w, dtype=torch.float32, device=x.device)
-    # the pack says which kernel it is for: 12 transformed + 9 direct rows per input channel (conv_wino.hip) or 9 taps (conv.hip);
-    # the shape survives save_for_backward, a Python attribute on the tensor would not
-    if wpack.dim() != 2 or wpack.shape[0] not in (9 * cin, 21 * cin, 27 * cin) or wpack.shape[1] != cout:
-        raise ValueError("conv3x3_forward: weight pack %s does not fit cin=%d cout=%d" % (tuple(wpack.shape), cin, cout))
-    fn = "vocr_conv3x3_wino_fwd" if wpack.shape[0] != 9 * cin else "vocr_conv3x3_fwd"
+    # the pack says which kernel it is for: transformed + 9 direct rows per input channel (conv_wino.hip: 21 for the F(2,3) kernel, 27 for
+    # F(4,3) - the library decides by the output channel count, so the row count is checked against ITS answer: a pack built for another
+    # format would be read out of bounds) or the 9 taps alone (conv.hip); the shape survives save_for_backward, an attribute would not
+    lib = _lib.load()
+    rows = wpack.shape[0] if wpack.dim() == 2 else -1
+    wino_rows = lib.vocr_conv3x3_wino_pack_floats(cout, cin) // (cout * cin) * cin if lib.vocr_conv3x3_wino_supported(cin, cout) else -2
+    if wpack.dim() != 2 or wpack.shape[1] != cout or rows not in (9 * cin, wino_rows):
+        raise ValueError("conv3x3_forward: weight pack %s does not fit cin=%d cout=%d (expected %d or %d rows)"
+                         % (tuple(wpack.shape), cin, cout, 9 * cin, wino_rows))
+    if rows != 9 * cin and n * max(cin, cout) * h * w >= (1 << 29):
+        # the minimal-filtering kernels address tensors with 32-bit byte offsets (< 2^29 elements); a larger one takes the direct kernel
+        # on the direct-form rows that trail every transformed pack (the tail pieces' operand)
+        wpack = wpack[rows - 9 * cin:]
+        rows = 9 * cin
+    fn = "vocr_conv3x3_wino_fwd" if rows != 9 * cin else "vocr_conv3x3_fwd"
     call(fn, _p(x), _p(wpack), _p(bias), _p(y), n, cin, h, w, cout, _stream())
     return y
 
