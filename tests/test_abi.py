@@ -86,6 +86,21 @@ def test_argument_validation_without_gpu():
     assert rc == -1 and b"leading dimension" in lib.vocr_last_error()
     assert lib.vocr_conv3x3_wgrad_workspace_bytes(32, 256, 7, 294, 256) > 0
     assert lib.vocr_ctc_workspace_bytes(294, 32, 96, 20) > 0
+    # round 5 entry points: shape answers that need no device, and argument validation in front of any launch
+    assert lib.vocr_f16_padded_row(294) == 304 and lib.vocr_f16_padded_row(600) == 608 and lib.vocr_f16_padded_row(0) == 0
+    assert lib.vocr_conv3x3_h16_supported(256, 256) == 1 and lib.vocr_conv3x3_h16_supported(1, 16) == 0 and lib.vocr_conv3x3_h16_supported(24, 64) == 0
+    assert lib.vocr_conv3x3_wgrad_h16_supported(64, 64) == 1 and lib.vocr_conv3x3_wgrad_h16_supported(16, 64) == 0
+    assert lib.vocr_conv3x3_wgrad_h16_supported(128, 192) == 0                       # Cout must be 64 or a multiple of 128
+    assert lib.vocr_conv3x3_c1_wgrad_workspace_bytes(32, 60, 16) > 0
+    assert lib.vocr_lstm_packed_supported(0, 512) == 0 and lib.vocr_lstm_packed_supported(33, 512) == 0 and lib.vocr_lstm_packed_supported(32, 128) == 0
+    assert lib.vocr_seq_rowmap(None, 4, 4, 16, None, None, None) == -1 and b"vocr_seq_rowmap" in lib.vocr_last_error()
+    assert lib.vocr_seq_rowmap(one, 4, 4, 15, one, None, None) == -1                 # rows must be a multiple of 4
+    assert lib.vocr_gather_rows(one, one, None, 4, 8, None, None) == -1
+    assert lib.vocr_lstm_fwd_packed(one, one, one, one, one, one, one, one, 4, 4, 512, 0, None, None) == -1
+    assert lib.vocr_f32_to_f16_layouts(one, None, None, 1, 16, 4, 4, None) == -1      # at least one output
+    assert lib.vocr_f32_to_f16_layouts(one, one, None, 1, 24, 4, 4, None) == -1       # the channel-blocked copy needs C % 16 == 0
+    assert lib.vocr_conv3x3_h16_fwd(one, one, None, one, 1, 24, 4, 4, 64, None) == -1
+    assert lib.vocr_conv3x3_c1_fwd(None, one, None, one, 1, 4, 4, 16, 0, None) == -1
 
 
 def test_product_never_imports_oracle():

@@ -227,3 +227,12 @@ def test_bench_flop_accounting_of_the_minimal_filtering_kernels():
     assert b.executed_share("vocr_conv3x3_wgrad_wino", args(32, 5, 7, 294, 7)) == pytest.approx(2.0 / 3.0)      # Cin * Cout % 4 != 0: one-row kernel
     assert b.executed_share("vocr_gemm", (0,) * 10) == 1.0
     assert sorted(b.WORKLOADS) == ["c1", "c4", "c5"]
+
+
+def test_packed_row_count_is_the_layouts_formula():
+    """include/vocr.h: rows = 4 * (sum of the chains' longest lengths + chains + 1); a uniform batch of B % 4 == 0 lines packs to more rows
+    than T*B (the zero groups), which is why CnnOcrModel keeps such a batch dense (pack_threshold)."""
+    from vistaocr_amd import ops
+    assert ops.packed_row_count([9, 9, 7, 7, 7, 3, 2, 2, 1], 9) == 4 * (9 + 7 + 1 + 3 + 1)
+    assert ops.packed_row_count([294] * 32, 32) == 4 * (8 * 294 + 9) > 294 * 32
+    assert ops.packed_row_count([12], 1) == 4 * (12 + 2)
