@@ -383,7 +383,7 @@ def test_fit_on_the_hip_path(tmp_path):
         from vistaocr_amd.loop import test_on_val
         torch.manual_seed(7)                                   # FractionalMaxPool draws samples in eval too
         loss, cer, wer = test_on_val(loader, m, crit)
-        seen.append((loss, cer, wer, float(next(m.parameters()).flatten()[0])))
+        seen.append((loss, cer, wer, float(next(m.parameters()).detach().flatten()[0])))
         # a metric that improves once and then plateaus, so that with patience 0 the second non-improving validation
         # lowers the LR (the real CER/WER of an untrained model is ~1.0 throughout)
         fake = [0.9, 0.8, 0.85, 0.86, 0.87, 0.88, 0.89, 0.90, 0.91, 0.92][len(seen) - 1]
