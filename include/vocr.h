@@ -89,11 +89,13 @@ int vocr_conv3x3_wgrad_wino(const float* x, const float* dy, float* dw, void* wo
  * bound by writing its output once, not by 576 FLOP per pixel.  w = the layer's own weight [cout][1][3][3] (no pack), y fp32
  * [n][cout][h][wd] (+ bias); round_f16 != 0 rounds x and w to fp16 first (the fp16-operand configuration's arithmetic; fp32 accumulate
  * either way).  vocr_conv3x3_c1_wgrad: dw[cout][1][3][3] from x [n][1][h][wd] and dy [n][cout][h][wd], exact fp32, split partial sums
- * added in a fixed order (workspace: vocr_conv3x3_c1_wgrad_workspace_bytes). */
+ * added in a fixed order (workspace: vocr_conv3x3_c1_wgrad_workspace_bytes); dbias[cout] (may be NULL) = the per-channel sum of dy, from
+ * the same pass over dy. */
 int vocr_conv3x3_c1_fwd(const float* x, const float* w, const float* bias, float* y, int n, int h, int wd, int cout, int round_f16,
                         void* stream);
 size_t vocr_conv3x3_c1_wgrad_workspace_bytes(int n, int h, int cout);
-int vocr_conv3x3_c1_wgrad(const float* x, const float* dy, float* dw, void* workspace, int n, int h, int wd, int cout, void* stream);
+int vocr_conv3x3_c1_wgrad(const float* x, const float* dy, float* dw, float* dbias, void* workspace, int n, int h, int wd, int cout,
+                          void* stream);
 /* fp16-operand variant (BASELINE config 5: "fp16 conv MFMA", fp32 accumulate): tensors stay fp32 in HBM, operands are
  * rounded to fp16 on the way into the matrix cores (v_mfma_f32_32x32x16_f16).  Weight packs are fp16:
  * fwd  [ceil(cin/16)][9][2][cout][8],  dgrad [ceil(cout/16)][9][2][cin][8] (taps flipped); sizes from *_pack_bytes.

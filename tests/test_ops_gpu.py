@@ -156,10 +156,13 @@ def test_conv3x3_one_input_channel_kernels(dev, n, h, w, cout):
     def c1_wgrad():          # the C entry point directly (ops.conv3x3_wgrad picks it for fewer than 32 output channels only)
         dw_ = torch.empty(cout, 1, 3, 3, device=dev)
         ws = torch.empty(lib.vocr_conv3x3_c1_wgrad_workspace_bytes(n, h, cout) // 4 + 4, device=dev)
-        call("vocr_conv3x3_c1_wgrad", xd.data_ptr(), dyd.data_ptr(), dw_.data_ptr(), ws.data_ptr(), n, h, w, cout, torch.cuda.current_stream().cuda_stream)
+        call("vocr_conv3x3_c1_wgrad", xd.data_ptr(), dyd.data_ptr(), dw_.data_ptr(), db_.data_ptr(), ws.data_ptr(), n, h, w, cout,
+             torch.cuda.current_stream().cuda_stream)
         return dw_
     xd, dyd = x.to(dev), dy.to(dev)
+    db_ = torch.empty(cout, device=dev)
     dw = c1_wgrad()
+    _close(db_, dy.sum(dim=(0, 2, 3)), 1e-4, 2e-4 * math.sqrt(n * h * w), "conv Cin=1 bias gradient from the same pass")
     _close(dw, torch.nn.grad.conv2d_weight(x, wt.shape, dy, padding=1), 1e-4, 2e-4 * math.sqrt(n * h * w), "conv Cin=1 wgrad")
     assert torch.equal(dw, c1_wgrad())
     _close(ops.conv3x3_wgrad(xd, dyd), dw.cpu(), 1e-4, 2e-4 * math.sqrt(n * h * w), "conv Cin=1 wgrad through ops")

@@ -34,7 +34,7 @@ SIGNATURES = {
     "vocr_conv3x3_wgrad_f16": (I, [P, P, P, P, I, I, I, I, I, P]),
     "vocr_conv3x3_c1_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
     "vocr_conv3x3_c1_wgrad_workspace_bytes": (Z, [I, I, I]),
-    "vocr_conv3x3_c1_wgrad": (I, [P, P, P, P, I, I, I, I, P]),
+    "vocr_conv3x3_c1_wgrad": (I, [P, P, P, P, P, I, I, I, I, P]),
     "vocr_conv3x3_h16_supported": (I, [I, I]),
     "vocr_conv3x3_h16_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
     "vocr_f16_padded_row": (I, [I]),

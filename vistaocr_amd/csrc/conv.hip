@@ -1542,20 +1542,21 @@ __global__ __launch_bounds__(256) void conv3x3_c1_fwd_kernel(const float* __rest
 // the image rows); a thread keeps 4 x 9 accumulators over its pixel lane of every row of the split, dy streams through once (one
 // coalesced load per channel and row strip), the nine x neighbours come from the cache; block tree in LDS, then the splits are added
 // in a fixed order by the second kernel (bitwise reproducible).
+// The bias gradient (sum of dy per channel) rides along as a tenth accumulator: part[split][co][10].
 __global__ __launch_bounds__(256) void conv3x3_c1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                float* __restrict__ part, int N, int H, int W, int Cout, int rows_per_split) {
-    __shared__ float red[36][257];
+    __shared__ float red[40][257];
     const int tid = threadIdx.x;
     const int cg = blockIdx.x, split = blockIdx.y;
     const int co0 = cg * 4;
     const int nco = min(4, Cout - co0);
     const long HW = (long)H * W;
     const int r0 = split * rows_per_split, r1 = min(N * H, r0 + rows_per_split);
-    float acc[4][9];
+    float acc[4][10];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int t = 0; t < 9; ++t) acc[c][t] = 0.f;
+        for (int t = 0; t < 10; ++t) acc[c][t] = 0.f;
     // the split's pixels as one flat range of QUADS (4 consecutive pixels of a row; rows hold QW = ceil(W / 4) of them): a thread reads
     // its 3 x 6 input window with three 16-byte loads + the two edge columns, and one 16-byte load of dy per channel
     const int QW = (W + 3) >> 2;
@@ -1596,36 +1597,47 @@ __global__ __launch_bounds__(256) void conv3x3_c1_wgrad_kernel(const float* __re
                     for (int p = 0; p < 4; ++p) g[p] = w0 + p < W ? dyb[c * HW + p] : 0.f;
                 }
 #pragma unroll
-                for (int p = 0; p < 4; ++p)
+                for (int p = 0; p < 4; ++p) {
 #pragma unroll
                     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
                         for (int kw = 0; kw < 3; ++kw) acc[c][kh * 3 + kw] = __builtin_fmaf(g[p], win[kh][p + kw], acc[c][kh * 3 + kw]);
+                    acc[c][9] += g[p];
+                }
             }
         }
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int t = 0; t < 9; ++t) red[c * 9 + t][tid] = acc[c][t];
+        for (int t = 0; t < 10; ++t) red[c * 10 + t][tid] = acc[c][t];
     __syncthreads();
-    // 36 rows of 256 partial sums: wave w reduces rows w, w + 4, ... with a fixed shuffle tree (a shuffle tree per accumulator in every
+    // 40 rows of 256 partial sums: wave w reduces rows w, w + 4, ... with a fixed shuffle tree (a shuffle tree per accumulator in every
     // wave and twice as many, shorter splits measured 100 / 188 us against 69 / 116)
     const int wave = tid >> 6, lane = tid & 63;
-    for (int row = wave; row < 36; row += 4) {
+    for (int row = wave; row < 40; row += 4) {
         float v = (red[row][lane] + red[row][lane + 64]) + (red[row][lane + 128] + red[row][lane + 192]);
         v = wave_sum(v);
-        const int c = row / 9, t = row % 9;
-        if (lane == 0 && c < nco) part[((long)split * Cout + co0 + c) * 9 + t] = v;
+        const int c = row / 10, t = row % 10;
+        if (lane == 0 && c < nco) part[((long)split * Cout + co0 + c) * 10 + t] = v;
     }
 }
 
-__global__ void conv3x3_c1_wgrad_final_kernel(const float* __restrict__ part, float* __restrict__ dw, int n_out, int splits) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per output: lane l adds the splits l, l + 64, ... in order, then a fixed shuffle tree (a thread per output walking all <= 1024
+// splits was 60 us at the very end of the step)
+__global__ __launch_bounds__(256) void conv3x3_c1_wgrad_final_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ dbias,
+                                                                     int cout, int splits) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;       // (co, t): t < 9 taps, t = 9 the bias gradient
+    const int n_out = cout * 10;
     if (i >= n_out) return;
     float v = 0.f;
-    for (int s = 0; s < splits; ++s) v += part[(long)s * n_out + i];
-    dw[i] = v;
+    for (int s = lane; s < splits; s += 64) v += part[(long)s * n_out + i];
+    v = wave_sum(v);
+    if (lane == 0) {
+        const int co = i / 10, t = i % 10;
+        if (t < 9) dw[co * 9 + t] = v;
+        else if (dbias) dbias[co] = v;
+    }
 }
 
 inline int c1_wgrad_splits(int n, int h, int cout) {
@@ -1648,17 +1660,18 @@ extern "C" int vocr_conv3x3_c1_fwd(const float* x, const float* w, const float* 
 
 extern "C" size_t vocr_conv3x3_c1_wgrad_workspace_bytes(int n, int h, int cout) {
     if (n <= 0 || h <= 0 || cout <= 0) return 0;
-    return (size_t)c1_wgrad_splits(n, h, cout) * cout * 9 * sizeof(float);
+    return (size_t)c1_wgrad_splits(n, h, cout) * cout * 10 * sizeof(float);
 }
 
-extern "C" int vocr_conv3x3_c1_wgrad(const float* x, const float* dy, float* dw, void* workspace, int n, int h, int wd, int cout, void* stream) {
+extern "C" int vocr_conv3x3_c1_wgrad(const float* x, const float* dy, float* dw, float* dbias, void* workspace, int n, int h, int wd, int cout,
+                                     void* stream) {
     VOCR_CHECK_ARG(x && dy && dw && workspace && n > 0 && h > 0 && wd > 0 && cout > 0, "vocr_conv3x3_c1_wgrad: bad argument");
     const int splits = c1_wgrad_splits(n, h, cout);
     const int rps = vocr_cdiv((long)n * h, splits);
     hipStream_t s = (hipStream_t)stream;
     conv3x3_c1_wgrad_kernel<<<dim3(vocr_cdiv(cout, 4), splits), 256, 0, s>>>(x, dy, (float*)workspace, n, h, wd, cout, rps);
     VOCR_CHECK_LAUNCH("vocr_conv3x3_c1_wgrad");
-    conv3x3_c1_wgrad_final_kernel<<<vocr_cdiv(cout * 9, 64), 64, 0, s>>>((const float*)workspace, dw, cout * 9, splits);
+    conv3x3_c1_wgrad_final_kernel<<<vocr_cdiv(cout * 10, 4), 256, 0, s>>>((const float*)workspace, dw, dbias, cout, splits);
     VOCR_CHECK_LAUNCH("vocr_conv3x3_c1_wgrad(final)");
     return VOCR_OK;
 }

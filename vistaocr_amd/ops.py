@@ -340,17 +340,24 @@ def conv3x3_c1_forward(x, weight, bias, f16=False):
     return y
 
 
-def conv3x3_wgrad(x, dy, out=None, f16=False, x16p=None, dy16p=None):
+def conv3x3_c1_wgrad_takes(cin, cout):
+    """One input channel and few output channels: the vector-arithmetic weight-gradient kernel (which can deliver the bias gradient too)."""
+    return cin == 1 and cout < 32
+
+
+def conv3x3_wgrad(x, dy, out=None, f16=False, x16p=None, dy16p=None, dbias_out=None):
+    """dbias_out: where the layer's bias gradient (per-channel sum of dy) goes if the kernel that runs can produce it in the same pass
+    over dy (ask conv3x3_c1_wgrad_takes); ignored by the other kernels."""
     n, cin, h, w = x.shape
     cout = dy.shape[1]
     lib = _lib.load()
     dw = out if out is not None else torch.empty(cout, cin, 3, 3, dtype=torch.float32, device=x.device)
-    if cin == 1 and cout < 32:
+    if conv3x3_c1_wgrad_takes(cin, cout):
         # one input channel and few output channels (configs[4]'s rapid_ds stage, 1 -> 16): stream dy once, exact fp32 in either
         # configuration (116 us against 200 on the MFMA kernel below, whose 64-channel tile is three quarters empty there; with 64
         # output channels that kernel stays ahead, 52 against 69 us)
         ws = _ws(lib.vocr_conv3x3_c1_wgrad_workspace_bytes(n, h, cout), x.device)
-        call("vocr_conv3x3_c1_wgrad", _p(x), _p(dy), _p(dw), _p(ws), n, h, w, cout, _stream())
+        call("vocr_conv3x3_c1_wgrad", _p(x), _p(dy), _p(dw), _p(dbias_out), _p(ws), n, h, w, cout, _stream())
         return dw
     if f16 and x16p is not None and dy16p is not None:
         # fp16 operands from the channel-major padded copies (conv3x3_wgrad_h16_kernel): all-DMA staging, 9 tap accumulators per wave
@@ -563,8 +570,13 @@ class ConvReluPoolFn(torch.autograd.Function):
         dy = torch.zeros(n, cout, h, w, dtype=torch.float32, device=x.device)
         call("vocr_relu_maxpool2_bwd", _p(dout), _p(out), _p(idx), _p(dy), n, cout, h, w, _stream())
         sinks = _sinks(ctx.prefs)
-        dbias = channel_sum(dy, out=sinks[1] if sinks else None)
-        dw = conv3x3_wgrad(x, dy, out=sinks[0] if sinks else None, f16=ctx.f16)
+        if conv3x3_c1_wgrad_takes(cin, cout):
+            # one pass over dy for both parameter gradients
+            dbias = sinks[1] if sinks else torch.empty(cout, dtype=torch.float32, device=x.device)
+            dw = conv3x3_wgrad(x, dy, out=sinks[0] if sinks else None, f16=ctx.f16, dbias_out=dbias)
+        else:
+            dbias = channel_sum(dy, out=sinks[1] if sinks else None)
+            dw = conv3x3_wgrad(x, dy, out=sinks[0] if sinks else None, f16=ctx.f16)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = conv3x3_forward_f16(dy, pd, None, cin) if ctx.f16 else conv3x3_forward(dy, pd, None, cin)
