@@ -492,8 +492,6 @@ class ConvBnReluFn(torch.autograd.Function):
             dbeta = torch.empty_like(beta)
             dbias = torch.empty(cout, dtype=torch.float32, device=x.device)
         ws = _ws(lib.vocr_bn_workspace_bytes(n, cout, h * w), x.device)
-        if not ctx.needs_input_grad[0]:
-            join_side_stream()          # first layer = last backward op: everything issued on the side stream is done after this
         if fused_pool_bwd:
             # pooled layer: pooling gradient (gather form) + ReLU + BatchNorm backward in one pass over the plane; the two
             # BatchNorm sums come from the pooled tensors alone
@@ -524,6 +522,12 @@ class ConvBnReluFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = conv3x3_forward_f16(dy, pd, None, cin, dy_nhwc) if ctx.f16 else conv3x3_forward(dy, pd, None, cin)
+        else:
+            # first layer = last backward op: whoever reads the gradients on this stream next finds the side stream's weight gradients
+            # done.  BEHIND this layer's own kernels: in front of them (round 4) the main stream sat idle for the tail of the second
+            # layer's weight gradient before it started this layer's BatchNorm backward and weight gradient (same-box A/B 15.43 / 15.42
+            # against 15.38 / 15.40 ms)
+            join_side_stream()
         if sinks is not None:
             return (dx,) + (None,) * 15
         return (dx, dw, dbias, dgamma, dbeta) + (None,) * 11
@@ -565,8 +569,6 @@ class ConvReluPoolFn(torch.autograd.Function):
         n, cin, _, _ = x.shape
         cout = out.shape[1]
         h, w = ctx.hw
-        if not ctx.needs_input_grad[0]:
-            join_side_stream()
         dy = torch.zeros(n, cout, h, w, dtype=torch.float32, device=x.device)
         call("vocr_relu_maxpool2_bwd", _p(dout), _p(out), _p(idx), _p(dy), n, cout, h, w, _stream())
         sinks = _sinks(ctx.prefs)
@@ -580,6 +582,8 @@ class ConvReluPoolFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = conv3x3_forward_f16(dy, pd, None, cin) if ctx.f16 else conv3x3_forward(dy, pd, None, cin)
+        else:
+            join_side_stream()          # last backward op of the model: behind its own kernels (see ConvBnReluFn.backward)
         if sinks is not None:
             return dx, None, None, None
         return dx, dw, dbias, None
