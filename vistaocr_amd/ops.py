@@ -186,19 +186,19 @@ class ForwardPrep(object):
         self.packs = {}          # weight.data_ptr() -> (pack_fwd, pack_dgrad)
         self.lstm = {}           # w_hh_f.data_ptr() -> (bsum, wt_f, wt_r)
         self.event = None        # everything done (the LSTM items come last: they are needed ~4 ms into the step)
-        self.packs_event = None  # the conv packs alone (needed by the second conv layer ~0.2 ms into the step)
+        self.pack_events = {}    # weight.data_ptr() -> event behind THAT layer's pack (the second conv layer needs its pack ~0.15 ms into
+                                 # the step; one event behind all ~25 pack launches made it wait ~50 us for the deeper layers' packs)
         self._waited = False
-        self._waited_packs = False
 
     def wait(self):
         if not self._waited and self.event is not None:
             torch.cuda.current_stream().wait_event(self.event)
-            self._waited = self._waited_packs = True
+            self._waited = True
 
-    def wait_packs(self):
-        if not self._waited_packs and self.packs_event is not None:
-            torch.cuda.current_stream().wait_event(self.packs_event)
-            self._waited_packs = True
+    def wait_pack(self, key):
+        ev = self.pack_events.get(key)
+        if ev is not None and not self._waited:
+            torch.cuda.current_stream().wait_event(ev)
 
 
 def forward_prep(conv_weights, lstm_layers, with_transposes):
@@ -215,8 +215,9 @@ def forward_prep(conv_weights, lstm_layers, with_transposes):
             pk = conv3x3_pack(w)
             prep.packs[w.data_ptr()] = pk
             made.extend(pk)
-        prep.packs_event = torch.cuda.Event()
-        prep.packs_event.record(side)
+            ev = torch.cuda.Event()
+            ev.record(side)
+            prep.pack_events[w.data_ptr()] = ev
         for (w_hh_f, b_ih_f, b_hh_f, w_hh_r, b_ih_r, b_hh_r) in lstm_layers:
             H4 = b_ih_f.numel()
             bsum = torch.empty(2, H4, dtype=torch.float32, device=b_ih_f.device)
@@ -413,7 +414,7 @@ class ConvBnReluFn(torch.autograd.Function):
             y = conv3x3_forward_f16(x, pf, bias, cout, x_nhwc)
         else:
             if prep is not None and weight.data_ptr() in prep.packs:
-                prep.wait_packs()
+                prep.wait_pack(weight.data_ptr())
                 pf, pd = prep.packs[weight.data_ptr()]
             else:
                 pf, pd = conv3x3_pack(weight)
