@@ -221,14 +221,15 @@ class CnnOcrModel(nn.Module):
             raise RuntimeError("vistaocr_amd.CnnOcrModel.forward needs the model on an MI355X (model.cuda()); "
                                "there is no CPU fallback")
         x = x.to(dev, non_blocking=True)
-        # weight-only preparation (conv packs of layers 2.., LSTM bias sums and W_hh transposes) on the idle side stream
-        # (the fp16-operand configuration packs its conv weights inside the layer ops; its LSTM transposes and bias sums are prepared here
-        # all the same - on the main stream they cost 1.1 ms of the round-5 configs[4] step, starved beside the weight-gradient GEMMs)
-        convs = [st[0].weight for st in self._plan if st != "pool"][1:] if self.conv_dtype == "fp32" else []
+        # weight-only preparation (conv weight packs - fp32 or fp16 form -, LSTM bias sums and W_hh transposes) on the idle side stream;
+        # every layer waits for its own pack's event only
+        f16 = self.conv_dtype == "fp16"
+        convs = [st[0].weight for st in self._plan if st != "pool"]
+        convs = [w_ for w_ in convs if w_.shape[1] > 1]             # a one-input-channel layer runs straight on its weight
         layers = [(self.lstm.layer(l, "")[1], self.lstm.layer(l, "")[2], self.lstm.layer(l, "")[3],
                    self.lstm.layer(l, "_reverse")[1], self.lstm.layer(l, "_reverse")[2], self.lstm.layer(l, "_reverse")[3])
                   for l in range(self.num_lstm_layers)]
-        prep = ops.forward_prep(convs, layers, torch.is_grad_enabled())
+        prep = ops.forward_prep(convs, layers, torch.is_grad_enabled(), f16)
         a = x
         for i in range(self.num_rds_layers):
             conv = getattr(self.rapid_ds, "%02d-conv" % i)

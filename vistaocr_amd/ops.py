@@ -201,8 +201,9 @@ class ForwardPrep(object):
             torch.cuda.current_stream().wait_event(ev)
 
 
-def forward_prep(conv_weights, lstm_layers, with_transposes):
-    """conv_weights: 4-D fp32 weights to pack; lstm_layers: [(w_hh_f, b_ih_f, b_hh_f, w_hh_r, b_ih_r, b_hh_r), ...]."""
+def forward_prep(conv_weights, lstm_layers, with_transposes, f16=False):
+    """conv_weights: 4-D fp32 weights to pack (f16: into the fp16-operand kernels' packs); lstm_layers: [(w_hh_f, b_ih_f, b_hh_f, w_hh_r,
+    b_ih_r, b_hh_r), ...]."""
     if not _SIDE_ENABLED or _exp("VOCR_FWD_PREP", "1") != "1":
         return None
     prep = ForwardPrep()
@@ -212,7 +213,7 @@ def forward_prep(conv_weights, lstm_layers, with_transposes):
     made = []
     with torch.cuda.stream(side):
         for w in conv_weights:
-            pk = conv3x3_pack(w)
+            pk = conv3x3_pack_f16(w) if f16 else conv3x3_pack(w)
             prep.packs[w.data_ptr()] = pk
             made.extend(pk)
             ev = torch.cuda.Event()
@@ -406,7 +407,11 @@ class ConvBnReluFn(torch.autograd.Function):
             pf = pd = None
             y = conv3x3_c1_forward(x, weight, bias, ctx.f16)
         elif ctx.f16:
-            pf, pd = conv3x3_pack_f16(weight)
+            if prep is not None and weight.data_ptr() in prep.packs:
+                prep.wait_pack(weight.data_ptr())
+                pf, pd = prep.packs[weight.data_ptr()]
+            else:
+                pf, pd = conv3x3_pack_f16(weight)
             x_nhwc = None
             if lib.vocr_conv3x3_h16_supported(cin, cout):
                 # one pass over x: the forward operand and (training) the weight gradient's channel-major copy, kept for the backward
