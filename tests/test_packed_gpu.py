@@ -182,3 +182,33 @@ def test_model_packed_matches_dense_on_a_ragged_batch(dev, drop):
     for k in gd:
         rel = float((gd[k] - gp[k]).norm() / (gd[k].norm() + 1e-30))
         assert rel <= (2e-3 if k.startswith(("cnn.", "rapid_ds")) else 2e-4), (k, rel)
+
+
+def test_packed_sweep_refuses_a_row_count_that_does_not_fit_the_lengths(dev):
+    """The packed sweeps derive every row address from the device-side lengths; `rows` is the caller's allocation.  A count too small for the
+    lengths must not write out of bounds: the sweep raises the health word and touches nothing."""
+    from vistaocr_amd import _lib, ops
+    from vistaocr_amd._lib import call
+    lib = _lib.load()
+    T, B, H = 20, 8, 512
+    lens = [20, 18, 18, 17, 9, 9, 4, 2]
+    rows = ops.packed_row_count(lens, B)
+    lens_dev = torch.tensor(lens, dtype=torch.int32, device=dev)
+    short = rows - 16
+    xp = torch.zeros(2, rows, 4 * H, device=dev)
+    wf = torch.zeros(4 * H, H, device=dev)
+    y = torch.full((rows, 2 * H), 7.0, device=dev)
+    gt = torch.empty(2, rows, 4 * H, device=dev)
+    c = torch.empty(2, rows, H, device=dev)
+    ws = torch.zeros(lib.vocr_lstm_workspace_bytes(T, B, H) // 4 + 16, device=dev)
+    hw = torch.zeros(4, dtype=torch.int32, device=dev)
+    call("vocr_lstm_fwd_packed", xp.data_ptr(), wf.data_ptr(), wf.data_ptr(), lens_dev.data_ptr(), y.data_ptr(), gt.data_ptr(), c.data_ptr(),
+         ws.data_ptr(), T, B, H, short, hw.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert int(hw[0]) == 1                                     # reported ...
+    assert float((y[short:] - 7.0).abs().max()) == 0.0         # ... and nothing behind the claimed end was written
+    hw.zero_()
+    call("vocr_lstm_fwd_packed", xp.data_ptr(), wf.data_ptr(), wf.data_ptr(), lens_dev.data_ptr(), y.data_ptr(), gt.data_ptr(), c.data_ptr(),
+         ws.data_ptr(), T, B, H, rows, hw.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert int(hw[0]) == 0

@@ -586,6 +586,12 @@ __device__ __forceinline__ SeqRows seq_rows(const int32_t* __restrict__ lens, in
     return r;
 }
 
+// packed rows only: the chain's last group and the zero group behind it lie inside the plane the caller allocated (its `rows` must be
+// packed_row_count(lens): a mismatch would write out of bounds)
+__device__ __forceinline__ bool seq_rows_fit(const SeqRows& r, int packed_rows) {
+    return packed_rows == 0 || (long)r.base + 4l * r.steps + 4 <= r.total;
+}
+
 template <int N, int I = 0, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) {
@@ -663,6 +669,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_chain4v(const float* __restrict_
     const SeqRows sr = seq_rows(lens, T, B, bt, packed_rows);
     const int Tc = sr.steps;
     s1 = min(s1, Tc);
+    if (!seq_rows_fit(sr, packed_rows)) {             // the caller's row count does not belong to these lengths: fail loudly, touch nothing
+        if (tid == 0) raise_timeout(status, health);
+        return;
+    }
     // the cell thread's own element of step t: plane-local row = sr.base + sr.stride*t + bl
     const long crow0 = (long)dir * sr.total + sr.base + bl;
     float cstate = 0.f;
@@ -861,6 +871,10 @@ __global__ __launch_bounds__(512) void lstm_fwd_chain4w(const float* __restrict_
     const SeqRows sr = seq_rows(lens, T, B, bt, packed_rows);
     const int Tc = sr.steps;
     s1 = min(s1, Tc);
+    if (!seq_rows_fit(sr, packed_rows)) {             // the caller's row count does not belong to these lengths: fail loudly, touch nothing
+        if (tid == 0) raise_timeout(status, health);
+        return;
+    }
     // the cell thread's own element of step t: plane-local row = sr.base + sr.stride*t + crow
     const long crow0 = (long)dir * sr.total + sr.base + crow;
     float cstate = 0.f;
@@ -1317,6 +1331,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_chain4v(const float* __restrict_
     const int len = lens[ebs];
     const SeqRows sr = seq_rows(lens, T, B, bt, packed_rows);
     const int Tc = sr.steps;
+    if (!seq_rows_fit(sr, packed_rows)) {             // the caller's row count does not belong to these lengths: fail loudly, touch nothing
+        if (tid == 0) raise_timeout(status, health);
+        return;
+    }
     const long prow0 = (long)dir * sr.total + sr.base + (ebs - b0);       // plane-local row of the lane's cell at t = 0
     const long yrow0 = sr.base + (ebs - b0);
     float dcar = 0.f;
@@ -1534,6 +1552,10 @@ __global__ __launch_bounds__(512) void lstm_bwd_chain4w(const float* __restrict_
     const int len = lens[cellw ? ebs : b0];
     const SeqRows sr = seq_rows(lens, T, B, bt, packed_rows);
     const int Tc = sr.steps;
+    if (!seq_rows_fit(sr, packed_rows)) {             // the caller's row count does not belong to these lengths: fail loudly, touch nothing
+        if (tid == 0) raise_timeout(status, health);
+        return;
+    }
     const long prow0 = (long)dir * sr.total + sr.base + (cellw ? ebs - b0 : 0);      // plane-local row of the thread's cell at t = 0
     const long yrow0 = sr.base + (cellw ? ebs - b0 : 0);
     float dcar = 0.f;
