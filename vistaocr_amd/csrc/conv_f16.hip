@@ -234,7 +234,8 @@ extern "C" int vocr_conv3x3_f16_fwd(const float* x, const void* wpack, const flo
 //   WCO = 2: 128 channels x 8 segments per workgroup, WCO = 1 (64-channel layers): 64 x 16.
 //   LDS stage (one 16-channel chunk = one MFMA k-step per tap), two stages:
 //     weights [tap][half][co][8 halfs]           (the existing fp16 pack: A fragment = one conflict-free ds_read_b128)
-//     input   [seg][kh][half][36 pixels][8]      (B fragment of tap (kh, kw) = piece li + kw: 16 consecutive lanes = 256 contiguous bytes)
+//     input   [patch row][half][36 pixels][8]    (B fragment of segment j, tap (kh, kw) = row j + kh, piece li + kw: 16 consecutive
+//                                                 lanes = 256 contiguous bytes; the segments of a workgroup are a strip of rows and share halo rows)
 //   Source layout: with plain [N][H][W][C] a DMA instruction's 64 pieces touched 64 different 128-byte lines and used 16 bytes of each
 //   (fill-bound at 600 TFLOP/s on 256 -> 256, 236 on 64 -> 64); channel-blocked, a patch row of a chunk is one contiguous run: 645 / 341.
 //   one barrier per chunk (72 MFMAs of 32 cycles per wave between barriers); the DMAs of chunk c + 1 fly under the MFMAs of chunk c.
@@ -257,7 +258,7 @@ __device__ __forceinline__ void conv3x3_h16_body(const _Float16* __restrict__ x1
     constexpr int NSEG = SPW * WSG;
     constexpr int WP = 9 * 2 * CO_T;                  // 16-byte pieces of a stage's weights
     constexpr int PP = 36;                            // pieces per patch row: 34 pixels + 2 never-read ones
-    constexpr int IP = NSEG * 3 * 2 * PP;             // ... and of its input patches
+    constexpr int IP = (NSEG + 2) * 2 * PP;           // ... and of its input patch: the NSEG rows of the strip + one above and below
     constexpr int IPA = (IP + 63) / 64 * 64;          // ... rounded up to whole waves of pieces (a DMA instruction writes 64)
     constexpr int SP = WP + IPA;
     constexpr int NQ = (WP + 511) / 512, NJ = (IPA + 511) / 512;
@@ -265,25 +266,18 @@ __device__ __forceinline__ void conv3x3_h16_body(const _Float16* __restrict__ x1
     static_assert(WP % 64 == 0, "whole waves of DMA pieces");
     static_assert(2 * SP * 16 <= 160 * 1024, "two stages in LDS");
     __shared__ __attribute__((aligned(16))) _Float16 lds[2 * SP * 8];
-    __shared__ SegInfo16 segs[NSEG];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lk = lane >> 5;
     const int co0 = blockIdx.y * CO_T;
-    const int seg0 = blockIdx.x * NSEG;
     const long HW = (long)H * W;
-    if (tid < NSEG) {
-        const int g = seg0 + tid;
-        SegInfo16 s;
-        s.valid = g < nseg_total;
-        const int gg = s.valid ? g : 0;
-        const int n = gg / (H * SW), rem = gg % (H * SW);
-        s.h = rem / SW;
-        s.w0 = (rem % SW) * SEGW;
-        s.base = n;                                   // image index (the NHWC offset is formed below, the NCHW one in the epilogue)
-        segs[tid] = s;
-    }
-    __syncthreads();
+    // The workgroup's NSEG segments are a STRIP: rows h0 .. h0 + NSEG - 1 of one image at one 32-pixel column block, so that they share
+    // their halo rows - the patch is NSEG + 2 rows instead of 3 NSEG (raster-order segments fetched every input row three times: 27.6 of
+    // the 64.6 KB a 128 x 8 workgroup fills per 16-channel chunk, and the fill is what bounds the kernel)
+    const int HB = (H + NSEG - 1) / NSEG;             // strips per column block (nseg_total = N * HB * SW tiles)
+    const int tile = blockIdx.x;
+    const int img = tile / (HB * SW), trem = tile % (HB * SW);
+    const int h0 = (trem / SW) * NSEG, w0 = (trem % SW) * SEGW;
 
     // ---- DMA source offsets, once per launch.  Piece P = tid + 512 j of a stage lands at LDS byte 16 P (the DMA writes a wave's 64
     // pieces contiguously); a chunk advances every source by a scalar offset
@@ -299,13 +293,11 @@ __device__ __forceinline__ void conv3x3_h16_body(const _Float16* __restrict__ x1
         const int p = tid + 512 * j;
         unsigned o = OOB;
         if (p < IP) {
-            const int sg = p / (6 * PP), r = p % (6 * PP);
-            const int kh = r / (2 * PP), r2 = r % (2 * PP);
+            const int prow = p / (2 * PP), r2 = p % (2 * PP);
             const int half = r2 / PP, px = r2 % PP;
-            const SegInfo16 s = segs[sg];
-            const int hh = s.h + kh - 1, ww = s.w0 - 1 + px;
-            if (s.valid && px < PROW && hh >= 0 && hh < H && ww >= 0 && ww < W)
-                o = (unsigned)(((((long)s.base * (Cin / CI_C)) * H + hh) * W + ww) * 32 + half * 16);     // [N][C/16][H][W][16]: chunk 0
+            const int hh = h0 - 1 + prow, ww = w0 - 1 + px;
+            if (px < PROW && hh >= 0 && hh < H && ww >= 0 && ww < W)
+                o = (unsigned)(((((long)img * (Cin / CI_C)) * H + hh) * W + ww) * 32 + half * 16);        // [N][C/16][H][W][16]: chunk 0
         }
         xo[j] = o;
     }
@@ -357,7 +349,7 @@ __device__ __forceinline__ void conv3x3_h16_body(const _Float16* __restrict__ x1
 #pragma unroll
             for (int i = 0; i < 2; ++i) fa[set][i] = *(const half8*)(wl + ((tap * 2 + lk) * CO_T + wco + 32 * i + li) * 8);
 #pragma unroll
-            for (int j = 0; j < SPW; ++j) fb[set][j] = *(const half8*)(il + ((((wsg + j) * 3 + kh) * 2 + lk) * PP + li + kw) * 8);
+            for (int j = 0; j < SPW; ++j) fb[set][j] = *(const half8*)(il + (((wsg + j + kh) * 2 + lk) * PP + li + kw) * 8);
         };
         load_frags(0, 0);
 #pragma unroll
@@ -380,10 +372,9 @@ __device__ __forceinline__ void conv3x3_h16_body(const _Float16* __restrict__ x1
     }
 #pragma unroll
     for (int j = 0; j < SPW; ++j) {
-        const SegInfo16 s = segs[wsg + j];
-        const int wx = s.w0 + li;
-        if (!s.valid || wx >= W) continue;
-        const long obase = (long)s.base * Cout * HW + (long)s.h * W + wx;
+        const int hrow = h0 + wsg + j, wx = w0 + li;
+        if (hrow >= H || wx >= W) continue;
+        const long obase = (long)img * Cout * HW + (long)hrow * W + wx;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -417,13 +408,14 @@ extern "C" int vocr_conv3x3_h16_fwd(const void* x16, const void* wpack, const fl
     const long xb = (long)n * h * w * cin * 2, wb = 9l * cin * cout * 2;
     VOCR_CHECK_ARG(xb < (1l << 31) && wb < (1l << 31), "vocr_conv3x3_h16_fwd: tensor too large for 32-bit buffer offsets");
     const int SW = vocr_cdiv(w, SEGW);
-    const long nseg = (long)n * h * SW;
-    VOCR_CHECK_ARG(nseg < (1l << 30), "vocr_conv3x3_h16_fwd: too many segments");
+    // tiles of NSEG rows x 32 pixels: n * ceil(h / NSEG) * SW of them
+    auto tiles_of = [&](int nseg_rows) { return (long)n * vocr_cdiv(h, nseg_rows) * SW; };
+    VOCR_CHECK_ARG(tiles_of(8) < (1l << 30), "vocr_conv3x3_h16_fwd: too many tiles");
     hipStream_t s = (hipStream_t)stream;
     const _Float16* xp = (const _Float16*)x16;
     const _Float16* wp = (const _Float16*)wpack;
     if (cout > 64) {
-        // 8 or 12 segments per workgroup: whichever needs less time in whole rounds of one workgroup per CU
+        // strips of 8 or 12 rows per workgroup: whichever needs less time in whole rounds of one workgroup per CU
         int ncu = 256;
         {
             int dev = 0;
@@ -431,11 +423,13 @@ extern "C" int vocr_conv3x3_h16_fwd(const void* x16, const void* wpack, const fl
             if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
         }
         const int ct = vocr_cdiv(cout, 128);
-        const long r2 = (long)vocr_cdiv((long)vocr_cdiv(nseg, 8) * ct, ncu) * 2, r3 = (long)vocr_cdiv((long)vocr_cdiv(nseg, 12) * ct, ncu) * 3;
-        if (r3 < r2) conv3x3_h16_kernel_128x3<<<dim3(vocr_cdiv(nseg, 12), ct), 512, 0, s>>>(xp, wp, bias, y, n, cin, h, w, cout, SW, (int)nseg, (unsigned)xb, (unsigned)wb);
-        else conv3x3_h16_kernel_128x2<<<dim3(vocr_cdiv(nseg, 8), ct), 512, 0, s>>>(xp, wp, bias, y, n, cin, h, w, cout, SW, (int)nseg, (unsigned)xb, (unsigned)wb);
+        const long t2 = tiles_of(8), t3 = tiles_of(12);
+        const long r2 = (long)vocr_cdiv(t2 * ct, ncu) * 2, r3 = (long)vocr_cdiv(t3 * ct, ncu) * 3;
+        if (r3 < r2) conv3x3_h16_kernel_128x3<<<dim3((unsigned)t3, ct), 512, 0, s>>>(xp, wp, bias, y, n, cin, h, w, cout, SW, (int)t3, (unsigned)xb, (unsigned)wb);
+        else conv3x3_h16_kernel_128x2<<<dim3((unsigned)t2, ct), 512, 0, s>>>(xp, wp, bias, y, n, cin, h, w, cout, SW, (int)t2, (unsigned)xb, (unsigned)wb);
     } else {
-        conv3x3_h16_kernel_64x2<<<dim3(vocr_cdiv(nseg, 16), 1), 512, 0, s>>>(xp, wp, bias, y, n, cin, h, w, cout, SW, (int)nseg, (unsigned)xb, (unsigned)wb);
+        const long t = tiles_of(16);
+        conv3x3_h16_kernel_64x2<<<dim3((unsigned)t, 1), 512, 0, s>>>(xp, wp, bias, y, n, cin, h, w, cout, SW, (int)t, (unsigned)xb, (unsigned)wb);
     }
     VOCR_CHECK_LAUNCH("vocr_conv3x3_h16_fwd");
     return VOCR_OK;
