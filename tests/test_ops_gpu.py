@@ -179,7 +179,10 @@ def test_conv3x3_one_input_channel_kernels(dev, n, h, w, cout):
 
 @pytest.mark.parametrize("n,cin,h,w,cout", [(2, 1, 30, 70, 64), (2, 64, 15, 45, 128), (1, 128, 7, 33, 256), (1, 16, 9, 40, 64), (1, 24, 12, 31, 16),
                                             # the NHWC-fp16 kernel (Cin % 16 == 0) at sizes with several workgroups, partial segments and both channel tilings
-                                            (3, 64, 30, 131, 64), (2, 256, 7, 294, 256), (4, 128, 15, 97, 128), (2, 16, 30, 100, 64), (1, 48, 5, 33, 80)])
+                                            (3, 64, 30, 131, 64), (2, 256, 7, 294, 256), (4, 128, 15, 97, 128), (2, 16, 30, 100, 64), (1, 48, 5, 33, 80),
+                                            # tile shapes of the forward kernel that only larger launches pick on a 256-CU chip: 16 rows x 32 pixels
+                                            # (tiles(8 rows) x 2 channel tiles = 320 > 256 >= 160 = tiles(16 rows) x 2) and 12 rows (384 > 256 >= 256)
+                                            (10, 32, 16, 256, 256), (8, 16, 24, 256, 256)])
 def test_conv3x3_f16_operands(dev, n, cin, h, w, cout):
     """fp16-operand MFMA conv (config 5): products of fp16-rounded operands, fp32 accumulation — compared with the same
     rounding done on the CPU, so the only difference left is the summation order."""

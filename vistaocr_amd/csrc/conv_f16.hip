@@ -249,16 +249,18 @@ namespace {
 // (a __device__ template behind plain kernels: a device builtin inside a TEMPLATE __global__ makes the host pass drop the launch stub)
 // WCO = waves along the output channels (2: 128 channels per workgroup, 1: 64), SPW = segments per wave (2 or 3).  Eight waves = two per
 // SIMD: one wave's fragment reads and DMA issues are covered by the other's MFMAs.
-template <int WCO, int SPW>
+template <int WCO, int SPW, int NCB>
 __device__ __forceinline__ void conv3x3_h16_body(const _Float16* __restrict__ x16, const _Float16* __restrict__ wpack,
                                                  const float* __restrict__ bias, float* __restrict__ out, int N, int Cin, int H,
                                                  int W, int Cout, int SW, int nseg_total, unsigned x_bytes, unsigned w_bytes) {
     constexpr int CO_T = 64 * WCO;
     constexpr int WSG = 8 / WCO;                      // waves along the segments
     constexpr int NSEG = SPW * WSG;
+    constexpr int NR = NSEG / NCB;                    // rows of the tile; NCB = its 32-pixel column blocks (segment j = row j % NR, block j / NR)
+    static_assert(NR * NCB == NSEG, "tile = rows x column blocks");
     constexpr int WP = 9 * 2 * CO_T;                  // 16-byte pieces of a stage's weights
-    constexpr int PP = 36;                            // pieces per patch row: 34 pixels + 2 never-read ones
-    constexpr int IP = (NSEG + 2) * 2 * PP;           // ... and of its input patch: the NSEG rows of the strip + one above and below
+    constexpr int PP = 32 * NCB + 4;                  // pieces per patch row: 32 NCB + 2 pixels + 2 never-read ones
+    constexpr int IP = (NR + 2) * 2 * PP;             // ... and of its input patch: the tile's rows + one above and below
     constexpr int IPA = (IP + 63) / 64 * 64;          // ... rounded up to whole waves of pieces (a DMA instruction writes 64)
     constexpr int SP = WP + IPA;
     constexpr int NQ = (WP + 511) / 512, NJ = (IPA + 511) / 512;
@@ -274,10 +276,10 @@ __device__ __forceinline__ void conv3x3_h16_body(const _Float16* __restrict__ x1
     // The workgroup's NSEG segments are a STRIP: rows h0 .. h0 + NSEG - 1 of one image at one 32-pixel column block, so that they share
     // their halo rows - the patch is NSEG + 2 rows instead of 3 NSEG (raster-order segments fetched every input row three times: 27.6 of
     // the 64.6 KB a 128 x 8 workgroup fills per 16-channel chunk, and the fill is what bounds the kernel)
-    const int HB = (H + NSEG - 1) / NSEG;             // strips per column block (nseg_total = N * HB * SW tiles)
+    const int HB = (H + NR - 1) / NR;                 // tile rows per image; SW = tile columns (N * HB * SW tiles)
     const int tile = blockIdx.x;
     const int img = tile / (HB * SW), trem = tile % (HB * SW);
-    const int h0 = (trem / SW) * NSEG, w0 = (trem % SW) * SEGW;
+    const int h0 = (trem / SW) * NR, w0 = (trem % SW) * SEGW * NCB;
 
     // ---- DMA source offsets, once per launch.  Piece P = tid + 512 j of a stage lands at LDS byte 16 P (the DMA writes a wave's 64
     // pieces contiguously); a chunk advances every source by a scalar offset
@@ -296,7 +298,7 @@ __device__ __forceinline__ void conv3x3_h16_body(const _Float16* __restrict__ x1
             const int prow = p / (2 * PP), r2 = p % (2 * PP);
             const int half = r2 / PP, px = r2 % PP;
             const int hh = h0 - 1 + prow, ww = w0 - 1 + px;
-            if (px < PROW && hh >= 0 && hh < H && ww >= 0 && ww < W)
+            if (px < 32 * NCB + 2 && hh >= 0 && hh < H && ww >= 0 && ww < W)
                 o = (unsigned)(((((long)img * (Cin / CI_C)) * H + hh) * W + ww) * 32 + half * 16);        // [N][C/16][H][W][16]: chunk 0
         }
         xo[j] = o;
@@ -349,7 +351,8 @@ __device__ __forceinline__ void conv3x3_h16_body(const _Float16* __restrict__ x1
 #pragma unroll
             for (int i = 0; i < 2; ++i) fa[set][i] = *(const half8*)(wl + ((tap * 2 + lk) * CO_T + wco + 32 * i + li) * 8);
 #pragma unroll
-            for (int j = 0; j < SPW; ++j) fb[set][j] = *(const half8*)(il + (((wsg + j + kh) * 2 + lk) * PP + li + kw) * 8);
+            for (int j = 0; j < SPW; ++j)
+                fb[set][j] = *(const half8*)(il + ((((wsg + j) % NR + kh) * 2 + lk) * PP + 32 * ((wsg + j) / NR) + li + kw) * 8);
         };
         load_frags(0, 0);
 #pragma unroll
@@ -372,7 +375,7 @@ __device__ __forceinline__ void conv3x3_h16_body(const _Float16* __restrict__ x1
     }
 #pragma unroll
     for (int j = 0; j < SPW; ++j) {
-        const int hrow = h0 + wsg + j, wx = w0 + li;
+        const int hrow = h0 + (wsg + j) % NR, wx = w0 + 32 * ((wsg + j) / NR) + li;
         if (hrow >= H || wx >= W) continue;
         const long obase = (long)img * Cout * HW + (long)hrow * W + wx;
 #pragma unroll
@@ -385,15 +388,17 @@ __device__ __forceinline__ void conv3x3_h16_body(const _Float16* __restrict__ x1
     }
 }
 
-#define VOCR_H16_KERNEL(NAME, WCO, SPW)                                                                                                   \
+#define VOCR_H16_KERNEL(NAME, WCO, SPW, NCB)                                                                                              \
     __global__ __launch_bounds__(512) void NAME(const _Float16* __restrict__ x16, const _Float16* __restrict__ wpack,                     \
                                                 const float* __restrict__ bias, float* __restrict__ out, int N, int Cin, int H, int W,    \
                                                 int Cout, int SW, int nseg_total, unsigned x_bytes, unsigned w_bytes) {                   \
-        conv3x3_h16_body<WCO, SPW>(x16, wpack, bias, out, N, Cin, H, W, Cout, SW, nseg_total, x_bytes, w_bytes);                           \
+        conv3x3_h16_body<WCO, SPW, NCB>(x16, wpack, bias, out, N, Cin, H, W, Cout, SW, nseg_total, x_bytes, w_bytes);                      \
     }
-VOCR_H16_KERNEL(conv3x3_h16_kernel_128x2, 2, 2)       // 128 channels x  8 segments
-VOCR_H16_KERNEL(conv3x3_h16_kernel_128x3, 2, 3)       // 128 channels x 12 segments
-VOCR_H16_KERNEL(conv3x3_h16_kernel_64x2, 1, 2)        //  64 channels x 16 segments
+VOCR_H16_KERNEL(conv3x3_h16_kernel_128x2, 2, 2, 1)    // 128 channels x  8 rows x 32 pixels
+VOCR_H16_KERNEL(conv3x3_h16_kernel_128x3, 2, 3, 1)    // 128 channels x 12 rows x 32 pixels
+VOCR_H16_KERNEL(conv3x3_h16_kernel_128x4, 2, 4, 1)    // 128 channels x 16 rows x 32 pixels
+VOCR_H16_KERNEL(conv3x3_h16_kernel_128x4c2, 2, 4, 2)  // 128 channels x  8 rows x 64 pixels
+VOCR_H16_KERNEL(conv3x3_h16_kernel_64x2, 1, 2, 1)     //  64 channels x 16 rows x 32 pixels
 #undef VOCR_H16_KERNEL
 
 }  // namespace
@@ -407,15 +412,19 @@ extern "C" int vocr_conv3x3_h16_fwd(const void* x16, const void* wpack, const fl
     VOCR_CHECK_ARG(((((uintptr_t)wpack) | ((uintptr_t)x16)) & 15) == 0, "vocr_conv3x3_h16_fwd: 16-byte alignment");
     const long xb = (long)n * h * w * cin * 2, wb = 9l * cin * cout * 2;
     VOCR_CHECK_ARG(xb < (1l << 31) && wb < (1l << 31), "vocr_conv3x3_h16_fwd: tensor too large for 32-bit buffer offsets");
-    const int SW = vocr_cdiv(w, SEGW);
-    // tiles of NSEG rows x 32 pixels: n * ceil(h / NSEG) * SW of them
-    auto tiles_of = [&](int nseg_rows) { return (long)n * vocr_cdiv(h, nseg_rows) * SW; };
-    VOCR_CHECK_ARG(tiles_of(8) < (1l << 30), "vocr_conv3x3_h16_fwd: too many tiles");
     hipStream_t s = (hipStream_t)stream;
     const _Float16* xp = (const _Float16*)x16;
     const _Float16* wp = (const _Float16*)wpack;
+    // a workgroup's tile = rows x column blocks of 32 pixels; tiles = n * ceil(h / rows) * ceil(w / (32 blocks))
+    auto tiles_of = [&](int rows, int blocks) { return (long)n * vocr_cdiv(h, rows) * vocr_cdiv(w, SEGW * blocks); };
+    VOCR_CHECK_ARG(tiles_of(8, 1) < (1l << 30), "vocr_conv3x3_h16_fwd: too many tiles");
+#define VOCR_H16_LAUNCH(K, ROWS, BLOCKS, CT)                                                                                            \
+    K<<<dim3((unsigned)tiles_of(ROWS, BLOCKS), CT), 512, 0, s>>>(xp, wp, bias, y, n, cin, h, w, cout, vocr_cdiv(w, SEGW * BLOCKS),          \
+                                                                (int)tiles_of(ROWS, BLOCKS), (unsigned)xb, (unsigned)wb)
     if (cout > 64) {
-        // strips of 8 or 12 rows per workgroup: whichever needs less time in whole rounds of one workgroup per CU
+        // the tile shape that needs the least time in whole rounds of one workgroup per CU.  Cost of a tile = its segments, a 16-segment
+        // tile at 0.8 of two 8-segment ones (it fills 58 instead of 2 x 48 KB per chunk, and the fill is what bounds the kernel);
+        // H16_TILE (experiments): force a shape
         int ncu = 256;
         {
             int dev = 0;
@@ -423,14 +432,23 @@ extern "C" int vocr_conv3x3_h16_fwd(const void* x16, const void* wpack, const fl
             if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
         }
         const int ct = vocr_cdiv(cout, 128);
-        const long t2 = tiles_of(8), t3 = tiles_of(12);
-        const long r2 = (long)vocr_cdiv(t2 * ct, ncu) * 2, r3 = (long)vocr_cdiv(t3 * ct, ncu) * 3;
-        if (r3 < r2) conv3x3_h16_kernel_128x3<<<dim3((unsigned)t3, ct), 512, 0, s>>>(xp, wp, bias, y, n, cin, h, w, cout, SW, (int)t3, (unsigned)xb, (unsigned)wb);
-        else conv3x3_h16_kernel_128x2<<<dim3((unsigned)t2, ct), 512, 0, s>>>(xp, wp, bias, y, n, cin, h, w, cout, SW, (int)t2, (unsigned)xb, (unsigned)wb);
+        static const int force = VOCR_EXPERIMENT_INT("VOCR_H16_TILE", 0);
+        const double c2 = (double)vocr_cdiv(tiles_of(8, 1) * ct, ncu) * 2, c3 = (double)vocr_cdiv(tiles_of(12, 1) * ct, ncu) * 3,
+                     c4 = (double)vocr_cdiv(tiles_of(16, 1) * ct, ncu) * 4 * 0.8, c42 = (double)vocr_cdiv(tiles_of(8, 2) * ct, ncu) * 4 * 0.8;
+        int pick = 2;
+        double best = c2;
+        if (c3 < best) { best = c3; pick = 3; }
+        if (c4 < best) { best = c4; pick = 4; }
+        if (c42 < best) { best = c42; pick = 5; }
+        if (force) pick = force;
+        if (pick == 3) VOCR_H16_LAUNCH(conv3x3_h16_kernel_128x3, 12, 1, ct);
+        else if (pick == 4) VOCR_H16_LAUNCH(conv3x3_h16_kernel_128x4, 16, 1, ct);
+        else if (pick == 5) VOCR_H16_LAUNCH(conv3x3_h16_kernel_128x4c2, 8, 2, ct);
+        else VOCR_H16_LAUNCH(conv3x3_h16_kernel_128x2, 8, 1, ct);
     } else {
-        const long t = tiles_of(16);
-        conv3x3_h16_kernel_64x2<<<dim3((unsigned)t, 1), 512, 0, s>>>(xp, wp, bias, y, n, cin, h, w, cout, SW, (int)t, (unsigned)xb, (unsigned)wb);
+        VOCR_H16_LAUNCH(conv3x3_h16_kernel_64x2, 16, 1, 1);
     }
+#undef VOCR_H16_LAUNCH
     VOCR_CHECK_LAUNCH("vocr_conv3x3_h16_fwd");
     return VOCR_OK;
 }
