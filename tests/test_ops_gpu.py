@@ -182,7 +182,9 @@ def test_conv3x3_one_input_channel_kernels(dev, n, h, w, cout):
                                             (3, 64, 30, 131, 64), (2, 256, 7, 294, 256), (4, 128, 15, 97, 128), (2, 16, 30, 100, 64), (1, 48, 5, 33, 80),
                                             # tile shapes of the forward kernel that only larger launches pick on a 256-CU chip: 16 rows x 32 pixels
                                             # (tiles(8 rows) x 2 channel tiles = 320 > 256 >= 160 = tiles(16 rows) x 2) and 12 rows (384 > 256 >= 256)
-                                            (10, 32, 16, 256, 256), (8, 16, 24, 256, 256)])
+                                            (10, 32, 16, 256, 256), (8, 16, 24, 256, 256),
+                                            # ... and 8 rows x 64 pixels: a 7-row image whose 320 tiles of 8 x 32 would need two rounds, 160 of 8 x 64 one
+                                            (20, 16, 7, 250, 256)])
 def test_conv3x3_f16_operands(dev, n, cin, h, w, cout):
     """fp16-operand MFMA conv (config 5): products of fp16-rounded operands, fp32 accumulation — compared with the same
     rounding done on the CPU, so the only difference left is the summation order."""
