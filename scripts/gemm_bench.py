@@ -20,7 +20,7 @@ for ta, tb, m, n, k, hb in shapes:
     t = timeit(lambda: ops.gemm(ta, tb, m, n, k, a, a.shape[1], b, b.shape[1], c, n, bias=bias))
     print("  %-32s %7.1f us %6.1f TF/s" % ((ta, tb, m, n, k, hb), t * 1e6, 2.0 * m * n * k / t / 1e12))
 print("pairs (mode, ta, tb, m, n, k): both directions of a layer")
-pairs = [(0, 0, 1, M, 2048, 1024), (0, 0, 1, M, 2048, 128), (1, 0, 0, M, 1024, 2048), (1, 0, 0, M, 128, 2048), (0, 1, 0, 2048, 1024, M), (0, 1, 0, 2048, 128, M),
+pairs = [(0, 0, 1, M, 2048, 1024), (0, 0, 1, M, 2048, 128), (1, 0, 0, M, 1024, 2048), (1, 0, 1, M, 1024, 2048), (1, 0, 0, M, 128, 2048), (0, 1, 0, 2048, 1024, M), (0, 1, 0, 2048, 128, M),
          (0, 1, 0, 2048, 512, M - 32)]
 for mode, ta, tb, m, n, k in pairs:
     a0 = torch.randn((k, m) if ta else (m, k), device=dev); a1 = torch.randn_like(a0)

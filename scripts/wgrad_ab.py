@@ -27,6 +27,6 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         print("  wgrad %-22s %7.1f us %6.1f TF algorithmic" % ((cin, cout, h, w), c * 1e6, fl / c / 1e12))
     print("  six launches of a step: %.1f us" % (tot * 1e6))
 else:
-    for mode in sys.argv[1:] or ["1", "2"]:
+    for mode in sys.argv[1:] or ["2", "3"]:       # 2: one-row piece stream, 3: row pairs (round 3's modes 0 / 1 are gone)
         print("VOCR_WGRAD_WINO_DMA=%s" % mode, flush=True)
         subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=dict(os.environ, VOCR_WGRAD_WINO_DMA=mode))

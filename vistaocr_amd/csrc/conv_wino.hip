@@ -92,8 +92,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // Forward / data-gradient geometry: the column pairs of all image rows form ONE stream - a row contributes its T = ceil(W/2) pairs and
 // one gap slot (the pair after the last one of a row must not see the next row's first columns) - and a segment is any 32 consecutive
 // slots, so only 1 of T+1 lane positions is idle (whole 32-pair segments per row idled 8 % of them at W = 294, 6 % at 420 / 600).
-// Slot q -> image n, row h, pair k (k == T: the gap).  The weight-gradient kernel keeps whole segments per row (nsr, per_img, nseg).
-struct WGeom { int nsr, per_img, nseg; int T, S, slots_img, nslot; };
+// Slot q -> image n, row h, pair k (k == T: the gap).
+struct WGeom { int nseg; int T, S, slots_img, nslot; };
 struct WSlot { int n, h, k, valid; };
 __device__ __forceinline__ WSlot wslot(int q, const WGeom& g) {
     WSlot s;
@@ -869,380 +869,13 @@ VOCR_WINO4_KERNEL(conv3x3_wino4x2_kernel_64, 64, 4, 2, 2)
 // forward transform: 4 multiplications per pair, channel pair and kh instead of 6:
 //   a0 = g0   a1 = (g0+g1)/2   a2 = (g0-g1)/2   a3 = g1          b0 = d0 - d2   b1 = d1 + d2   b2 = d2 - d1   b3 = d3 - d1
 //   M_x += a_x * b_x  over all pairs                              dw(kw=0) = M0+M1+M2   dw(1) = M1-M2   dw(2) = M1+M2+M3
-// The output transform is linear, so it is applied once to the accumulators at the end.  A workgroup (4 waves) owns 64 output x 64
-// input channels and a range of 64-pixel row segments; a wave holds 3 kh x 4 accumulator tiles (192 registers: one wave per SIMD).
-// Per segment: barrier, one burst of loads (dy 64x64, x 64 channels x 3 rows x 66 columns split into even / odd columns), LDS
-// stores, barrier, 16 k-steps of 12 MFMAs.  (Loads beside running MFMAs are throttled on this chip - see conv.hip's weight-gradient
-// kernel - so the burst sits between the k-loops on purpose.)
-constexpr int GW_DYP = 65;                 // dy row pitch (odd: conflict-free across channels)
-constexpr int GW_XCI = 3 * PRW + 1;        // 205: x pitch per channel (odd)
-
-__global__ __launch_bounds__(256) void conv3x3_wgrad_wino_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                                 float* __restrict__ slab, int N, int Cin, int H, int W, int Cout,
-                                                                 WGeom geo, int segs_per_split) {
-    __shared__ float lds[64 * GW_DYP + 64 * GW_XCI + 64];
-    float* const dyS = lds;
-    float* const xS = lds + 64 * GW_DYP;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31, lk = lane >> 5;
-    // the 16 (ci, co) tiles of a split on one XCD (see conv3x3_wgrad_kernel)
-    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    if ((gridDim.z & 7) == 0) {
-        const int nxy = gridDim.x * gridDim.y;
-        const int b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        const int k = b & 7, slot = b >> 3;
-        bz = k + 8 * (slot / nxy);
-        const int xy = slot - (slot / nxy) * nxy;
-        bx = xy % gridDim.x;
-        by = xy / gridDim.x;
-    }
-    const int ci0 = bx * 64, co0 = by * 64, split = bz;
-    const int wco = (wave >> 1) * 32, wci = (wave & 1) * 32;
-    const long HW = (long)H * W;
-
-    f32x16 acc[3][4];
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[kh][q][r] = 0.f;
-
-    const int sbeg = split * segs_per_split;
-    const int send = min(geo.nseg, sbeg + segs_per_split);
-    // Loader: 16-byte buffer loads (a load outside the tensor returns 0, so nothing needs an address clamp at the tensor's ends).
-    //   dy: lane = (row slot lane>>4, piece lane&15 = pixels 4*piece .. +3); load e covers channels 16*wave + 4*e + slot: 4 loads
-    //   x : a staged row is raw index j = 0..65 <-> column w0-1+j; pieces q = 1..16 cover j = 4q-3 .. 4q (columns w0-4+4q .. +3), item
-    //       t = lane + 64*i <-> (row 4*i + (lane>>4) of the wave's 48 (c, kh) rows, q = (lane&15) + 1): 12 loads; j = 0 and j = 65 of
-    //       all 48 rows take two dword loads.  A piece's elements go to O[2q-2], E[2q-1], O[2q-1], E[2q]: two ds_write2.
-    // (66 dword loads and ~380 vector instructions per segment took 8000 cycles beside the 12300 of the MFMAs; this form ~4000.)
-    const __amdgpu_buffer_rsrc_t dyrs = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)((long)N * Cout * HW * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((long)N * Cin * HW * 4), 0x00020000);
-    const int slot = lane >> 4, piece = lane & 15;
-    int d_off[4], d_lds[4];
-    float d_m[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int col = wave * 16 + 4 * e + slot, co = co0 + col;
-        d_off[e] = min(co, Cout - 1) * (int)HW + 4 * piece;
-        d_m[e] = co < Cout ? 1.f : 0.f;
-        d_lds[e] = col * GW_DYP + 4 * piece;
-    }
-    int x_ch[12], x_kh[12], x_lds[12];
-    float x_m[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) {
-        const int row = 4 * i + slot, c = row / 3, kh = row - 3 * c, ci = ci0 + wave * 16 + c;
-        x_ch[i] = min(ci, Cin - 1) * (int)HW + 4 * piece;            // + column w0 of the segment: first element = column w0 + 4*piece
-        x_kh[i] = kh;
-        x_m[i] = ci < Cin ? 1.f : 0.f;
-        x_lds[i] = (wave * 16 + c) * GW_XCI + kh * PRW + 2 * piece;   // q = piece + 1: E[2q-1] = E[2*piece + 1], O[2q-2] = O[2*piece]
-    }
-    for (int g = sbeg; g < send; ++g) {
-        const int n = g / geo.per_img, loc = g - n * geo.per_img, h = loc / geo.nsr, w0 = (loc - h * geo.nsr) * 2 * TS;
-        __syncthreads();                                             // every wave is done with the previous segment's tiles
-        {
-            u32x4w rd[4], rx4[12];
-            float rxh[2];
-            // the whole offset goes through the range-checked vector operand: a piece that runs past the end of the tensor reads zeros
-            const int dbase = n * Cout * (int)HW + h * W + w0;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) rd[e] = __builtin_amdgcn_raw_buffer_load_b128(dyrs, (d_off[e] + dbase) * 4, 0, 0);
-            const int xbase = n * Cin * (int)HW + w0;
-#pragma unroll
-            for (int i = 0; i < 12; ++i) {
-                const int hh = min(max(h + x_kh[i] - 1, 0), H - 1);
-                rx4[i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (x_ch[i] + hh * W + xbase) * 4, 0, 0);
-            }
-            const long xb = (long)n * Cin * HW;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {                               // raw index 0 (column w0-1, item parity 0) and 65 (column w0+64)
-                const int t = lane + 64 * j, row = min(t >> 1, 47), c = row / 3, kh = row - 3 * c, hcol = (t & 1) ? w0 + 64 : w0 - 1;
-                const int ci = ci0 + wave * 16 + c, hh = h + kh - 1;
-                const float m = (t < 96 && ci < Cin && hcol >= 0 && hcol < W && hh >= 0 && hh < H) ? 1.f : 0.f;
-                rxh[j] = x[xb + (long)min(ci, Cin - 1) * HW + (long)min(max(hh, 0), H - 1) * W + min(max(hcol, 0), W - 1)] * m;
-            }
-            // dy: elements at pixels 4*piece + k
-            float pm[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) pm[k] = (w0 + 4 * piece + k) < W ? 1.f : 0.f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) dyS[d_lds[e] + k] = __uint_as_float(rd[e][k]) * (pm[k] * d_m[e]);
-            // x: element k of piece q is column w0 + 4*piece + k, raw index j = 4*piece + k + 1
-#pragma unroll
-            for (int i = 0; i < 12; ++i) {
-                const int hh = h + x_kh[i] - 1;
-                const float rm = (hh >= 0 && hh < H) ? x_m[i] : 0.f;
-                float* o = xS + x_lds[i];
-                o[POFF] = __uint_as_float(rx4[i][0]) * (pm[0] * rm);          // j = 4p+1 -> O[2p]
-                o[1] = __uint_as_float(rx4[i][1]) * (pm[1] * rm);             // j = 4p+2 -> E[2p+1]
-                o[POFF + 1] = __uint_as_float(rx4[i][2]) * (pm[2] * rm);      // j = 4p+3 -> O[2p+1]
-                o[2] = __uint_as_float(rx4[i][3]) * (pm[3] * rm);             // j = 4p+4 -> E[2p+2]
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int t = lane + 64 * j, row = min(t >> 1, 47), c = row / 3, kh = row - 3 * c;
-                xS[t < 96 ? (wave * 16 + c) * GW_XCI + kh * PRW + ((t & 1) ? POFF + 32 : 0) : 64 * GW_XCI + (lane & 31)] = rxh[j];
-            }
-        }
-        __syncthreads();
-        // k-step s multiplies pairs 2s (lanes 0-31) and 2s+1 (lanes 32-63)
-        const float* ap = dyS + (wco + li) * GW_DYP + 2 * lk;
-        const float* bp = xS + (wci + li) * GW_XCI + lk;
-        float g0 = ap[0], g1 = ap[1], e0[3], e1[3], o0[3], o1[3];
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) { e0[kh] = bp[kh * PRW]; e1[kh] = bp[kh * PRW + 1]; o0[kh] = bp[kh * PRW + POFF]; o1[kh] = bp[kh * PRW + POFF + 1]; }
-#pragma unroll
-        for (int s = 0; s < TS / 2; ++s) {
-            float ng0 = 0.f, ng1 = 0.f, ne0[3], ne1[3], no0[3], no1[3];
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh) ne0[kh] = ne1[kh] = no0[kh] = no1[kh] = 0.f;
-            if (s + 1 < TS / 2) {
-                ng0 = ap[4 * (s + 1)]; ng1 = ap[4 * (s + 1) + 1];
-#pragma unroll
-                for (int kh = 0; kh < 3; ++kh) {
-                    const float* q = bp + kh * PRW + 2 * (s + 1);
-                    ne0[kh] = q[0]; ne1[kh] = q[1]; no0[kh] = q[POFF]; no1[kh] = q[POFF + 1];
-                }
-            }
-            const float a[4] = {g0, 0.5f * (g0 + g1), 0.5f * (g0 - g1), g1};
-            float b[3][4];
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh) { b[kh][0] = e0[kh] - e1[kh]; b[kh][1] = o0[kh] + e1[kh]; b[kh][2] = e1[kh] - o0[kh]; b[kh][3] = o1[kh] - o0[kh]; }
-            __builtin_amdgcn_sched_barrier(0);      // next step's ds_reads stay above this step's MFMAs
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[kh][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[kh][q], acc[kh][q], 0, 0, 0);
-            g0 = ng0; g1 = ng1;
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh) { e0[kh] = ne0[kh]; e1[kh] = ne1[kh]; o0[kh] = no0[kh]; o1[kh] = no1[kh]; }
-        }
-    }
-    // slab[split][tap][co][ci]  (ci contiguous -> coalesced stores); output transform per (co, ci)
-    const long plane = (long)Cout * Cin;
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co0 + wco + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            const int ci = ci0 + wci + li;
-            if (co < Cout && ci < Cin) {
-                const float m0 = acc[kh][0][r], m1 = acc[kh][1][r], m2 = acc[kh][2][r], m3 = acc[kh][3][r];
-                float* o = slab + ((long)split * 9 + kh * 3) * plane + (long)co * Cin + ci;
-                o[0] = (m0 + m1) + m2;
-                o[plane] = m1 - m2;
-                o[2 * plane] = (m1 + m2) + m3;
-            }
-        }
-}
-
-// ---------------------------------------------------------------- weight gradient F(3,2), operands staged by LDS-DMA
-// The same contraction as conv3x3_wgrad_wino_kernel; what changes is how a segment's operands reach LDS.  There the four waves
-// load them through registers between two k-loops (a burst of 66 KB per workgroup that runs at the memory system's rate with the
-// matrix pipe idle: 37 % of the kernel).  Loads that return into VGPRs beside running MFMAs are throttled on this chip and 192
-// accumulator registers leave no room for loader waves, but an LDS-DMA (buffer_load ... lds, 16 bytes per lane) returns nothing to
-// a register: each wave issues the 18 DMAs of the NEXT segment in front of its k-loop into the other LDS buffer and only waits for
-// them behind it.  A DMA writes 64 consecutive 16-byte pieces, so the LDS layouts are piece-linear and bank conflicts are handled
-// by XOR-swizzling the piece position with the channel (source addresses are per lane, so the swizzle costs nothing to write):
-//   dy  [co 64][16 pieces]            piece p of channel co at position p ^ (co & 15)
-//   x   [ci 64][56 pieces]            logical piece L = kh*18 + q (q = 0..17: columns w0-4+4q .. +3; 54, 55 unused) at L ^ (ci & 7)
-// Padding (rows above / below the image, columns left of it, channels past the end, whole pieces right of the row) = a load outside
-// the buffer's range, which delivers zeros; a piece that straddles the END of an image row (W % 4 != 0) is patched with zeros after
-// it has landed.
-constexpr int GD_DYB = 64 * 64;            // floats of dy per buffer
-constexpr int GD_XCI = 56 * 4;             // floats of x per input channel (224 = 0 mod 32 banks)
-constexpr int GD_XB = 64 * GD_XCI;         // floats of x per buffer
-
-__global__ __launch_bounds__(256) void conv3x3_wgrad_wino_dma_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                                     float* __restrict__ slab, int N, int Cin, int H, int W, int Cout,
-                                                                     WGeom geo, int segs_per_split) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * (GD_DYB + GD_XB)];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31, lk = lane >> 5;
-    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    if ((gridDim.z & 7) == 0) {             // the (ci, co) tiles of a split on one XCD (see conv3x3_wgrad_kernel)
-        const int nxy = gridDim.x * gridDim.y;
-        const int b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        const int k = b & 7, slot = b >> 3;
-        bz = k + 8 * (slot / nxy);
-        const int xy = slot - (slot / nxy) * nxy;
-        bx = xy % gridDim.x;
-        by = xy / gridDim.x;
-    }
-    const int ci0 = bx * 64, co0 = by * 64, split = bz;
-    const int wco = (wave >> 1) * 32, wci = (wave & 1) * 32;
-    const long HW = (long)H * W;
-    const int iHW = (int)HW;
-
-    f32x16 acc[3][4];
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[kh][q][r] = 0.f;
-
-    const int sbeg = split * segs_per_split;
-    const int send = min(geo.nseg, sbeg + segs_per_split);
-    const __amdgpu_buffer_rsrc_t dyrs = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)((long)N * Cout * HW * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((long)N * Cin * HW * 4), 0x00020000);
-    constexpr unsigned OOB = 0xFFFFFFF0u;
-
-    // ---- DMA maps (kernel constants per lane): instruction m of a wave covers pieces [64m, 64m+64) of the buffer
-    int d_off[4], d_px[4];             // dy: element offset co*HW + 4p, first pixel 4p; d_off < 0: channel past the end
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int id = 64 * (wave + 4 * e) + lane, co = id >> 4, p = (id & 15) ^ (co & 15);
-        d_px[e] = 4 * p;
-        d_off[e] = co0 + co < Cout ? (co0 + co) * iHW + 4 * p : -1;
-    }
-    int x_off[14], x_meta[14];         // x: element offset ci*HW + 4q; meta = kh | q << 2, or -1: unused piece / channel past the end
-#pragma unroll
-    for (int i = 0; i < 14; ++i) {
-        const int id = 64 * (wave + 4 * i) + lane, ci = id / 56, L = (id - 56 * ci) ^ (ci & 7), kh = L / 18, q = L - 18 * kh;
-        const bool ok = L < 54 && ci0 + ci < Cin;
-        x_off[i] = (ci0 + ci) * iHW + 4 * q;
-        x_meta[i] = ok ? (kh | (q << 2)) : -1;
-    }
-    auto seg_of = [&](int g, int& n, int& h, int& w0) {
-        n = g / geo.per_img;
-        const int loc = g - n * geo.per_img;
-        h = loc / geo.nsr;
-        w0 = (loc - h * geo.nsr) * 2 * TS;
-    };
-    auto issue = [&](int g, int buf) {
-        int n, h, w0;
-        seg_of(g, n, h, w0);
-        float* const dyb = lds + buf * (GD_DYB + GD_XB);
-        float* const xb = dyb + GD_DYB;
-        const int dbase = n * Cout * iHW + h * W + w0;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const unsigned vo = (d_off[e] >= 0 && w0 + d_px[e] < W) ? (unsigned)(dbase + d_off[e]) * 4u : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(dyrs, (__attribute__((address_space(3))) void*)(dyb + (wave + 4 * e) * 256), 16, vo, 0, 0, 0);
-        }
-        const int xbase = n * Cin * iHW + w0 - 4;
-#pragma unroll
-        for (int i = 0; i < 14; ++i) {
-            const int kh = x_meta[i] & 3, q = x_meta[i] >> 2, row = h + kh - 1, col0 = w0 - 4 + 4 * q;
-            const bool ok = x_meta[i] >= 0 && row >= 0 && row < H && col0 >= 0 && col0 < W;
-            const unsigned vo = ok ? (unsigned)(xbase + x_off[i] + row * W) * 4u : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(xb + (wave + 4 * i) * 256), 16, vo, 0, 0, 0);
-        }
-    };
-    // a piece that straddles the end of its image row carries the next row's first columns: zero them (after the DMA has landed)
-    auto patch = [&](int g, int buf) {
-        int n, h, w0;
-        seg_of(g, n, h, w0);
-        if ((W & 3) == 0 || w0 + 68 <= W) return;                       // wave-uniform
-        float* const dyb = lds + buf * (GD_DYB + GD_XB);
-        float* const xb = dyb + GD_DYB;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int c0 = w0 + d_px[e];
-            if (d_off[e] >= 0 && c0 < W && c0 + 4 > W) {
-                float* o = dyb + (wave + 4 * e) * 256 + lane * 4;
-#pragma unroll
-                for (int k = 1; k < 4; ++k)
-                    if (c0 + k >= W) o[k] = 0.f;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 14; ++i) {
-            const int q = x_meta[i] >> 2, c0 = w0 - 4 + 4 * q;
-            if (x_meta[i] >= 0 && c0 >= 0 && c0 < W && c0 + 4 > W) {
-                float* o = xb + (wave + 4 * i) * 256 + lane * 4;
-#pragma unroll
-                for (int k = 1; k < 4; ++k)
-                    if (c0 + k >= W) o[k] = 0.f;
-            }
-        }
-    };
-
-    // ---- fragment addressing (kernel constants per lane)
-    const int cA = wco + li, sA = cA & 15, baseA = cA * 64 + 2 * lk;
-    const int cB = wci + li, s7 = cB & 7, baseB = cB * GD_XCI;
-    int dpi[4], doi[4];                 // element i of pair p = 2s + lk sits in piece s + dpi[i] at offset doi[i] (raw index 3 + 2p + i)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { dpi[i] = (3 + 2 * lk + i) >> 2; doi[i] = (3 + 2 * lk + i) & 3; }
-
-    if (sbeg < send) {
-        issue(sbeg, 0);
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        patch(sbeg, 0);
-    }
-    __syncthreads();
-    for (int g = sbeg; g < send; ++g) {
-        const int cur = (g - sbeg) & 1;
-        if (g + 1 < send) issue(g + 1, cur ^ 1);
-        const float* dyb = lds + cur * (GD_DYB + GD_XB);
-        const float* xb = dyb + GD_DYB;
-        auto readA = [&](int s, float& g0, float& g1) {
-            const float* a = dyb + baseA + 4 * (s ^ sA);
-            g0 = a[0]; g1 = a[1];
-        };
-        auto readB = [&](int s, float (&d)[3][4]) {
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) d[kh][i] = xb[baseB + 4 * ((kh * 18 + s + dpi[i]) ^ s7) + doi[i]];
-        };
-        float g0, g1, d[3][4];
-        readA(0, g0, g1);
-        readB(0, d);
-#pragma unroll
-        for (int s = 0; s < TS / 2; ++s) {
-            float ng0 = 0.f, ng1 = 0.f, nd[3][4];
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) nd[kh][i] = 0.f;
-            if (s + 1 < TS / 2) { readA(s + 1, ng0, ng1); readB(s + 1, nd); }
-            const float a[4] = {g0, 0.5f * (g0 + g1), 0.5f * (g0 - g1), g1};
-            float b[3][4];
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh) { b[kh][0] = d[kh][0] - d[kh][2]; b[kh][1] = d[kh][1] + d[kh][2]; b[kh][2] = d[kh][2] - d[kh][1]; b[kh][3] = d[kh][3] - d[kh][1]; }
-            __builtin_amdgcn_sched_barrier(0);      // next step's ds_reads stay above this step's MFMAs
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[kh][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[kh][q], acc[kh][q], 0, 0, 0);
-            g0 = ng0; g1 = ng1;
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) d[kh][i] = nd[kh][i];
-        }
-        if (g + 1 < send) {
-            __builtin_amdgcn_s_waitcnt(0x0F70);     // the next segment's DMAs have landed
-            patch(g + 1, cur ^ 1);
-        }
-        __syncthreads();                            // next buffer complete, this one free
-    }
-    const long plane = (long)Cout * Cin;
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co0 + wco + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            const int ci = ci0 + wci + li;
-            if (co < Cout && ci < Cin) {
-                const float m0 = acc[kh][0][r], m1 = acc[kh][1][r], m2 = acc[kh][2][r], m3 = acc[kh][3][r];
-                float* o = slab + ((long)split * 9 + kh * 3) * plane + (long)co * Cin + ci;
-                o[0] = (m0 + m1) + m2;
-                o[plane] = m1 - m2;
-                o[2 * plane] = (m1 + m2) + m3;
-            }
-        }
-}
+// The output transform is linear, so it is applied once to the accumulators at the end.
+// (Round 3's two kernels of this contraction - 64-pixel row segments staged through registers, then by LDS-DMA - were the default
+// until round 4 and are gone: HISTORY.md describes them; the piece-stream kernel below serves the channel counts the row-pair kernel
+// does not take.)
 
 // ---------------------------------------------------------------- weight gradient F(3,2), piece stream, twelve waves (round 4)
-// The same contraction again; what changes against conv3x3_wgrad_wino_dma_kernel, and why:
+// What changed against round 3's segment kernels, and why:
 //   * THE BUDGET.  On this chip the f32 MFMA peak IS the vector f32 peak, and nothing vector hides behind a v_mfma_f32_32x32x2_f32:
 //     beside a stream of them (64 cycles each) every plain VALU instruction costs 4 - 5 cycles of MFMA time, a packed one
 //     (v_pk_add_f32) the same 5, a ds_read 2, an LDS-DMA 7 - 14 (scripts/mfma_valu_probe.hip, three waves per SIMD).  The segment
@@ -2002,7 +1635,6 @@ extern "C" int vocr_conv3x3_wino_fwd(const float* x, const float* wpack, const f
     geo.slots_img = h * geo.S;
     geo.nslot = n * geo.slots_img;
     geo.nseg = vocr_cdiv(geo.nslot, TS);
-    geo.nsr = 0; geo.per_img = 0;
     const float* zp = wino_zero_page_ptr();
     VOCR_CHECK_ARG(zp != nullptr, "vocr_conv3x3_wino_fwd: no device zero page");
     hipStream_t s = (hipStream_t)stream;
@@ -2067,20 +1699,6 @@ extern "C" int vocr_conv3x3_wino_fwd(const float* x, const float* wpack, const f
 void vocr_internal_wgrad_reduce(const float* slab, float* dw, int cout, int cin, int splits, hipStream_t s);     // conv.hip
 
 namespace {
-int wgrad_wino_splits(int n, int cin, int h, int w, int cout, int* segs_per_split) {
-    const int nsr = vocr_cdiv(vocr_cdiv(w, 2), TS);
-    const long nseg = (long)n * h * nsr;
-    const int tiles = vocr_cdiv(cin, 64) * vocr_cdiv(cout, 64);
-    long s = (256 + tiles - 1) / tiles;                      // one workgroup per CU (192 accumulator registers per lane)
-    if (s > nseg) s = nseg;
-    if (s < 1) s = 1;
-    const int sps = (int)((nseg + s - 1) / s);
-    *segs_per_split = sps;
-    return (int)((nseg + sps - 1) / sps);
-}
-}  // namespace
-
-namespace {
 // piece-stream geometry of conv3x3_wgrad_wino3_kernel
 int wgrad_wino3_splits(int n, int cin, int h, int w, int cout, W3Geom* geo, int* segs_per_split) {
     geo->np = vocr_cdiv(w, 4);
@@ -2115,11 +1733,11 @@ int wgrad_wino2d_splits(int n, int cin, int h, int w, int cout, W3Geom* geo, int
     *segs_per_split = sps;
     return (geo->nseg + sps - 1) / sps;
 }
-// VOCR_WGRAD_WINO_DMA: 3 (default) row pairs (F(3,2) across rows too) / eight waves, 2 piece stream / twelve waves, 1 round 3's
-// segment kernel with LDS-DMA, 0 its register-staged form
+// VOCR_WGRAD_WINO_DMA (experiments): 3 (default) row pairs (F(3,2) across rows too) / eight waves where Cin x Cout is a multiple of 4,
+// 2 the one-row piece stream / twelve waves everywhere
 int wgrad_wino_mode() {
     static const int m = VOCR_EXPERIMENT_INT("VOCR_WGRAD_WINO_DMA", 3);
-    return m;
+    return m == 2 ? 2 : 3;
 }
 }  // namespace
 
@@ -2128,8 +1746,7 @@ extern "C" size_t vocr_conv3x3_wgrad_wino_workspace_bytes(int n, int cin, int h,
     int sps;
     W3Geom g3;
     if (wgrad_wino_mode() == 3 && (cout * cin) % 4 == 0) return (size_t)wgrad_wino2d_splits(n, cin, h, w, cout, &g3, &sps) * 12 * cout * cin * sizeof(float);
-    const int splits = wgrad_wino_mode() >= 2 ? wgrad_wino3_splits(n, cin, h, w, cout, &g3, &sps) : wgrad_wino_splits(n, cin, h, w, cout, &sps);
-    return (size_t)splits * 9 * cout * cin * sizeof(float);
+    return (size_t)wgrad_wino3_splits(n, cin, h, w, cout, &g3, &sps) * 9 * cout * cin * sizeof(float);
 }
 
 extern "C" int vocr_conv3x3_wgrad_wino(const float* x, const float* dy, float* dw, void* workspace, int n, int cin, int h, int w,
@@ -2152,22 +1769,10 @@ extern "C" int vocr_conv3x3_wgrad_wino(const float* x, const float* dy, float* d
         VOCR_CHECK_LAUNCH("vocr_conv3x3_wgrad_wino(row pairs, reduce)");
         return VOCR_OK;
     }
-    if (wgrad_wino_mode() >= 2) {
-        W3Geom g3;
-        splits = wgrad_wino3_splits(n, cin, h, w, cout, &g3, &sps);
-        dim3 grid(vocr_cdiv(cin, 64), vocr_cdiv(cout, 64), splits);
-        conv3x3_wgrad_wino3_kernel<<<grid, 768, 0, s>>>(x, dy, (float*)workspace, n, cin, h, w, cout, g3, sps);
-    } else {
-        WGeom geo;
-        geo.nsr = vocr_cdiv(vocr_cdiv(w, 2), TS);
-        geo.per_img = h * geo.nsr;
-        geo.nseg = n * geo.per_img;
-        geo.T = geo.S = geo.slots_img = geo.nslot = 0;
-        splits = wgrad_wino_splits(n, cin, h, w, cout, &sps);
-        dim3 grid(vocr_cdiv(cin, 64), vocr_cdiv(cout, 64), splits);
-        if (wgrad_wino_mode() == 1) conv3x3_wgrad_wino_dma_kernel<<<grid, 256, 0, s>>>(x, dy, (float*)workspace, n, cin, h, w, cout, geo, sps);
-        else conv3x3_wgrad_wino_kernel<<<grid, 256, 0, s>>>(x, dy, (float*)workspace, n, cin, h, w, cout, geo, sps);
-    }
+    W3Geom g3;
+    splits = wgrad_wino3_splits(n, cin, h, w, cout, &g3, &sps);
+    dim3 grid(vocr_cdiv(cin, 64), vocr_cdiv(cout, 64), splits);
+    conv3x3_wgrad_wino3_kernel<<<grid, 768, 0, s>>>(x, dy, (float*)workspace, n, cin, h, w, cout, g3, sps);
     VOCR_CHECK_LAUNCH("vocr_conv3x3_wgrad_wino");
     vocr_internal_wgrad_reduce((const float*)workspace, dw, cout, cin, splits, s);
     VOCR_CHECK_LAUNCH("vocr_conv3x3_wgrad_wino(reduce)");

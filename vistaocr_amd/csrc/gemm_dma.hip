@@ -78,14 +78,16 @@ __global__ __launch_bounds__(512) void gemm_dma_kernel(const DmaGemmArgs g) {
     const int prob = t_ / g.ksplit;
     const int n0 = panel * DN;
 
-    // rows of this group: the 32-row tiles are dealt evenly over the groups; a group walks them in chunks of 8 tiles (the last chunk
-    // takes what is left), and inside a chunk the first ceil(n/2) tiles belong to waves 0-3, the rest to waves 4-7
+    // rows of this group: the 32-row tiles are dealt evenly over the groups; a group walks them in chunks of <= 8 tiles, and inside a chunk the first ceil(n/2) tiles belong to waves 0-3, the rest to waves 4-7
     const int mt = (g.M + 31) >> 5;
     const int tb_ = mt / g.groups, te_ = mt % g.groups;
     // (K split into slabs: whole 8-tile groups, because the slab reduce maps slab tile (group, panel) to rows group * 256)
     const int gtiles = g.ksplit > 1 ? min(8, mt - 8 * group) : tb_ + (group < te_ ? 1 : 0);
     const int gstart = g.ksplit > 1 ? 8 * group : group * tb_ + min(group, te_);
     const int nch = (gtiles + 7) >> 3;
+    // ... in nch chunks of EVEN size (19 tiles = 7 + 6 + 6, not 8 + 8 + 3): every K-tile step moves the 16 KB weight tile and pays its barrier
+    // whatever the chunk holds, so a 1 - 3 tile last chunk ran at a fraction of the matrix rate
+    const int cbase = nch > 0 ? gtiles / nch : 0, cext = nch > 0 ? gtiles % nch : 0;
     const int kbeg = split * g.kps, kend = min(g.K, kbeg + g.kps);
     const int kts = (kend - kbeg + DK - 1) / DK;          // K-tiles of one segment
     const int KT = kts * g.nseg;
@@ -113,8 +115,8 @@ __global__ __launch_bounds__(512) void gemm_dma_kernel(const DmaGemmArgs g) {
         Step st;
         st.seg = cu.kt >= kts ? 1 : 0;
         st.k0 = kbeg + (cu.kt - st.seg * kts) * DK;
-        st.ntile = min(8, gtiles - 8 * cu.c);
-        st.row0 = 32 * (gstart + 8 * cu.c);
+        st.ntile = cbase + (cu.c < cext ? 1 : 0);
+        st.row0 = 32 * (gstart + cu.c * cbase + min(cu.c, cext));
         st.slot = cu.slot;
         return st;
     };
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(512) void gemm_dma_kernel(const DmaGemmArgs g) {
     };
 
     for (int c = 0; c < nch; ++c) {
-        const int nt = min(8, gtiles - 8 * c), na = (nt + 1) >> 1;
+        const int nt = cbase + (c < cext ? 1 : 0), na = (nt + 1) >> 1;
         const int mine = kh ? nt - na : na, toff = kh ? na : 0;
         switch (mine) {
             case 0: run_chunk(std::integral_constant<int, 0>{}, toff); break;
