@@ -719,9 +719,13 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             gemm(0, 0, m, k, n, dz, n, weight, k, dx, k)            # dx[m,k] = dz[m,n] W[n,k]
-        if sinks is not None and _SIDE_ENABLED and ctx.needs_input_grad[0] and _exp("VOCR_LINEAR_DW_OVERLAP", "1") == "1":
-            # parameter gradients go straight into the optimiser's buffers: nothing downstream of this node reads them, so they run on
-            # the low-priority side stream (joined before the optimiser step like every other weight gradient)
+        # The bridge's parameter gradients go straight into the optimiser's buffers and nothing downstream of this node reads them, so they
+        # run on the low-priority side stream (joined before the optimiser step like every other weight gradient).  The prob layer's
+        # stay on the main stream: on the side stream its 0.05-ms product sat beside the top layer's persistent backward sweep for the
+        # sweep's whole length and cost it 0.09 ms (same-box 15.35 / 15.38 -> 15.34 / 15.34 ms).  VOCR_LINEAR_DW_OVERLAP (experiments):
+        # 1 both layers on the side stream, 0 neither.
+        ov = _exp("VOCR_LINEAR_DW_OVERLAP", "2")
+        if sinks is not None and _SIDE_ENABLED and ctx.needs_input_grad[0] and (ov == "1" or (ov == "2" and ctx.relu)):
             side = side_stream()
             side.wait_stream(torch.cuda.current_stream())
             for t_ in (dz, x):
