@@ -28,6 +28,8 @@ print("VOCR_ROCTX=1 rocprofv3 --kernel-trace --marker-trace -- python3 bench.py 
 for k, (n, us) in acc.items():
     print("  %-24s calls %4d   mean host span %9.1f us" % (k, n, us / n))
 PY
+# the final bench line reports the traffic measured by THIS run's passes (on the box only; copy gpurun_out/$T/kernel_traffic.json into profiles/ to keep it)
+if [ "$CFG" = c1 ] && [ -s gpurun_out/$T/kernel_traffic.json ]; then cp gpurun_out/$T/kernel_traffic.json profiles/kernel_traffic.json; fi
 python bench.py --config $CFG > gpurun_out/$T/bench.json 2> gpurun_out/$T/bench.err; echo "bench rc $?"
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/$T/smoke.txt 2>&1; tail -2 gpurun_out/$T/smoke.txt
 /tmp/clock_calib >> gpurun_out/$T/clock_calib.txt 2>&1

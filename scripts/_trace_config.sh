@@ -1,4 +1,4 @@
-cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; C=${1:-c4}; T=r05c_$C; mkdir -p gpurun_out/$T
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; C=${1:-c4}; T=${2:-r05c}_$C; mkdir -p gpurun_out/$T
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$T/trace -- python3 bench.py --config $C --steps 8 --warmup 3 --no-cpu-baseline --no-gemm-alone > gpurun_out/$T/bench_profiled.json 2> gpurun_out/$T/bench_profiled.err
 python scripts/timeline.py $(find gpurun_out/$T/trace -name "*kernel_trace.csv" | head -1) 5 > gpurun_out/$T/timeline.txt 2>&1
 cp $(find gpurun_out/$T/trace -name "*kernel_stats.csv" | head -1) gpurun_out/$T/kernel_stats.csv
