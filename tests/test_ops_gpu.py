@@ -729,3 +729,38 @@ def test_clamp_adam_matches_torch(dev):
             opt.step()
             ops.clamp_adam(pg, g.to(dev), m, v, 1e-3, 0.9, 0.999, 1e-8, wd, 5.0, 1.0, step)
         _close(pg, pr, 1e-6, 1e-7, "adam wd=%g" % wd)
+
+
+@pytest.mark.parametrize("n,p", [(1 << 20, 0.5), (4099, 0.3), (3, 0.5), (1 << 18, 0.0)])
+def test_device_drawn_dropout_is_a_function_of_seed_and_element(dev, n, p):
+    """nn.LSTM(dropout=p)'s inter-layer mask drawn on the device (vocr_dropout_fwd; no reference stream to match: torch's own Philox
+    offsets are not part of the contract).  What IS: mask values are exactly 0 or 1 / (1 - p), out == x * mask bit for bit, the mask is a
+    function of (seed, element index) alone - same seed: same mask, whatever the length or the 16-byte / scalar-tail split; another seed:
+    another mask - the keep rate sits inside a 5-sigma binomial band, and the backward multiplies by the SAME mask."""
+    from vistaocr_amd import ops
+    x = (_rand((n,), 31) + 2.0).to(dev)                        # no zeros in x: out == 0 <=> mask == 0
+
+    def draw(t, seed):
+        tt = t.clone().requires_grad_(True)
+        out = ops.DropoutFn.apply(tt, p, seed)
+        out.backward(torch.ones_like(out))
+        return out.detach(), tt.grad.detach()
+
+    out, mask = draw(x, 1234)
+    scale = 1.0 / (1.0 - p)
+    vals = torch.unique(mask).cpu().tolist()
+    assert set(vals) <= {0.0, float(np.float32(scale))}, vals
+    assert torch.equal(out, x * mask)
+    keep = float((mask != 0).double().mean())
+    assert abs(keep - (1.0 - p)) <= 5.0 * math.sqrt(max(p * (1.0 - p), 1e-12) / n) + (0.5 if n < 16 else 0.0), keep
+    out2, mask2 = draw(x, 1234)
+    assert torch.equal(mask, mask2) and torch.equal(out, out2)
+    if n > 8:
+        # element e's draw does not depend on the tensor's length (so neither on which loop of the kernel handled it)
+        _, mask_short = draw(x[: n - 3].contiguous(), 1234)
+        assert torch.equal(mask_short, mask[: n - 3])
+        if p > 0:
+            _, mask3 = draw(x, 1235)
+            assert not torch.equal(mask, mask3)
+            agree = float((mask3 == mask).double().mean())
+            assert abs(agree - (p * p + (1 - p) * (1 - p))) < 0.05, agree      # independent streams
