@@ -141,7 +141,7 @@ def lstm_flops(args, first_dim_arg):
 
 
 # MFMA FLOPs a launch EXECUTES per algorithmic FLOP: the F(2,3) kernels issue 4 multiplications where the direct form needs 6, the
-# F(4,3) kernel (forward / data-gradient launches with >= 128 output channels) 6 where it needs 12.  The shipped library has one code
+# F(4,3) kernel (forward / data-gradient launches with >= 64 output channels) 6 where it needs 12.  The shipped library has one code
 # path per shape (the kernel-variant switches exist only in -DVOCR_EXPERIMENTS builds), so these are constants of the product
 _WINO4 = True
 # the weight gradient applies F(3,2) along the row AND across row pairs: 16 multiplications where the direct form needs 36, times
@@ -151,7 +151,7 @@ _WGRAD2D = True
 
 def executed_share(name, args):
     if name == "vocr_conv3x3_wino_fwd":
-        return 0.5 if (_WINO4 and args[8] >= 128) else 2.0 / 3.0
+        return 0.5 if (_WINO4 and args[8] >= 64) else 2.0 / 3.0
     if name == "vocr_conv3x3_wgrad_wino":
         h = args[6]
         return (4.0 / 9.0) * (2.0 * ((h + 1) // 2) / h) if (_WGRAD2D and (args[5] * args[8]) % 4 == 0) else 2.0 / 3.0
@@ -584,7 +584,7 @@ def run_rank(args):
                         executed_achieved=round(cf_ex / (cf_ms * 1e-3) / 1e12, 2) if cf_ms > 0 else 0.0,
                         avg_launch_ms=round(cf_ms / max(1, len(fwd_only)), 4), launches_timed=len(fwd_only),
                         what="forward-pass launches of the conv kernels only (nothing else on the chip); achieved = algorithmic direct-convolution "
-                             "FLOPs / time, executed = what the kernels issue: 1/2 of them in the F(4,3) launches (>= 128 output channels), 2/3 in the F(2,3) ones")
+                             "FLOPs / time, executed = what the kernels issue: 1/2 of them in the F(4,3) launches (>= 64 output channels), 2/3 in the F(2,3) ones")
         conv_fwd["frac"] = round(conv_fwd["achieved"] / peak, 4)
         conv_fwd["executed_frac"] = round(conv_fwd["executed_achieved"] / peak, 4)
         # whole step: algorithmic and executed MFMA FLOPs from the shapes of the calls the step made (un-timed profile pass)

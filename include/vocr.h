@@ -65,7 +65,7 @@ size_t vocr_conv3x3_wgrad_workspace_bytes(int n, int cin, int h, int w, int cout
 int vocr_conv3x3_wgrad(const float* x, const float* dy, float* dw, void* workspace,
                        int n, int cin, int h, int w, int cout, void* stream);
 /* Same op with a minimal-filtering transform ALONG THE ROW (conv_wino.hip), fp32 operands and accumulation: F(4,3) - half of the
- * direct form's multiplications - for a convolution with at least 128 output channels, F(2,3) - two thirds - below.  A weight pack is
+ * direct form's multiplications - for a convolution with at least 64 output channels, F(2,3) - two thirds - below.  A weight pack is
  * OPAQUE: the transformed filter rows in the layout of the kernel that vocr_conv3x3_wino_fwd will pick for a convolution with THAT
  * many output channels, followed by the direct pack's 9 rows per channel (the last partial round of tiles is computed in the direct
  * form).  vocr_conv3x3_wino_pack_floats(cout, cin) = floats of the pack of a convolution with `cout` outputs and `cin` inputs

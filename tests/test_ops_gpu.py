@@ -50,7 +50,7 @@ def _close(a, b, rtol, atol, what="", max_bad_frac=0.0):
 @pytest.mark.parametrize("form", ["transform", "direct"])
 def test_conv3x3_fwd_dgrad_wgrad(dev, n, cin, h, w, cout, form, monkeypatch):
     """Both forms of the three conv kernels against F.conv2d: "transform" = minimal filtering along the row (conv_wino.hip, the default
-    for Cin >= 4: F(4,3) for forward / data-gradient launches with >= 128 output channels, F(2,3) below, F(3,2) weight gradient),
+    for Cin >= 4: F(4,3) for forward / data-gradient launches with >= 64 output channels, F(2,3) below, F(3,2) weight gradient),
     "direct" = conv.hip (VOCR_CONV_WINO=0 / VOCR_WGRAD_WINO=0, and what Cin < 4 always uses)."""
     from vistaocr_amd import ops
     monkeypatch.setattr(ops, "_WINO", form == "transform")

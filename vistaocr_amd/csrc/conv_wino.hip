@@ -69,16 +69,19 @@ static int wino2_mode() {
     static const int v = VOCR_EXPERIMENT_INT("VOCR_CONV_WINO2", 1);
     return v;
 }
-// VOCR_CONV_WINO4 (default 1): F(4,3) along the row (conv3x3_wino4_body) for the forward / data-gradient launches with >= 128 output
+// VOCR_CONV_WINO4 (default 1): F(4,3) along the row (conv3x3_wino4_body) for the forward / data-gradient launches with >= 64 output
 // channels: own pack (18 transformed + 9 direct rows per channel); 0: F(2,3) everywhere (round 3 / early round 4)
 static int wino4_mode() {
     static const int v = VOCR_EXPERIMENT_INT("VOCR_CONV_WINO4", 1);
     return v;
 }
-// which packs / launches take the F(4,3) kernel: convolutions with at least 128 OUTPUT channels (the forward of a layer with Cout >= 128, the
-// data gradient of a layer with Cin >= 128); measured slower than F(2,3) with 64 (eight segments per workgroup)
+// which packs / launches take the F(4,3) kernel: convolutions with at least 64 OUTPUT channels (the forward of a layer with Cout >= 64, the
+// data gradient of a layer with Cin >= 64).  Round 4 measured the 64-channel launches slower than F(2,3) (one 8-wave workgroup of eight
+// segments) and kept them on F(2,3); with two 4-wave workgroups per CU (conv3x3_wino4x2_kernel_64) they are faster: 64 -> 64 at 30x600
+// 255 -> 247 us forward, 249 -> 240 data gradient, the 64-channel data gradient of 64 -> 128 at 15x420 179 -> 162 (same-box step
+// 15.27 / 15.28 / 15.29 -> 15.24 / 15.24 / 15.26 ms)
 static int wino4_min_cout() {
-    static const int v = VOCR_EXPERIMENT_INT("VOCR_CONV_WINO4_MINCO", 128);      // experiments: 64
+    static const int v = VOCR_EXPERIMENT_INT("VOCR_CONV_WINO4_MINCO", 64);       // experiments: 128 = rounds 4 - 5's rule
     return v;
 }
 static bool wino4_for(int cout) { return wino4_mode() != 0 && cout >= wino4_min_cout() && cout % 4 == 0; }
