@@ -9,7 +9,7 @@ def timeit(fn, n=20):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n
-for n, cin, c, h, w in [(32, 8, 64, 30, 600), (32, 8, 128, 15, 420), (32, 8, 256, 7, 294)]:
+for n, cin, c, h, w in [(32, 8, 64, 30, 600), (32, 8, 128, 15, 420), (32, 8, 256, 7, 294), (32, 8, 64, 30, 1178), (32, 8, 64, 30, 1180)]:      # 1178: configs[3]'s widest line (W % 4 = 2)
     oh, ow = h // 2, int(w * 0.7)
     x = torch.randn(n, cin, h, w, device=dev); wt = torch.randn(c, cin, 3, 3, device=dev) * 0.1
     bias = torch.zeros(c, device=dev); gamma = torch.ones(c, device=dev); beta = torch.zeros(c, device=dev)
