@@ -3,7 +3,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$T/trace -- p
 python scripts/timeline.py $(find gpurun_out/$T/trace -name "*kernel_trace.csv" | head -1) 5 > gpurun_out/$T/timeline.txt 2>&1
 cp $(find gpurun_out/$T/trace -name "*kernel_stats.csv" | head -1) gpurun_out/$T/kernel_stats.csv
 rm -rf gpurun_out/$T/trace
-timeout 600 python bench.py --config $C --no-cpu-baseline > gpurun_out/$T/bench.json 2> gpurun_out/$T/bench.err; echo "rc $?"
+timeout 900 python bench.py --config $C > gpurun_out/$T/bench.json 2> gpurun_out/$T/bench.err; echo "rc $?"
 python - <<PY
 import json
 d=json.load(open('gpurun_out/$T/bench.json'))
