@@ -40,9 +40,11 @@ const char* vocr_last_error(void);
 /* The contract this header describes.  History: 2 = round 2 (caller-owned health word); 3 = round 3/4 (health words report-only and
  * cleared by the caller, LSTM workspace survives between the vocr_lstm_fwd_range calls of a sweep, larger vocr_gemm_workspace_bytes,
  * vocr_gemm_pair / vocr_lstm_bwd_parts / vocr_profile_range_*, x-fastest conv weight pack); 4 = round 5 (packed sequence rows:
- * vocr_lstm_*_packed, vocr_seq_rowmap, vocr_gather_rows; VOCR_LSTM_SWEEP validated; experiment switches compiled out).  A binding compares vocr_abi_version()
+ * vocr_lstm_*_packed, vocr_seq_rowmap, vocr_gather_rows; VOCR_LSTM_SWEEP validated; experiment switches compiled out); 5 = round 6
+ * (the next layer's x-projection behind the forward sweep: vocr_lstm_fwd_lead / vocr_lstm_xproj_follow / vocr_lstm_xproj_pack,
+ * vocr_dropout_mask).  A binding compares vocr_abi_version()
  * with the VOCR_ABI_VERSION it was written against and refuses a library that answers anything else. */
-#define VOCR_ABI_VERSION 4
+#define VOCR_ABI_VERSION 5
 int  vocr_abi_version(void);
 /* Named ranges on the profiler's timeline (rocprofv3 --marker-trace), nested push / pop on the calling thread.  roctx is dlopen'ed on
  * first use; returns 0 when the range was recorded, 1 when roctx is not available (not an error), negative on a bad argument.  The
@@ -237,6 +239,9 @@ int vocr_add(const float* x, const float* y, float* out, size_t count, void* str
 int vocr_scale_dev(const float* x, const float* scalar, float* out, size_t count, void* stream);
 /* mask[i] = (hash(seed,i) >= p) ? 1/(1-p) : 0 ; out = x*mask */
 int vocr_dropout_fwd(const float* x, float* out, float* mask, size_t count, float p, uint64_t seed, void* stream);
+/* the mask of vocr_dropout_fwd alone (it depends on the seed and the element index only): lets a consumer that applies the mask itself
+ * (vocr_lstm_xproj_follow) have it before x exists */
+int vocr_dropout_mask(float* mask, size_t count, float p, uint64_t seed, void* stream);
 
 /* ---- nn.LSTM recurrence on a packed, length-sorted batch — src/models/cnnlstm.py:148-149,288-290 ---------- */
 /* One direction pair of one layer.  xproj[dir][T][B][4H] = x W_ih^T + b_ih + b_hh (gate order i,f,g,o),
@@ -312,6 +317,32 @@ int vocr_lstm_fwd_packed(const float* xproj, const float* whh_fwd, const float* 
 int vocr_lstm_bwd_packed(const float* dy, const float* dy_mask, const float* whht_fwd, const float* whht_rev, const int32_t* lens,
                          const float* gates, const float* cell, float* dgates, float* dbias, void* workspace, int t, int b, int h,
                          int rows, int32_t* health, void* stream);
+
+/* ---- the next layer's x-projection BEHIND the forward sweep — src/models/cnnlstm.py:148-149,288-290 (cuDNN's multi-layer RNN ---------
+ * overlaps layer l+1's input GEMM with layer l's recurrence; nn.LSTM's inter-layer dropout: src/train_cnn_lstm.py:331) */
+/* A forward sweep is latency-bound and leaves most of every CU's matrix pipe idle.  vocr_lstm_xproj_follow is a kernel that runs BESIDE
+ * the sweep of layer l (launch it on a second stream, in either order with the sweep; one 4-wave workgroup per CU next to the sweep's
+ * 8-wave workgroup, wave priority below the sweep's) and computes layer l+1's x-projection from the rows the sweep has produced so
+ * far: every chain (direction, 4 batch rows) of the sweep publishes its step count, the follower multiplies 16 steps of a chain at a
+ * time - the chain's OWN direction half of y (x `mask`, the pre-scaled inter-layer dropout mask [rows][2H], or NULL), K = H - by the
+ * matching half of W_ih of both directions of layer l+1, so neither direction waits for the other:
+ *     out[src][tgt][row][4H] = y[row][src*H .. src*H+H) . W_ih(l+1, tgt)[:, src*H .. src*H+H)^T  (+ bias[tgt][4H] in the src = 0 plane)
+ * and layer l+1's sweep, vocr_lstm_fwd_lead, adds the two source planes: xproj = out[0] ([2][rows][4H], the layout vocr_lstm_fwd
+ * takes), xproj2 = out[1].  vocr_lstm_fwd_lead is vocr_lstm_fwd (rows = 0) / vocr_lstm_fwd_packed (rows > 0) with that second addend
+ * (NULL: none) and the follower's protocol: epoch != 0 makes the sweep publish its progress under that number (the caller passes the
+ * same fresh non-zero number to the sweep and to its follower; a stale word of an earlier sweep in the shared workspace then never
+ * matches) and store y write-through; epoch = 0: nobody follows.  Both calls take the SAME workspace (vocr_lstm_workspace_bytes).
+ * wpack: W_ih(l+1) of both directions in MFMA-fragment order, vocr_lstm_xproj_pack_bytes(h) bytes, rebuilt by vocr_lstm_xproj_pack
+ * whenever the weights change.  A follower whose sweep never arrives gives up after a bounded wait: NaN output + health[0].
+ * Shapes: vocr_lstm_follow_supported (16 < B <= 32, H = 512 = the next layer's H, the wide 4-row chain sweep); rows < 262144. */
+int vocr_lstm_follow_supported(int b, int h);
+size_t vocr_lstm_xproj_pack_bytes(int h);
+int vocr_lstm_xproj_pack(const float* w_ih_fwd, const float* w_ih_rev, float* wpack, int h, void* stream);
+int vocr_lstm_fwd_lead(const float* xproj, const float* xproj2, const float* whh_fwd, const float* whh_rev, const int32_t* lens,
+                       float* y, float* gates, float* cell, void* workspace, int t, int b, int h, int rows, unsigned epoch,
+                       int32_t* health, void* stream);
+int vocr_lstm_xproj_follow(const float* y, const float* mask, const float* wpack, const float* bias, float* out, const int32_t* lens,
+                           const void* workspace, int t, int b, int h, int rows, unsigned epoch, int32_t* health, void* stream);
 
 /* ---- CTC: warpctc_pytorch.CTCLoss — src/train_cnn_lstm.py:358,138 ------------------------------------------ */
 /* logits[T][B][V] pre-softmax, blank = 0.  labels flat int32 (device), label_offsets[B], label_lens[B],

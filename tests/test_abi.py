@@ -23,8 +23,8 @@ def test_library_builds_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "libvocr.so does not export %s" % name
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
-    assert lib.vocr_abi_version() == _lib.ABI_VERSION == 4
-    assert re.search(r"#define VOCR_ABI_VERSION\s+4\b", open(os.path.join(ROOT, "include", "vocr.h")).read())
+    assert lib.vocr_abi_version() == _lib.ABI_VERSION == 5
+    assert re.search(r"#define VOCR_ABI_VERSION\s+5\b", open(os.path.join(ROOT, "include", "vocr.h")).read())
 
 
 def test_stale_or_foreign_library_is_refused(monkeypatch):

@@ -4,12 +4,12 @@ There is NO fallback: if the shared library is missing or a call fails, a Runtim
 product path never computes on the CPU and never imports oracle/."""
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_size_t, c_uint64, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_size_t, c_uint32, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvocr.so")
 
-P, I, F, Z, U64 = c_void_p, c_int, c_float, c_size_t, c_uint64
+P, I, F, Z, U64, U32 = c_void_p, c_int, c_float, c_size_t, c_uint64, c_uint32
 
 # name -> (restype, argtypes); mirrors include/vocr.h one to one (tests/test_abi.py checks both directions)
 SIGNATURES = {
@@ -71,6 +71,7 @@ SIGNATURES = {
     "vocr_add": (I, [P, P, P, Z, P]),
     "vocr_scale_dev": (I, [P, P, P, Z, P]),
     "vocr_dropout_fwd": (I, [P, P, P, Z, F, U64, P]),
+    "vocr_dropout_mask": (I, [P, Z, F, U64, P]),
     "vocr_lstm_workspace_bytes": (Z, [I, I, I]),
     "vocr_lstm_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, P, P]),
     "vocr_lstm_fwd_range": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, P, P]),
@@ -83,6 +84,11 @@ SIGNATURES = {
     "vocr_seq_rowmap": (I, [P, I, I, I, P, P, P]),
     "vocr_gather_rows": (I, [P, P, P, ctypes.c_long, I, P, P]),
     "vocr_lstm_fwd_packed": (I, [P, P, P, P, P, P, P, P, I, I, I, I, P, P]),
+    "vocr_lstm_follow_supported": (I, [I, I]),
+    "vocr_lstm_xproj_pack_bytes": (Z, [I]),
+    "vocr_lstm_xproj_pack": (I, [P, P, P, I, P]),
+    "vocr_lstm_fwd_lead": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, U32, P, P]),
+    "vocr_lstm_xproj_follow": (I, [P, P, P, P, P, P, P, I, I, I, I, U32, P, P]),
     "vocr_lstm_bwd_packed": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P]),
     "vocr_ctc_workspace_bytes": (Z, [I, I, I, I]),
     "vocr_ctc_loss_grad": (I, [P, P, P, P, P, P, P, P, I, I, I, I, P]),
@@ -96,7 +102,7 @@ SIGNATURES = {
     "vocr_comm_destroy": (I, [P]),
 }
 
-ABI_VERSION = 4          # include/vocr.h: VOCR_ABI_VERSION
+ABI_VERSION = 5          # include/vocr.h: VOCR_ABI_VERSION
 
 _lib = None
 

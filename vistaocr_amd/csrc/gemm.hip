@@ -369,6 +369,14 @@ __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ 
     }
 }
 
+__global__ void dropout_mask_kernel(float* __restrict__ mask, size_t n, float p, float scale, uint64_t seed) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const float u = (float)(mix32(seed * 0x9e3779b97f4a7c15ull + e) >> 8) * (1.0f / 16777216.0f);
+        mask[e] = (u >= p) ? scale : 0.f;
+    }
+}
+
 // bchw -> [w][b][c*h]: one workgroup transposes a 64(w) x 64(ch) tile of one image through LDS so both the
 // read (along w) and the write (along c*h) are coalesced.
 __global__ void bchw_to_wbch_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int CH, int W, int fwd) {
@@ -685,6 +693,15 @@ extern "C" int vocr_scale_dev(const float* x, const float* scalar, float* out, s
     if (count == 0) return VOCR_OK;
     scale_dev_kernel<<<ew_grid(count), 256, 0, (hipStream_t)stream>>>(x, scalar, out, count, ew_vec(x, out, out));
     VOCR_CHECK_LAUNCH("vocr_scale_dev");
+    return VOCR_OK;
+}
+
+extern "C" int vocr_dropout_mask(float* mask, size_t count, float p, uint64_t seed, void* stream) {
+    VOCR_CHECK_ARG(mask, "vocr_dropout_mask: null pointer");
+    VOCR_CHECK_ARG(p >= 0.f && p < 1.f, "vocr_dropout_mask: p must be in [0,1)");
+    if (count == 0) return VOCR_OK;
+    dropout_mask_kernel<<<ew_grid(count), 256, 0, (hipStream_t)stream>>>(mask, count, p, 1.0f / (1.0f - p), seed);
+    VOCR_CHECK_LAUNCH("vocr_dropout_mask");
     return VOCR_OK;
 }
 

@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_chain(const float* __restrict__ 
     const int kbase = wave * (H >> 2) + q * 4;
     const float* whh = dir ? whh_r : whh_f;
     unsigned* cflags = flags + chain * 32;
-    const bool local = chain_is_xcd_local(ids + chain * 32, members, member, status, health, (unsigned*)(lds + 4 * 16 * 65)) && !force_wt;
+    const bool local = chain_is_xcd_local(ids + chain * 32, members, member, status, health, (unsigned*)(lds + 4 * 16 * 65)) && !(force_wt & 1);
 
     // resident W_hh fragments: tile j holds units unit0+4j..+3; B-operand lane lr = gate (lr>>2), unit 4j + (lr&3)
     f32x4 wv[4][KQ4];
@@ -649,7 +649,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_chain4v(const float* __restrict_
     const int nrows = min(B - b0, 4);
     const int kbase = wave * KW;
     const float* whh = dir ? whh_r : whh_f;
-    const bool local = chain_is_xcd_local(ids + chain * 32, members, member, status, health, (unsigned*)(lds + 4 * 4 * 65), kHandoffSentinel) && !force_wt;
+    const bool local = chain_is_xcd_local(ids + chain * 32, members, member, status, health, (unsigned*)(lds + 4 * 4 * 65), kHandoffSentinel) && !(force_wt & 1);
 
     // resident B operand: lane = gate column (gate, local unit) = (lane >> 4, lane & 15), the wave's KW k
     f32x4 wv[NL];
@@ -831,7 +831,8 @@ __global__ __launch_bounds__(512) void lstm_fwd_chain4w(const float* __restrict_
                                                         const float* __restrict__ whh_r, const int32_t* __restrict__ lens,
                                                         float* y, float* __restrict__ gates, float* __restrict__ cell,
                                                         float* hx, unsigned* ids, unsigned* status, unsigned* health, int T, int B, int NT4,
-                                                        int force_wt, int s0, int s1, int nap, int packed_rows) {
+                                                        int force_wt, int s0, int s1, int nap, int packed_rows,
+                                                        const float* __restrict__ xproj2, unsigned long long* prog, unsigned* done, unsigned epoch) {
     constexpr int H = 64 * KQ4;
     constexpr int members = H >> 5;                   // 32 units each
     constexpr int KW = H / 8;                         // k per wave
@@ -851,7 +852,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_chain4w(const float* __restrict_
     const int nrows = min(B - b0, 4);
     const int kbase = wave * KW;
     const float* whh = dir ? whh_r : whh_f;
-    const bool local = chain_is_xcd_local(ids + chain * 32, members, member, status, health, (unsigned*)(lds + 8 * 4 * RP), kHandoffSentinel) && !force_wt;
+    const bool local = chain_is_xcd_local(ids + chain * 32, members, member, status, health, (unsigned*)(lds + 8 * 4 * RP), kHandoffSentinel) && !(force_wt & 1);
 
     // resident B operand: column 64*cb + lane of the workgroup's 128 = (gate, local unit) = (col >> 5, col & 31)
     f32x4 wv[2][NL];
@@ -892,12 +893,19 @@ __global__ __launch_bounds__(512) void lstm_fwd_chain4w(const float* __restrict_
         const int kk = kbase + 4 * (lane >> 2);
         poff = (((kk >> 5) * 4 + prow) * 32 + (kk & 31)) * 4;
     }
-    const float* xrowp = xproj + ((long)dir * sr.total + sr.base + (erowok ? erow : 0)) * 4 * H + (long)egate * H + unit0 + eu;
-    const long xstep = (long)sr.stride * 4 * H;
+    const long xoff0 = ((long)dir * sr.total + sr.base + (erowok ? erow : 0)) * 4 * H + (long)egate * H + unit0 + eu;
+    const float* xrowp = xproj + xoff0;
+    const float* xrowp2 = xproj2 ? xproj2 + xoff0 : nullptr;       // second addend: the other direction's half of the layer below
+    const long xstep = (long)sr.stride * 4 * H;                    // (vocr_lstm_xproj_follow writes one plane per source direction)
     auto x_load = [&](int st) {
         const int tt = dir == 0 ? st : Tc - 1 - st;
-        return xrowp[tt * xstep];
+        float v = xrowp[tt * xstep];
+        if (xrowp2) v += xrowp2[tt * xstep];
+        return v;
     };
+    // a follower (lstm_xproj_follow) multiplies this sweep's rows while it runs: its waves share this CU's matrix pipe at the
+    // lowest priority, the chain is the latency-bound one
+    if (prog && !(force_wt & 2)) __builtin_amdgcn_s_setprio(3);
     float xn = s0 < s1 ? x_load(s0) : 0.f;
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
@@ -905,6 +913,9 @@ __global__ __launch_bounds__(512) void lstm_fwd_chain4w(const float* __restrict_
         for (int i = 0; i < NL; ++i) asm volatile("" : "+v"(wv[cb][i]));      // complete before the loop (see lstm_fwd_chain4v)
 
     LSTM_STAMP_DECL;
+#ifdef VOCR_FOLLOW_PROBE
+    const unsigned long long pc0 = __builtin_amdgcn_s_memtime(), pr0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int step = s0; step < s1; ++step) {
         const int t = dir == 0 ? step : Tc - 1 - step;
         LSTM_STAMP(7);
@@ -955,6 +966,10 @@ __global__ __launch_bounds__(512) void lstm_fwd_chain4w(const float* __restrict_
             for (int r = 0; r < 4; ++r) red[wave][r][64 * cb + lane] = acc[cb][r];
         LSTM_STAMP(1);              // MFMA + partial tile to LDS
         __syncthreads();
+        // every wave of this member has seen its slice of h_{step-1}: each member's cell waves passed the poll of step - 1 before they
+        // stored that (a poll's vmcnt(0) drains the wave's own stores of the step before), so y of steps <= step - 2 has landed
+        if (prog && member == 0 && tid == 0)
+            __hip_atomic_store(prog + chain, ((unsigned long long)epoch << 32) | (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         LSTM_STAMP(2);
         {
             const float pre = (((red[0][erow][ecol] + red[1][erow][ecol]) + (red[2][erow][ecol] + red[3][erow][ecol])) +
@@ -991,12 +1006,30 @@ __global__ __launch_bounds__(512) void lstm_fwd_chain4w(const float* __restrict_
                 __hip_atomic_store(xo, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // write-through (sc1)
                 if (step >= 2) __hip_atomic_store((unsigned*)xr, kHandoffSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            *yo = h;
+            if (prog) __hip_atomic_store(yo, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // the follower may sit on another XCD
+            else *yo = h;
             *go = gv;
             cell[sidx] = c;
         }
         if (tid < 128 && lane == 0) __hip_atomic_store(&sig[wave], step + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         LSTM_STAMP(5);              // cell update + stores issued (waves 0, 1)
+    }
+#ifdef VOCR_FOLLOW_PROBE
+    if (blockIdx.x == 0 && tid == 0) {
+        unsigned long long* o = (unsigned long long*)(ids + 900);
+        o[0] = __builtin_amdgcn_s_memtime() - pc0;
+        o[1] = __builtin_amdgcn_s_memrealtime() - pr0;
+        o[2] = pr0;
+        o[3] = xcc_id();
+    }
+#endif
+    if (prog) {                     // this member's last rows are out: the follower's tail waits for all 16 words of the chain
+        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_store(done + chain * 16 + member, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 #ifdef VOCR_LSTM_STAMPS
     if (lane == 0 && (wave == 0 || wave == 7) && g_lstm_stamp_out) {
@@ -1157,7 +1190,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kowner(const float* __restrict__
     unsigned* cflags = flags + chain * 32;
     // chain on one XCD: partials and flags stay in its L2 (sc0 stores); the loads stay sc1 (L1 bypassed) because a
     // partial block is rewritten every other step, so an L1 copy of it would be stale
-    const bool local = chain_is_xcd_local(ids + chain * 32, members, member, status, health, (unsigned*)(dgl + 16 * DP)) && !force_wt;
+    const bool local = chain_is_xcd_local(ids + chain * 32, members, member, status, health, (unsigned*)(dgl + 16 * DP)) && !(force_wt & 1);
 
     // resident A fragments: aw[j][i][e] = W_hh[q*H + unit0 + 4i + e][n0 + lr] = whht[n0 + lr][q*H + unit0 + 4i + e]
     f32x4 aw[TPW][4];
@@ -1301,7 +1334,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_chain4v(const float* __restrict_
     if (chain >= nch) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int dir = chain / NT4, bt = chain % NT4, unit0 = member * 16, b0 = bt * 4;
-    const bool local = chain_is_xcd_local(ids + chain * 32, members, member, status, health, (unsigned*)(dgl + 2 * 4 * DP), kHandoffSentinel) && !force_wt;
+    const bool local = chain_is_xcd_local(ids + chain * 32, members, member, status, health, (unsigned*)(dgl + 2 * 4 * DP), kHandoffSentinel) && !(force_wt & 1);
 
     // resident A operand: lane = unit u of the wave's column block cb; aw[cb][gate][i][e] = W_hh[gate*H + unit0 + 4i + e][u]
     f32x4 aw[NCB][4][4];
@@ -1527,7 +1560,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_chain4w(const float* __restrict_
     if (chain >= nch) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int dir = chain / NT4, bt = chain % NT4, unit0 = member * 32, b0 = bt * 4;
-    const bool local = chain_is_xcd_local(ids + chain * 32, members, member, status, health, (unsigned*)(dgl + 2 * 4 * DP), kHandoffSentinel) && !force_wt;
+    const bool local = chain_is_xcd_local(ids + chain * 32, members, member, status, health, (unsigned*)(dgl + 2 * 4 * DP), kHandoffSentinel) && !(force_wt & 1);
 
     // resident A operand: lane = unit u = 64*wave + lane; aw[gate][i][e] = W_hh[gate*H + unit0 + 4i + e][u], i < 8
     f32x4 aw[4][8];
@@ -1760,6 +1793,237 @@ bool launch_fwd_fast(int rt, dim3 grid, hipStream_t s, const float* xproj, const
     return false;
 }
 
+
+// ------------------------------------------------------------------------------------------------ x-projection behind the sweep
+// The next layer's x-projection, computed WHILE this layer's forward sweep runs (cuDNN's RNN overlaps the two:
+// src/models/cnnlstm.py:148-149,288-290).  A sweep is latency-bound: its 4x4x1 MFMAs keep a CU's matrix pipe ~42 % busy.  This kernel
+// runs beside it - one 4-wave workgroup per CU (128 KB of LDS: never two on a CU, so the sweep's 256 workgroups stay co-resident
+// whatever the dispatch order; registers: 2 x 176 of the sweep + 1 x <= 160 here per SIMD lane) at wave priority 0 under the
+// sweep's 3 - and multiplies the rows the sweep has already produced:
+//   workgroup (chain, slice) <-> the sweep's (chain, member) numbering, so it normally shares the chain's XCD (never assumed: the
+//   sweep stores y write-through while it is followed and every load of y here is an sc1 load);
+//   unit = 16 consecutive steps of the chain = 64 rows x K = H (the chain's OWN direction half of y: a direction's rows appear in
+//   its own time order, so neither direction waits for the other) x the slice's 256 of the 8H columns (both directions of the next
+//   layer); out[src dir][tgt dir][row][4H'] - the next sweep adds the two source planes (lstm_fwd_chain4w's xproj2);
+//   gate = the chain's progress word {epoch, step} (published by member 0 after the first barrier of a step: y of steps <= step - 2
+//   is complete), the 16 per-member `done` words for the tail.  The epoch makes a stale word of an earlier sweep harmless: no
+//   ordering against the sweep's own 0xFF fill is needed, the caller launches the two kernels on two streams in either order.
+//   A = the 64 x 512 panel (x the inter-layer dropout mask, if any) staged once per unit into LDS as MFMA fragments
+//   [16-byte piece kq][row ^ 8*(kq & 1)] (conflict-free 16-byte writes and reads); B = vocr_lstm_xproj_pack's fragment order: one
+//   contiguous KB per (32 columns, 8 k) straight into registers; v_mfma_f32_32x32x2_f32, wave tile 64 x 64.
+// A timeout (the sweep never arrives) poisons the output and raises the health word; it never hangs.
+__global__ __launch_bounds__(256) void lstm_xproj_pack_kernel(const float* __restrict__ w_f, const float* __restrict__ w_r, float* __restrict__ wpack, int H) {
+    // wpack[src dir d][column tile ct (8H/32)][chunk j (H/8)][lane][4]: lane (c = lane & 31, hh = lane >> 5) holds
+    // W[32 ct + c][d*H + 8j + 4hh .. +3], W = [w_f; w_r] ([8H][2H])
+    const long piece = (long)blockIdx.x * 256 + threadIdx.x;
+    const int lane = piece & 63;
+    const long rest = piece >> 6;
+    const int nj = H / 8, nct = 8 * H / 32;
+    const int j = rest % nj, ct = (rest / nj) % nct, d = rest / ((long)nj * nct);
+    if (d >= 2) return;
+    const int col = 32 * ct + (lane & 31);
+    const float* w = col < 4 * H ? w_f + (long)col * 2 * H : w_r + (long)(col - 4 * H) * 2 * H;
+    ((f32x4*)wpack)[piece] = *(const f32x4*)(w + d * H + 8 * j + 4 * (lane >> 5));
+}
+
+// one wave that sleeps ~us microseconds: launched in front of the follower on ITS stream so that the follower's waves are dispatched
+// behind the sweep's (on a SIMD the older waves win the issue arbitration: the sweep must be the older kernel)
+__global__ void lstm_follow_nap_kernel(int us) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();          // 100 MHz
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)us * 100ull) __builtin_amdgcn_s_sleep(16);
+}
+
+constexpr int kFollowDoneWordC = 640;
+template <bool MASK, int VARIANT = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) void lstm_xproj_follow(const float* y, const float* __restrict__ mask, const float* __restrict__ wpack,
+                                                         const float* __restrict__ bias, float* __restrict__ out,
+                                                         const int32_t* __restrict__ lens, const unsigned long long* prog, const unsigned* done,
+                                                         const unsigned* sweep_status, unsigned epoch, unsigned* health, int T, int B, int NT4,
+                                                         int packed_rows, int probe_nap = 0) {
+    constexpr int H = 512, G = 4 * H, TG = 16, NJ = H / 8;
+    // [128 pieces kq][64 rows][4]: 128 KB, DYNAMIC on purpose: with a static array the compiler derives "one wave per SIMD at most" from
+    // the LDS size and pads the kernel's register allocation to 257 so that nothing else fits on the CU - the sweep must
+    extern __shared__ __attribute__((aligned(16))) float panel[];
+    __shared__ int gate_ok;
+    const int nch = 2 * NT4;
+    const int chain = (int)(blockIdx.x & 7) + 8 * (int)((blockIdx.x >> 3) & 1), slice = blockIdx.x >> 4;
+    if (chain >= nch) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = chain / NT4, bt = chain % NT4;
+    const int nrows = min(B - 4 * bt, 4);
+    const SeqRows sr = seq_rows(lens, T, B, bt, packed_rows);
+    const int Tc = sr.steps;
+    if (!seq_rows_fit(sr, packed_rows)) return;              // the sweep raises the error
+    const long R = sr.total;
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, (int)(R * 2 * H * 4), 0x00020000);
+    // staging: lane = (row_lo = lane & 7, kq_lo = lane >> 3): 8 rows x 128 contiguous bytes per instruction
+    const int srow_lo = lane & 7, skq_lo = lane >> 3;
+    // B fragments of this wave's two 32-column tiles: scalar offset = (tile, chunk), vector offset = lane
+    const int col0 = slice * 256 + wave * 64;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wpack, 0, 2 * 8 * H * H * 4, 0x00020000);
+    const int wbase = ((dir * (8 * H / 32) + col0 / 32) * NJ) * 1024;        // bytes; tile ct: + NJ KB, chunk j: + 1 KB
+    auto b_load = [&](int ct, int j) {
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane * 16, wbase + (ct * NJ + j) * 1024, 0);
+        return (f32x4){__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+    };
+    // the slice's 256 columns lie in ONE of the four [src dir][tgt dir] planes
+    const int tgt = col0 / G;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (long)(dir * 2 + tgt) * R * G), 0, (int)(R * G * 4), 0x00020000);
+    const int li = lane & 31, lk = lane >> 5;
+    float bv[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) bv[ct] = (dir == 0 && bias) ? bias[col0 + 32 * ct + li] : 0.f;
+    bool failed = false;
+    const int units = (Tc + TG - 1) / TG;
+    for (int u = 0; u < units; ++u) {
+        const int s_lo = u * TG, s_hi = min(s_lo + TG, Tc);
+        // ---- gate: rows of steps < s_hi are complete
+        if (tid == 0) {
+            int ok = 0;
+            if (!failed) {
+                unsigned spins = 0;
+                for (;;) {
+                    const unsigned long long pv = __hip_atomic_load(prog + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const bool mine = (unsigned)(pv >> 32) == epoch;
+                    if (mine && (int)(unsigned)pv >= s_hi + 1) { ok = 1; break; }
+                    if (s_hi + 1 >= Tc) {                    // the chain's last steps: every member says so itself
+                        bool all = true;
+                        for (int m = 0; m < 16; ++m) all = all && __hip_atomic_load(done + chain * 16 + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+                        if (all) { ok = 1; break; }
+                    }
+                    if (mine && __hip_atomic_load(sweep_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u) break;      // the sweep gave up
+                    __builtin_amdgcn_s_sleep(32);
+                    // the chain may live on ANOTHER XCD (the dispatcher's round robin continues where the previous kernel stopped: measured,
+                    // sweep workgroup 0 on XCC 7, follower workgroup 0 on XCC 0): this XCD's L2 then keeps serving the line it fetched at
+                    // the first look, sc1 or not, until it is invalidated
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    if (++spins > (1u << 21)) break;
+                }
+                if (ok) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            gate_ok = ok;
+        }
+        __syncthreads();                                     // also: every wave is done with the previous unit's panel
+        if (!gate_ok) failed = true;
+#ifdef VOCR_FOLLOW_PROBE
+        if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 100) && u < 24) {
+            unsigned long long* o = (unsigned long long*)(done - kFollowDoneWordC + 1100) + (blockIdx.x ? 32 : 0);
+            o[u] = __builtin_amdgcn_s_memrealtime();
+            if (u == 0) o[30] = xcc_id();
+        }
+#endif
+        // ---- stage the 64 x 512 panel
+        if (!failed) {
+#pragma unroll 1
+            for (int i = 0; i < 32; i += 4) {
+                u32x4_t v[4];
+                f32x4 mk[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = (i + q) * 4 + wave, row = (c & 7) * 8 + srow_lo, kq = (c >> 3) * 8 + skq_lo;
+                    const int s = s_lo + (row >> 2), r = row & 3;
+                    const bool ok = s < s_hi && r < nrows;
+                    const int t = dir == 0 ? s : Tc - 1 - s;
+                    const long grow = sr.base + (long)sr.stride * t + r;
+                    // rows past the chain's end / the batch: an out-of-range offset reads as zeros
+                    v[q] = __builtin_amdgcn_raw_buffer_load_b128(yrsrc, ok ? (int)((grow * 2 * H + dir * H + 4 * kq) * 4) : -16, 0, kPollAux);
+                    if (MASK) mk[q] = *(const f32x4*)(mask + (ok ? grow * 2 * H + dir * H + 4 * kq : 0));
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = (i + q) * 4 + wave, row = (c & 7) * 8 + srow_lo, kq = (c >> 3) * 8 + skq_lo;
+                    f32x4 a = (f32x4){__uint_as_float(v[q][0]), __uint_as_float(v[q][1]), __uint_as_float(v[q][2]), __uint_as_float(v[q][3])};
+                    if (MASK) a = a * mk[q];
+                    *(f32x4*)(panel + ((long)kq * 64 + (row ^ ((kq & 1) << 3))) * 4) = a;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- 64 x 64 wave tile over K = 512
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        if (!failed) {
+            constexpr int D = 4;                              // B chunks in flight
+            f32x4 bq[D][2];
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) bq[d][ct] = b_load(ct, d);
+            const float* ap = panel + ((long)lk * 64 + (li ^ (lk << 3))) * 4;       // piece kq = 2j + lk, row tile rt: + 32 rows
+            f32x4 af[2][2];                                   // [parity of the chunk][row tile]: one chunk ahead
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) af[0][rt] = *(const f32x4*)(ap + 32 * rt * 4);
+#pragma unroll 1
+            for (int j0 = 0; j0 < NJ; j0 += D) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    const int j = j0 + d, jn = min(j + 1, NJ - 1), jl = min(j + D, NJ - 1);      // clamped: the last loads repeat, nothing branches
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt) af[(d + 1) & 1][rt] = *(const f32x4*)(ap + ((long)(2 * jn) * 64 + 32 * rt) * 4);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                            for (int ct = 0; ct < 2; ++ct) {
+                                if (VARIANT == 0) acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[d & 1][rt][e], bq[d][ct][e], acc[rt][ct], 0, 0, 0);
+#ifdef VOCR_FOLLOW_PROBE       // timing probes only (WRONG results): the same matrix-pipe cycles in shorter instructions
+                                if (VARIANT == 1) {
+#pragma unroll
+                                    for (int h2 = 0; h2 < 2; ++h2) {
+                                        f32x4 c = {acc[rt][ct][4 * h2], acc[rt][ct][4 * h2 + 1], acc[rt][ct][4 * h2 + 2], acc[rt][ct][4 * h2 + 3]};
+                                        c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[d & 1][rt][e], bq[d][ct][e], c, 0, 0, 0);
+#pragma unroll
+                                        for (int z = 0; z < 4; ++z) acc[rt][ct][4 * h2 + z] = c[z];
+                                    }
+                                }
+                                if (VARIANT == 2) {
+#pragma unroll
+                                    for (int h2 = 0; h2 < 8; ++h2) {
+                                        f32x4 c = {acc[rt][ct][4 * (h2 & 3)], acc[rt][ct][4 * (h2 & 3) + 1], acc[rt][ct][4 * (h2 & 3) + 2], acc[rt][ct][4 * (h2 & 3) + 3]};
+                                        c = __builtin_amdgcn_mfma_f32_4x4x1f32(af[d & 1][rt][e], bq[d][ct][e], c, 0, 0, 0);
+#pragma unroll
+                                        for (int z = 0; z < 4; ++z) acc[rt][ct][4 * (h2 & 3) + z] = c[z];
+                                    }
+                                }
+#endif
+                            }
+                    if (probe_nap > 0) __builtin_amdgcn_s_sleep(8);
+                    if (probe_nap > 1) __builtin_amdgcn_s_sleep(8);
+                    if (probe_nap > 2) __builtin_amdgcn_s_sleep(16);
+                    if (probe_nap > 3) __builtin_amdgcn_s_sleep(32);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // the slot just consumed takes chunk j + D: D - 1 chunks (3 x 1024 MFMA cycles) of flight
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) bq[d][ct] = b_load(ct, jl);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        // ---- plane[row][4H]: C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const int s = s_lo + (row >> 2), rr = row & 3;
+                const int t = dir == 0 ? s : Tc - 1 - s;
+                const long grow = sr.base + (long)sr.stride * t + rr;
+                const int off = (s < s_hi && rr < nrows) ? (int)((grow * G + col0 % G + li) * 4) : -4;      // out of range: dropped
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(failed ? __uint_as_float(0x7FC00000u) : acc[rt][ct][r] + bv[ct]), orsrc, off, 32 * ct * 4, 0);
+            }
+    }
+    if (failed && tid == 0 && health) __hip_atomic_store(health, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 // workgroups of 256 threads that are certainly co-resident: one per CU (a persistent sweep deadlocks if a
@@ -1863,9 +2127,13 @@ extern "C" size_t vocr_lstm_workspace_bytes(int t, int b, int h) {
 
 static bool lstm_packed_kind_ok(int b, int h);
 
+// words of the sweep's 4-KB block (behind the XCC ids [0, 512) and the status word [512]) that a followed sweep publishes to
+// lstm_xproj_follow: progress {epoch, step} per chain, one `done` word per (chain, member)
+constexpr int kFollowProgWord = 576, kFollowDoneWord = 640;
+
 static int lstm_fwd_impl(const float* xproj, const float* whh_fwd, const float* whh_rev, const int32_t* lens, float* y,
                          float* gates, float* cell, void* workspace, int t, int b, int h, int step_begin, int step_end,
-                         int packed_rows, int32_t* health, void* stream) {
+                         int packed_rows, int32_t* health, void* stream, const float* xproj2 = nullptr, unsigned epoch = 0) {
     VOCR_CHECK_ARG(xproj && whh_fwd && whh_rev && lens && y && gates && cell && workspace, "vocr_lstm_fwd: null pointer");
     VOCR_CHECK_ARG(t > 0 && b > 0 && b <= 64 && h > 0 && h % 16 == 0, "vocr_lstm_fwd: need 1<=B<=64 and H%%16==0 (B=%d H=%d)", b, h);
     VOCR_CHECK_ARG(0 <= step_begin && step_begin < step_end && step_end <= t, "vocr_lstm_fwd: bad step range [%d, %d) of %d", step_begin, step_end, t);
@@ -1884,13 +2152,18 @@ static int lstm_fwd_impl(const float* xproj, const float* whh_fwd, const float* 
                        "vocr_lstm_fwd_packed: the packed row layout needs a 4-row chain sweep (ask vocr_lstm_packed_supported; B=%d H=%d)", b, h);
         VOCR_CHECK_ARG(packed_rows % 4 == 0 && packed_rows >= 4 * (1 + 2 * ((b + 3) / 4)), "vocr_lstm_fwd_packed: bad row count %d", packed_rows);
     }
+    VOCR_CHECK_ARG((!xproj2 && !epoch) || (kind == SWEEP_WIDE4 && step_begin == 0 && step_end == t),
+                   "vocr_lstm_fwd_lead: two-plane x-projections / a follower need the wide 4-row chain sweep (ask vocr_lstm_follow_supported; B=%d H=%d)", b, h);
     if (kind != SWEEP_STEP) {
         // arrival flags: [chain <= 8][32 workgroups] at [0..255], XCC ids at [256..511]; status words at [512..]
         unsigned* flags = (unsigned*)workspace;
         unsigned* status = flags + 512;          // the sweep's own status word is per call; a timeout is also reported in the caller's health word
         unsigned* hword = (unsigned*)health;
         const dim3 cg(8 * (h / 16));
-        const int fwt = sweep_write_through() ? 1 : 0;
+        int fwt = sweep_write_through() ? 1 : 0;
+#ifdef VOCR_FOLLOW_PROBE
+        if (getenv("VOCR_FOLLOW_NOPRIO")) fwt |= 2;
+#endif
         const int nt4 = (b + 3) / 4;
         if (kind == SWEEP_WIDE4 || kind == SWEEP_CHAIN4) {
             // self-validating hand-off: the ring starts as the "not written yet" pattern (first range of a sweep only)
@@ -1900,7 +2173,8 @@ static int lstm_fwd_impl(const float* xproj, const float* whh_fwd, const float* 
             if (kind == SWEEP_WIDE4) {
                 static const int nap4w = VOCR_EXPERIMENT_INT("VOCR_LSTM_NAP", 0);      // -1: polls start at once (experiments)
                 lstm_fwd_chain4w<8><<<256, 512, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, hx, blk, blk + 512, hword, t, b, nt4, fwt, step_begin, step_end, nap4w,
-                                                        packed_rows);
+                                                        packed_rows, xproj2, epoch ? (unsigned long long*)(blk + kFollowProgWord) : nullptr,
+                                                        blk + kFollowDoneWord, epoch);
             } else {
                 const dim3 cg4((2 * nt4 > 8 ? 16 : 8) * (h / 16));
                 if (h == 512) lstm_fwd_chain4v<8><<<cg4, 256, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, hx, blk, blk + 512, hword, t, b, nt4, fwt, step_begin, step_end, packed_rows);
@@ -1962,6 +2236,79 @@ extern "C" int vocr_lstm_fwd_packed(const float* xproj, const float* whh_fwd, co
                                     void* stream) {
     VOCR_CHECK_ARG(rows > 0, "vocr_lstm_fwd_packed: rows must be positive");
     return lstm_fwd_impl(xproj, whh_fwd, whh_rev, lens, y, gates, cell, workspace, t, b, h, 0, t, rows, health, stream);
+}
+
+// ---- the next layer's x-projection behind the sweep (lstm_xproj_follow above)
+extern "C" int vocr_lstm_follow_supported(int b, int h) {
+    if (b <= 16 || b > 32 || h != 512) return 0;
+    return lstm_sweep_kind(false, b, h, 8 * (h / 16) <= resident_workgroup_capacity()) == SWEEP_WIDE4 ? 1 : 0;
+}
+
+extern "C" size_t vocr_lstm_xproj_pack_bytes(int h) { return h > 0 ? (size_t)2 * 8 * h * h * sizeof(float) : 0; }
+
+extern "C" int vocr_lstm_xproj_pack(const float* w_ih_fwd, const float* w_ih_rev, float* wpack, int h, void* stream) {
+    VOCR_CHECK_ARG(w_ih_fwd && w_ih_rev && wpack, "vocr_lstm_xproj_pack: null pointer");
+    VOCR_CHECK_ARG(h == 512, "vocr_lstm_xproj_pack: H must be 512 (got %d)", h);
+    VOCR_CHECK_ARG(aligned16(w_ih_fwd) && aligned16(w_ih_rev) && aligned16(wpack), "vocr_lstm_xproj_pack: pointers must be 16-byte aligned");
+    const long pieces = 2l * (8 * h / 32) * (h / 8) * 64;
+    lstm_xproj_pack_kernel<<<(unsigned)(pieces / 256), 256, 0, (hipStream_t)stream>>>(w_ih_fwd, w_ih_rev, wpack, h);
+    VOCR_CHECK_LAUNCH("vocr_lstm_xproj_pack");
+    return VOCR_OK;
+}
+
+extern "C" int vocr_lstm_fwd_lead(const float* xproj, const float* xproj2, const float* whh_fwd, const float* whh_rev, const int32_t* lens,
+                                  float* y, float* gates, float* cell, void* workspace, int t, int b, int h, int rows, unsigned epoch,
+                                  int32_t* health, void* stream) {
+    VOCR_CHECK_ARG(rows >= 0, "vocr_lstm_fwd_lead: rows must be >= 0 (0: dense)");
+    return lstm_fwd_impl(xproj, whh_fwd, whh_rev, lens, y, gates, cell, workspace, t, b, h, 0, t, rows, health, stream, xproj2, epoch);
+}
+
+extern "C" int vocr_lstm_xproj_follow(const float* y, const float* mask, const float* wpack, const float* bias, float* out,
+                                      const int32_t* lens, const void* workspace, int t, int b, int h, int rows, unsigned epoch,
+                                      int32_t* health, void* stream) {
+    VOCR_CHECK_ARG(y && wpack && out && lens && workspace, "vocr_lstm_xproj_follow: null pointer");
+    VOCR_CHECK_ARG(vocr_lstm_follow_supported(b, h), "vocr_lstm_xproj_follow: shape not taken (ask vocr_lstm_follow_supported; B=%d H=%d)", b, h);
+    VOCR_CHECK_ARG(t > 0 && rows >= 0 && epoch != 0, "vocr_lstm_xproj_follow: need t > 0, rows >= 0, epoch != 0");
+    VOCR_CHECK_ARG(aligned16(y) && aligned16(wpack) && aligned16(out) && (!mask || aligned16(mask)), "vocr_lstm_xproj_follow: pointers must be 16-byte aligned");
+    VOCR_CHECK_ARG((rows ? (long)rows : (long)t * b) * 2 * h * 4 < (1l << 31), "vocr_lstm_xproj_follow: y must stay below 2 GB");
+    const unsigned* blk = (const unsigned*)((const char*)workspace + lstm_ws_handoff_offset(b, h));
+    const int nt4 = (b + 3) / 4;
+    hipStream_t s = (hipStream_t)stream;
+    const int nap_us = getenv("VOCR_FOLLOW_NAP_US") ? atoi(getenv("VOCR_FOLLOW_NAP_US")) : 0;
+    if (nap_us > 0) lstm_follow_nap_kernel<<<1, 64, 0, s>>>(nap_us);
+    constexpr int kPanelBytes = 128 * 64 * 4 * 4;
+    static bool lds_ok[2] = {false, false};
+    if (!lds_ok[mask != nullptr]) {
+        const hipError_t e = mask ? hipFuncSetAttribute((const void*)lstm_xproj_follow<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPanelBytes)
+                                  : hipFuncSetAttribute((const void*)lstm_xproj_follow<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPanelBytes);
+        if (e != hipSuccess) {
+            vocr_set_error("vocr_lstm_xproj_follow: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed: %s", hipGetErrorString(e));
+            return VOCR_ELAUNCH;
+        }
+        lds_ok[mask != nullptr] = true;
+    }
+#ifdef VOCR_FOLLOW_PROBE
+    const int variant = getenv("VOCR_FOLLOW_VARIANT") ? atoi(getenv("VOCR_FOLLOW_VARIANT")) : 0;
+    const int pnap = getenv("VOCR_FOLLOW_DUTY") ? atoi(getenv("VOCR_FOLLOW_DUTY")) : 0;
+    if (variant || pnap) {
+        hipFuncSetAttribute((const void*)lstm_xproj_follow<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kPanelBytes);
+        hipFuncSetAttribute((const void*)lstm_xproj_follow<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kPanelBytes);
+        hipFuncSetAttribute((const void*)lstm_xproj_follow<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kPanelBytes);
+#define VOCR_FP(V) lstm_xproj_follow<true, V><<<256, 256, kPanelBytes, s>>>(y, mask ? mask : y, wpack, bias, out, lens, (const unsigned long long*)(blk + kFollowProgWord), blk + kFollowDoneWord, blk + 512, epoch, (unsigned*)health, t, b, nt4, rows, pnap)
+        if (variant == 1) VOCR_FP(1); else if (variant == 2) VOCR_FP(2); else VOCR_FP(0);
+#undef VOCR_FP
+        VOCR_CHECK_LAUNCH("vocr_lstm_xproj_follow(probe)");
+        return VOCR_OK;
+    }
+#endif
+    if (mask)
+        lstm_xproj_follow<true><<<256, 256, kPanelBytes, s>>>(y, mask, wpack, bias, out, lens, (const unsigned long long*)(blk + kFollowProgWord), blk + kFollowDoneWord,
+                                                    blk + 512, epoch, (unsigned*)health, t, b, nt4, rows);
+    else
+        lstm_xproj_follow<false><<<256, 256, kPanelBytes, s>>>(y, mask, wpack, bias, out, lens, (const unsigned long long*)(blk + kFollowProgWord), blk + kFollowDoneWord,
+                                                     blk + 512, epoch, (unsigned*)health, t, b, nt4, rows);
+    VOCR_CHECK_LAUNCH("vocr_lstm_xproj_follow");
+    return VOCR_OK;
 }
 
 // to_packed[t*B + b] = packed row of frame (t, b), or -1 where the packed layout has none (t >= the length of b's chain);

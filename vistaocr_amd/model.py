@@ -229,7 +229,12 @@ class CnnOcrModel(nn.Module):
         layers = [(self.lstm.layer(l, "")[1], self.lstm.layer(l, "")[2], self.lstm.layer(l, "")[3],
                    self.lstm.layer(l, "_reverse")[1], self.lstm.layer(l, "_reverse")[2], self.lstm.layer(l, "_reverse")[3])
                   for l in range(self.num_lstm_layers)]
-        prep = ops.forward_prep(convs, layers, torch.is_grad_enabled(), f16)
+        # layers whose x-projection runs BESIDE the forward sweep of the layer below (ops.BiLstmLayerFn's `follow`): decided per batch
+        # below (the sweep kind depends on the batch size); their W_ih packs are weight-only work like the rest of the preparation
+        H = self.num_lstm_hidden_units
+        follow_w = [(self.lstm.layer(l, "")[0], self.lstm.layer(l, "_reverse")[0]) for l in range(1, self.num_lstm_layers)]
+        may_follow = ops.lstm_follow_ok(x.shape[0], H, 2 * H, H)
+        prep = ops.forward_prep(convs, layers, torch.is_grad_enabled(), f16, follow_w if may_follow else ())
         a = x
         for i in range(self.num_rds_layers):
             conv = getattr(self.rapid_ds, "%02d-conv" % i)
@@ -297,6 +302,8 @@ class CnnOcrModel(nn.Module):
             hseq = ops.GatherRowsFn.apply(hseq, maps.to_dense, maps.to_packed, maps.rows)
         rows = maps.rows if maps is not None else 0
         drop = self.lstm.training and self.p_lstm_dropout > 0      # nn.LSTM reads its own .training flag
+        following = may_follow and 16 < b <= 32
+        pre = None
         for l in range(self.num_lstm_layers):
             f = self.lstm.layer(l, "")
             r = self.lstm.layer(l, "_reverse")
@@ -305,6 +312,27 @@ class CnnOcrModel(nn.Module):
             fused = draw and b <= 64
             if draw:
                 self._dropout_calls += 1
+            if following:
+                # layer l + 1's x-projection beside this layer's sweep; an explicit mask rides inside the layer op too
+                fol, mk = None, None
+                if l < self.num_lstm_layers - 1:
+                    nf, nr = self.lstm.layer(l + 1, ""), self.lstm.layer(l + 1, "_reverse")
+                    key = nf[1].data_ptr()
+                    fol = {"w_ih": (nf[0], nr[0]), "out": [],
+                           "bias": prep.lstm[key][0] if prep is not None and key in prep.lstm else ops.lstm_bias_sum(nf[2], nf[3], nr[2], nr[3]),
+                           "wpack": prep.xpack.get(nf[0].data_ptr()) if prep is not None else None}
+                    if self.dropout_masks is not None:
+                        mk = self.dropout_masks[l].to(dev).reshape(T * b, -1)
+                        if maps is not None:
+                            mk = ops.gather_rows(mk, maps.to_dense, maps.rows)
+                    if prep is not None:
+                        prep.wait()
+                with prof_range("model.lstm.l%d" % l):
+                    dp, ds = (self.p_lstm_dropout, self.dropout_seed + self._dropout_calls) if draw else (0.0, 0)
+                    hseq = ops.BiLstmLayerFn.apply(hseq, lens_dev, T, b, f[0], f[1], f[2], f[3], r[0], r[1], r[2], r[3], prep, True, dp, ds, rows,
+                                                   pre, fol, mk)
+                pre = fol["out"][0] if fol is not None else None
+                continue
             with prof_range("model.lstm.l%d" % l):
                 hseq = self._bilstm_layer(hseq, lens_dev, out_w, T, b, f, r, prep,
                                           (self.p_lstm_dropout, self.dropout_seed + self._dropout_calls) if fused else None, rows)

@@ -84,6 +84,37 @@ def side_stream(device=None):
     return _side(device)["stream"]
 
 
+# The stream of the x-projection followers (vocr_lstm_xproj_follow: layer l+1's input GEMM beside layer l's forward sweep) and
+# the number every (sweep, follower) pair shares: never 0, never repeated within 2^32 sweeps.
+_FOLLOW = {}
+_EPOCH = [0]
+
+
+def follow_stream(device=None):
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    st = _FOLLOW.get(idx)
+    if st is None:
+        lo, hi = torch.cuda.Stream.priority_range()
+        with torch.cuda.device(idx):
+            st = _FOLLOW[idx] = torch.cuda.Stream(priority=lo)
+    return st
+
+
+def next_epoch():
+    _EPOCH[0] = (_EPOCH[0] % 0xFFFFFFFE) + 1
+    return _EPOCH[0]
+
+
+_LSTM_FOLLOW = _exp("VOCR_LSTM_FOLLOW", "0") == "1"
+
+
+def lstm_follow_ok(b, h, din_next, h_next):
+    """Layer l+1's x-projection can run behind layer l's forward sweep (include/vocr.h: vocr_lstm_follow_supported)."""
+    return _LSTM_FOLLOW and h_next == h and din_next == 2 * h and bool(_lib.load().vocr_lstm_follow_supported(int(b), int(h)))
+
+
 def mark_side_pending(device=None):
     _side(device)["pending"] = True
 
@@ -185,6 +216,7 @@ class ForwardPrep(object):
     def __init__(self):
         self.packs = {}          # weight.data_ptr() -> (pack_fwd, pack_dgrad)
         self.lstm = {}           # w_hh_f.data_ptr() -> (bsum, wt_f, wt_r)
+        self.xpack = {}          # w_ih_f.data_ptr() -> W_ih of both directions in the follower's fragment order (vocr_lstm_xproj_pack)
         self.event = None        # everything done (the LSTM items come last: they are needed ~4 ms into the step)
         self.pack_events = {}    # weight.data_ptr() -> event behind THAT layer's pack (the second conv layer needs its pack ~0.15 ms into
                                  # the step; one event behind all ~25 pack launches made it wait ~50 us for the deeper layers' packs)
@@ -201,9 +233,25 @@ class ForwardPrep(object):
             torch.cuda.current_stream().wait_event(ev)
 
 
-def forward_prep(conv_weights, lstm_layers, with_transposes, f16=False):
+def lstm_bias_sum(b_ih_f, b_hh_f, b_ih_r, b_hh_r):
+    """[2, 4H]: b_ih + b_hh of both directions (what the x-projection adds)."""
+    H4 = b_ih_f.numel()
+    bsum = torch.empty(2, H4, dtype=torch.float32, device=b_ih_f.device)
+    call("vocr_add", _p(b_ih_f), _p(b_hh_f), _p(bsum[0]), H4, _stream())
+    call("vocr_add", _p(b_ih_r), _p(b_hh_r), _p(bsum[1]), H4, _stream())
+    return bsum
+
+
+def lstm_xproj_pack(w_ih_f, w_ih_r):
+    h = w_ih_f.shape[0] // 4
+    wpack = torch.empty(_lib.load().vocr_lstm_xproj_pack_bytes(h) // 4, dtype=torch.float32, device=w_ih_f.device)
+    call("vocr_lstm_xproj_pack", _p(w_ih_f), _p(w_ih_r), _p(wpack), h, _stream())
+    return wpack
+
+
+def forward_prep(conv_weights, lstm_layers, with_transposes, f16=False, follow_layers=()):
     """conv_weights: 4-D fp32 weights to pack (f16: into the fp16-operand kernels' packs); lstm_layers: [(w_hh_f, b_ih_f, b_hh_f, w_hh_r,
-    b_ih_r, b_hh_r), ...]."""
+    b_ih_r, b_hh_r), ...]; follow_layers: [(w_ih_f, w_ih_r), ...] of the layers whose x-projection runs behind the sweep below them."""
     if not _SIDE_ENABLED or _exp("VOCR_FWD_PREP", "1") != "1":
         return None
     prep = ForwardPrep()
@@ -227,6 +275,9 @@ def forward_prep(conv_weights, lstm_layers, with_transposes, f16=False):
             wt = (transpose2d(w_hh_f), transpose2d(w_hh_r)) if with_transposes else (None, None)
             prep.lstm[w_hh_f.data_ptr()] = (bsum, wt[0], wt[1])
             made.extend(t for t in (bsum,) + wt if t is not None)
+        for (w_ih_f, w_ih_r) in follow_layers:
+            prep.xpack[w_ih_f.data_ptr()] = lstm_xproj_pack(w_ih_f, w_ih_r)
+            made.append(prep.xpack[w_ih_f.data_ptr()])
         prep.event = torch.cuda.Event()
         prep.event.record(side)
     for t in made:
@@ -837,9 +888,14 @@ class BiLstmLayerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, lens_dev, T, B, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r, prep=None, direct_grads=True,
-                drop_p=0.0, drop_seed=0, rows=0):
+                drop_p=0.0, drop_seed=0, rows=0, pre=None, follow=None, drop_mask=None):
         """drop_p > 0: nn.LSTM's inter-layer dropout on this layer's OUTPUT (counter-based mask of vocr_dropout_fwd, as DropoutFn) -
-        here so that its backward can ride on the backward sweep's read of dy instead of being a pass of its own."""
+        here so that its backward can ride on the backward sweep's read of dy instead of being a pass of its own.  drop_mask: the same
+        with a mask that already exists ([R, 2H], pre-scaled; explicit test masks, or vocr_dropout_mask's draw made ahead of the sweep).
+        pre: (plane0, plane1), this layer's x-projection as the two source-direction planes a follower behind the layer below wrote
+        (each [2, R, 4H]; x is then only kept for the backward).  follow: {"w_ih": (f, r) of the NEXT layer, "bias": its [2, 4H] bias
+        sums or None, "wpack": its vocr_lstm_xproj_pack or None, "out": list} - the next layer's x-projection runs on the follow stream
+        beside this layer's sweep (vocr_lstm_xproj_follow) and its two planes are appended to follow["out"]."""
         _need_gpu(x, lens_dev, w_ih_f, w_hh_f, w_ih_r, w_hh_r)
         x = _f32c(x)
         lib = _lib.load()
@@ -848,7 +904,7 @@ class BiLstmLayerFn(torch.autograd.Function):
         dev = x.device
         R = int(rows) if rows else T * B              # rows of every sequence-side matrix of this layer
         assert x.shape[0] == R, (x.shape, R)
-        xproj = torch.empty(2, R, 4 * H, dtype=torch.float32, device=dev)
+        xproj = torch.empty(2, R, 4 * H, dtype=torch.float32, device=dev) if pre is None else None
         ctx.wt = None
         if prep is not None and w_hh_f.data_ptr() in prep.lstm:
             prep.wait()
@@ -866,9 +922,41 @@ class BiLstmLayerFn(torch.autograd.Function):
         ws = _ws(lib.vocr_lstm_workspace_bytes(T, B, H), dev)
         G = 4 * H
 
-        # both directions' x-projections in one launch: 2 x (columns / 128) panels x row groups == the CU count
-        gemm_pair(0, 0, 1, R, G, din, x, x, din, w_ih_f, w_ih_r, din, xproj[0], xproj[1], G, bias0=bsum[0], bias1=bsum[1])
-        if rows:
+        if pre is None:
+            # both directions' x-projections in one launch: 2 x (columns / 128) panels x row groups == the CU count
+            gemm_pair(0, 0, 1, R, G, din, x, x, din, w_ih_f, w_ih_r, din, xproj[0], xproj[1], G, bias0=bsum[0], bias1=bsum[1])
+        mask = drop_mask
+        if follow is not None:
+            # the NEXT layer's x-projection beside this layer's sweep: the follower starts where the main stream stands now
+            # (its inputs - the pack, the mask, the bias sums - are ordered before this point), never behind the sweep itself
+            main = torch.cuda.current_stream()
+            fs = follow_stream(dev)
+            nf, nr = follow["w_ih"]
+            wpack = follow.get("wpack")
+            if wpack is None:
+                wpack = lstm_xproj_pack(nf, nr)
+            nbias = follow.get("bias")
+            if mask is None and drop_p and float(drop_p) > 0.0:
+                mask = torch.empty_like(y)
+                call("vocr_dropout_mask", _p(mask), mask.numel(), float(drop_p), int(drop_seed), _stream())
+            planes = torch.empty(2, 2, R, G, dtype=torch.float32, device=dev)
+            epoch = next_epoch()
+            fs.wait_stream(main)
+            p0, p1 = (pre if pre is not None else (xproj, None))
+            call("vocr_lstm_fwd_lead", _p(p0), _p(p1), _p(w_hh_f), _p(w_hh_r), _p(lens_dev), _p(y), _p(gates), _p(cell), _p(ws), T, B, H, R if rows else 0,
+                 epoch, _p(health(dev)), _stream())
+            with torch.cuda.stream(fs):
+                call("vocr_lstm_xproj_follow", _p(y), _p(mask), _p(wpack), _p(nbias), _p(planes), _p(lens_dev), _p(ws), T, B, H, R if rows else 0,
+                     epoch, _p(health(dev)), _stream())
+            for t_ in (y, mask, wpack, nbias, planes, lens_dev, ws):
+                if t_ is not None:
+                    t_.record_stream(fs)
+            follow["out"].append((planes[0], planes[1]))
+            follow["join"] = fs
+        elif pre is not None:
+            call("vocr_lstm_fwd_lead", _p(pre[0]), _p(pre[1]), _p(w_hh_f), _p(w_hh_r), _p(lens_dev), _p(y), _p(gates), _p(cell), _p(ws), T, B, H,
+                 R if rows else 0, 0, _p(health(dev)), _stream())
+        elif rows:
             call("vocr_lstm_fwd_packed", _p(xproj), _p(w_hh_f), _p(w_hh_r), _p(lens_dev), _p(y), _p(gates), _p(cell), _p(ws), T, B, H, R,
                  _p(health(dev)), _stream())
         else:
@@ -877,12 +965,17 @@ class BiLstmLayerFn(torch.autograd.Function):
         ctx.dims = (T, B, H, din, int(rows))
         ctx.direct_grads = bool(direct_grads)       # False: the layer runs as several batch tiles, autograd adds their weight gradients
         ctx.b_refs = (b_ih_f, b_hh_f, b_ih_r, b_hh_r)
-        mask = None
         out = y
-        if drop_p and float(drop_p) > 0.0:
+        if mask is not None:
+            # what the NEXT layer's weight gradient multiplies; beside a follower this pass runs under the follower's tail
+            out = torch.empty_like(y)
+            call("vocr_mul", _p(y), _p(mask), _p(out), y.numel(), _stream())
+        elif drop_p and float(drop_p) > 0.0:
             out = torch.empty_like(y)
             mask = torch.empty_like(y)
             call("vocr_dropout_fwd", _p(y), _p(out), _p(mask), y.numel(), float(drop_p), int(drop_seed), _stream())
+        if follow is not None:
+            torch.cuda.current_stream().wait_stream(follow["join"])         # the next sweep reads the planes
         ctx.has_mask = mask is not None
         ctx.save_for_backward(x, lens_dev, y, gates, cell, w_ih_f, w_hh_f, w_ih_r, w_hh_r, mask)
         return out
@@ -965,13 +1058,13 @@ class BiLstmLayerFn(torch.autograd.Function):
             with torch.cuda.stream(side):
                 weight_grads(sinks)                 # under the next layer's persistent sweep
             mark_side_pending()
-            return (dx, None, None, None) + (None,) * 13
+            return (dx, None, None, None) + (None,) * 16
         if direct:
             weight_grads(sinks)
-            return (dx, None, None, None) + (None,) * 13
+            return (dx, None, None, None) + (None,) * 16
         outs = [torch.empty_like(p) for p in params]
         weight_grads(outs)
-        return (dx, None, None, None) + tuple(outs) + (None, None, None, None, None)
+        return (dx, None, None, None) + tuple(outs) + (None,) * 8
 
 
 # ------------------------------------------------------------------------------------------------ CTC
