@@ -41,7 +41,7 @@ const char* vocr_last_error(void);
  * cleared by the caller, LSTM workspace survives between the vocr_lstm_fwd_range calls of a sweep, larger vocr_gemm_workspace_bytes,
  * vocr_gemm_pair / vocr_lstm_bwd_parts / vocr_profile_range_*, x-fastest conv weight pack); 4 = round 5 (packed sequence rows:
  * vocr_lstm_*_packed, vocr_seq_rowmap, vocr_gather_rows; VOCR_LSTM_SWEEP validated; experiment switches compiled out); 5 = round 6
- * (the next layer's x-projection behind the forward sweep: vocr_lstm_fwd_lead / vocr_lstm_xproj_follow / vocr_lstm_xproj_pack,
+ * (the next layer's x-projection behind the forward sweep: vocr_lstm_fwd_lead / vocr_lstm_xproj_pack,
  * vocr_dropout_mask).  A binding compares vocr_abi_version()
  * with the VOCR_ABI_VERSION it was written against and refuses a library that answers anything else. */
 #define VOCR_ABI_VERSION 5
@@ -117,6 +117,10 @@ int vocr_conv3x3_wgrad_f16(const float* x, const float* dy, float* dw, void* wor
  * vocr_conv3x3_f16_fwd's bit for bit (same operand rounding, same summation order per output).
  * dgrad = vocr_conv3x3_h16_fwd(dy16, wpack_dgrad, NULL, dx, n, cout, h, w, cin). */
 int vocr_conv3x3_h16_supported(int cin, int cout);
+/* which forward / data-gradient kernel vocr_conv3x3_h16_fwd takes for a launch (0: shape not taken; 1 = 64-channel tile of 16 rows x 32
+ * pixels; 2 / 3 / 4 = 128 channels x 8 / 12 / 16 rows x 32 pixels; 5 = 128 channels x 8 rows x 64 pixels): the tests assert that every
+ * variant a BASELINE configuration runs is seen by them */
+int vocr_conv3x3_h16_plan(int n, int cin, int h, int w, int cout);
 int vocr_conv3x3_h16_fwd(const void* x16, const void* wpack, const float* bias, float* y,
                          int n, int cin, int h, int w, int cout, void* stream);
 /* Round 5, weight gradient with fp16 operands: both operands as channel-major fp16 copies [n][c][h][WP] whose rows are zero-padded to
@@ -303,14 +307,19 @@ int vocr_lstm_bias_from_parts(float* dbias, const void* workspace, int t, int b,
  * vocr_lstm_bwd_packed (the zero groups, a last chain's rows >= B and nothing else stay untouched by the sweeps); rows of a chain past
  * their own length are written as zeros like in the dense layout.  Results per frame are those of the dense entry points (same
  * kernels, same summation orders).  Shapes: ask vocr_lstm_packed_supported (B <= 32, H in {256, 512} on a device that can hold the
- * persistent sweep); otherwise use the dense entry points above.
+ * persistent sweep's grid) and keep rows * 2H * 4 below 2 GB (the sweeps' 32-bit offsets); otherwise use the dense entry points above.
  * vocr_seq_rowmap builds both index maps on the device from lens: to_packed[T*B] (packed row of frame (t, b), -1: none) and
  * to_dense[rows] (t*B + b of a packed row, -1: zero group / beyond B); either may be NULL.  vocr_gather_rows moves rows through such a
- * map: dst[r][0..n) = src[map[r]][0..n), or fill[0..n) (NULL: zeros) where map[r] < 0 — packing (map = to_dense, nrows = rows) and
+ * map: dst[r][0..n) = src[map[r]][0..n), or fill[0..n) (NULL: zeros) where map[r] < 0 (16-byte pieces when n % 4 == 0 and src, dst, fill
+ * are 16-byte aligned, element by element otherwise) — packing (map = to_dense, nrows = rows) and
  * unpacking (map = to_packed, nrows = T*B; fill = the output layer's bias reproduces the reference's logits of a padded frame). */
 int vocr_lstm_packed_supported(int b, int h);
 int vocr_seq_rowmap(const int32_t* lens, int t, int b, int rows, int32_t* to_packed, int32_t* to_dense, void* stream);
 int vocr_gather_rows(const float* src, float* dst, const int32_t* map, long nrows, int n, const float* fill, void* stream);
+/* gradient of vocr_gather_rows' fill row: dfill[0..n) = sum of dout[r][0..n) over the rows with map[r] < 0 (fixed summation order);
+ * workspace: vocr_gather_rows_fill_grad_workspace_bytes(n) */
+size_t vocr_gather_rows_fill_grad_workspace_bytes(int n);
+int vocr_gather_rows_fill_grad(const float* dout, const int32_t* map, long nrows, int n, float* dfill, void* workspace, void* stream);
 int vocr_lstm_fwd_packed(const float* xproj, const float* whh_fwd, const float* whh_rev, const int32_t* lens, float* y,
                          float* gates, float* cell, void* workspace, int t, int b, int h, int rows, int32_t* health, void* stream);
 /* dy_mask (may be NULL) as in vocr_lstm_bwd_parts; dbias (may be NULL) as in vocr_lstm_bwd_bias */
@@ -320,29 +329,26 @@ int vocr_lstm_bwd_packed(const float* dy, const float* dy_mask, const float* whh
 
 /* ---- the next layer's x-projection BEHIND the forward sweep — src/models/cnnlstm.py:148-149,288-290 (cuDNN's multi-layer RNN ---------
  * overlaps layer l+1's input GEMM with layer l's recurrence; nn.LSTM's inter-layer dropout: src/train_cnn_lstm.py:331) */
-/* A forward sweep is latency-bound and leaves most of every CU's matrix pipe idle.  vocr_lstm_xproj_follow is a kernel that runs BESIDE
- * the sweep of layer l (launch it on a second stream, in either order with the sweep; one 4-wave workgroup per CU next to the sweep's
- * 8-wave workgroup, wave priority below the sweep's) and computes layer l+1's x-projection from the rows the sweep has produced so
- * far: every chain (direction, 4 batch rows) of the sweep publishes its step count, the follower multiplies 16 steps of a chain at a
- * time - the chain's OWN direction half of y (x `mask`, the pre-scaled inter-layer dropout mask [rows][2H], or NULL), K = H - by the
- * matching half of W_ih of both directions of layer l+1, so neither direction waits for the other:
- *     out[src][tgt][row][4H] = y[row][src*H .. src*H+H) . W_ih(l+1, tgt)[:, src*H .. src*H+H)^T  (+ bias[tgt][4H] in the src = 0 plane)
- * and layer l+1's sweep, vocr_lstm_fwd_lead, adds the two source planes: xproj = out[0] ([2][rows][4H], the layout vocr_lstm_fwd
- * takes), xproj2 = out[1].  vocr_lstm_fwd_lead is vocr_lstm_fwd (rows = 0) / vocr_lstm_fwd_packed (rows > 0) with that second addend
- * (NULL: none) and the follower's protocol: epoch != 0 makes the sweep publish its progress under that number (the caller passes the
- * same fresh non-zero number to the sweep and to its follower; a stale word of an earlier sweep in the shared workspace then never
- * matches) and store y write-through; epoch = 0: nobody follows.  Both calls take the SAME workspace (vocr_lstm_workspace_bytes).
- * wpack: W_ih(l+1) of both directions in MFMA-fragment order, vocr_lstm_xproj_pack_bytes(h) bytes, rebuilt by vocr_lstm_xproj_pack
- * whenever the weights change.  A follower whose sweep never arrives gives up after a bounded wait: NaN output + health[0].
+/* A forward sweep is latency-bound and leaves most of every CU's matrix pipe idle.  vocr_lstm_fwd_lead is vocr_lstm_fwd (rows = 0) /
+ * vocr_lstm_fwd_packed (rows > 0) with two additions:
+ *  - xproj2 (may be NULL): a second addend of this layer's x-projection, same layout as xproj ([2][rows][4H]); the sweep reads
+ *    xproj + xproj2.
+ *  - next_wpack != NULL: four more waves in every workgroup of the sweep compute the NEXT layer's x-projection from the rows the sweep
+ *    has produced so far (16 steps of a chain at a time, throttled by the chain so that they use the matrix pipe while it waits for its
+ *    hand-off): the chain's OWN direction half of y (x y_mask, the pre-scaled inter-layer dropout mask [rows][2H], or NULL), K = H, by
+ *    the matching half of W_ih of both directions of the next layer, so neither direction waits for the other:
+ *        next_planes[src][tgt][row][4H] = y[row][src*H .. src*H+H) . W_ih(next, tgt)[:, src*H .. src*H+H)^T  (+ next_bias[tgt][4H] in src = 0)
+ *    and the next layer's vocr_lstm_fwd_lead takes xproj = next_planes (planes [0][.]), xproj2 = next_planes + 2*rows*4H.
+ *    next_wpack: W_ih of the next layer, both directions, in MFMA-fragment order: vocr_lstm_xproj_pack_bytes(h) bytes written by
+ *    vocr_lstm_xproj_pack whenever the weights change; next_bias [2][4H] may be NULL.
  * Shapes: vocr_lstm_follow_supported (16 < B <= 32, H = 512 = the next layer's H, the wide 4-row chain sweep); rows < 262144. */
 int vocr_lstm_follow_supported(int b, int h);
 size_t vocr_lstm_xproj_pack_bytes(int h);
 int vocr_lstm_xproj_pack(const float* w_ih_fwd, const float* w_ih_rev, float* wpack, int h, void* stream);
 int vocr_lstm_fwd_lead(const float* xproj, const float* xproj2, const float* whh_fwd, const float* whh_rev, const int32_t* lens,
-                       float* y, float* gates, float* cell, void* workspace, int t, int b, int h, int rows, unsigned epoch,
+                       float* y, float* gates, float* cell, void* workspace, int t, int b, int h, int rows,
+                       const float* next_wpack, const float* next_bias, const float* y_mask, float* next_planes,
                        int32_t* health, void* stream);
-int vocr_lstm_xproj_follow(const float* y, const float* mask, const float* wpack, const float* bias, float* out, const int32_t* lens,
-                           const void* workspace, int t, int b, int h, int rows, unsigned epoch, int32_t* health, void* stream);
 
 /* ---- CTC: warpctc_pytorch.CTCLoss — src/train_cnn_lstm.py:358,138 ------------------------------------------ */
 /* logits[T][B][V] pre-softmax, blank = 0.  labels flat int32 (device), label_offsets[B], label_lens[B],

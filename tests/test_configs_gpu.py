@@ -46,6 +46,12 @@ CASES = {
                         labels_per_line=[39, 38, 38, 37, 36, 35, 34, 28, 28, 26, 25, 24, 23, 23, 22, 21, 21, 21, 19, 19, 18, 18, 14, 13, 13, 12, 12,
                                          12, 8, 6, 4, 4], seed=10, ltr=False, want_margin=3e-4, tries=60,
                         state_kw=dict(lstm_scale=0.08, prob_scale=2.0), masks=(576, 32, 512, 2, 46)),
+    # config 5 at BATCH SIZE (round 6): bench.py --config c5's shape - 32 x 1x60x1200, rapid_ds 60 -> 30, fp16 conv operands, 3 x BiLSTM-512,
+    # T = 294 - forward AND backward; the fp16 forward / data-gradient launches of this shape take the tile variants 64x2, 128x2, 128x4
+    # and 128x4c2 (vocr_conv3x3_h16_plan), which the B = 3 case above does not
+    "config5_b32": dict(hp=_hp(h_img=60, din=128, layers=3, hidden=512, drop=0.5, conv_dtype="fp16"), alphabet="english", B=32,
+                        widths=[1200] * 32, labels_per_line=[40] * 32, seed=1, loss_rtol=1e-2, logit_rtol=2e-2, grad_rtol=0.1,
+                        min_label_agreement=0.97, state_kw=dict(lstm_scale=0.08, prob_scale=0.5), masks=(294, 32, 512, 2, 48)),
     # the reference's own speed_test.py shape (src/speed_test.py:16-30): batch 64, height 30, lstm_input_dim 128, 3 x BiLSTM-512, dropout 0.5,
     # 5 labels per line, one of its widths (300); the LSTM sweeps run as two 32-row batch tiles
     "speed_test_b64": dict(hp=_hp(din=128, layers=3, hidden=512, drop=0.5), alphabet="english", B=64, widths=[300] * 64, labels_per_line=[5] * 64,
@@ -224,6 +230,28 @@ def test_config4_at_batch_size_32_hidden512():
     assert CASES["config4_b32"]["widths"] == bench.WORKLOADS["c4"]["widths"] and CASES["config4_b32"]["labels_per_line"] == bench.WORKLOADS["c4"]["labels"]
     model, logits, lens = _run_pair("config4_b32")
     assert logits.shape[1:] == (32, 166) and lens[0] == logits.shape[0] and lens.tolist() == sorted(lens.tolist(), reverse=True)
+
+
+def test_config5_at_batch_size_32():
+    """BASELINE configs[4] at the size bench.py --config c5 runs, with a backward pass: loss <= 1e-2, per-frame agreement >= 0.97 on safe
+    frames, every gradient at the fp16 bar - and every fp16 forward / data-gradient tile variant that shape takes is one GPUTEST sees."""
+    import math
+    import bench
+    from vistaocr_amd import _lib
+    case = CASES["config5_b32"]
+    wl = bench.WORKLOADS["c5"]
+    assert case["widths"] == wl["widths"] and case["labels_per_line"] == wl["labels"] and wl["conv_dtype"] == "fp16" and wl["himg"] == 60
+    lib = _lib.load()
+    h, w, seen = 30, 600, set()
+    for st in [(16, 64), (64, 64), "pool", (64, 128), (128, 128), "pool", (128, 256), (256, 256), (256, 256)]:
+        if st == "pool":
+            h, w = math.floor(h * 0.5), math.floor(w * 0.7)
+            continue
+        seen.add(lib.vocr_conv3x3_h16_plan(32, st[0], h, w, st[1]))            # forward
+        seen.add(lib.vocr_conv3x3_h16_plan(32, st[1], h, w, st[0]))            # data gradient
+    assert seen == {1, 2, 4, 5}, seen                    # 64x2, 128x2, 128x4, 128x4c2 (128x3: other batch sizes)
+    model, logits, lens = _run_pair("config5_b32")
+    assert logits.shape[0] == 294 and lens.tolist() == [294] * 32
 
 
 def test_validation_pass_and_snapshot_roundtrip(tmp_path):

@@ -80,7 +80,7 @@ def test_fit_control_flow_and_checkpoint_schema(tmp_path):
 
     def fake_val(loader, model, crit):
         w = next(wers)
-        marks.append((w, float(next(model.parameters()).flatten()[0])))
+        marks.append((w, float(next(model.parameters()).detach().flatten()[0])))
         return 1.0, w / 2, w
     prefix = os.path.join(tmp_path, "run")
     w0 = float(next(m.parameters()).detach().flatten()[0])

@@ -36,6 +36,7 @@ SIGNATURES = {
     "vocr_conv3x3_c1_wgrad_workspace_bytes": (Z, [I, I, I]),
     "vocr_conv3x3_c1_wgrad": (I, [P, P, P, P, P, I, I, I, I, P]),
     "vocr_conv3x3_h16_supported": (I, [I, I]),
+    "vocr_conv3x3_h16_plan": (I, [I, I, I, I, I]),
     "vocr_conv3x3_h16_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
     "vocr_f16_padded_row": (I, [I]),
     "vocr_f32_to_f16_layouts": (I, [P, P, P, I, I, I, I, P]),
@@ -83,12 +84,13 @@ SIGNATURES = {
     "vocr_lstm_packed_supported": (I, [I, I]),
     "vocr_seq_rowmap": (I, [P, I, I, I, P, P, P]),
     "vocr_gather_rows": (I, [P, P, P, ctypes.c_long, I, P, P]),
+    "vocr_gather_rows_fill_grad_workspace_bytes": (Z, [I]),
+    "vocr_gather_rows_fill_grad": (I, [P, P, ctypes.c_long, I, P, P, P]),
     "vocr_lstm_fwd_packed": (I, [P, P, P, P, P, P, P, P, I, I, I, I, P, P]),
     "vocr_lstm_follow_supported": (I, [I, I]),
     "vocr_lstm_xproj_pack_bytes": (Z, [I]),
     "vocr_lstm_xproj_pack": (I, [P, P, P, I, P]),
-    "vocr_lstm_fwd_lead": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, U32, P, P]),
-    "vocr_lstm_xproj_follow": (I, [P, P, P, P, P, P, P, I, I, I, I, U32, P, P]),
+    "vocr_lstm_fwd_lead": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, P, P, P, P, P, P]),
     "vocr_lstm_bwd_packed": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P]),
     "vocr_ctc_workspace_bytes": (Z, [I, I, I, I]),
     "vocr_ctc_loss_grad": (I, [P, P, P, P, P, P, P, P, I, I, I, I, P]),

@@ -405,6 +405,37 @@ VOCR_H16_KERNEL(conv3x3_h16_kernel_64x2, 1, 2, 1)     //  64 channels x 16 rows 
 
 extern "C" int vocr_conv3x3_h16_supported(int cin, int cout) { return cin > 0 && cout > 0 && cin % 16 == 0 ? 1 : 0; }
 
+// Which forward / data-gradient kernel a launch takes: 1 = 64x2 (cout <= 64: 16 rows x 32 pixels), 2 = 128x2 (8 rows x 32), 3 = 128x3
+// (12 x 32), 4 = 128x4 (16 x 32), 5 = 128x4c2 (8 rows x 64).  Above 64 output channels: the tile shape that needs the least time in
+// whole rounds of one workgroup per CU; cost of a tile = its segments, a 16-segment tile at 0.8 of two 8-segment ones (it fills 58
+// instead of 2 x 48 KB per chunk, and the fill is what bounds the kernel); VOCR_H16_TILE (experiments build): force a shape
+static int h16_fwd_pick(int n, int h, int w, int cout) {
+    if (cout <= 64) return 1;
+    int ncu = 256;
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+    }
+    auto tiles_of = [&](int rows, int blocks) { return (long)n * vocr_cdiv(h, rows) * vocr_cdiv(w, SEGW * blocks); };
+    const int ct = vocr_cdiv(cout, 128);
+    static const int force = VOCR_EXPERIMENT_INT("VOCR_H16_TILE", 0);
+    const double c2 = (double)vocr_cdiv(tiles_of(8, 1) * ct, ncu) * 2, c3 = (double)vocr_cdiv(tiles_of(12, 1) * ct, ncu) * 3,
+                 c4 = (double)vocr_cdiv(tiles_of(16, 1) * ct, ncu) * 4 * 0.8, c42 = (double)vocr_cdiv(tiles_of(8, 2) * ct, ncu) * 4 * 0.8;
+    int pick = 2;
+    double best = c2;
+    if (c3 < best) { best = c3; pick = 3; }
+    if (c4 < best) { best = c4; pick = 4; }
+    if (c42 < best) { best = c42; pick = 5; }
+    if (force) pick = force;
+    return pick;
+}
+
+extern "C" int vocr_conv3x3_h16_plan(int n, int cin, int h, int w, int cout) {
+    if (n <= 0 || h <= 0 || w <= 0 || !vocr_conv3x3_h16_supported(cin, cout)) return 0;
+    return h16_fwd_pick(n, h, w, cout);
+}
+
 extern "C" int vocr_conv3x3_h16_fwd(const void* x16, const void* wpack, const float* bias, float* y, int n, int cin, int h, int w,
                                     int cout, void* stream) {
     VOCR_CHECK_ARG(x16 && wpack && y, "vocr_conv3x3_h16_fwd: null pointer");
@@ -421,32 +452,13 @@ extern "C" int vocr_conv3x3_h16_fwd(const void* x16, const void* wpack, const fl
 #define VOCR_H16_LAUNCH(K, ROWS, BLOCKS, CT)                                                                                            \
     K<<<dim3((unsigned)tiles_of(ROWS, BLOCKS), CT), 512, 0, s>>>(xp, wp, bias, y, n, cin, h, w, cout, vocr_cdiv(w, SEGW * BLOCKS),          \
                                                                 (int)tiles_of(ROWS, BLOCKS), (unsigned)xb, (unsigned)wb)
-    if (cout > 64) {
-        // the tile shape that needs the least time in whole rounds of one workgroup per CU.  Cost of a tile = its segments, a 16-segment
-        // tile at 0.8 of two 8-segment ones (it fills 58 instead of 2 x 48 KB per chunk, and the fill is what bounds the kernel);
-        // H16_TILE (experiments): force a shape
-        int ncu = 256;
-        {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
-        }
-        const int ct = vocr_cdiv(cout, 128);
-        static const int force = VOCR_EXPERIMENT_INT("VOCR_H16_TILE", 0);
-        const double c2 = (double)vocr_cdiv(tiles_of(8, 1) * ct, ncu) * 2, c3 = (double)vocr_cdiv(tiles_of(12, 1) * ct, ncu) * 3,
-                     c4 = (double)vocr_cdiv(tiles_of(16, 1) * ct, ncu) * 4 * 0.8, c42 = (double)vocr_cdiv(tiles_of(8, 2) * ct, ncu) * 4 * 0.8;
-        int pick = 2;
-        double best = c2;
-        if (c3 < best) { best = c3; pick = 3; }
-        if (c4 < best) { best = c4; pick = 4; }
-        if (c42 < best) { best = c42; pick = 5; }
-        if (force) pick = force;
-        if (pick == 3) VOCR_H16_LAUNCH(conv3x3_h16_kernel_128x3, 12, 1, ct);
-        else if (pick == 4) VOCR_H16_LAUNCH(conv3x3_h16_kernel_128x4, 16, 1, ct);
-        else if (pick == 5) VOCR_H16_LAUNCH(conv3x3_h16_kernel_128x4c2, 8, 2, ct);
-        else VOCR_H16_LAUNCH(conv3x3_h16_kernel_128x2, 8, 1, ct);
-    } else {
-        VOCR_H16_LAUNCH(conv3x3_h16_kernel_64x2, 16, 1, 1);
+    const int ct = vocr_cdiv(cout, 128);
+    switch (h16_fwd_pick(n, h, w, cout)) {
+        case 1: VOCR_H16_LAUNCH(conv3x3_h16_kernel_64x2, 16, 1, 1); break;
+        case 3: VOCR_H16_LAUNCH(conv3x3_h16_kernel_128x3, 12, 1, ct); break;
+        case 4: VOCR_H16_LAUNCH(conv3x3_h16_kernel_128x4, 16, 1, ct); break;
+        case 5: VOCR_H16_LAUNCH(conv3x3_h16_kernel_128x4c2, 8, 2, ct); break;
+        default: VOCR_H16_LAUNCH(conv3x3_h16_kernel_128x2, 8, 1, ct); break;
     }
 #undef VOCR_H16_LAUNCH
     VOCR_CHECK_LAUNCH("vocr_conv3x3_h16_fwd");

@@ -377,31 +377,34 @@ __global__ void dropout_mask_kernel(float* __restrict__ mask, size_t n, float p,
     }
 }
 
-// bchw -> [w][b][c*h]: one workgroup transposes a 64(w) x 64(ch) tile of one image through LDS so both the
-// read (along w) and the write (along c*h) are coalesced.
+// bchw -> [w][b][c*h]: one workgroup transposes a 32(w) x 64(ch) tile of one image through LDS so both the read (along w) and the
+// write (along c*h) are coalesced.  8.3 KB of LDS (round 5: a 64 x 64 tile, 16.6 KB): in the step the backward permute runs on the main
+// stream while the panel GEMM of the layer-0 LSTM weight gradients holds every CU with 144 of its 160 KB - the 16.6-KB tile did not fit
+// beside it and the 30-us pass took 340 us in front of the CNN backward
 __global__ void bchw_to_wbch_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int CH, int W, int fwd) {
-    __shared__ float tile[64][65];
-    const int b = blockIdx.z, ch0 = blockIdx.y * 64, w0 = blockIdx.x * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 256 threads: 64 x 4
+    __shared__ float tile[32][65];                            // [w][ch]
+    const int b = blockIdx.z, ch0 = blockIdx.y * 64, w0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 channels x 4 columns
+    const int wx = threadIdx.x & 31, wy = threadIdx.x >> 5;   // 32 columns x 8 channels
     if (fwd) {
-        for (int r = ty; r < 64; r += 4) {
-            const int ch = ch0 + r, w = w0 + tx;
-            tile[r][tx] = (ch < CH && w < W) ? x[((long)b * CH + ch) * W + w] : 0.f;
+        for (int r = wy; r < 64; r += 8) {
+            const int ch = ch0 + r, w = w0 + wx;
+            tile[wx][r] = (ch < CH && w < W) ? x[((long)b * CH + ch) * W + w] : 0.f;
         }
         __syncthreads();
-        for (int r = ty; r < 64; r += 4) {
+        for (int r = ty; r < 32; r += 4) {
             const int w = w0 + r, ch = ch0 + tx;
-            if (w < W && ch < CH) out[((long)w * B + b) * CH + ch] = tile[tx][r];
+            if (w < W && ch < CH) out[((long)w * B + b) * CH + ch] = tile[r][tx];
         }
     } else {
-        for (int r = ty; r < 64; r += 4) {
+        for (int r = ty; r < 32; r += 4) {
             const int w = w0 + r, ch = ch0 + tx;
             tile[r][tx] = (w < W && ch < CH) ? x[((long)w * B + b) * CH + ch] : 0.f;
         }
         __syncthreads();
-        for (int r = ty; r < 64; r += 4) {
-            const int ch = ch0 + r, w = w0 + tx;
-            if (ch < CH && w < W) out[((long)b * CH + ch) * W + w] = tile[tx][r];
+        for (int r = wy; r < 64; r += 8) {
+            const int ch = ch0 + r, w = w0 + wx;
+            if (ch < CH && w < W) out[((long)b * CH + ch) * W + w] = tile[wx][r];
         }
     }
 }
@@ -716,7 +719,7 @@ extern "C" int vocr_dropout_fwd(const float* x, float* out, float* mask, size_t 
 
 extern "C" int vocr_bchw_to_wbch(const float* x, float* out, int b, int c, int h, int w, void* stream) {
     VOCR_CHECK_ARG(x && out && b > 0 && c > 0 && h > 0 && w > 0, "vocr_bchw_to_wbch: bad argument");
-    dim3 grid(vocr_cdiv(w, 64), vocr_cdiv(c * h, 64), b);
+    dim3 grid(vocr_cdiv(w, 32), vocr_cdiv(c * h, 64), b);
     bchw_to_wbch_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, out, b, c * h, w, 1);
     VOCR_CHECK_LAUNCH("vocr_bchw_to_wbch");
     return VOCR_OK;
@@ -724,7 +727,7 @@ extern "C" int vocr_bchw_to_wbch(const float* x, float* out, int b, int c, int h
 
 extern "C" int vocr_wbch_to_bchw(const float* x, float* out, int b, int c, int h, int w, void* stream) {
     VOCR_CHECK_ARG(x && out && b > 0 && c > 0 && h > 0 && w > 0, "vocr_wbch_to_bchw: bad argument");
-    dim3 grid(vocr_cdiv(w, 64), vocr_cdiv(c * h, 64), b);
+    dim3 grid(vocr_cdiv(w, 32), vocr_cdiv(c * h, 64), b);
     bchw_to_wbch_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, out, b, c * h, w, 0);
     VOCR_CHECK_LAUNCH("vocr_wbch_to_bchw");
     return VOCR_OK;

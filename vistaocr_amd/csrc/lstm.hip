@@ -818,6 +818,224 @@ __global__ __launch_bounds__(256) void lstm_fwd_chain4v(const float* __restrict_
 #endif
 }
 
+// The next layer's x-projection, computed WHILE this layer's forward sweep runs (cuDNN's RNN overlaps the two:
+// src/models/cnnlstm.py:148-149,288-290).  A sweep is latency-bound: its 4x4x1 MFMAs keep a CU's matrix pipe ~42 % busy.  Four MORE
+// waves of the sweep's own workgroup (waves 8 - 11 of lstm_fwd_chain4w<8, true>: one per SIMD, 168 registers each like the chain's)
+// multiply the rows the chain has already produced:
+//   unit = 16 consecutive steps of the chain = 64 rows x K = H (the chain's OWN direction half of y: a direction's rows appear in its
+//   own time order, so neither direction waits for the other) x this member's 256 of the next layer's 8H gate columns (both
+//   directions); out[src dir][tgt dir][row][4H'] - the next sweep adds the two source planes (xproj2);
+//   A = the 64 x 512 panel (x the inter-layer dropout mask, if any) staged once per unit into LDS as MFMA fragments
+//   [16-byte piece kq][row ^ 8 (kq & 1)] (conflict-free 16-byte writes and reads); B = vocr_lstm_xproj_pack's fragment order, one
+//   contiguous KB per (32 columns, 8 k) straight from L2 into registers, three chunks in flight; v_mfma_f32_32x32x2_f32, wave tile
+//   64 x 64 in 64 AGPRs.
+// Why inside the workgroup (all measured, scripts/follow_ab.py, HISTORY of round 6 in DESIGN.md): as a kernel of its own beside the
+// sweep (a) a never-stalling MFMA stream takes the matrix pipe from the chain whatever its instruction length, stream priority or
+// s_setprio - the sweep ran at HALF speed -, (b) its workgroups land on other XCDs than their chain (the dispatcher's round robin
+// continues where the previous kernel stopped) and sc1 stores are not seen there before the producer's final L2 write-back, (c) placed
+// first it can keep the sweep's workgroups off the CU.  Here the throttle is explicit: the chain's wave 0 raises `phase` (LDS) when its
+// MFMAs of a step begin; at the next yield point (after every 16 MFMAs = 1024 cycles of the pipe, in every wait loop) a follower wave
+// goes to the step's two barriers and sits there through the chain's MFMAs, reduction and activation - its window is the chain's
+// cell update + hand-off round trip, ~half of a step - and it arrives at the first barrier long before the chain does.
+// Gates: rows of chain steps <= joined - 3 are complete when this workgroup has passed `joined` first-barriers (every wave has then
+// seen its slice of h of step joined - 2, and a member's cell waves drain their own y stores before they store the next h); the
+// chain's last rows: the 32 `done` words (one per cell wave) of all 16 members, stored behind a release.  A chain spread over several
+// XCDs (never seen; the hand-off then runs write-through) only trusts the `done` words: its projection runs as a tail.
+// Sync among the four follower waves (panel staged / panel consumed): LDS counters, never s_barrier.
+// Stores through a wave-uniform 64-bit base (SGPR pair) + a 32-bit per-thread byte offset: the compiler keeps a 64-bit VGPR address per
+// stream instead (10 VGPRs in lstm_fwd_chain4w's cell section, which has none to spare beside the follower waves)
+__device__ __forceinline__ void sstore_b32(const void* sbase, unsigned voff, float v) {
+    asm volatile("global_store_dword %0, %1, %2" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void sstore_b32_sc0(const void* sbase, unsigned voff, unsigned v) {
+    asm volatile("global_store_dword %0, %1, %2 sc0" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void sstore_b32_sc1(const void* sbase, unsigned voff, unsigned v) {
+    asm volatile("global_store_dword %0, %1, %2 sc1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void sstore_b128(const void* sbase, unsigned voff, f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+}
+
+constexpr unsigned kFollowDone = 0xFFFFFFFCu;      // a member's `done` word (0xFF fill) once both its cell waves have cleared their bit
+struct FollowArgs {
+    const float* wpack;      // next layer's W_ih, vocr_lstm_xproj_pack order; nullptr: nobody follows
+    const float* mask;       // [rows][2H] pre-scaled dropout mask or nullptr
+    const float* bias;       // [2][4H'] or nullptr
+    float* out;              // [2 src][2 tgt][rows][4H']
+    unsigned* done;          // the sweep's id block: word [chain*32 + 16 + member] (the upper half of a chain's 32 id words is free)
+    unsigned long long* dbg; // -DVOCR_FOLLOW_PROBE builds: stamps (the workspace's first words, unused by a forward sweep)
+    int mode;                // -DVOCR_FOLLOW_PROBE builds: parts of the follower switched off (WRONG results)
+};
+
+template <bool MASK, typename Yield>
+__device__ __forceinline__ void xproj_follow_waves(const FollowArgs& fa, const float* y, float* panel, int* fsync, const SeqRows& sr, int dir, int nrows,
+                                                   int chain, int slice, bool local, const int& joined, Yield&& yield, unsigned* status, unsigned* health) {
+    constexpr int H = 512, G = 4 * H, TG = 16, NJ = H / 8;
+    const int tid = threadIdx.x - 512, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Tc = sr.steps;
+    const long R = sr.total;
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, (int)(R * 2 * H * 4), 0x00020000);
+    // staging: lane = (row_lo = lane & 7, kq_lo = lane >> 3): 8 rows x 128 contiguous bytes per instruction
+    const int srow_lo = lane & 7, skq_lo = lane >> 3;
+    // B fragments of this wave's two 32-column tiles: scalar offset = (tile, chunk), vector offset = lane
+    const int col0 = slice * 256 + wave * 64;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)fa.wpack, 0, 2 * 8 * H * H * 4, 0x00020000);
+    const int wbase = ((dir * (8 * H / 32) + col0 / 32) * NJ) * 1024;        // bytes; tile ct: + NJ KB, chunk j: + 1 KB
+    auto b_load = [&](int ct, int j) {
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane * 16, wbase + (ct * NJ + j) * 1024, 0);
+        return (f32x4){__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+    };
+    // the member's 256 columns lie in ONE of the four [src dir][tgt dir] planes
+    const int tgt = col0 / G;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(fa.out + (long)(dir * 2 + tgt) * R * G), 0, (int)(R * G * 4), 0x00020000);
+    const int li = lane & 31, lk = lane >> 5;
+    float bv[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) bv[ct] = (dir == 0 && fa.bias) ? fa.bias[col0 + 32 * ct + li] : 0.f;
+    int* fstaged = fsync;            // + 1 per wave and unit when its quarter of the panel is in LDS
+    int* fconsumed = fsync + 1;      // + 1 per wave and unit when it has read the panel for the last time
+    bool failed = false;
+    const int units = (Tc + TG - 1) / TG;
+    for (int u = 0; u < units; ++u) {
+        const int s_lo = u * TG, s_hi = min(s_lo + TG, Tc);
+#ifdef VOCR_FOLLOW_PROBE
+        if (tid == 0 && slice == 0 && chain < 2 && u < 24) fa.dbg[chain * 64 + u] = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0 && slice == 0 && chain < 2 && u < 24) fa.dbg[chain * 64 + 32 + u] = joined;
+#endif
+        // ---- gate: rows of steps < s_hi are complete, and every wave is done with the previous unit's panel
+        {
+            const bool by_done = !local || s_hi + 2 > Tc;                   // joined never exceeds Tc
+            unsigned spins = 0;
+            for (;;) {
+                yield();
+                bool ok;
+                if (by_done) {
+                    unsigned v = kFollowDone;
+                    if (lane < 16) v = __hip_atomic_load(fa.done + chain * 32 + 16 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = __all(v == kFollowDone);
+                    if (ok) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                } else {
+                    ok = joined >= s_hi + 2;
+                }
+                if (ok && __hip_atomic_load(fconsumed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= 4 * u) break;
+                if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u || ++spins > (1u << 24)) { failed = true; break; }
+                if (by_done) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(2);
+                if (by_done && !ok) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+        }
+#ifdef VOCR_FOLLOW_PROBE
+        const int pmode = fa.mode;
+#else
+        constexpr int pmode = 0;
+#endif
+        // ---- stage this wave's quarter of the 64 x 512 panel
+        if (!failed && pmode != 2) {
+#pragma unroll 1
+            for (int i = 0; i < 32; i += 4) {
+                u32x4_t v[4];
+                f32x4 mk[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = (i + q) * 4 + wave, row = (c & 7) * 8 + srow_lo, kq = (c >> 3) * 8 + skq_lo;
+                    const int s = s_lo + (row >> 2), r = row & 3;
+                    const bool ok = s < s_hi && r < nrows;
+                    const int t = dir == 0 ? s : Tc - 1 - s;
+                    const long grow = sr.base + (long)sr.stride * t + r;
+                    // rows past the chain's end / the batch: an out-of-range offset reads as zeros
+                    v[q] = __builtin_amdgcn_raw_buffer_load_b128(yrsrc, ok ? (int)((grow * 2 * H + dir * H + 4 * kq) * 4) : -16, 0, kPollAux);
+                    if (MASK) mk[q] = *(const f32x4*)(fa.mask + (ok ? grow * 2 * H + dir * H + 4 * kq : 0));
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = (i + q) * 4 + wave, row = (c & 7) * 8 + srow_lo, kq = (c >> 3) * 8 + skq_lo;
+                    f32x4 a = (f32x4){__uint_as_float(v[q][0]), __uint_as_float(v[q][1]), __uint_as_float(v[q][2]), __uint_as_float(v[q][3])};
+                    if (MASK) a = a * mk[q];
+                    *(f32x4*)(panel + ((long)kq * 64 + (row ^ ((kq & 1) << 3))) * 4) = a;
+                }
+                yield();
+            }
+        }
+        if (lane == 0) __hip_atomic_fetch_add(fstaged, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        {
+            unsigned spins = 0;
+            while (__hip_atomic_load(fstaged, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * (u + 1)) {
+                yield();
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 24)) { failed = true; break; }
+            }
+        }
+        // ---- 64 x 64 wave tile over K = 512
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        if (!failed && pmode != 1 && pmode != 2) {
+            constexpr int D = 4;                              // B chunks in flight
+            f32x4 bq[D][2];
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) bq[d][ct] = b_load(ct, d);
+            const float* ap = panel + ((long)lk * 64 + (li ^ (lk << 3))) * 4;       // piece kq = 2j + lk, row tile rt: + 32 rows
+            f32x4 af[2][2];                                   // [parity of the chunk][row tile]: one chunk ahead
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) af[0][rt] = *(const f32x4*)(ap + 32 * rt * 4);
+#pragma unroll 1
+            for (int j0 = 0; j0 < NJ; j0 += D) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    const int j = j0 + d, jn = min(j + 1, NJ - 1), jl = min(j + D, NJ - 1);      // clamped: the last loads repeat, nothing branches
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt) af[(d + 1) & 1][rt] = *(const f32x4*)(ap + ((long)(2 * jn) * 64 + 32 * rt) * 4);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                            for (int ct = 0; ct < 2; ++ct)
+                                acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[d & 1][rt][e], bq[d][ct][e], acc[rt][ct], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // the slot just consumed takes chunk j + D: D - 1 chunks (3 x 1024 MFMA cycles) of flight
+                    if (pmode != 3) {
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct) bq[d][ct] = b_load(ct, jl);
+                    }
+                    if (pmode == 4) __builtin_amdgcn_s_sleep(8);
+                    if (pmode == 5) __builtin_amdgcn_s_sleep(16);
+                    yield();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        if (lane == 0) __hip_atomic_fetch_add(fconsumed, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // ---- plane[row][4H]: C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const int s = s_lo + (row >> 2), rr = row & 3;
+                const int t = dir == 0 ? s : Tc - 1 - s;
+                const long grow = sr.base + (long)sr.stride * t + rr;
+                const int off = (s < s_hi && rr < nrows) ? (int)((grow * G + col0 % G + li) * 4) : -4;      // out of range: dropped
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(failed ? __uint_as_float(0x7FC00000u) : acc[rt][ct][r] + bv[ct]), orsrc, off, 32 * ct * 4, 0);
+            }
+            yield();
+        }
+    }
+#ifdef VOCR_FOLLOW_PROBE
+    if (tid == 0 && slice == 0 && chain < 2) fa.dbg[chain * 64 + 30] = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (failed && lane == 0) raise_timeout(status, health);
+}
+
 // Forward sweep for 16 < B <= 32 at H = 512 ("chain4w": 4-row chains with WIDE members): 16 chains of 16 members with 32
 // units (128 gate columns) each = ONE 8-wave workgroup per CU.  Same FLOPs per CU and step as two lstm_fwd_chain4v workgroups,
 // but nothing shares the CU: a chain no longer moves at the pace of its most-disturbed member (with two workgroups per CU the
@@ -826,13 +1044,13 @@ __global__ __launch_bounds__(256) void lstm_fwd_chain4v(const float* __restrict_
 // gate column of a 64-column block, two blocks: 128 VGPRs of W_hh per lane, no duplicates; A straight from the hand-off load (one
 // 16-byte load per lane and step) through the instruction's A broadcast.  Epilogue: wave w reduces and activates gate w & 3 of
 // rows 2(w >> 2), +1 (a wave-uniform activation function), waves 0-1 update the 128 cells.  Ring and reset: lstm_fwd_chain4v.
-template <int KQ4>
-__global__ __launch_bounds__(512) void lstm_fwd_chain4w(const float* __restrict__ xproj, const float* __restrict__ whh_f,
+template <int KQ4, bool FOLLOW>
+__global__ __launch_bounds__(FOLLOW ? 768 : 512) void lstm_fwd_chain4w(const float* __restrict__ xproj, const float* __restrict__ whh_f,
                                                         const float* __restrict__ whh_r, const int32_t* __restrict__ lens,
                                                         float* y, float* __restrict__ gates, float* __restrict__ cell,
                                                         float* hx, unsigned* ids, unsigned* status, unsigned* health, int T, int B, int NT4,
                                                         int force_wt, int s0, int s1, int nap, int packed_rows,
-                                                        const float* __restrict__ xproj2, unsigned long long* prog, unsigned* done, unsigned epoch) {
+                                                        const float* __restrict__ xproj2, FollowArgs fa) {
     constexpr int H = 64 * KQ4;
     constexpr int members = H >> 5;                   // 32 units each
     constexpr int KW = H / 8;                         // k per wave
@@ -843,6 +1061,10 @@ __global__ __launch_bounds__(512) void lstm_fwd_chain4w(const float* __restrict_
     float (*red)[4][RP] = (float (*)[4][RP])lds;                            // [wave][row][column]
     float (*actb)[128] = (float (*)[128])(lds + 8 * 4 * RP + 4);            // [row][gate*32 + unit]
     __shared__ int sig[2];                                                  // step count of the two cell waves' last h store
+    __shared__ int phase;                                                   // FOLLOW: steps whose MFMAs wave 0 has begun (the followers' cue)
+    __shared__ int fsync[2];                                                // FOLLOW: panel staged / consumed counters of the four follower waves
+    extern __shared__ __attribute__((aligned(16))) float panel[];           // FOLLOW: 128 KB, dynamic (a static array of that size makes the
+                                                                            // compiler assume one wave per SIMD and pad the register allocation)
     const int nch = 2 * NT4;
     const int chain = (int)(blockIdx.x & 7) + 8 * (int)((blockIdx.x >> 3) & 1), member = blockIdx.x >> 4;
     if (chain >= nch) return;
@@ -852,7 +1074,32 @@ __global__ __launch_bounds__(512) void lstm_fwd_chain4w(const float* __restrict_
     const int nrows = min(B - b0, 4);
     const int kbase = wave * KW;
     const float* whh = dir ? whh_r : whh_f;
+    if (FOLLOW && tid == 0) { phase = 0; fsync[0] = 0; fsync[1] = 0; }          // in front of chain_is_xcd_local's barriers
     const bool local = chain_is_xcd_local(ids + chain * 32, members, member, status, health, (unsigned*)(lds + 8 * 4 * RP), kHandoffSentinel) && !(force_wt & 1);
+    if constexpr (FOLLOW) {
+        if (tid >= 512) {
+            // waves 8 - 11: the next layer's x-projection (xproj_follow_waves above); two barriers per step of the chain, in step
+            const SeqRows fsr = seq_rows(lens, T, B, bt, packed_rows);
+            if (!seq_rows_fit(fsr, packed_rows)) return;
+            const int fTc = fsr.steps;
+            int joined = 0;
+            auto yield = [&]() {
+                if (joined < fTc && __hip_atomic_load(&phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > joined) {
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_s_barrier();
+                    ++joined;
+                }
+            };
+            if (fa.mask) xproj_follow_waves<true>(fa, y, panel, fsync, fsr, dir, nrows, chain, member, local, joined, yield, status, health);
+            else xproj_follow_waves<false>(fa, y, panel, fsync, fsr, dir, nrows, chain, member, local, joined, yield, status, health);
+            while (joined < fTc) {
+                yield();
+                __builtin_amdgcn_s_sleep(2);
+            }
+            return;
+        }
+        __builtin_amdgcn_s_setprio(3);                // the chain is the latency-bound half of the workgroup
+    }
 
     // resident B operand: column 64*cb + lane of the workgroup's 128 = (gate, local unit) = (col >> 5, col & 31)
     f32x4 wv[2][NL];
@@ -876,8 +1123,12 @@ __global__ __launch_bounds__(512) void lstm_fwd_chain4w(const float* __restrict_
         if (tid == 0) raise_timeout(status, health);
         return;
     }
-    // the cell thread's own element of step t: plane-local row = sr.base + sr.stride*t + crow
+    // the cell thread's own element of step t: plane-local row = sr.base + sr.stride*t + crow.  Addresses = a wave-uniform 64-bit base of
+    // the step (scalar arithmetic) + a 32-bit per-thread byte offset that never changes (the planes stay below 2 GB: host check)
     const long crow0 = (long)dir * sr.total + sr.base + crow;
+    const unsigned cvoff = (unsigned)((crow0 * H + unit) * 4);                          // cell; gates: x 4
+    const unsigned yvoff = (unsigned)((((long)sr.base + crow) * 2 * H + dir * H + unit) * 4);
+    const unsigned rvoff = (unsigned)(((member * 4 + crow) * 32 + cu) * 4);             // hand-off ring block of this member
     float cstate = 0.f;
     if (s0 > 0 && cellthr) {
         const int tp0 = dir == 0 ? s0 - 1 : Tc - s0;
@@ -893,19 +1144,15 @@ __global__ __launch_bounds__(512) void lstm_fwd_chain4w(const float* __restrict_
         const int kk = kbase + 4 * (lane >> 2);
         poff = (((kk >> 5) * 4 + prow) * 32 + (kk & 31)) * 4;
     }
-    const long xoff0 = ((long)dir * sr.total + sr.base + (erowok ? erow : 0)) * 4 * H + (long)egate * H + unit0 + eu;
-    const float* xrowp = xproj + xoff0;
-    const float* xrowp2 = xproj2 ? xproj2 + xoff0 : nullptr;       // second addend: the other direction's half of the layer below
-    const long xstep = (long)sr.stride * 4 * H;                    // (vocr_lstm_xproj_follow writes one plane per source direction)
+    const unsigned xvoff = (unsigned)((((long)dir * sr.total + sr.base + (erowok ? erow : 0)) * 4 * H + (long)egate * H + unit0 + eu) * 4);
+    const long xstep = (long)sr.stride * 4 * H * 4;                // bytes per time step
     auto x_load = [&](int st) {
         const int tt = dir == 0 ? st : Tc - 1 - st;
-        float v = xrowp[tt * xstep];
-        if (xrowp2) v += xrowp2[tt * xstep];
+        float v = *(const float*)((const char*)xproj + tt * xstep + xvoff);
+        // second addend: the other source direction's plane of the layer below (xproj_follow_waves writes one plane per direction)
+        if (xproj2) v += *(const float*)((const char*)xproj2 + tt * xstep + xvoff);
         return v;
     };
-    // a follower (lstm_xproj_follow) multiplies this sweep's rows while it runs: its waves share this CU's matrix pipe at the
-    // lowest priority, the chain is the latency-bound one
-    if (prog && !(force_wt & 2)) __builtin_amdgcn_s_setprio(3);
     float xn = s0 < s1 ? x_load(s0) : 0.f;
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
@@ -914,7 +1161,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_chain4w(const float* __restrict_
 
     LSTM_STAMP_DECL;
 #ifdef VOCR_FOLLOW_PROBE
-    const unsigned long long pc0 = __builtin_amdgcn_s_memtime(), pr0 = __builtin_amdgcn_s_memrealtime();
+    if (FOLLOW && tid == 0 && member == 0 && chain < 2) fa.dbg[chain * 64 + 28] = __builtin_amdgcn_s_memrealtime();
 #endif
     for (int step = s0; step < s1; ++step) {
         const int t = dir == 0 ? step : Tc - 1 - step;
@@ -948,6 +1195,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_chain4w(const float* __restrict_
             }
         }
         LSTM_STAMP(0);              // own slice of h_{t-1} arrived (polls)
+        if (FOLLOW && tid == 0) __hip_atomic_store(&phase, step + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // followers: to the barriers
         xn = x_load(step + 1 < Tc ? step + 1 : step);          // behind the polls: loads return in order
         if (step > 0) {
             static_for<NL>([&](auto bc) {
@@ -966,10 +1214,6 @@ __global__ __launch_bounds__(512) void lstm_fwd_chain4w(const float* __restrict_
             for (int r = 0; r < 4; ++r) red[wave][r][64 * cb + lane] = acc[cb][r];
         LSTM_STAMP(1);              // MFMA + partial tile to LDS
         __syncthreads();
-        // every wave of this member has seen its slice of h_{step-1}: each member's cell waves passed the poll of step - 1 before they
-        // stored that (a poll's vmcnt(0) drains the wave's own stores of the step before), so y of steps <= step - 2 has landed
-        if (prog && member == 0 && tid == 0)
-            __hip_atomic_store(prog + chain, ((unsigned long long)epoch << 32) | (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         LSTM_STAMP(2);
         {
             const float pre = (((red[0][erow][ecol] + red[1][erow][ecol]) + (red[2][erow][ecol] + red[3][erow][ecol])) +
@@ -982,9 +1226,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_chain4w(const float* __restrict_
         LSTM_STAMP(4);
         if (cellthr) {
             const bool active = t < len_b;
-            const long sidx = (crow0 + (long)sr.stride * t) * H + unit;
-            float* yo = y + (sr.base + crow + (long)sr.stride * t) * 2 * H + dir * H + unit;
-            f32x4* go = (f32x4*)(gates + sidx * 4);
+            const long srow = (long)sr.stride * t;                                      // wave-uniform
             float h = 0.f, c = 0.f;
             f32x4 gv = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (active) {
@@ -997,40 +1239,38 @@ __global__ __launch_bounds__(512) void lstm_fwd_chain4w(const float* __restrict_
             if (h != h) h = __uint_as_float(0x7FC00000u);                                // never the hand-off pattern
             if (step == s1 - 1 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u)
                 h = __uint_as_float(0x7FC00000u);                                        // a hand-off timed out: fail loudly
-            float* xo = hx + ((long)((step & 3) * nch + chain) * 4 * H + (member * 4 + crow) * 32 + cu);
-            float* xr = hx + ((long)(((step - 2) & 3) * nch + chain) * 4 * H + (member * 4 + crow) * 32 + cu);
-            if (local) {
-                __hip_atomic_store(xo, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // stays in this XCD's L2
-                if (step >= 2) __hip_atomic_store((unsigned*)xr, kHandoffSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            } else {
-                __hip_atomic_store(xo, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // write-through (sc1)
-                if (step >= 2) __hip_atomic_store((unsigned*)xr, kHandoffSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const char* xo = (const char*)hx + (long)((step & 3) * nch + chain) * (4 * H * 4);
+            const char* xr = (const char*)hx + (long)(((step - 2) & 3) * nch + chain) * (4 * H * 4);
+            if (local) {                                                                 // stays in this XCD's L2
+                sstore_b32_sc0(xo, rvoff, __float_as_uint(h));
+                if (step >= 2) sstore_b32_sc0(xr, rvoff, kHandoffSentinel);
+            } else {                                                                     // write-through (sc1)
+                sstore_b32_sc1(xo, rvoff, __float_as_uint(h));
+                if (step >= 2) sstore_b32_sc1(xr, rvoff, kHandoffSentinel);
             }
-            if (prog) __hip_atomic_store(yo, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // the follower may sit on another XCD
-            else *yo = h;
-            *go = gv;
-            cell[sidx] = c;
+            sstore_b32((const char*)y + srow * (2 * H * 4), yvoff, h);
+            sstore_b128((const char*)gates + srow * (H * 16), cvoff << 2, gv);
+            sstore_b32((const char*)cell + srow * (H * 4), cvoff, c);
         }
         if (tid < 128 && lane == 0) __hip_atomic_store(&sig[wave], step + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         LSTM_STAMP(5);              // cell update + stores issued (waves 0, 1)
     }
 #ifdef VOCR_FOLLOW_PROBE
-    if (blockIdx.x == 0 && tid == 0) {
-        unsigned long long* o = (unsigned long long*)(ids + 900);
-        o[0] = __builtin_amdgcn_s_memtime() - pc0;
-        o[1] = __builtin_amdgcn_s_memrealtime() - pr0;
-        o[2] = pr0;
-        o[3] = xcc_id();
-    }
+    if (FOLLOW && tid == 0 && member == 0 && chain < 2) fa.dbg[chain * 64 + 29] = __builtin_amdgcn_s_memrealtime();
 #endif
-    if (prog) {                     // this member's last rows are out: the follower's tail waits for all 16 words of the chain
-        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
-        __syncthreads();
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __hip_atomic_store(done + chain * 16 + member, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (FOLLOW && tid < 128) {      // this member's last rows are out: the followers' last units wait for all 16 members of the chain
+        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): this cell wave's stores have landed
+        if (lane == 0) {
+            if (!local) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_fetch_and(fa.done + chain * 32 + 16 + member, ~(1u << wave), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+#if defined(VOCR_LSTM_STAMPS) && defined(VOCR_FOLLOW_PROBE)
+    if (lane == 0 && (wave == 0 || wave == 7) && fa.dbg && blockIdx.x == 0) {
+        unsigned long long* o = fa.dbg + 256 + (wave == 7) * 8;
+        for (int k = 0; k < 8; ++k) o[k] = st_acc[k];
+    }
+#endif
 #ifdef VOCR_LSTM_STAMPS
     if (lane == 0 && (wave == 0 || wave == 7) && g_lstm_stamp_out) {
         unsigned long long* o = g_lstm_stamp_out + ((size_t)blockIdx.x * 2 + (wave == 7)) * 8;
@@ -1795,23 +2035,7 @@ bool launch_fwd_fast(int rt, dim3 grid, hipStream_t s, const float* xproj, const
 
 
 // ------------------------------------------------------------------------------------------------ x-projection behind the sweep
-// The next layer's x-projection, computed WHILE this layer's forward sweep runs (cuDNN's RNN overlaps the two:
-// src/models/cnnlstm.py:148-149,288-290).  A sweep is latency-bound: its 4x4x1 MFMAs keep a CU's matrix pipe ~42 % busy.  This kernel
-// runs beside it - one 4-wave workgroup per CU (128 KB of LDS: never two on a CU, so the sweep's 256 workgroups stay co-resident
-// whatever the dispatch order; registers: 2 x 176 of the sweep + 1 x <= 160 here per SIMD lane) at wave priority 0 under the
-// sweep's 3 - and multiplies the rows the sweep has already produced:
-//   workgroup (chain, slice) <-> the sweep's (chain, member) numbering, so it normally shares the chain's XCD (never assumed: the
-//   sweep stores y write-through while it is followed and every load of y here is an sc1 load);
-//   unit = 16 consecutive steps of the chain = 64 rows x K = H (the chain's OWN direction half of y: a direction's rows appear in
-//   its own time order, so neither direction waits for the other) x the slice's 256 of the 8H columns (both directions of the next
-//   layer); out[src dir][tgt dir][row][4H'] - the next sweep adds the two source planes (lstm_fwd_chain4w's xproj2);
-//   gate = the chain's progress word {epoch, step} (published by member 0 after the first barrier of a step: y of steps <= step - 2
-//   is complete), the 16 per-member `done` words for the tail.  The epoch makes a stale word of an earlier sweep harmless: no
-//   ordering against the sweep's own 0xFF fill is needed, the caller launches the two kernels on two streams in either order.
-//   A = the 64 x 512 panel (x the inter-layer dropout mask, if any) staged once per unit into LDS as MFMA fragments
-//   [16-byte piece kq][row ^ 8*(kq & 1)] (conflict-free 16-byte writes and reads); B = vocr_lstm_xproj_pack's fragment order: one
-//   contiguous KB per (32 columns, 8 k) straight into registers; v_mfma_f32_32x32x2_f32, wave tile 64 x 64.
-// A timeout (the sweep never arrives) poisons the output and raises the health word; it never hangs.
+// (the follower itself: xproj_follow_waves in front of lstm_fwd_chain4w)
 __global__ __launch_bounds__(256) void lstm_xproj_pack_kernel(const float* __restrict__ w_f, const float* __restrict__ w_r, float* __restrict__ wpack, int H) {
     // wpack[src dir d][column tile ct (8H/32)][chunk j (H/8)][lane][4]: lane (c = lane & 31, hh = lane >> 5) holds
     // W[32 ct + c][d*H + 8j + 4hh .. +3], W = [w_f; w_r] ([8H][2H])
@@ -1824,204 +2048,6 @@ __global__ __launch_bounds__(256) void lstm_xproj_pack_kernel(const float* __res
     const int col = 32 * ct + (lane & 31);
     const float* w = col < 4 * H ? w_f + (long)col * 2 * H : w_r + (long)(col - 4 * H) * 2 * H;
     ((f32x4*)wpack)[piece] = *(const f32x4*)(w + d * H + 8 * j + 4 * (lane >> 5));
-}
-
-// one wave that sleeps ~us microseconds: launched in front of the follower on ITS stream so that the follower's waves are dispatched
-// behind the sweep's (on a SIMD the older waves win the issue arbitration: the sweep must be the older kernel)
-__global__ void lstm_follow_nap_kernel(int us) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();          // 100 MHz
-    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)us * 100ull) __builtin_amdgcn_s_sleep(16);
-}
-
-constexpr int kFollowDoneWordC = 640;
-template <bool MASK, int VARIANT = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) void lstm_xproj_follow(const float* y, const float* __restrict__ mask, const float* __restrict__ wpack,
-                                                         const float* __restrict__ bias, float* __restrict__ out,
-                                                         const int32_t* __restrict__ lens, const unsigned long long* prog, const unsigned* done,
-                                                         const unsigned* sweep_status, unsigned epoch, unsigned* health, int T, int B, int NT4,
-                                                         int packed_rows, int probe_nap = 0) {
-    constexpr int H = 512, G = 4 * H, TG = 16, NJ = H / 8;
-    // [128 pieces kq][64 rows][4]: 128 KB, DYNAMIC on purpose: with a static array the compiler derives "one wave per SIMD at most" from
-    // the LDS size and pads the kernel's register allocation to 257 so that nothing else fits on the CU - the sweep must
-    extern __shared__ __attribute__((aligned(16))) float panel[];
-    __shared__ int gate_ok;
-    const int nch = 2 * NT4;
-    const int chain = (int)(blockIdx.x & 7) + 8 * (int)((blockIdx.x >> 3) & 1), slice = blockIdx.x >> 4;
-    if (chain >= nch) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int dir = chain / NT4, bt = chain % NT4;
-    const int nrows = min(B - 4 * bt, 4);
-    const SeqRows sr = seq_rows(lens, T, B, bt, packed_rows);
-    const int Tc = sr.steps;
-    if (!seq_rows_fit(sr, packed_rows)) return;              // the sweep raises the error
-    const long R = sr.total;
-    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, (int)(R * 2 * H * 4), 0x00020000);
-    // staging: lane = (row_lo = lane & 7, kq_lo = lane >> 3): 8 rows x 128 contiguous bytes per instruction
-    const int srow_lo = lane & 7, skq_lo = lane >> 3;
-    // B fragments of this wave's two 32-column tiles: scalar offset = (tile, chunk), vector offset = lane
-    const int col0 = slice * 256 + wave * 64;
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wpack, 0, 2 * 8 * H * H * 4, 0x00020000);
-    const int wbase = ((dir * (8 * H / 32) + col0 / 32) * NJ) * 1024;        // bytes; tile ct: + NJ KB, chunk j: + 1 KB
-    auto b_load = [&](int ct, int j) {
-        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane * 16, wbase + (ct * NJ + j) * 1024, 0);
-        return (f32x4){__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
-    };
-    // the slice's 256 columns lie in ONE of the four [src dir][tgt dir] planes
-    const int tgt = col0 / G;
-    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (long)(dir * 2 + tgt) * R * G), 0, (int)(R * G * 4), 0x00020000);
-    const int li = lane & 31, lk = lane >> 5;
-    float bv[2];
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) bv[ct] = (dir == 0 && bias) ? bias[col0 + 32 * ct + li] : 0.f;
-    bool failed = false;
-    const int units = (Tc + TG - 1) / TG;
-    for (int u = 0; u < units; ++u) {
-        const int s_lo = u * TG, s_hi = min(s_lo + TG, Tc);
-        // ---- gate: rows of steps < s_hi are complete
-        if (tid == 0) {
-            int ok = 0;
-            if (!failed) {
-                unsigned spins = 0;
-                for (;;) {
-                    const unsigned long long pv = __hip_atomic_load(prog + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const bool mine = (unsigned)(pv >> 32) == epoch;
-                    if (mine && (int)(unsigned)pv >= s_hi + 1) { ok = 1; break; }
-                    if (s_hi + 1 >= Tc) {                    // the chain's last steps: every member says so itself
-                        bool all = true;
-                        for (int m = 0; m < 16; ++m) all = all && __hip_atomic_load(done + chain * 16 + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
-                        if (all) { ok = 1; break; }
-                    }
-                    if (mine && __hip_atomic_load(sweep_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u) break;      // the sweep gave up
-                    __builtin_amdgcn_s_sleep(32);
-                    // the chain may live on ANOTHER XCD (the dispatcher's round robin continues where the previous kernel stopped: measured,
-                    // sweep workgroup 0 on XCC 7, follower workgroup 0 on XCC 0): this XCD's L2 then keeps serving the line it fetched at
-                    // the first look, sc1 or not, until it is invalidated
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    if (++spins > (1u << 21)) break;
-                }
-                if (ok) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            }
-            gate_ok = ok;
-        }
-        __syncthreads();                                     // also: every wave is done with the previous unit's panel
-        if (!gate_ok) failed = true;
-#ifdef VOCR_FOLLOW_PROBE
-        if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 100) && u < 24) {
-            unsigned long long* o = (unsigned long long*)(done - kFollowDoneWordC + 1100) + (blockIdx.x ? 32 : 0);
-            o[u] = __builtin_amdgcn_s_memrealtime();
-            if (u == 0) o[30] = xcc_id();
-        }
-#endif
-        // ---- stage the 64 x 512 panel
-        if (!failed) {
-#pragma unroll 1
-            for (int i = 0; i < 32; i += 4) {
-                u32x4_t v[4];
-                f32x4 mk[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int c = (i + q) * 4 + wave, row = (c & 7) * 8 + srow_lo, kq = (c >> 3) * 8 + skq_lo;
-                    const int s = s_lo + (row >> 2), r = row & 3;
-                    const bool ok = s < s_hi && r < nrows;
-                    const int t = dir == 0 ? s : Tc - 1 - s;
-                    const long grow = sr.base + (long)sr.stride * t + r;
-                    // rows past the chain's end / the batch: an out-of-range offset reads as zeros
-                    v[q] = __builtin_amdgcn_raw_buffer_load_b128(yrsrc, ok ? (int)((grow * 2 * H + dir * H + 4 * kq) * 4) : -16, 0, kPollAux);
-                    if (MASK) mk[q] = *(const f32x4*)(mask + (ok ? grow * 2 * H + dir * H + 4 * kq : 0));
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int c = (i + q) * 4 + wave, row = (c & 7) * 8 + srow_lo, kq = (c >> 3) * 8 + skq_lo;
-                    f32x4 a = (f32x4){__uint_as_float(v[q][0]), __uint_as_float(v[q][1]), __uint_as_float(v[q][2]), __uint_as_float(v[q][3])};
-                    if (MASK) a = a * mk[q];
-                    *(f32x4*)(panel + ((long)kq * 64 + (row ^ ((kq & 1) << 3))) * 4) = a;
-                }
-            }
-        }
-        __syncthreads();
-        // ---- 64 x 64 wave tile over K = 512
-        f32x16 acc[2][2];
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-        if (!failed) {
-            constexpr int D = 4;                              // B chunks in flight
-            f32x4 bq[D][2];
-#pragma unroll
-            for (int d = 0; d < D; ++d)
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct) bq[d][ct] = b_load(ct, d);
-            const float* ap = panel + ((long)lk * 64 + (li ^ (lk << 3))) * 4;       // piece kq = 2j + lk, row tile rt: + 32 rows
-            f32x4 af[2][2];                                   // [parity of the chunk][row tile]: one chunk ahead
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt) af[0][rt] = *(const f32x4*)(ap + 32 * rt * 4);
-#pragma unroll 1
-            for (int j0 = 0; j0 < NJ; j0 += D) {
-#pragma unroll
-                for (int d = 0; d < D; ++d) {
-                    const int j = j0 + d, jn = min(j + 1, NJ - 1), jl = min(j + D, NJ - 1);      // clamped: the last loads repeat, nothing branches
-#pragma unroll
-                    for (int rt = 0; rt < 2; ++rt) af[(d + 1) & 1][rt] = *(const f32x4*)(ap + ((long)(2 * jn) * 64 + 32 * rt) * 4);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                            for (int ct = 0; ct < 2; ++ct) {
-                                if (VARIANT == 0) acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[d & 1][rt][e], bq[d][ct][e], acc[rt][ct], 0, 0, 0);
-#ifdef VOCR_FOLLOW_PROBE       // timing probes only (WRONG results): the same matrix-pipe cycles in shorter instructions
-                                if (VARIANT == 1) {
-#pragma unroll
-                                    for (int h2 = 0; h2 < 2; ++h2) {
-                                        f32x4 c = {acc[rt][ct][4 * h2], acc[rt][ct][4 * h2 + 1], acc[rt][ct][4 * h2 + 2], acc[rt][ct][4 * h2 + 3]};
-                                        c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[d & 1][rt][e], bq[d][ct][e], c, 0, 0, 0);
-#pragma unroll
-                                        for (int z = 0; z < 4; ++z) acc[rt][ct][4 * h2 + z] = c[z];
-                                    }
-                                }
-                                if (VARIANT == 2) {
-#pragma unroll
-                                    for (int h2 = 0; h2 < 8; ++h2) {
-                                        f32x4 c = {acc[rt][ct][4 * (h2 & 3)], acc[rt][ct][4 * (h2 & 3) + 1], acc[rt][ct][4 * (h2 & 3) + 2], acc[rt][ct][4 * (h2 & 3) + 3]};
-                                        c = __builtin_amdgcn_mfma_f32_4x4x1f32(af[d & 1][rt][e], bq[d][ct][e], c, 0, 0, 0);
-#pragma unroll
-                                        for (int z = 0; z < 4; ++z) acc[rt][ct][4 * (h2 & 3) + z] = c[z];
-                                    }
-                                }
-#endif
-                            }
-                    if (probe_nap > 0) __builtin_amdgcn_s_sleep(8);
-                    if (probe_nap > 1) __builtin_amdgcn_s_sleep(8);
-                    if (probe_nap > 2) __builtin_amdgcn_s_sleep(16);
-                    if (probe_nap > 3) __builtin_amdgcn_s_sleep(32);
-                    __builtin_amdgcn_sched_barrier(0);
-                    // the slot just consumed takes chunk j + D: D - 1 chunks (3 x 1024 MFMA cycles) of flight
-#pragma unroll
-                    for (int ct = 0; ct < 2; ++ct) bq[d][ct] = b_load(ct, jl);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-        // ---- plane[row][4H]: C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                const int s = s_lo + (row >> 2), rr = row & 3;
-                const int t = dir == 0 ? s : Tc - 1 - s;
-                const long grow = sr.base + (long)sr.stride * t + rr;
-                const int off = (s < s_hi && rr < nrows) ? (int)((grow * G + col0 % G + li) * 4) : -4;      // out of range: dropped
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(failed ? __uint_as_float(0x7FC00000u) : acc[rt][ct][r] + bv[ct]), orsrc, off, 32 * ct * 4, 0);
-            }
-    }
-    if (failed && tid == 0 && health) __hip_atomic_store(health, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -2127,13 +2153,9 @@ extern "C" size_t vocr_lstm_workspace_bytes(int t, int b, int h) {
 
 static bool lstm_packed_kind_ok(int b, int h);
 
-// words of the sweep's 4-KB block (behind the XCC ids [0, 512) and the status word [512]) that a followed sweep publishes to
-// lstm_xproj_follow: progress {epoch, step} per chain, one `done` word per (chain, member)
-constexpr int kFollowProgWord = 576, kFollowDoneWord = 640;
-
 static int lstm_fwd_impl(const float* xproj, const float* whh_fwd, const float* whh_rev, const int32_t* lens, float* y,
                          float* gates, float* cell, void* workspace, int t, int b, int h, int step_begin, int step_end,
-                         int packed_rows, int32_t* health, void* stream, const float* xproj2 = nullptr, unsigned epoch = 0) {
+                         int packed_rows, int32_t* health, void* stream, const float* xproj2 = nullptr, const FollowArgs* follow = nullptr) {
     VOCR_CHECK_ARG(xproj && whh_fwd && whh_rev && lens && y && gates && cell && workspace, "vocr_lstm_fwd: null pointer");
     VOCR_CHECK_ARG(t > 0 && b > 0 && b <= 64 && h > 0 && h % 16 == 0, "vocr_lstm_fwd: need 1<=B<=64 and H%%16==0 (B=%d H=%d)", b, h);
     VOCR_CHECK_ARG(0 <= step_begin && step_begin < step_end && step_end <= t, "vocr_lstm_fwd: bad step range [%d, %d) of %d", step_begin, step_end, t);
@@ -2152,7 +2174,7 @@ static int lstm_fwd_impl(const float* xproj, const float* whh_fwd, const float* 
                        "vocr_lstm_fwd_packed: the packed row layout needs a 4-row chain sweep (ask vocr_lstm_packed_supported; B=%d H=%d)", b, h);
         VOCR_CHECK_ARG(packed_rows % 4 == 0 && packed_rows >= 4 * (1 + 2 * ((b + 3) / 4)), "vocr_lstm_fwd_packed: bad row count %d", packed_rows);
     }
-    VOCR_CHECK_ARG((!xproj2 && !epoch) || (kind == SWEEP_WIDE4 && step_begin == 0 && step_end == t),
+    VOCR_CHECK_ARG((!xproj2 && !follow) || (kind == SWEEP_WIDE4 && step_begin == 0 && step_end == t),
                    "vocr_lstm_fwd_lead: two-plane x-projections / a follower need the wide 4-row chain sweep (ask vocr_lstm_follow_supported; B=%d H=%d)", b, h);
     if (kind != SWEEP_STEP) {
         // arrival flags: [chain <= 8][32 workgroups] at [0..255], XCC ids at [256..511]; status words at [512..]
@@ -2160,10 +2182,7 @@ static int lstm_fwd_impl(const float* xproj, const float* whh_fwd, const float* 
         unsigned* status = flags + 512;          // the sweep's own status word is per call; a timeout is also reported in the caller's health word
         unsigned* hword = (unsigned*)health;
         const dim3 cg(8 * (h / 16));
-        int fwt = sweep_write_through() ? 1 : 0;
-#ifdef VOCR_FOLLOW_PROBE
-        if (getenv("VOCR_FOLLOW_NOPRIO")) fwt |= 2;
-#endif
+        const int fwt = sweep_write_through() ? 1 : 0;
         const int nt4 = (b + 3) / 4;
         if (kind == SWEEP_WIDE4 || kind == SWEEP_CHAIN4) {
             // self-validating hand-off: the ring starts as the "not written yet" pattern (first range of a sweep only)
@@ -2172,9 +2191,30 @@ static int lstm_fwd_impl(const float* xproj, const float* whh_fwd, const float* 
             if (lstm_fwd_selfval_prep(blk, (size_t)4 * 2 * nt4 * 4 * h * sizeof(float), step_begin == 0, s) != VOCR_OK) return VOCR_ELAUNCH;
             if (kind == SWEEP_WIDE4) {
                 static const int nap4w = VOCR_EXPERIMENT_INT("VOCR_LSTM_NAP", 0);      // -1: polls start at once (experiments)
-                lstm_fwd_chain4w<8><<<256, 512, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, hx, blk, blk + 512, hword, t, b, nt4, fwt, step_begin, step_end, nap4w,
-                                                        packed_rows, xproj2, epoch ? (unsigned long long*)(blk + kFollowProgWord) : nullptr,
-                                                        blk + kFollowDoneWord, epoch);
+                if (follow) {
+                    // waves 8 - 11 of every workgroup: the next layer's x-projection (xproj_follow_waves); 128 KB of dynamic LDS for their panel
+                    constexpr int kPanelBytes = 128 * 64 * 4 * 4;
+                    static bool lds_ok = false;
+                    if (!lds_ok) {
+                        const hipError_t e = hipFuncSetAttribute((const void*)lstm_fwd_chain4w<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPanelBytes);
+                        if (e != hipSuccess) {
+                            vocr_set_error("vocr_lstm_fwd_lead: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed: %s", hipGetErrorString(e));
+                            return VOCR_ELAUNCH;
+                        }
+                        lds_ok = true;
+                    }
+                    FollowArgs fa = *follow;
+                    fa.done = blk;
+                    fa.dbg = (unsigned long long*)workspace;
+#ifdef VOCR_FOLLOW_PROBE
+                    fa.mode = getenv("VOCR_FOLLOW_MODE") ? atoi(getenv("VOCR_FOLLOW_MODE")) : 0;
+#endif
+                    lstm_fwd_chain4w<8, true><<<256, 768, kPanelBytes, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, hx, blk, blk + 512, hword, t, b, nt4, fwt, step_begin,
+                                                                           step_end, nap4w, packed_rows, xproj2, fa);
+                } else {
+                    lstm_fwd_chain4w<8, false><<<256, 512, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, hx, blk, blk + 512, hword, t, b, nt4, fwt, step_begin,
+                                                                  step_end, nap4w, packed_rows, xproj2, FollowArgs{nullptr, nullptr, nullptr, nullptr, nullptr, (unsigned long long*)workspace, 0});
+                }
             } else {
                 const dim3 cg4((2 * nt4 > 8 ? 16 : 8) * (h / 16));
                 if (h == 512) lstm_fwd_chain4v<8><<<cg4, 256, 0, s>>>(xproj, whh_fwd, whh_rev, lens, y, gates, cell, hx, blk, blk + 512, hword, t, b, nt4, fwt, step_begin, step_end, packed_rows);
@@ -2222,7 +2262,10 @@ extern "C" int vocr_lstm_fwd(const float* xproj, const float* whh_fwd, const flo
 
 // ---- packed row layout (struct SeqRows above; include/vocr.h)
 static bool lstm_packed_kind_ok(int b, int h) {
-    const SweepKind kf = lstm_sweep_kind(false, b, h, true), kb = lstm_sweep_kind(true, b, h, true);
+    // the predicate of lstm_fwd_impl / lstm_bwd_impl minus what depends on the buffers (alignment; 32-bit offsets: rows * 2H * 4 < 2 GB,
+    // the caller's to check): a device or partition that cannot hold the persistent grid answers "not supported" here
+    const bool fits = 8 * (h / 16) <= resident_workgroup_capacity();
+    const SweepKind kf = lstm_sweep_kind(false, b, h, fits), kb = lstm_sweep_kind(true, b, h, fits);
     return (kf == SWEEP_WIDE4 || kf == SWEEP_CHAIN4) && (kb == SWEEP_WIDE4 || kb == SWEEP_CHAIN4);
 }
 
@@ -2257,58 +2300,20 @@ extern "C" int vocr_lstm_xproj_pack(const float* w_ih_fwd, const float* w_ih_rev
 }
 
 extern "C" int vocr_lstm_fwd_lead(const float* xproj, const float* xproj2, const float* whh_fwd, const float* whh_rev, const int32_t* lens,
-                                  float* y, float* gates, float* cell, void* workspace, int t, int b, int h, int rows, unsigned epoch,
+                                  float* y, float* gates, float* cell, void* workspace, int t, int b, int h, int rows,
+                                  const float* next_wpack, const float* next_bias, const float* y_mask, float* next_planes,
                                   int32_t* health, void* stream) {
     VOCR_CHECK_ARG(rows >= 0, "vocr_lstm_fwd_lead: rows must be >= 0 (0: dense)");
-    return lstm_fwd_impl(xproj, whh_fwd, whh_rev, lens, y, gates, cell, workspace, t, b, h, 0, t, rows, health, stream, xproj2, epoch);
-}
-
-extern "C" int vocr_lstm_xproj_follow(const float* y, const float* mask, const float* wpack, const float* bias, float* out,
-                                      const int32_t* lens, const void* workspace, int t, int b, int h, int rows, unsigned epoch,
-                                      int32_t* health, void* stream) {
-    VOCR_CHECK_ARG(y && wpack && out && lens && workspace, "vocr_lstm_xproj_follow: null pointer");
-    VOCR_CHECK_ARG(vocr_lstm_follow_supported(b, h), "vocr_lstm_xproj_follow: shape not taken (ask vocr_lstm_follow_supported; B=%d H=%d)", b, h);
-    VOCR_CHECK_ARG(t > 0 && rows >= 0 && epoch != 0, "vocr_lstm_xproj_follow: need t > 0, rows >= 0, epoch != 0");
-    VOCR_CHECK_ARG(aligned16(y) && aligned16(wpack) && aligned16(out) && (!mask || aligned16(mask)), "vocr_lstm_xproj_follow: pointers must be 16-byte aligned");
-    VOCR_CHECK_ARG((rows ? (long)rows : (long)t * b) * 2 * h * 4 < (1l << 31), "vocr_lstm_xproj_follow: y must stay below 2 GB");
-    const unsigned* blk = (const unsigned*)((const char*)workspace + lstm_ws_handoff_offset(b, h));
-    const int nt4 = (b + 3) / 4;
-    hipStream_t s = (hipStream_t)stream;
-    const int nap_us = getenv("VOCR_FOLLOW_NAP_US") ? atoi(getenv("VOCR_FOLLOW_NAP_US")) : 0;
-    if (nap_us > 0) lstm_follow_nap_kernel<<<1, 64, 0, s>>>(nap_us);
-    constexpr int kPanelBytes = 128 * 64 * 4 * 4;
-    static bool lds_ok[2] = {false, false};
-    if (!lds_ok[mask != nullptr]) {
-        const hipError_t e = mask ? hipFuncSetAttribute((const void*)lstm_xproj_follow<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPanelBytes)
-                                  : hipFuncSetAttribute((const void*)lstm_xproj_follow<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPanelBytes);
-        if (e != hipSuccess) {
-            vocr_set_error("vocr_lstm_xproj_follow: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed: %s", hipGetErrorString(e));
-            return VOCR_ELAUNCH;
-        }
-        lds_ok[mask != nullptr] = true;
+    if (!next_wpack) {
+        VOCR_CHECK_ARG(!next_planes, "vocr_lstm_fwd_lead: next_planes without next_wpack");
+        return lstm_fwd_impl(xproj, whh_fwd, whh_rev, lens, y, gates, cell, workspace, t, b, h, 0, t, rows, health, stream, xproj2, nullptr);
     }
-#ifdef VOCR_FOLLOW_PROBE
-    const int variant = getenv("VOCR_FOLLOW_VARIANT") ? atoi(getenv("VOCR_FOLLOW_VARIANT")) : 0;
-    const int pnap = getenv("VOCR_FOLLOW_DUTY") ? atoi(getenv("VOCR_FOLLOW_DUTY")) : 0;
-    if (variant || pnap) {
-        hipFuncSetAttribute((const void*)lstm_xproj_follow<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kPanelBytes);
-        hipFuncSetAttribute((const void*)lstm_xproj_follow<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kPanelBytes);
-        hipFuncSetAttribute((const void*)lstm_xproj_follow<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kPanelBytes);
-#define VOCR_FP(V) lstm_xproj_follow<true, V><<<256, 256, kPanelBytes, s>>>(y, mask ? mask : y, wpack, bias, out, lens, (const unsigned long long*)(blk + kFollowProgWord), blk + kFollowDoneWord, blk + 512, epoch, (unsigned*)health, t, b, nt4, rows, pnap)
-        if (variant == 1) VOCR_FP(1); else if (variant == 2) VOCR_FP(2); else VOCR_FP(0);
-#undef VOCR_FP
-        VOCR_CHECK_LAUNCH("vocr_lstm_xproj_follow(probe)");
-        return VOCR_OK;
-    }
-#endif
-    if (mask)
-        lstm_xproj_follow<true><<<256, 256, kPanelBytes, s>>>(y, mask, wpack, bias, out, lens, (const unsigned long long*)(blk + kFollowProgWord), blk + kFollowDoneWord,
-                                                    blk + 512, epoch, (unsigned*)health, t, b, nt4, rows);
-    else
-        lstm_xproj_follow<false><<<256, 256, kPanelBytes, s>>>(y, mask, wpack, bias, out, lens, (const unsigned long long*)(blk + kFollowProgWord), blk + kFollowDoneWord,
-                                                     blk + 512, epoch, (unsigned*)health, t, b, nt4, rows);
-    VOCR_CHECK_LAUNCH("vocr_lstm_xproj_follow");
-    return VOCR_OK;
+    VOCR_CHECK_ARG(next_planes, "vocr_lstm_fwd_lead: next_wpack without next_planes");
+    VOCR_CHECK_ARG(vocr_lstm_follow_supported(b, h), "vocr_lstm_fwd_lead: shape not taken (ask vocr_lstm_follow_supported; B=%d H=%d)", b, h);
+    VOCR_CHECK_ARG(aligned16(next_wpack) && aligned16(next_planes) && (!y_mask || aligned16(y_mask)), "vocr_lstm_fwd_lead: pointers must be 16-byte aligned");
+    VOCR_CHECK_ARG((rows ? (long)rows : (long)t * b) < (1l << 18), "vocr_lstm_fwd_lead: a plane of the next x-projection must stay below 2 GB (rows < 262144)");
+    const FollowArgs fa{next_wpack, y_mask, next_bias, next_planes, nullptr, nullptr, 0};
+    return lstm_fwd_impl(xproj, whh_fwd, whh_rev, lens, y, gates, cell, workspace, t, b, h, 0, t, rows, health, stream, xproj2, &fa);
 }
 
 // to_packed[t*B + b] = packed row of frame (t, b), or -1 where the packed layout has none (t >= the length of b's chain);
@@ -2353,13 +2358,13 @@ extern "C" int vocr_seq_rowmap(const int32_t* lens, int t, int b, int rows, int3
 
 // dst[r][:] = src[map[r]][:] (map[r] >= 0) or fill[:] / 0 (map[r] < 0): one wave per row, 16-byte pieces when n % 4 == 0
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, const int32_t* __restrict__ map,
-                                                          long nrows, int n, const float* __restrict__ fill) {
+                                                          long nrows, int n, const float* __restrict__ fill, int vec) {
     const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= nrows) return;
     const int lane = threadIdx.x & 63;
     const int m = map[r];
     float* d = dst + r * n;
-    if ((n & 3) == 0) {
+    if (vec) {
         const f32x4* s4 = m >= 0 ? (const f32x4*)(src + (long)m * n) : nullptr;
         for (int i = lane; i < (n >> 2); i += 64) {
             f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -2375,9 +2380,40 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 extern "C" int vocr_gather_rows(const float* src, float* dst, const int32_t* map, long nrows, int n, const float* fill, void* stream) {
     VOCR_CHECK_ARG(src && dst && map, "vocr_gather_rows: null pointer");
     VOCR_CHECK_ARG(nrows > 0 && n > 0, "vocr_gather_rows: bad shape (%ld x %d)", nrows, n);
-    VOCR_CHECK_ARG((n & 3) != 0 || ((((uintptr_t)src | (uintptr_t)dst | (uintptr_t)fill) & 15) == 0), "vocr_gather_rows: 16-byte alignment");
-    gather_rows_kernel<<<vocr_cdiv(nrows, 4), 256, 0, (hipStream_t)stream>>>(src, dst, map, nrows, n, fill);
+    // 16-byte pieces when the row length and every pointer allow it (a fill row that is a view into a flat parameter buffer need not be
+    // aligned), element by element otherwise
+    const int vec = (n & 3) == 0 && ((((uintptr_t)src | (uintptr_t)dst | (uintptr_t)fill) & 15) == 0);
+    gather_rows_kernel<<<vocr_cdiv(nrows, 4), 256, 0, (hipStream_t)stream>>>(src, dst, map, nrows, n, fill, vec);
     VOCR_CHECK_LAUNCH("vocr_gather_rows");
+    return VOCR_OK;
+}
+
+// Gradient of vocr_gather_rows' fill row: dfill[j] = sum over the rows r with map[r] < 0 of dout[r][j], in a fixed order (64 row
+// ranges, then their partial sums one after the other)
+__global__ __launch_bounds__(256) void gather_fill_grad_partial(const float* __restrict__ dout, const int32_t* __restrict__ map, long nrows, int n,
+                                                                float* __restrict__ part) {
+    const long chunk = (nrows + gridDim.x - 1) / gridDim.x, r0 = blockIdx.x * chunk, r1 = min(r0 + chunk, nrows);
+    for (int j = threadIdx.x; j < n; j += 256) {
+        float a = 0.f;
+        for (long r = r0; r < r1; ++r)
+            if (map[r] < 0) a += dout[r * n + j];
+        part[(long)blockIdx.x * n + j] = a;
+    }
+}
+__global__ void gather_fill_grad_final(const float* __restrict__ part, int nparts, int n, float* __restrict__ dfill) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    float a = 0.f;
+    for (int p = 0; p < nparts; ++p) a += part[(long)p * n + j];
+    dfill[j] = a;
+}
+extern "C" size_t vocr_gather_rows_fill_grad_workspace_bytes(int n) { return n > 0 ? (size_t)64 * n * sizeof(float) : 0; }
+extern "C" int vocr_gather_rows_fill_grad(const float* dout, const int32_t* map, long nrows, int n, float* dfill, void* workspace, void* stream) {
+    VOCR_CHECK_ARG(dout && map && dfill && workspace, "vocr_gather_rows_fill_grad: null pointer");
+    VOCR_CHECK_ARG(nrows > 0 && n > 0, "vocr_gather_rows_fill_grad: bad shape (%ld x %d)", nrows, n);
+    gather_fill_grad_partial<<<64, 256, 0, (hipStream_t)stream>>>(dout, map, nrows, n, (float*)workspace);
+    gather_fill_grad_final<<<vocr_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>((const float*)workspace, 64, n, dfill);
+    VOCR_CHECK_LAUNCH("vocr_gather_rows_fill_grad");
     return VOCR_OK;
 }
 

@@ -297,6 +297,7 @@ class CnnOcrModel(nn.Module):
         # the output layer's bias, exactly what the dense path computes from its all-zero LSTM output).  A uniform batch stays dense.
         maps = None
         if self.pack_sequences and b <= 32 and ops.packed_row_count(out_w, b) <= self.pack_threshold * T * b \
+                and ops.packed_row_count(out_w, b) * 2 * self.num_lstm_hidden_units * 4 < 2 ** 31 \
                 and _lib.load().vocr_lstm_packed_supported(b, self.num_lstm_hidden_units):
             maps = ops.SeqRowMaps(lens_dev, out_w, T, b)
             hseq = ops.GatherRowsFn.apply(hseq, maps.to_dense, maps.to_packed, maps.rows)
@@ -309,40 +310,41 @@ class CnnOcrModel(nn.Module):
             r = self.lstm.layer(l, "_reverse")
             # nn.LSTM's inter-layer dropout (every layer's output but the last's); drawn inside the layer op when it is one op
             draw = drop and l < self.num_lstm_layers - 1 and self.dropout_masks is None
-            fused = draw and b <= 64
             if draw:
                 self._dropout_calls += 1
-            if following:
-                # layer l + 1's x-projection beside this layer's sweep; an explicit mask rides inside the layer op too
+            last = l == self.num_lstm_layers - 1
+            if b <= 64:
+                # one op per layer.  The inter-layer dropout rides inside it: an explicit mask, or - on packed rows - the drawn mask of the
+                # DENSE frame order moved through the row map, so that a frame's draw does not depend on whether the batch was packed
                 fol, mk = None, None
-                if l < self.num_lstm_layers - 1:
+                if not last and self.dropout_masks is not None:
+                    mk = self.dropout_masks[l].to(dev).reshape(T * b, -1)
+                    if maps is not None:
+                        mk = ops.gather_rows(mk, maps.to_dense, maps.rows)
+                elif draw and maps is not None:
+                    mk = ops.gather_rows(ops.dropout_mask(T * b, 2 * H, self.p_lstm_dropout, self.dropout_seed + self._dropout_calls, dev),
+                                         maps.to_dense, maps.rows)
+                if following and not last:
+                    # layer l + 1's x-projection inside this layer's sweep (ops.BiLstmLayerFn's `follow`)
                     nf, nr = self.lstm.layer(l + 1, ""), self.lstm.layer(l + 1, "_reverse")
                     key = nf[1].data_ptr()
+                    if prep is not None:
+                        prep.wait()
                     fol = {"w_ih": (nf[0], nr[0]), "out": [],
                            "bias": prep.lstm[key][0] if prep is not None and key in prep.lstm else ops.lstm_bias_sum(nf[2], nf[3], nr[2], nr[3]),
                            "wpack": prep.xpack.get(nf[0].data_ptr()) if prep is not None else None}
-                    if self.dropout_masks is not None:
-                        mk = self.dropout_masks[l].to(dev).reshape(T * b, -1)
-                        if maps is not None:
-                            mk = ops.gather_rows(mk, maps.to_dense, maps.rows)
-                    if prep is not None:
-                        prep.wait()
                 with prof_range("model.lstm.l%d" % l):
-                    dp, ds = (self.p_lstm_dropout, self.dropout_seed + self._dropout_calls) if draw else (0.0, 0)
+                    dp, ds = (self.p_lstm_dropout, self.dropout_seed + self._dropout_calls) if draw and mk is None else (0.0, 0)
                     hseq = ops.BiLstmLayerFn.apply(hseq, lens_dev, T, b, f[0], f[1], f[2], f[3], r[0], r[1], r[2], r[3], prep, True, dp, ds, rows,
                                                    pre, fol, mk)
                 pre = fol["out"][0] if fol is not None else None
                 continue
             with prof_range("model.lstm.l%d" % l):
-                hseq = self._bilstm_layer(hseq, lens_dev, out_w, T, b, f, r, prep,
-                                          (self.p_lstm_dropout, self.dropout_seed + self._dropout_calls) if fused else None, rows)
-            if l < self.num_lstm_layers - 1:
+                hseq = self._bilstm_layer(hseq, lens_dev, out_w, T, b, f, r, prep)
+            if not last:
                 if self.dropout_masks is not None:
-                    mk = self.dropout_masks[l].to(dev).reshape(T * b, -1)
-                    if maps is not None:
-                        mk = ops.gather_rows(mk, maps.to_dense, maps.rows)
-                    hseq = ops.MulMaskFn.apply(hseq, mk)
-                elif draw and not fused:
+                    hseq = ops.MulMaskFn.apply(hseq, self.dropout_masks[l].to(dev).reshape(T * b, -1))
+                elif draw:
                     hseq = ops.DropoutFn.apply(hseq, self.p_lstm_dropout, self.dropout_seed + self._dropout_calls)
         pr = getattr(self.prob_layer, "0")
         with prof_range("model.prob"):
@@ -352,14 +354,11 @@ class CnnOcrModel(nn.Module):
             prob_output = prob_output.view(T, b, -1)
         return prob_output, lens_cpu
 
-    def _bilstm_layer(self, hseq, lens_dev, out_w, T, b, f, r, prep, drop=None, rows=0):
-        """One bidirectional layer.  The sweep kernels take up to 64 batch rows per call (include/vocr.h); the reference's --batch-size is
-        free (src/train_cnn_lstm.py:155), so a larger batch runs as tiles of <= 64 rows: the recurrence never couples batch rows, the
-        widths are sorted, so a tile is itself a valid packed batch and only sweeps its own longest sequence.  A tile's weight
-        gradients go through autograd (which adds the tiles' contributions) instead of the direct sinks."""
-        if b <= 64:
-            dp, ds = drop if drop is not None else (0.0, 0)
-            return ops.BiLstmLayerFn.apply(hseq, lens_dev, T, b, f[0], f[1], f[2], f[3], r[0], r[1], r[2], r[3], prep, True, dp, ds, rows)
+    def _bilstm_layer(self, hseq, lens_dev, out_w, T, b, f, r, prep):
+        """One bidirectional layer of a batch of MORE than 64 rows.  The sweep kernels take up to 64 batch rows per call (include/vocr.h);
+        the reference's --batch-size is free (src/train_cnn_lstm.py:155), so a larger batch runs as tiles of <= 64 rows: the recurrence
+        never couples batch rows, the widths are sorted, so a tile is itself a valid packed batch and only sweeps its own longest
+        sequence.  A tile's weight gradients go through autograd (which adds the tiles' contributions) instead of the direct sinks."""
         ntile = (b + 63) // 64
         rows = (b + ntile - 1) // ntile
         h3 = hseq.view(T, b, -1)

@@ -84,30 +84,7 @@ def side_stream(device=None):
     return _side(device)["stream"]
 
 
-# The stream of the x-projection followers (vocr_lstm_xproj_follow: layer l+1's input GEMM beside layer l's forward sweep) and
-# the number every (sweep, follower) pair shares: never 0, never repeated within 2^32 sweeps.
-_FOLLOW = {}
-_EPOCH = [0]
-
-
-def follow_stream(device=None):
-    idx = torch.cuda.current_device() if device is None else torch.device(device).index
-    if idx is None:
-        idx = torch.cuda.current_device()
-    st = _FOLLOW.get(idx)
-    if st is None:
-        lo, hi = torch.cuda.Stream.priority_range()
-        with torch.cuda.device(idx):
-            st = _FOLLOW[idx] = torch.cuda.Stream(priority=lo)
-    return st
-
-
-def next_epoch():
-    _EPOCH[0] = (_EPOCH[0] % 0xFFFFFFFE) + 1
-    return _EPOCH[0]
-
-
-_LSTM_FOLLOW = _exp("VOCR_LSTM_FOLLOW", "0") == "1"
+_LSTM_FOLLOW = _exp("VOCR_LSTM_FOLLOW", "0") == "1"          # measured slower than the GEMM in front of the next sweep: an experiment switch
 
 
 def lstm_follow_ok(b, h, din_next, h_next):
@@ -342,12 +319,19 @@ def f16_layouts(x, want_nhwc=True, want_nchwp=False):
     return nhwc, nchwp
 
 
+def h16_takes(n, cin, h, w, cout):
+    """The all-DMA fp16 kernels (and the one-pass layout conversion in front of them) take this launch: channel counts
+    (vocr_conv3x3_h16_supported) AND sizes - the conversion pass walks n*h rows in one grid dimension (<= 65535), the kernels address the
+    fp16 copies with 32-bit byte offsets (< 2 GB).  Beyond that the register-staged fp16 kernels run, straight on the fp32 tensors."""
+    return bool(_lib.load().vocr_conv3x3_h16_supported(cin, cout)) and n * h <= 65535 and n * h * w * max(cin, cout) * 2 < 2 ** 31
+
+
 def conv3x3_forward_f16(x, wpack16, bias, cout, x_nhwc=None):
     """fp16 operands, fp32 accumulate, fp32 NCHW in and out (BASELINE configs[4]).  Cin % 16 == 0: the all-DMA kernel on an NHWC fp16
     copy of x (`x_nhwc`, made here unless the caller has it); otherwise (the rapid_ds stage's Cin = 1) the register-staged kernel."""
     n, cin, h, w = x.shape
     y = torch.empty(n, cout, h, w, dtype=torch.float32, device=x.device)
-    if _lib.load().vocr_conv3x3_h16_supported(cin, cout):
+    if h16_takes(n, cin, h, w, cout):
         if x_nhwc is None:
             x_nhwc = f16_layouts(x)[0]
         call("vocr_conv3x3_h16_fwd", _p(x_nhwc), _p(wpack16), _p(bias), _p(y), n, cin, h, w, cout, _stream())
@@ -464,7 +448,7 @@ class ConvBnReluFn(torch.autograd.Function):
             else:
                 pf, pd = conv3x3_pack_f16(weight)
             x_nhwc = None
-            if lib.vocr_conv3x3_h16_supported(cin, cout):
+            if h16_takes(n, cin, h, w, cout):
                 # one pass over x: the forward operand and (training) the weight gradient's channel-major copy, kept for the backward
                 x_nhwc, x16p = f16_layouts(x, True, bool(training) and wgrad_f16_layouts_ok(cin, cout))
             y = conv3x3_forward_f16(x, pf, bias, cout, x_nhwc)
@@ -560,7 +544,7 @@ class ConvBnReluFn(torch.autograd.Function):
         dy_nhwc = dy16p = None
         if ctx.f16:
             # one pass over dy: the data gradient's NHWC operand and the weight gradient's channel-major padded one
-            want_nhwc = bool(ctx.needs_input_grad[0]) and bool(lib.vocr_conv3x3_h16_supported(cout, cin))
+            want_nhwc = bool(ctx.needs_input_grad[0]) and h16_takes(dy.shape[0], cout, dy.shape[2], dy.shape[3], cin)
             if want_nhwc or x16p is not None:
                 dy_nhwc, dy16p = f16_layouts(dy, want_nhwc, x16p is not None)
         if sinks is not None and _SIDE_ENABLED and ctx.needs_input_grad[0] and _exp("VOCR_CONV_OVERLAP", "1") == "1":
@@ -815,6 +799,13 @@ class MulMaskFn(torch.autograd.Function):
         return dx, None
 
 
+def dropout_mask(nrows, ncols, p, seed, device):
+    """[nrows, ncols] pre-scaled mask of vocr_dropout_fwd's counter-based draw (element index = row * ncols + col)."""
+    mask = torch.empty(int(nrows), int(ncols), dtype=torch.float32, device=device)
+    call("vocr_dropout_mask", _p(mask), mask.numel(), float(p), int(seed), _stream())
+    return mask
+
+
 class DropoutFn(torch.autograd.Function):
     """nn.LSTM(dropout=p) between layers in training: counter-based mask drawn on device."""
 
@@ -871,13 +862,22 @@ class GatherRowsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, fwd_map, bwd_map, nrows_out, fill=None):
         _need_gpu(x)
-        ctx.bwd = (bwd_map, x.shape[0])
+        ctx.bwd = (bwd_map, x.shape[0], fwd_map if fill is not None else None)
         return gather_rows(x, fwd_map, nrows_out, fill)
 
     @staticmethod
     def backward(ctx, dout):
-        bwd_map, nrows_in = ctx.bwd
-        return gather_rows(dout, bwd_map, nrows_in), None, None, None, None
+        bwd_map, nrows_in, fill_map = ctx.bwd
+        dfill = None
+        if fill_map is not None and ctx.needs_input_grad[4]:
+            # the fill row stood in every row without a source: its gradient is their column sum (what the dense path's bias gradient
+            # collects from the padded frames; zero under the CTC criterion, not under any other loss on the returned logits)
+            dout = _f32c(dout)
+            n = dout.shape[1]
+            dfill = torch.empty(n, dtype=torch.float32, device=dout.device)
+            ws = _ws(_lib.load().vocr_gather_rows_fill_grad_workspace_bytes(n), dout.device)
+            call("vocr_gather_rows_fill_grad", _p(dout), _p(fill_map), dout.shape[0], n, _p(dfill), _p(ws), _stream())
+        return gather_rows(dout, bwd_map, nrows_in), None, None, None, dfill
 
 
 # ------------------------------------------------------------------------------------------------ LSTM layer
@@ -894,8 +894,8 @@ class BiLstmLayerFn(torch.autograd.Function):
         with a mask that already exists ([R, 2H], pre-scaled; explicit test masks, or vocr_dropout_mask's draw made ahead of the sweep).
         pre: (plane0, plane1), this layer's x-projection as the two source-direction planes a follower behind the layer below wrote
         (each [2, R, 4H]; x is then only kept for the backward).  follow: {"w_ih": (f, r) of the NEXT layer, "bias": its [2, 4H] bias
-        sums or None, "wpack": its vocr_lstm_xproj_pack or None, "out": list} - the next layer's x-projection runs on the follow stream
-        beside this layer's sweep (vocr_lstm_xproj_follow) and its two planes are appended to follow["out"]."""
+        sums or None, "wpack": its vocr_lstm_xproj_pack or None, "out": list} - the next layer's x-projection runs inside this layer's
+        sweep (vocr_lstm_fwd_lead's follower waves) and its two planes are appended to follow["out"]."""
         _need_gpu(x, lens_dev, w_ih_f, w_hh_f, w_ih_r, w_hh_r)
         x = _f32c(x)
         lib = _lib.load()
@@ -927,10 +927,7 @@ class BiLstmLayerFn(torch.autograd.Function):
             gemm_pair(0, 0, 1, R, G, din, x, x, din, w_ih_f, w_ih_r, din, xproj[0], xproj[1], G, bias0=bsum[0], bias1=bsum[1])
         mask = drop_mask
         if follow is not None:
-            # the NEXT layer's x-projection beside this layer's sweep: the follower starts where the main stream stands now
-            # (its inputs - the pack, the mask, the bias sums - are ordered before this point), never behind the sweep itself
-            main = torch.cuda.current_stream()
-            fs = follow_stream(dev)
+            # the NEXT layer's x-projection inside this layer's sweep (four more waves per workgroup: include/vocr.h, vocr_lstm_fwd_lead)
             nf, nr = follow["w_ih"]
             wpack = follow.get("wpack")
             if wpack is None:
@@ -940,22 +937,13 @@ class BiLstmLayerFn(torch.autograd.Function):
                 mask = torch.empty_like(y)
                 call("vocr_dropout_mask", _p(mask), mask.numel(), float(drop_p), int(drop_seed), _stream())
             planes = torch.empty(2, 2, R, G, dtype=torch.float32, device=dev)
-            epoch = next_epoch()
-            fs.wait_stream(main)
             p0, p1 = (pre if pre is not None else (xproj, None))
             call("vocr_lstm_fwd_lead", _p(p0), _p(p1), _p(w_hh_f), _p(w_hh_r), _p(lens_dev), _p(y), _p(gates), _p(cell), _p(ws), T, B, H, R if rows else 0,
-                 epoch, _p(health(dev)), _stream())
-            with torch.cuda.stream(fs):
-                call("vocr_lstm_xproj_follow", _p(y), _p(mask), _p(wpack), _p(nbias), _p(planes), _p(lens_dev), _p(ws), T, B, H, R if rows else 0,
-                     epoch, _p(health(dev)), _stream())
-            for t_ in (y, mask, wpack, nbias, planes, lens_dev, ws):
-                if t_ is not None:
-                    t_.record_stream(fs)
+                 _p(wpack), _p(nbias), _p(mask), _p(planes), _p(health(dev)), _stream())
             follow["out"].append((planes[0], planes[1]))
-            follow["join"] = fs
         elif pre is not None:
             call("vocr_lstm_fwd_lead", _p(pre[0]), _p(pre[1]), _p(w_hh_f), _p(w_hh_r), _p(lens_dev), _p(y), _p(gates), _p(cell), _p(ws), T, B, H,
-                 R if rows else 0, 0, _p(health(dev)), _stream())
+                 R if rows else 0, None, None, None, None, _p(health(dev)), _stream())
         elif rows:
             call("vocr_lstm_fwd_packed", _p(xproj), _p(w_hh_f), _p(w_hh_r), _p(lens_dev), _p(y), _p(gates), _p(cell), _p(ws), T, B, H, R,
                  _p(health(dev)), _stream())
@@ -967,15 +955,14 @@ class BiLstmLayerFn(torch.autograd.Function):
         ctx.b_refs = (b_ih_f, b_hh_f, b_ih_r, b_hh_r)
         out = y
         if mask is not None:
-            # what the NEXT layer's weight gradient multiplies; beside a follower this pass runs under the follower's tail
+            # what the NEXT layer's weight gradient multiplies (the follower waves applied the mask on their own read of y)
             out = torch.empty_like(y)
             call("vocr_mul", _p(y), _p(mask), _p(out), y.numel(), _stream())
         elif drop_p and float(drop_p) > 0.0:
             out = torch.empty_like(y)
             mask = torch.empty_like(y)
             call("vocr_dropout_fwd", _p(y), _p(out), _p(mask), y.numel(), float(drop_p), int(drop_seed), _stream())
-        if follow is not None:
-            torch.cuda.current_stream().wait_stream(follow["join"])         # the next sweep reads the planes
+
         ctx.has_mask = mask is not None
         ctx.save_for_backward(x, lens_dev, y, gates, cell, w_ih_f, w_hh_f, w_ih_r, w_hh_r, mask)
         return out
