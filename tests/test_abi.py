@@ -101,6 +101,20 @@ def test_argument_validation_without_gpu():
     assert lib.vocr_f32_to_f16_layouts(one, one, None, 1, 24, 4, 4, None) == -1       # the channel-blocked copy needs C % 16 == 0
     assert lib.vocr_conv3x3_h16_fwd(one, one, None, one, 1, 24, 4, 4, 64, None) == -1
     assert lib.vocr_conv3x3_c1_fwd(None, one, None, one, 1, 4, 4, 16, 0, None) == -1
+    # round 6 entry points
+    assert lib.vocr_lstm_xproj_pack_bytes(512) == 2 * 8 * 512 * 512 * 4 and lib.vocr_lstm_xproj_pack_bytes(0) == 0
+    assert lib.vocr_lstm_xproj_pack(one, one, one, 256, None) == -1 and b"H must be 512" in lib.vocr_last_error()
+    assert lib.vocr_lstm_follow_supported(16, 512) == 0 and lib.vocr_lstm_follow_supported(33, 512) == 0 and lib.vocr_lstm_follow_supported(32, 256) == 0
+    # planes without a pack / a pack without planes / a follower on a shape that has none: refused in front of any launch
+    lead = lambda *tail: lib.vocr_lstm_fwd_lead(one, None, one, one, one, one, one, one, one, 8, 32, 512, 0, *tail)
+    assert lead(None, None, None, one, None, None) == -1 and b"next_planes without next_wpack" in lib.vocr_last_error()
+    assert lead(one, None, None, None, None, None) == -1 and b"next_wpack without next_planes" in lib.vocr_last_error()
+    assert lib.vocr_lstm_fwd_lead(one, None, one, one, one, one, one, one, one, 8, 8, 512, 0, one, None, None, one, None, None) == -1
+    assert lib.vocr_dropout_mask(one, 16, 1.0, 1, None) == -1 and lib.vocr_dropout_mask(None, 16, 0.5, 1, None) == -1
+    assert lib.vocr_gather_rows_fill_grad_workspace_bytes(96) == 64 * 96 * 4
+    assert lib.vocr_gather_rows_fill_grad(one, None, 4, 8, one, one, None) == -1
+    assert lib.vocr_conv3x3_h16_plan(32, 64, 30, 600, 64) == 1 and lib.vocr_conv3x3_h16_plan(32, 24, 30, 600, 64) == 0
+    assert lib.vocr_conv3x3_h16_plan(32, 128, 15, 420, 128) in (2, 3, 4, 5)
 
 
 def test_product_never_imports_oracle():

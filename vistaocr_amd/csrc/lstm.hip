@@ -1566,7 +1566,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_chain4v(const float* __restrict_
     constexpr int members = H / 16;
     constexpr int UW = H / 4;                         // units per wave
     constexpr int NCB = UW / 64;                      // 64-unit column blocks per wave
-    constexpr int DP = 68;
+    constexpr int DP = 80;                            // row pitch (floats), = 16 mod 64: the B-fragment read of lane (row j, group g) starts at bank
+                                                      // 16 j + 4 g - 16 distinct 4-bank pieces, conflict-free (68: j + g collided, 4-way)
     __shared__ float dgl[2 * 4 * DP + 4];             // own dgates [parity][row][gate*16 + local unit] (+ one scratch word)
     const int nch = 2 * NT4;
     const int chain = nch > 8 ? (int)(blockIdx.x & 7) + 8 * (int)((blockIdx.x >> 3) & 1) : (int)(blockIdx.x & 7);
@@ -1793,7 +1794,8 @@ __global__ __launch_bounds__(512) void lstm_bwd_chain4w(const float* __restrict_
     constexpr int H = 128 * NCH;
     static_assert(H == 512, "8 waves x 64 units");
     constexpr int members = H / 32;
-    constexpr int DP = 132;
+    constexpr int DP = 144;                           // = 16 mod 64 (see lstm_bwd_chain4v; at 132 the eight 16-byte fragment reads of a step cost 32
+                                                      // conflict cycles per wave: SQ_LDS_BANK_CONFLICT 1.9e7 per sweep)
     __shared__ float dgl[2 * 4 * DP + 4];             // own dgates [parity][row][gate*32 + local unit] (+ one scratch word)
     const int nch = 2 * NT4;
     const int chain = (int)(blockIdx.x & 7) + 8 * (int)((blockIdx.x >> 3) & 1), member = blockIdx.x >> 4;
