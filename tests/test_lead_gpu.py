@@ -190,3 +190,4 @@ def test_fill_row_gradient_of_the_packed_path(dev, tmp_path):
     for n in a["grads"]:
         tol = 3e-4 * max(1e-3, a["grads"][n].abs().max().item())
         assert (a["grads"][n] - b["grads"][n]).abs().max().item() <= tol, n
+

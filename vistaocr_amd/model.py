@@ -214,6 +214,11 @@ class CnnOcrModel(nn.Module):
                 out_w = math.floor((out_w + 2.0 * 1 - 1 * (3 - 1) - 1) / 1 + 1)
         return (out_h, out_w)
 
+    def output_lengths(self, widths):
+        """Frames per line the forward pass will report for these pixel widths (cnnlstm.py:281-283), on the host."""
+        widths = widths.data if torch.is_tensor(widths) else widths
+        return torch.tensor([self.cnn_input_size_to_output_size((self.input_line_height, int(wd)))[1] for wd in widths], dtype=torch.int32)
+
     # ------------------------------------------------------------------ forward (cnnlstm.py:268-296)
     def forward(self, x, actual_minibatch_widths):
         dev = next(self.parameters()).device
