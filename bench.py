@@ -155,13 +155,22 @@ def executed_share(name, args):
     if name == "vocr_conv3x3_wgrad_wino":
         h = args[6]
         return (4.0 / 9.0) * (2.0 * ((h + 1) // 2) / h) if (_WGRAD2D and (args[5] * args[8]) % 4 == 0) else 2.0 / 3.0
+    if name == "vocr_gemm_x6":
+        return 6.0
     return 1.0
+
+
 def lstm_packed_flops(args, h_arg):
     h, rows = args[h_arg], args[h_arg + 1]       # packed rows (include/vocr.h): the frames the sweep computes, plus the zero groups
     return 2.0 * 2 * rows * h * 4 * h
 
 
-FLOPS_OF = {"vocr_conv3x3_fwd": conv_flops, "vocr_conv3x3_wino_fwd": conv_flops, "vocr_conv3x3_wgrad": conv_flops,
+def gemm_x6_flops(args):
+    m, n, k = args[10:13]
+    return 2.0 * m * n * k
+
+
+FLOPS_OF = {"vocr_gemm_x6": gemm_x6_flops, "vocr_conv3x3_fwd": conv_flops, "vocr_conv3x3_wino_fwd": conv_flops, "vocr_conv3x3_wgrad": conv_flops,
             "vocr_conv3x3_wgrad_wino": conv_flops, "vocr_conv3x3_f16_fwd": conv_flops, "vocr_conv3x3_wgrad_f16": conv_flops,
             "vocr_conv3x3_h16_fwd": conv_flops, "vocr_conv3x3_wgrad_h16": conv_flops,
             "vocr_gemm": gemm_flops, "vocr_gemm_pair": gemm_pair_flops,
@@ -170,9 +179,11 @@ FLOPS_OF = {"vocr_conv3x3_fwd": conv_flops, "vocr_conv3x3_wino_fwd": conv_flops,
             "vocr_lstm_fwd_packed": lambda a: lstm_packed_flops(a, 10), "vocr_lstm_bwd_packed": lambda a: lstm_packed_flops(a, 12)}
 _F16_CONV = ("conv3x3 with fp16 operands, fp32 accumulate (conv3x3_h16_kernel on NHWC fp16 activations: forward + data gradient; conv3x3_wgrad_h16_kernel on "
              "channel-major fp16 copies: weight gradient; the register-staged kernels where the channel counts do not fit; v_mfma_f32_32x32x16_f16)")
+_X6_GEMM = ("dense GEMMs on the bf16 matrix pipe (gemm_x6_kernel behind vocr_gemm_x6: every fp32 operand split EXACTLY into three bf16 planes, six "
+            "v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate - the LSTM projections and their dX / dW; executed = 6 x the algorithmic FLOPs)")
 # a family's own roofline where it is not the f32 matrix pipe
-FAMILY_PEAK = {_F16_CONV: F16_MFMA_PEAK_TFLOPS}
-FAMILY = {"vocr_conv3x3_fwd": "conv3x3 forward + data gradient (conv3x3_wino4 / conv3x3_wino2 kernels: F(4,3) / F(2,3) along the row)",
+FAMILY_PEAK = {_F16_CONV: F16_MFMA_PEAK_TFLOPS, _X6_GEMM: F16_MFMA_PEAK_TFLOPS}
+FAMILY = {"vocr_gemm_x6": _X6_GEMM, "vocr_conv3x3_fwd": "conv3x3 forward + data gradient (conv3x3_wino4 / conv3x3_wino2 kernels: F(4,3) / F(2,3) along the row)",
           "vocr_conv3x3_wino_fwd": "conv3x3 forward + data gradient (conv3x3_wino4 / conv3x3_wino2 kernels: F(4,3) / F(2,3) along the row)",
           "vocr_conv3x3_wgrad": "conv3x3 weight gradient (conv3x3_wgrad_wino2d_kernel: F(3,2) along the row and across row pairs, piece stream)",
           "vocr_conv3x3_wgrad_wino": "conv3x3 weight gradient (conv3x3_wgrad_wino2d_kernel: F(3,2) along the row and across row pairs, piece stream)",
@@ -468,7 +479,7 @@ def run_rank(args):
         torch.cuda.synchronize()
 
     MFMA_NAMES = ["vocr_conv3x3_fwd", "vocr_conv3x3_wino_fwd", "vocr_conv3x3_wgrad", "vocr_conv3x3_wgrad_wino", "vocr_conv3x3_f16_fwd",
-                  "vocr_conv3x3_wgrad_f16", "vocr_conv3x3_h16_fwd", "vocr_conv3x3_wgrad_h16", "vocr_gemm", "vocr_gemm_pair", "vocr_lstm_fwd", "vocr_lstm_fwd_range", "vocr_lstm_bwd_bias",
+                  "vocr_conv3x3_wgrad_f16", "vocr_conv3x3_h16_fwd", "vocr_conv3x3_wgrad_h16", "vocr_gemm", "vocr_gemm_pair", "vocr_gemm_x6", "vocr_lstm_fwd", "vocr_lstm_fwd_range", "vocr_lstm_bwd_bias",
                   "vocr_lstm_fwd_packed", "vocr_lstm_bwd_packed"]
 
     rank_dt = [0.0, 0.0]          # [min, max] over ranks of the last timed loop's wall time
@@ -519,7 +530,8 @@ def run_rank(args):
     names = MFMA_NAMES + ["vocr_bn_train_stats", "vocr_bn_relu_apply", "vocr_bn_relu_fracpool2x2_fwd", "vocr_bn_train_relu_apply",
                           "vocr_bn_train_relu_fracpool2x2_fwd", "vocr_bn_relu_bwd",
                           "vocr_fracpool2x2_bwd", "vocr_bn_relu_fracpool2x2_bwd", "vocr_ctc_loss_grad", "vocr_clamp_adam", "vocr_bchw_to_wbch", "vocr_wbch_to_bchw",
-                          "vocr_relu_maxpool2_fwd", "vocr_relu_maxpool2_bwd", "vocr_gather_rows", "vocr_dropout_fwd", "vocr_mul", "vocr_f32_to_f16_layouts", "vocr_conv3x3_c1_fwd", "vocr_conv3x3_c1_wgrad"]
+                          "vocr_relu_maxpool2_fwd", "vocr_relu_maxpool2_bwd", "vocr_gather_rows", "vocr_dropout_fwd", "vocr_mul", "vocr_f32_to_f16_layouts", "vocr_conv3x3_c1_fwd", "vocr_conv3x3_c1_wgrad",
+                          "vocr_gemm_x6_split"]
     _lib.enable_timing(names)
     for _ in range(PROFILE_STEPS):
         va.train(batch_dev, model, crit, opt)

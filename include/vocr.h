@@ -295,6 +295,29 @@ int vocr_lstm_bwd_parts(const float* dy, const float* dy_mask, const float* whht
                         int32_t* health, void* stream);
 int vocr_lstm_bias_from_parts(float* dbias, const void* workspace, int t, int b, int h, void* stream);
 
+/* ---- fp32 GEMM on the bf16 matrix pipe by EXACT operand splitting ("bf16x6") — the LSTM projections and their gradients (cnnlstm.py:143-154) ---- */
+/* Every fp32 operand element is written as a0 + a1 + a2 (three bf16 values whose sum is the fp32 value exactly) and a product is accumulated in fp32
+ * from the six partial products of order <= 2^-16; the three dropped ones are <= 2^-23 |a b| (one unit roundoff of an fp32 product).
+ * v_mfma_f32_32x32x16_bf16 runs at 16x the rate of the f32 MFMA: six per product = 2.67x the f32 matrix peak.
+ * vocr_gemm_x6_split writes the three planes of an operand in MFMA-fragment order (vocr_gemm_x6_planes_bytes(rows, k) bytes; rows padded to 256, K to
+ * 32): x is [rows][k] with leading dimension ld (k_contiguous = 1) or [k][rows] (k_contiguous = 0: the transposed operands of the weight
+ * gradients).  vocr_gemm_x6: C[m][n] = A[m][k] . B[n][k]^T (+ bias)(relu) from the planes of A and B, both outputs with ldc.  What is left of the
+ * last round of 256 x 128 tiles (one workgroup per CU) is cut along K into slabs in `workspace` (vocr_gemm_x6_workspace_bytes; NULL: no cut)
+ * that are added in a fixed order. */
+size_t vocr_gemm_x6_planes_bytes(int rows, int k);
+/* x may come in two pieces (the two direction planes of the LSTM's gate tensors, the two directions' weights): seg_axis = 0: k < seg from x, the
+ * rest from x2 at k - seg; seg_axis = 1: row < seg from x, the rest from x2 at row - seg (seg <= 0: one piece; seg %% 8 == 0; both pieces with ld).
+ * mask (K-contiguous only, may be NULL): an element-wise factor with x's addressing (the inter-layer dropout mask rides on the operand's read). */
+int vocr_gemm_x6_split(const float* x, const float* x2, int seg, int seg_axis, const float* mask, long ld, int rows, int k, int k_contiguous,
+                       void* planes, void* stream);
+size_t vocr_gemm_x6_workspace_bytes(int m, int n, int k);
+/* A = rows a_row0 .. + m and k16 steps a_kk0 .. + k/16 of a plane set written for (a_rows, a_k) - a view: the row-shifted operands of the recurrent
+ * weight gradient are k windows of ONE plane set -; B likewise (its rows are the output columns).  Two outputs: columns >= csplit go to c1 at
+ * col - csplit, or rows >= rsplit to c1 at row - rsplit (<= 0: no cut). */
+int vocr_gemm_x6(const void* a_planes, int a_rows, int a_k, int a_row0, int a_kk0, const void* b_planes, int b_rows, int b_k, int b_row0, int b_kk0,
+                 int m, int n, int k, float* c0, float* c1, int csplit, int rsplit, int ldc, const float* bias0, const float* bias1, int relu,
+                 void* workspace, void* stream);
+
 /* ---- the same recurrence without the padding: pack_padded_sequence's economy — src/models/cnnlstm.py:285-290 ---------- */
 /* The reference packs the length-sorted batch before nn.LSTM, so cuDNN never computes a padded frame.  Here the rows of every
  * sequence-side tensor (bridge output, xproj, y, gates, cell, dy, dgates) can be kept in a PACKED, chain-major order instead of

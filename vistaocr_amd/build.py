@@ -16,7 +16,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-SOURCES = ["gemm.hip", "gemm_dma.hip", "conv.hip", "conv_wino.hip", "conv_f16.hip", "bn_pool.hip", "lstm.hip", "ctc.hip", "misc.cpp", "comm.cpp"]
+SOURCES = ["gemm.hip", "gemm_dma.hip", "gemm_x6.hip", "conv.hip", "conv_wino.hip", "conv_f16.hip", "bn_pool.hip", "lstm.hip", "ctc.hip", "misc.cpp", "comm.cpp"]
 HEADERS = [os.path.join(CSRC, "vocr_common.h"), os.path.join(CSRC, "conv_tail.h"), os.path.join(CSRC, "gemm_dma.h"),
            os.path.join(CSRC, "..", "..", "include", "vocr.h")]
 LIB = os.path.join(CSRC, "libvocr.so")

@@ -1,0 +1,391 @@
+// fp32 GEMM on the bf16 matrix pipe by exact operand splitting ("bf16x6"): every fp32 operand element a is written as a0 + a1 + a2 with
+// a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1) - EXACT (3 x 8 significant bits cover fp32's 24; the residuals are computed in
+// fp32 without rounding) - and a*b is accumulated from the six partial products of order <= 2^-16 (a0b0, a0b1, a1b0, a0b2, a2b0, a1b1),
+// each of them exact in the fp32 accumulator's input (8 x 8 bits); the three dropped ones (a1b2, a2b1, a2b2) are <= 2^-23 |a b|, one unit
+// roundoff of the fp32 product the f32 MFMA would have formed.  v_mfma_f32_32x32x16_bf16 runs at 16x the rate of v_mfma_f32_32x32x2_f32, so six
+// of them per product are 2.67x the f32 matrix peak (417 TFLOP/s of fp32-equivalent work on an MI355X).
+//
+// Operands are kept as three bf16 planes in MFMA-FRAGMENT order (written by the split kernels below, one pass over the fp32 tensor):
+//     plane[p][row tile rt][k16 step kk][lane][8]   lane (r = lane & 31, h = lane >> 5) holds X[32 rt + r][16 kk + 8 h + 0..7]
+// so that a fragment is 1 KB contiguous in memory AND in LDS: it reaches LDS by one DMA instruction of a wave and comes back with one
+// conflict-free ds_read_b128 per lane.  Rows are padded to 256, K to 32 (zeros).  The source may be K-contiguous ([row][k], vocr_gemm_x6_split_rk) or
+// K-strided ([k][row], _split_kr: the transposed operands of the weight gradients); the product kernel is the same for every transpose form.
+//
+// gemm_x6_kernel: workgroup tile 256 x 128, eight waves as 4 (rows) x 2 (columns) with 64 x 64 wave tiles (4 accumulator tiles, 64 VGPRs),
+// stages of one k16 step (36 fragments of 1 KB: five or four DMA instructions per wave), a ring of four LDS slots: the DMAs of stage s + 3 are
+// issued one at a time between the MFMA groups of stage s (24 MFMAs per wave = 1536 matrix-pipe cycles per SIMD), one barrier per stage.  Long-K products with few tiles are cut along K into
+// slabs that gemm_x6_reduce_kernel adds in a fixed order.
+#include "vocr_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4x __attribute__((ext_vector_type(4)));
+#define X6_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+constexpr int X6_BM = 256, X6_BN = 128;
+constexpr int X6_STAGE = 36 * 1024;                 // bytes: one k16 step = 24 A fragments + 12 B fragments of 1 KB
+constexpr int X6_NS = 4;                            // ring slots (144 KB)
+
+__device__ __forceinline__ void split3(float a, __bf16& b0, __bf16& b1, __bf16& b2) {
+    b0 = (__bf16)a;
+    const float r1 = a - (float)b0;
+    b1 = (__bf16)r1;
+    const float r2 = r1 - (float)b1;
+    b2 = (__bf16)r2;
+}
+
+// A source matrix may come in two pieces (the two direction planes of the LSTM's gate tensors, the two directions' weight matrices): along K
+// (axis 0: k < seg from x, the rest from x2 at k - seg) or along the rows (axis 1: row < seg from x, the rest from x2 at row - seg); seg <= 0: one
+// piece; seg is a multiple of 8, so a lane's eight k lie in one piece.
+struct X6Src {
+    const float* x;
+    const float* x2;
+    const float* mask;       // K-contiguous source only: element-wise factor with x's addressing (the inter-layer dropout mask), or nullptr
+    long ld;
+    int seg, axis;
+};
+
+// K-contiguous source X[row][k]: one wave per fragment (rt, kk), lane = (row, k half)
+__global__ __launch_bounds__(256) void x6_split_rk_kernel(const X6Src src, int rows, int K, bf16x8* __restrict__ planes, int RT, int KK) {
+    const long frag = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (frag >= (long)RT * KK) return;
+    const int lane = threadIdx.x & 63, rt = (int)(frag / KK), kk = (int)(frag % KK);
+    const int row = 32 * rt + (lane & 31), k0 = 16 * kk + 8 * (lane >> 5);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    if (row < rows && k0 < K) {
+        const bool second = src.seg > 0 && (src.axis == 0 ? k0 : row) >= src.seg;
+        const int r_ = second && src.axis == 1 ? row - src.seg : row, k_ = second && src.axis == 0 ? k0 - src.seg : k0;
+        const long e = (long)r_ * src.ld + k_;
+        const float* p = (second ? src.x2 : src.x) + e;
+        if (k0 + 8 <= K && ((((uintptr_t)p) & 15) == 0)) {
+            const f32x4 q0 = *(const f32x4*)p, q1 = *(const f32x4*)(p + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] = q0[j]; v[4 + j] = q1[j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (k0 + j < K) v[j] = p[j];
+        }
+        if (src.mask) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (k0 + j < K) v[j] *= src.mask[e + j];
+        }
+    }
+    bf16x8 o0, o1, o2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        __bf16 b0, b1, b2;
+        split3(v[j], b0, b1, b2);
+        o0[j] = b0; o1[j] = b1; o2[j] = b2;
+    }
+    const long pstride = (long)RT * KK * 64;
+    bf16x8* o = planes + frag * 64 + lane;
+    o[0] = o0;
+    o[pstride] = o1;
+    o[2 * pstride] = o2;
+}
+
+// K-strided source X[k][row] (K along the memory rows): lane (row, k half) gathers its eight k
+__global__ __launch_bounds__(256) void x6_split_kr_kernel(const X6Src src, int rows, int K, bf16x8* __restrict__ planes, int RT, int KK) {
+    const long frag = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (frag >= (long)RT * KK) return;
+    // consecutive fragments of a workgroup share kk and take consecutive row tiles: 128 consecutive floats of each source row
+    const int lane = threadIdx.x & 63, kk = (int)(frag / RT), rt = (int)(frag % RT);
+    const int row = 32 * rt + (lane & 31), k0 = 16 * kk + 8 * (lane >> 5);
+    const bool second = src.seg > 0 && (src.axis == 0 ? k0 : row) >= src.seg;
+    const int r_ = second && src.axis == 1 ? row - src.seg : row, k_ = second && src.axis == 0 ? k0 - src.seg : k0;
+    const float* base = (second ? src.x2 : src.x) + (long)k_ * src.ld + r_;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (row < rows && k0 + j < K) ? base[(long)j * src.ld] : 0.f;
+    bf16x8 o0, o1, o2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        __bf16 b0, b1, b2;
+        split3(v[j], b0, b1, b2);
+        o0[j] = b0; o1[j] = b1; o2[j] = b2;
+    }
+    const long pstride = (long)RT * KK * 64;
+    bf16x8* o = planes + ((long)rt * KK + kk) * 64 + lane;
+    o[0] = o0;
+    o[pstride] = o1;
+    o[2 * pstride] = o2;
+}
+
+struct X6Args {
+    const void* a;           // planes of A: [3][RTa][KKa][64][8] bf16
+    const void* b;           // planes of B: [3][RTb][KKb][64][8] bf16
+    float* c[2];             // two outputs, both with ldc: cut along the columns (col >= csplit -> c[1] at col - csplit) or the rows (rsplit)
+    const float* bias[2];
+    float* slab;             // K cut: [split][tile of this launch][256][128] partial sums
+    int M, N, nkk;           // rows, columns, k16 steps of the product
+    int RTa, RTb, KKa, KKb;  // padded row tiles and k16 steps of the two plane sets (their strides)
+    int a_rt0, a_kk0, b_rt0, b_kk0;      // where the product's operands start inside the plane sets (views: shifted rows / k windows)
+    int csplit, rsplit, ldc;
+    int mtiles, ntiles, tile0, ntile_launch, ksplit, stages_per_split;
+    int relu;
+};
+
+__global__ __launch_bounds__(512) void gemm_x6_kernel(const X6Args g) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];          // X6_NS x 36 KB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3, wn = wave >> 2;
+    // tile order: column tiles fastest, so that consecutive workgroups (one XCD takes every eighth) share A rows
+    const int ltile = blockIdx.x % g.ntile_launch, split = blockIdx.x / g.ntile_launch;
+    const int t = g.tile0 + ltile;
+    const int nt = t % g.ntiles, mt = t / g.ntiles;
+    const int s_beg = split * g.stages_per_split, s_end = min(g.nkk, s_beg + g.stages_per_split);      // K16 stages
+    if (s_beg >= s_end) return;
+
+    const long pa = (long)g.RTa * g.KKa * 1024, pb = (long)g.RTb * g.KKb * 1024;       // plane strides in bytes
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)g.a, 0, (int)(3 * pa), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)g.b, 0, (int)(3 * pb), 0x00020000);
+    const int voff = lane * 16;
+    // A stage = one k16 step: 24 A fragments (f = plane * 8 + row tile) + 12 B fragments (24 + plane * 4 + column tile) of 1 KB.  Wave w moves
+    // fragments w, w + 8, w + 16, w + 24 and - waves 0 - 3 - w + 32: 5 or 4 instructions per stage, a wave-uniform constant.
+    // A stage past the end is "moved" from out of range (zeros into a slot nobody reads), so that the counts never change.
+    auto dma_one = [&](int s, int slot, int i) {
+        const int f = wave + 8 * i;
+        unsigned char* dst = lds + slot * X6_STAGE + f * 1024;
+        const bool live = s < s_end;
+        if (f < 24) {
+            const long off = (f >> 3) * pa + ((long)(g.a_rt0 + 8 * mt + (f & 7)) * g.KKa + g.a_kk0 + s) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, X6_LDS_PTR(dst), 16, live ? voff : -16, live ? (int)off : 0, 0, 0);
+        } else {
+            const int fb = f - 24;
+            const long off = (fb >> 2) * pb + ((long)(g.b_rt0 + 4 * nt + (fb & 3)) * g.KKb + g.b_kk0 + s) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, X6_LDS_PTR(dst), 16, live ? voff : -16, live ? (int)off : 0, 0, 0);
+        }
+    };
+    auto dma_stage = [&](int s, int slot) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma_one(s, slot, i);
+        if (wave < 4) dma_one(s, slot, 4);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // prologue: three stages in flight
+#pragma unroll
+    for (int i = 0; i < X6_NS - 1; ++i) dma_stage(s_beg + i, i);
+#ifndef X6_CUT
+#define X6_CUT 0              // diagnostic builds (scripts/x6_bench.py), WRONG results: 1 no DMA in the loop, 2 no MFMA, 4 no fragment reads, 8 no barrier
+#endif
+    int slot = 0;
+    bf16x8 af[2][3], bf[2][3];
+    if (X6_CUT & 4) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) { af[q][p] = *(const bf16x8*)(lds + lane * 16 + (p * 2 + q) * 1024); bf[q][p] = *(const bf16x8*)(lds + lane * 16 + (8 + p * 2 + q) * 1024); }
+    }
+    for (int s = s_beg; s < s_end; ++s) {
+        // stage s has landed for this wave when only the two younger stages' DMAs are outstanding
+        if (!(X6_CUT & 1)) { if (wave < 4) __builtin_amdgcn_s_waitcnt(0x0F70 | 10); else __builtin_amdgcn_s_waitcnt(0x0F70 | 8); }
+        if (!(X6_CUT & 8)) __builtin_amdgcn_s_barrier();     // ... for everybody; and everybody is done reading the slot of stage s - 1
+        const unsigned char* base = lds + slot * X6_STAGE + lane * 16;
+        // fragments in the order the MFMAs want them: plane pairs of tile (0, 0) first
+        if (!(X6_CUT & 4)) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                af[0][p] = *(const bf16x8*)(base + (p * 8 + 2 * wm) * 1024);
+                bf[0][p] = *(const bf16x8*)(base + (24 + p * 4 + 2 * wn) * 1024);
+            }
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                af[1][p] = *(const bf16x8*)(base + (p * 8 + 2 * wm + 1) * 1024);
+                bf[1][p] = *(const bf16x8*)(base + (24 + p * 4 + 2 * wn + 1) * 1024);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int snext = s + X6_NS - 1, slot_next = slot == 0 ? X6_NS - 1 : slot - 1;      // the slot of stage s - 1
+        int d = 0;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+                // the small partial products first
+                if (!(X6_CUT & 2)) {
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][1], bf[tn][1], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][0], bf[tn][2], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][2], bf[tn][0], acc[tm][tn], 0, 0, 0);
+                }
+                // the DMAs of stage s + 3 one at a time between the MFMA groups
+                if (d < 4 && !(X6_CUT & 1)) { dma_one(snext, slot_next, d); }
+                ++d;
+                if (!(X6_CUT & 2)) {
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][0], bf[tn][1], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][1], bf[tn][0], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][0], bf[tn][0], acc[tm][tn], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        if (wave < 4 && !(X6_CUT & 1)) dma_one(snext, slot_next, 4);
+        slot = slot == X6_NS - 1 ? 0 : slot + 1;
+    }
+
+    // ---- C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    const int li = lane & 31, lk = lane >> 5;
+    const bool slabbed = g.slab != nullptr;
+    float* const sl = slabbed ? g.slab + ((long)split * g.ntile_launch + ltile) * (X6_BM * X6_BN) : nullptr;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        const int lcol = 64 * wn + 32 * tn + li, col = X6_BN * nt + lcol;
+        if (col >= g.N) continue;
+        const int cw = col >= g.csplit ? 1 : 0;
+        const float bvc = (!slabbed && g.bias[cw]) ? g.bias[cw][col - cw * g.csplit] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lrow = 64 * wm + 32 * tm + (r & 3) + 8 * (r >> 2) + 4 * lk, row = X6_BM * mt + lrow;
+                if (row < g.M) {
+                    if (slabbed) {
+                        sl[lrow * X6_BN + lcol] = acc[tm][tn][r];
+                    } else {
+                        const int rw = row >= g.rsplit ? 1 : 0, which = cw | rw;
+                        float v = acc[tm][tn][r] + bvc;
+                        if (g.relu) v = fmaxf(v, 0.f);
+                        g.c[which][(long)(row - rw * g.rsplit) * g.ldc + (col - cw * g.csplit)] = v;
+                    }
+                }
+            }
+    }
+}
+
+// the tiles of a K-cut launch: C = sum over the splits' slabs in split order (+ bias)(relu)
+__global__ __launch_bounds__(256) void gemm_x6_reduce_kernel(const X6Args g) {
+    const int ltile = blockIdx.x / 32, part = blockIdx.x % 32;                   // 32 workgroups per 256 x 128 tile: 8 rows each
+    const int t = g.tile0 + ltile, nt = t % g.ntiles, mt = t / g.ntiles;
+    const int lcol = threadIdx.x & 127, col = X6_BN * nt + lcol;
+    if (col >= g.N) return;
+    const int cw = col >= g.csplit ? 1 : 0;
+    const float bv = g.bias[cw] ? g.bias[cw][col - cw * g.csplit] : 0.f;
+    for (int rr = threadIdx.x >> 7; rr < 8; rr += 2) {
+        const int lrow = 8 * part + rr, row = X6_BM * mt + lrow;
+        if (row >= g.M) continue;
+        float v = 0.f;
+        for (int s = 0; s < g.ksplit; ++s) v += g.slab[((long)s * g.ntile_launch + ltile) * (X6_BM * X6_BN) + lrow * X6_BN + lcol];
+        v += bv;
+        if (g.relu) v = fmaxf(v, 0.f);
+        const int rw = row >= g.rsplit ? 1 : 0, which = cw | rw;
+        g.c[which][(long)(row - rw * g.rsplit) * g.ldc + (col - cw * g.csplit)] = v;
+    }
+}
+
+int x6_cu_count() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cus[dev]) {
+        hipDeviceProp_t prop;
+        cus[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return cus[dev];
+}
+
+}  // namespace
+
+static inline int x6_rt(int rows) { return vocr_cdiv(rows, 256) * 8; }
+static inline int x6_kk(int k) { return vocr_cdiv(k, 32) * 2; }
+
+extern "C" size_t vocr_gemm_x6_planes_bytes(int rows, int k) {
+    if (rows <= 0 || k <= 0) return 0;
+    return (size_t)3 * x6_rt(rows) * x6_kk(k) * 1024;
+}
+
+extern "C" int vocr_gemm_x6_split(const float* x, const float* x2, int seg, int seg_axis, const float* mask, long ld, int rows, int k, int k_contiguous,
+                                  void* planes, void* stream) {
+    VOCR_CHECK_ARG(x && planes, "vocr_gemm_x6_split: null pointer");
+    VOCR_CHECK_ARG(rows > 0 && k > 0 && ld > 0, "vocr_gemm_x6_split: bad shape (%d x %d, ld %ld)", rows, k, ld);
+    VOCR_CHECK_ARG((((uintptr_t)planes) & 15) == 0, "vocr_gemm_x6_split: the planes must be 16-byte aligned");
+    VOCR_CHECK_ARG(seg <= 0 || (x2 && seg % 8 == 0 && (seg_axis == 0 || seg_axis == 1)), "vocr_gemm_x6_split: a second piece needs x2, seg %% 8 == 0, axis 0 / 1");
+    VOCR_CHECK_ARG(!mask || k_contiguous, "vocr_gemm_x6_split: a mask only with a K-contiguous source");
+    const int RT = x6_rt(rows), KK = x6_kk(k);
+    VOCR_CHECK_ARG((long)3 * RT * KK * 1024 < (1l << 31), "vocr_gemm_x6_split: operand too large for 32-bit fragment offsets");
+    const long frags = (long)RT * KK;
+    const X6Src src = {x, x2, mask, ld, seg, seg_axis};
+    if (k_contiguous) x6_split_rk_kernel<<<(unsigned)vocr_cdiv(frags, 4), 256, 0, (hipStream_t)stream>>>(src, rows, k, (bf16x8*)planes, RT, KK);
+    else x6_split_kr_kernel<<<(unsigned)vocr_cdiv(frags, 4), 256, 0, (hipStream_t)stream>>>(src, rows, k, (bf16x8*)planes, RT, KK);
+    VOCR_CHECK_LAUNCH("vocr_gemm_x6_split");
+    return VOCR_OK;
+}
+
+extern "C" size_t vocr_gemm_x6_workspace_bytes(int m, int n, int k) {
+    if (m <= 0 || n <= 0 || k <= 0) return 0;
+    // at most one round of workgroups writes slabs: CU count tiles of 256 x 128
+    return (size_t)(x6_cu_count() + 8) * X6_BM * X6_BN * sizeof(float);
+}
+
+// C[m][n] = A . B^T (+ bias)(relu) from split planes.  A: rows a_row0 .. + m and k16 steps a_kk0 .. + k/16 of a plane set written for
+// (a_rows, a_k); B likewise (rows = output columns).  Two outputs: columns >= csplit go to c1 at col - csplit, or rows >= rsplit to c1 at
+// row - rsplit (0: no cut); a_row0 / b_row0 multiples of 32, k a multiple of 16.
+extern "C" int vocr_gemm_x6(const void* a_planes, int a_rows, int a_k, int a_row0, int a_kk0, const void* b_planes, int b_rows, int b_k, int b_row0,
+                            int b_kk0, int m, int n, int k, float* c0, float* c1, int csplit, int rsplit, int ldc, const float* bias0,
+                            const float* bias1, int relu, void* workspace, void* stream) {
+    VOCR_CHECK_ARG(a_planes && b_planes && c0, "vocr_gemm_x6: null pointer");
+    VOCR_CHECK_ARG(m > 0 && n > 0 && k > 0 && ldc > 0 && k % 16 == 0, "vocr_gemm_x6: bad shape (k %% 16 == 0)");
+    VOCR_CHECK_ARG(a_row0 % 32 == 0 && b_row0 % 32 == 0 && a_row0 >= 0 && b_row0 >= 0 && a_kk0 >= 0 && b_kk0 >= 0, "vocr_gemm_x6: views start on tile boundaries");
+    VOCR_CHECK_ARG((csplit <= 0 && rsplit <= 0) || c1, "vocr_gemm_x6: a second output needs c1");
+    VOCR_CHECK_ARG(!(csplit > 0 && rsplit > 0), "vocr_gemm_x6: one cut, along the columns or along the rows");
+    X6Args g;
+    g.a = a_planes; g.b = b_planes;
+    g.c[0] = c0; g.c[1] = c1 ? c1 : c0;
+    g.bias[0] = bias0; g.bias[1] = bias1;
+    g.M = m; g.N = n; g.nkk = k / 16;
+    g.RTa = x6_rt(a_rows); g.KKa = x6_kk(a_k); g.RTb = x6_rt(b_rows); g.KKb = x6_kk(b_k);
+    g.a_rt0 = a_row0 / 32; g.a_kk0 = a_kk0; g.b_rt0 = b_row0 / 32; g.b_kk0 = b_kk0;
+    g.mtiles = vocr_cdiv(m, X6_BM); g.ntiles = vocr_cdiv(n, X6_BN);
+    // a tile reads whole 256-row / 128-column blocks of fragments: they must exist in the plane sets (zero padding or later rows)
+    VOCR_CHECK_ARG(g.a_rt0 + 8 * g.mtiles <= g.RTa && g.b_rt0 + 4 * g.ntiles <= g.RTb && g.a_kk0 + g.nkk <= g.KKa && g.b_kk0 + g.nkk <= g.KKb,
+                   "vocr_gemm_x6: the view leaves its plane set");
+    g.csplit = csplit > 0 ? csplit : (1 << 30);
+    g.rsplit = rsplit > 0 ? rsplit : (1 << 30);
+    g.ldc = ldc;
+    g.relu = relu;
+    static bool lds_ok = false;
+    if (!lds_ok) {
+        if (hipFuncSetAttribute((const void*)gemm_x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, X6_NS * X6_STAGE) != hipSuccess) {
+            vocr_set_error("vocr_gemm_x6: hipFuncSetAttribute failed");
+            return VOCR_ELAUNCH;
+        }
+        lds_ok = true;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int tiles = g.mtiles * g.ntiles, ncu = x6_cu_count();
+    // whole rounds of one workgroup per CU run their tiles over the full K; what is left of the last round - when it would leave more than
+    // half of the chip idle - is cut along K into slabs, so that it takes 1 / ksplit of a round (294 x 8 tiles of the data gradient: 1 + 1/6
+    // rounds instead of 2)
+    const int full = (tiles / ncu) * ncu, rem = tiles - full;
+    int ks = 1;
+    if (rem > 0 && rem * 2 <= ncu && g.nkk >= 32 && workspace) {
+        ks = ncu / rem;
+        if (ks > 8) ks = 8;
+        if (ks > g.nkk / 8) ks = g.nkk / 8;
+        if (ks < 1) ks = 1;
+    }
+    const int main_tiles = ks > 1 ? full : tiles;
+    if (main_tiles > 0) {
+        g.tile0 = 0; g.ntile_launch = main_tiles; g.ksplit = 1; g.stages_per_split = g.nkk; g.slab = nullptr;
+        gemm_x6_kernel<<<main_tiles, 512, X6_NS * X6_STAGE, s>>>(g);
+    }
+    if (ks > 1) {
+        g.tile0 = full; g.ntile_launch = rem;
+        g.stages_per_split = vocr_cdiv(g.nkk, ks);
+        g.ksplit = vocr_cdiv(g.nkk, g.stages_per_split);
+        g.slab = (float*)workspace;
+        gemm_x6_kernel<<<rem * g.ksplit, 512, X6_NS * X6_STAGE, s>>>(g);
+        gemm_x6_reduce_kernel<<<rem * 32, 256, 0, s>>>(g);
+    }
+    VOCR_CHECK_LAUNCH("vocr_gemm_x6");
+    return VOCR_OK;
+}

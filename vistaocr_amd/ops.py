@@ -194,6 +194,8 @@ class ForwardPrep(object):
         self.packs = {}          # weight.data_ptr() -> (pack_fwd, pack_dgrad)
         self.lstm = {}           # w_hh_f.data_ptr() -> (bsum, wt_f, wt_r)
         self.xpack = {}          # w_ih_f.data_ptr() -> W_ih of both directions in the follower's fragment order (vocr_lstm_xproj_pack)
+        self.x6w = {}            # w_ih_f.data_ptr() -> (planes of [W_f; W_r] rows = gate rows, k = input: the x-projection's B;
+                                 #                       planes of its transpose rows = input, k = gate rows: the data gradient's B or None)
         self.event = None        # everything done (the LSTM items come last: they are needed ~4 ms into the step)
         self.pack_events = {}    # weight.data_ptr() -> event behind THAT layer's pack (the second conv layer needs its pack ~0.15 ms into
                                  # the step; one event behind all ~25 pack launches made it wait ~50 us for the deeper layers' packs)
@@ -226,9 +228,17 @@ def lstm_xproj_pack(w_ih_f, w_ih_r):
     return wpack
 
 
-def forward_prep(conv_weights, lstm_layers, with_transposes, f16=False, follow_layers=()):
+def x6_weight_planes(w_ih_f, w_ih_r, with_transpose):
+    g4, din = w_ih_f.shape
+    wk = x6_planes(w_ih_f, 2 * g4, din, True, din, x2=w_ih_r, seg=g4, axis=1)
+    wt = x6_planes(w_ih_f, din, 2 * g4, False, din, x2=w_ih_r, seg=g4, axis=0) if with_transpose else None
+    return wk, wt
+
+
+def forward_prep(conv_weights, lstm_layers, with_transposes, f16=False, follow_layers=(), x6_layers=()):
     """conv_weights: 4-D fp32 weights to pack (f16: into the fp16-operand kernels' packs); lstm_layers: [(w_hh_f, b_ih_f, b_hh_f, w_hh_r,
-    b_ih_r, b_hh_r), ...]; follow_layers: [(w_ih_f, w_ih_r), ...] of the layers whose x-projection runs behind the sweep below them."""
+    b_ih_r, b_hh_r), ...]; follow_layers: [(w_ih_f, w_ih_r), ...] of the layers whose x-projection runs behind the sweep below them;
+    x6_layers: [(w_ih_f, w_ih_r), ...] of the layers whose GEMMs run as bf16x6 products (their weight planes are made here)."""
     if not _SIDE_ENABLED or _exp("VOCR_FWD_PREP", "1") != "1":
         return None
     prep = ForwardPrep()
@@ -252,6 +262,11 @@ def forward_prep(conv_weights, lstm_layers, with_transposes, f16=False, follow_l
             wt = (transpose2d(w_hh_f), transpose2d(w_hh_r)) if with_transposes else (None, None)
             prep.lstm[w_hh_f.data_ptr()] = (bsum, wt[0], wt[1])
             made.extend(t for t in (bsum,) + wt if t is not None)
+        for (w_ih_f, w_ih_r) in x6_layers:
+            # the x-projection of a narrow input (layer 0) is a small product: it keeps the f32 kernels, its weights need no planes
+            if w_ih_f.shape[1] >= 512:
+                prep.x6w[w_ih_f.data_ptr()] = x6_weight_planes(w_ih_f, w_ih_r, with_transposes)
+                made.extend(t for t in prep.x6w[w_ih_f.data_ptr()] if t is not None)
         for (w_ih_f, w_ih_r) in follow_layers:
             prep.xpack[w_ih_f.data_ptr()] = lstm_xproj_pack(w_ih_f, w_ih_r)
             made.append(prep.xpack[w_ih_f.data_ptr()])
@@ -676,6 +691,31 @@ def gemm_pair(mode, ta, tb, m, n, k, a0, a1, lda, b0, b1, ldb, c0, c1, ldc, bias
          _p(bias0), _p(bias1), int(relu), _p(ws), nb, _stream())
 
 
+# ---- fp32 GEMM on the bf16 matrix pipe by exact operand splitting (include/vocr.h: vocr_gemm_x6*): the LSTM projections and their gradients
+_GEMM_X6 = _exp("VOCR_GEMM_X6", "1") == "1"
+
+
+def x6_layer_ok(T, B, H, rows):
+    """The BiLSTM layer's GEMMs run as bf16x6 products: dense rows whose time shift (B rows) is a whole number of k16 steps."""
+    return _GEMM_X6 and not rows and B % 16 == 0 and (4 * H) % 128 == 0 and T * B >= 256
+
+
+def x6_planes(x, rows, k, k_contiguous, ld, x2=None, seg=0, axis=0, mask=None):
+    """The three bf16 planes of an fp32 operand in MFMA-fragment order (one pass over x; a torch.bfloat16 buffer)."""
+    lib = _lib.load()
+    buf = torch.empty(lib.vocr_gemm_x6_planes_bytes(int(rows), int(k)) // 2, dtype=torch.bfloat16, device=x.device)
+    call("vocr_gemm_x6_split", _p(x), _p(x2), int(seg), int(axis), _p(mask), int(ld), int(rows), int(k), int(bool(k_contiguous)), _p(buf), _stream())
+    return buf
+
+
+def gemm_x6(a, a_rows, a_k, b, b_rows, b_k, m, n, k, c0, ldc, c1=None, csplit=0, rsplit=0, bias0=None, bias1=None, a_row0=0, a_kk0=0, b_row0=0,
+            b_kk0=0, relu=False):
+    """c = A . B^T from split planes (views: row / k16 offsets into plane sets written for (a_rows, a_k) and (b_rows, b_k))."""
+    ws = _ws(_lib.load().vocr_gemm_x6_workspace_bytes(m, n, k), c0.device)
+    call("vocr_gemm_x6", _p(a), int(a_rows), int(a_k), int(a_row0), int(a_kk0), _p(b), int(b_rows), int(b_k), int(b_row0), int(b_kk0), int(m), int(n),
+         int(k), _p(c0), _p(c1), int(csplit), int(rsplit), int(ldc), _p(bias0), _p(bias1), int(relu), _p(ws), _stream())
+
+
 def colsum(x2d, out=None):
     m, n = x2d.shape
     out = out if out is not None else torch.empty(n, dtype=torch.float32, device=x2d.device)
@@ -922,7 +962,17 @@ class BiLstmLayerFn(torch.autograd.Function):
         ws = _ws(lib.vocr_lstm_workspace_bytes(T, B, H), dev)
         G = 4 * H
 
-        if pre is None:
+        ctx.x6 = x6_layer_ok(T, B, H, rows)
+        ctx.x6_wt = None
+        if pre is None and ctx.x6 and din >= 512:
+            # bf16x6: the operands as three exact bf16 planes, six bf16 MFMAs per product (include/vocr.h: vocr_gemm_x6)
+            if prep is not None and w_ih_f.data_ptr() in prep.x6w:
+                wk, ctx.x6_wt = prep.x6w[w_ih_f.data_ptr()]
+            else:
+                wk, ctx.x6_wt = x6_weight_planes(w_ih_f, w_ih_r, torch.is_grad_enabled())
+            xa = x6_planes(x, R, din, True, din)
+            gemm_x6(xa, R, din, wk, 2 * G, din, R, 2 * G, din, xproj[0], G, c1=xproj[1], csplit=G, bias0=bsum[0], bias1=bsum[1])
+        elif pre is None:
             # both directions' x-projections in one launch: 2 x (columns / 128) panels x row groups == the CU count
             gemm_pair(0, 0, 1, R, G, din, x, x, din, w_ih_f, w_ih_r, din, xproj[0], xproj[1], G, bias0=bsum[0], bias1=bsum[1])
         mask = drop_mask
@@ -1009,7 +1059,12 @@ class BiLstmLayerFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             # dx = dg_fwd W_ih_fwd + dg_rev W_ih_rev as ONE product whose K runs through both pairs (no accumulating second pass)
-            gemm_pair(1, 0, 0, R, din, G, dg[0], dg[1], G, w_ih_f, w_ih_r, din, dx, None, din)
+            if ctx.x6 and din >= 512:
+                wt = ctx.x6_wt if ctx.x6_wt is not None else x6_weight_planes(w_ih_f, w_ih_r, True)[1]
+                da = x6_planes(dg[0], R, 2 * G, True, G, x2=dg[1], seg=G, axis=0)
+                gemm_x6(da, R, 2 * G, wt, din, 2 * G, R, din, 2 * G, dx, din)
+            else:
+                gemm_pair(1, 0, 0, R, din, G, dg[0], dg[1], G, w_ih_f, w_ih_r, din, dx, None, din)
 
         # weight gradients: if every parameter already owns a gradient buffer (FlatClampAdam aliases them into one
         # flat buffer), write them there from the side stream so they overlap the next layer's sweep; otherwise
@@ -1022,6 +1077,20 @@ class BiLstmLayerFn(torch.autograd.Function):
             dwi_f, dwh_f, dbi_f, dbh_f, dwi_r, dwh_r, dbi_r, dbh_r = outs
             if parts:
                 call("vocr_lstm_bias_from_parts", _p(dbias), _p(ws), T, B, H, _stream())
+            if ctx.x6 and T > 1:
+                # bf16x6: the gate gradients of both directions as ONE transposed plane set (rows = gate columns, k = the frames); the input's and
+                # the output's transposes; the recurrent product's time shift (B rows = B / 16 k16 steps) is a k window of the same planes
+                dgt = x6_planes(dg[0], 2 * G, R, False, G, x2=dg[1], seg=G, axis=1)
+                xt = x6_planes(x, din, R, False, din)
+                gemm_x6(dgt, 2 * G, R, xt, din, R, 2 * G, din, R, dwi_f, din, c1=dwi_r, rsplit=G)
+                yt = x6_planes(y, 2 * H, R, False, 2 * H)
+                gemm_x6(dgt, 2 * G, R, yt, 2 * H, R, G, H, R - B, dwh_f, H, a_row0=0, a_kk0=B // 16, b_row0=0, b_kk0=0)
+                gemm_x6(dgt, 2 * G, R, yt, 2 * H, R, G, H, R - B, dwh_r, H, a_row0=G, a_kk0=0, b_row0=H, b_kk0=B // 16)
+                dbi_f.copy_(dbias[0])
+                dbi_r.copy_(dbias[1])
+                dbh_f.copy_(dbias[0])
+                dbh_r.copy_(dbias[1])
+                return
             gemm_pair(co, 1, 0, G, din, R, dg[0], dg[1], G, x, x, din, dwi_f, dwi_r, din)
             if T > 1:
                 # forward dir: h_{t-1} = y[t-1, :, :H];   reverse dir: h_{t+1} = y[t+1, :, H:]  (zero past the length).  Dense rows:
