@@ -155,8 +155,6 @@ def executed_share(name, args):
     if name == "vocr_conv3x3_wgrad_wino":
         h = args[6]
         return (4.0 / 9.0) * (2.0 * ((h + 1) // 2) / h) if (_WGRAD2D and (args[5] * args[8]) % 4 == 0) else 2.0 / 3.0
-    if name == "vocr_gemm_x6":
-        return 6.0
     return 1.0
 
 
@@ -179,10 +177,12 @@ FLOPS_OF = {"vocr_gemm_x6": gemm_x6_flops, "vocr_conv3x3_fwd": conv_flops, "vocr
             "vocr_lstm_fwd_packed": lambda a: lstm_packed_flops(a, 10), "vocr_lstm_bwd_packed": lambda a: lstm_packed_flops(a, 12)}
 _F16_CONV = ("conv3x3 with fp16 operands, fp32 accumulate (conv3x3_h16_kernel on NHWC fp16 activations: forward + data gradient; conv3x3_wgrad_h16_kernel on "
              "channel-major fp16 copies: weight gradient; the register-staged kernels where the channel counts do not fit; v_mfma_f32_32x32x16_f16)")
-_X6_GEMM = ("dense GEMMs on the bf16 matrix pipe (gemm_x6_kernel behind vocr_gemm_x6: every fp32 operand split EXACTLY into three bf16 planes, six "
-            "v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate - the LSTM projections and their dX / dW; executed = 6 x the algorithmic FLOPs)")
+_X6_GEMM = ("dense fp32 GEMMs on the bf16 matrix pipe (gemm_x6_kernel behind vocr_gemm_x6: every fp32 operand split EXACTLY into three bf16 planes, six "
+            "v_mfma_f32_32x32x16_bf16 per fp32 product, fp32 accumulate, error below the f32-MFMA kernels' against fp64 - the LSTM projections and their "
+            "dX / dW; FLOPs counted as the fp32 products they replace, peak = the bf16 MFMA peak / 6 = 416.7 TFLOP/s)")
+X6_EQUIV_PEAK_TFLOPS = F16_MFMA_PEAK_TFLOPS / 6.0      # six bf16 MFMAs per fp32 product
 # a family's own roofline where it is not the f32 matrix pipe
-FAMILY_PEAK = {_F16_CONV: F16_MFMA_PEAK_TFLOPS, _X6_GEMM: F16_MFMA_PEAK_TFLOPS}
+FAMILY_PEAK = {_F16_CONV: F16_MFMA_PEAK_TFLOPS, _X6_GEMM: X6_EQUIV_PEAK_TFLOPS}
 FAMILY = {"vocr_gemm_x6": _X6_GEMM, "vocr_conv3x3_fwd": "conv3x3 forward + data gradient (conv3x3_wino4 / conv3x3_wino2 kernels: F(4,3) / F(2,3) along the row)",
           "vocr_conv3x3_wino_fwd": "conv3x3 forward + data gradient (conv3x3_wino4 / conv3x3_wino2 kernels: F(4,3) / F(2,3) along the row)",
           "vocr_conv3x3_wgrad": "conv3x3 weight gradient (conv3x3_wgrad_wino2d_kernel: F(3,2) along the row and across row pairs, piece stream)",
@@ -195,14 +195,33 @@ FAMILY = {"vocr_gemm_x6": _X6_GEMM, "vocr_conv3x3_fwd": "conv3x3 forward + data 
           "vocr_lstm_fwd_packed": "LSTM sweeps (lstm_fwd_chain4w / lstm_bwd_chain4w)", "vocr_lstm_bwd_packed": "LSTM sweeps (lstm_fwd_chain4w / lstm_bwd_chain4w)"}
 
 
+def ops_x6_on():
+    from vistaocr_amd import ops
+    return bool(ops._GEMM_X6)
+
+
 def gemm_alone(hidden, din=128):
     """The step's large GEMM launches ALONE on the chip (both directions of a BiLSTM layer per launch, random operands): inside the
     step the side-stream launches also wait for CUs that the persistent sweeps hold, so their in-step durations say little about the
-    kernel.  ~0.1 s."""
+    kernel.  With the bf16x6 products on: those (and the split passes that feed them), against the bf16 MFMA peak / 6.  ~0.2 s."""
     import torch
     from vistaocr_amd import ops
     dev = torch.device("cuda", torch.cuda.current_device())
     M, G, H = 294 * B, 4 * hidden, hidden
+    x6 = ops_x6_on()
+    peak = X6_EQUIV_PEAK_TFLOPS if x6 else F32_MFMA_PEAK_TFLOPS
+
+    def timed(fn, n=20):
+        for _ in range(8):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
     out = []
     for what, mode, ta, tb, m, n, k in (("x-projection, layers 1-2", 0, 0, 1, M, G, 2 * H), ("data gradient, layers 1-2", 1, 0, 0, M, 2 * H, G),
                                         ("weight gradient W_ih, layers 1-2", 0, 1, 0, G, 2 * H, M), ("weight gradient W_hh", 0, 1, 0, G, H, M - B)):
@@ -212,18 +231,34 @@ def gemm_alone(hidden, din=128):
         b1 = torch.randn_like(b0)
         c0 = torch.empty(m, n, device=dev)
         c1 = torch.empty(m, n, device=dev) if mode == 0 else None
-        fn = lambda: ops.gemm_pair(mode, ta, tb, m, n, k, a0, a1, a0.shape[1], b0, b1, b0.shape[1], c0, c1, n)
-        for _ in range(15):
-            fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(20):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 20
+        rec = {"what": what, "m_n_k": [m, n, k], "products_per_launch": 2}
+        if x6:
+            # the same two products as ONE bf16x6 launch (or two, for the recurrent weight gradient) from plane sets made outside the timed loop
+            if mode == 1:          # c0 = a0 b0 + a1 b1: K runs through both pairs
+                pa = ops.x6_planes(a0, m, 2 * k, True, k, x2=a1, seg=k, axis=0)
+                pb = ops.x6_planes(b0, n, 2 * k, False, n, x2=b1, seg=k, axis=0)
+                fn = lambda: ops.gemm_x6(pa, m, 2 * k, pb, n, 2 * k, m, n, 2 * k, c0, n)
+                split = lambda: ops.x6_planes(a0, m, 2 * k, True, k, x2=a1, seg=k, axis=0)
+            elif ta:               # weight gradients: both operands K-strided, the two gate planes along the rows
+                pa = ops.x6_planes(a0, 2 * m, k, False, m, x2=a1, seg=m, axis=1)
+                pb = ops.x6_planes(b0, n, k, False, n)
+                k16 = k // 16 * 16
+                fn = lambda: ops.gemm_x6(pa, 2 * m, k, pb, n, k, 2 * m, n, k16, c0, n, c1=c1, rsplit=m)
+                split = lambda: (ops.x6_planes(a0, 2 * m, k, False, m, x2=a1, seg=m, axis=1), ops.x6_planes(b0, n, k, False, n))
+            else:                  # x-projection: one input, the two weight matrices along the rows
+                pa = ops.x6_planes(a0, m, k, True, k)
+                pb = ops.x6_planes(b0, 2 * n, k, True, k, x2=b1, seg=n, axis=1)
+                fn = lambda: ops.gemm_x6(pa, m, k, pb, 2 * n, k, m, 2 * n, k, c0, n, c1=c1, csplit=n)
+                split = lambda: ops.x6_planes(a0, m, k, True, k)
+            rec["kernel"] = "gemm_x6_kernel"
+            rec["split_ms"] = round(timed(split), 4)
+        else:
+            fn = lambda: ops.gemm_pair(mode, ta, tb, m, n, k, a0, a1, a0.shape[1], b0, b1, b0.shape[1], c0, c1, n)
+            rec["kernel"] = "gemm_dma_kernel"
+        ms = timed(fn)
         tf = 2 * 2.0 * m * n * k / (ms * 1e-3) / 1e12
-        out.append({"what": what, "m_n_k": [m, n, k], "products_per_launch": 2, "ms": round(ms, 4), "achieved": round(tf, 1), "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4)})
+        rec.update({"ms": round(ms, 4), "achieved": round(tf, 1), "peak": round(peak, 1), "frac": round(tf / peak, 4)})
+        out.append(rec)
         del a0, a1, b0, b1, c0, c1
     return out
 
@@ -627,7 +662,9 @@ def run_rank(args):
             "value": round(value, 2), "unit": "line-images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if conv_dtype == "fp32" else "f32 with fp16 conv operands (fp32 accumulate)", "data": "synthetic",
+            "dtype": ("f32" if conv_dtype == "fp32" else "f32 with fp16 conv operands (fp32 accumulate)") +
+                     (" (the LSTM's large GEMMs as bf16x6 products: fp32 operands split exactly into three bf16 planes, six bf16 MFMAs per fp32 "
+                      "product, fp32 accumulate; ops.VOCR_GEMM_X6=0 restores the f32-MFMA kernels)" if ops_x6_on() else ""), "data": "synthetic",
             "config": {"workload": wl["what"] + ", 3xBiLSTM-%d, train() = H2D of the batch + fwd+CTC+bwd+allreduce+clamp+Adam, loss returned as a float" % args.hidden,
                        "name": args.config, "widths": "%d .. %d px, mean %.0f" % (min(wl["widths"]), max(wl["widths"]), sum(wl["widths"]) / float(B)),
                        "conv_dtype": conv_dtype,

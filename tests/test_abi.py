@@ -115,6 +115,15 @@ def test_argument_validation_without_gpu():
     assert lib.vocr_gather_rows_fill_grad(one, None, 4, 8, one, one, None) == -1
     assert lib.vocr_conv3x3_h16_plan(32, 64, 30, 600, 64) == 1 and lib.vocr_conv3x3_h16_plan(32, 24, 30, 600, 64) == 0
     assert lib.vocr_conv3x3_h16_plan(32, 128, 15, 420, 128) in (2, 3, 4, 5)
+    # bf16x6 GEMM: plane sizes (rows padded to 256, K to 32; three planes of bf16) and argument validation
+    assert lib.vocr_gemm_x6_planes_bytes(9408, 1024) == 3 * (37 * 8) * (32 * 2) * 1024 and lib.vocr_gemm_x6_planes_bytes(0, 8) == 0
+    assert lib.vocr_gemm_x6_workspace_bytes(4096, 1024, 9408) > 0
+    assert lib.vocr_gemm_x6_split(one, None, 8, 0, None, 64, 32, 64, 1, one, None) == -1 and b"second piece" in lib.vocr_last_error()
+    assert lib.vocr_gemm_x6_split(one, None, 0, 0, one, 64, 32, 64, 0, one, None) == -1          # a mask only with a K-contiguous source
+    x6 = lambda *a: lib.vocr_gemm_x6(one, 256, 64, 0, 0, one, 128, 64, 0, 0, *a)
+    assert x6(256, 128, 40, one, None, 0, 0, 128, None, None, 0, None, None) == -1 and b"k % 16" in lib.vocr_last_error()
+    assert x6(256, 128, 64, one, None, 64, 0, 128, None, None, 0, None, None) == -1               # a cut without a second output
+    assert lib.vocr_gemm_x6(one, 256, 64, 0, 2, one, 128, 64, 0, 0, 256, 128, 64, one, None, 0, 0, 128, None, None, 0, None, None) == -1   # view leaves its planes
 
 
 def test_product_never_imports_oracle():

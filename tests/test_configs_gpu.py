@@ -44,7 +44,7 @@ CASES = {
                         widths=[1178, 1154, 1142, 1123, 1089, 1063, 1025, 866, 863, 786, 779, 733, 715, 699, 660, 659, 639, 631, 589, 588, 567, 549,
                                 442, 413, 398, 373, 368, 364, 255, 199, 136, 131],
                         labels_per_line=[39, 38, 38, 37, 36, 35, 34, 28, 28, 26, 25, 24, 23, 23, 22, 21, 21, 21, 19, 19, 18, 18, 14, 13, 13, 12, 12,
-                                         12, 8, 6, 4, 4], seed=10, ltr=False, want_margin=3e-4, tries=60,
+                                         12, 8, 6, 4, 4], seed=23, ltr=False, want_margin=6e-4, tries=60,      # measured logit error 1.6e-4 (bf16x6 x-projections on packed rows)
                         state_kw=dict(lstm_scale=0.08, prob_scale=2.0), masks=(576, 32, 512, 2, 46)),
     # config 5 at BATCH SIZE (round 6): bench.py --config c5's shape - 32 x 1x60x1200, rapid_ds 60 -> 30, fp16 conv operands, 3 x BiLSTM-512,
     # T = 294 - forward AND backward; the fp16 forward / data-gradient launches of this shape take the tile variants 64x2, 128x2, 128x4

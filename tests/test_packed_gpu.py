@@ -181,7 +181,10 @@ def test_model_packed_matches_dense_on_a_ragged_batch(dev, drop):
     assert lab_d == lab_p
     for k in gd:
         rel = float((gd[k] - gp[k]).norm() / (gd[k].norm() + 1e-30))
-        assert rel <= (2e-3 if k.startswith(("cnn.", "rapid_ds")) else 2e-4), (k, rel)
+        # two fp32-grade paths with different summation orders AND (round 6) different product kernels where the row layouts differ (the
+        # packed path's recurrent weight gradient is an f32-MFMA product, the dense one a bf16x6 product): measured up to 2.1e-4 on the
+        # bridge; each path is held to the oracle at 3e-3 in tests/test_configs_gpu.py
+        assert rel <= (2e-3 if k.startswith(("cnn.", "rapid_ds")) else 5e-4), (k, rel)
 
 
 def test_packed_sweep_refuses_a_row_count_that_does_not_fit_the_lengths(dev):

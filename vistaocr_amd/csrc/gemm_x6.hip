@@ -23,9 +23,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4x __attribute__((ext_vector_type(4)));
 #define X6_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
-constexpr int X6_BM = 256, X6_BN = 128;
-constexpr int X6_STAGE = 36 * 1024;                 // bytes: one k16 step = 24 A fragments + 12 B fragments of 1 KB
-constexpr int X6_NS = 4;                            // ring slots (144 KB)
+constexpr int X6_BM = 256;
+constexpr int X6_LDS = 144 * 1024;                  // the ring: 4 x 36 KB (256 x 128 tiles) or 3 x 48 KB (256 x 256)
 
 __device__ __forceinline__ void split3(float a, __bf16& b0, __bf16& b1, __bf16& b2) {
     b0 = (__bf16)a;
@@ -128,11 +127,20 @@ struct X6Args {
     int relu;
 };
 
+// NCT = column tiles of 32 per workgroup tile: 4 (256 x 128: eight waves as 4 x 2 with 64 x 64 wave tiles, 36-KB stages, four ring slots) or 8
+// (256 x 256: 2 x 4 waves with 128 x 64 wave tiles - 128 accumulator registers -, 48-KB stages, three slots: half the DMA instructions per MFMA)
+template <int NCT>
 __global__ __launch_bounds__(512) void gemm_x6_kernel(const X6Args g) {
-    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];          // X6_NS x 36 KB
+    constexpr int BN = 32 * NCT;
+    constexpr int TM = NCT == 4 ? 2 : 4, TN = 2;
+    constexpr int NFRAG = 24 + 3 * NCT;                       // fragments (KB) of a stage
+    constexpr int NS = NCT == 4 ? 4 : 3;                      // ring slots: 144 KB either way
+    constexpr int STAGE = NFRAG * 1024;
+    constexpr int NDMA_MAX = (NFRAG + 7) / 8;                 // 5 (waves 0 - 3; 4 for the others) or 6
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave & 3, wn = wave >> 2;
+    const int wm = NCT == 4 ? (wave & 3) : (wave & 1), wn = NCT == 4 ? (wave >> 2) : (wave >> 1);
     // tile order: column tiles fastest, so that consecutive workgroups (one XCD takes every eighth) share A rows
     const int ltile = blockIdx.x % g.ntile_launch, split = blockIdx.x / g.ntile_launch;
     const int t = g.tile0 + ltile;
@@ -144,83 +152,77 @@ __global__ __launch_bounds__(512) void gemm_x6_kernel(const X6Args g) {
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)g.a, 0, (int)(3 * pa), 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)g.b, 0, (int)(3 * pb), 0x00020000);
     const int voff = lane * 16;
-    // A stage = one k16 step: 24 A fragments (f = plane * 8 + row tile) + 12 B fragments (24 + plane * 4 + column tile) of 1 KB.  Wave w moves
-    // fragments w, w + 8, w + 16, w + 24 and - waves 0 - 3 - w + 32: 5 or 4 instructions per stage, a wave-uniform constant.
-    // A stage past the end is "moved" from out of range (zeros into a slot nobody reads), so that the counts never change.
+    // A stage = one k16 step: 24 A fragments (f = plane * 8 + row tile) + 3 NCT B fragments (24 + plane * NCT + column tile) of 1 KB.  Wave w moves
+    // fragments w, w + 8, ...: a wave-uniform number of instructions per stage.  A stage past the end is "moved" from out of range (zeros into a slot
+    // nobody reads), so that the counts never change.
     auto dma_one = [&](int s, int slot, int i) {
         const int f = wave + 8 * i;
-        unsigned char* dst = lds + slot * X6_STAGE + f * 1024;
+        unsigned char* dst = lds + slot * STAGE + f * 1024;
         const bool live = s < s_end;
         if (f < 24) {
             const long off = (f >> 3) * pa + ((long)(g.a_rt0 + 8 * mt + (f & 7)) * g.KKa + g.a_kk0 + s) * 1024;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, X6_LDS_PTR(dst), 16, live ? voff : -16, live ? (int)off : 0, 0, 0);
         } else {
             const int fb = f - 24;
-            const long off = (fb >> 2) * pb + ((long)(g.b_rt0 + 4 * nt + (fb & 3)) * g.KKb + g.b_kk0 + s) * 1024;
+            const long off = (fb / NCT) * pb + ((long)(g.b_rt0 + NCT * nt + (fb % NCT)) * g.KKb + g.b_kk0 + s) * 1024;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, X6_LDS_PTR(dst), 16, live ? voff : -16, live ? (int)off : 0, 0, 0);
         }
     };
-    auto dma_stage = [&](int s, int slot) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dma_one(s, slot, i);
-        if (wave < 4) dma_one(s, slot, 4);
+    auto dma_nth = [&](int s, int slot, int i) {              // the i-th DMA of this wave's stage, if it has one
+        if (8 * i + 7 < NFRAG || wave + 8 * i < NFRAG) dma_one(s, slot, i);
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // prologue: three stages in flight
+    // prologue: NS - 1 stages in flight
 #pragma unroll
-    for (int i = 0; i < X6_NS - 1; ++i) dma_stage(s_beg + i, i);
+    for (int i = 0; i < NS - 1; ++i)
+#pragma unroll
+        for (int d = 0; d < NDMA_MAX; ++d) dma_nth(s_beg + i, i, d);
 #ifndef X6_CUT
 #define X6_CUT 0              // diagnostic builds (scripts/x6_bench.py), WRONG results: 1 no DMA in the loop, 2 no MFMA, 4 no fragment reads, 8 no barrier
 #endif
     int slot = 0;
-    bf16x8 af[2][3], bf[2][3];
-    if (X6_CUT & 4) {
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) { af[q][p] = *(const bf16x8*)(lds + lane * 16 + (p * 2 + q) * 1024); bf[q][p] = *(const bf16x8*)(lds + lane * 16 + (8 + p * 2 + q) * 1024); }
-    }
     for (int s = s_beg; s < s_end; ++s) {
-        // stage s has landed for this wave when only the two younger stages' DMAs are outstanding
-        if (!(X6_CUT & 1)) { if (wave < 4) __builtin_amdgcn_s_waitcnt(0x0F70 | 10); else __builtin_amdgcn_s_waitcnt(0x0F70 | 8); }
-        if (!(X6_CUT & 8)) __builtin_amdgcn_s_barrier();     // ... for everybody; and everybody is done reading the slot of stage s - 1
-        const unsigned char* base = lds + slot * X6_STAGE + lane * 16;
-        // fragments in the order the MFMAs want them: plane pairs of tile (0, 0) first
-        if (!(X6_CUT & 4)) {
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                af[0][p] = *(const bf16x8*)(base + (p * 8 + 2 * wm) * 1024);
-                bf[0][p] = *(const bf16x8*)(base + (24 + p * 4 + 2 * wn) * 1024);
-            }
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                af[1][p] = *(const bf16x8*)(base + (p * 8 + 2 * wm + 1) * 1024);
-                bf[1][p] = *(const bf16x8*)(base + (24 + p * 4 + 2 * wn + 1) * 1024);
-            }
+        // stage s has landed for this wave when only the NS - 2 younger stages' DMAs are outstanding
+        if (!(X6_CUT & 1)) {
+            if (NCT == 8) __builtin_amdgcn_s_waitcnt(0x0F70 | 6);
+            else if (wave < 4) __builtin_amdgcn_s_waitcnt(0x0F70 | 10);
+            else __builtin_amdgcn_s_waitcnt(0x0F70 | 8);
         }
+        if (!(X6_CUT & 8)) __builtin_amdgcn_s_barrier();     // ... for everybody; and everybody is done reading the slot of stage s - 1
+        const unsigned char* base = lds + slot * STAGE + lane * 16;
+        bf16x8 af[TM][3], bf[TN][3];
+        // fragments in the order the MFMAs want them
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bf[tn][p] = *(const bf16x8*)(base + (24 + p * NCT + TN * wn + tn) * 1024);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) af[tm][p] = *(const bf16x8*)(base + (p * 8 + TM * wm + tm) * 1024);
         __builtin_amdgcn_sched_barrier(0);
-        const int snext = s + X6_NS - 1, slot_next = slot == 0 ? X6_NS - 1 : slot - 1;      // the slot of stage s - 1
+        const int snext = s + NS - 1, slot_next = slot == 0 ? NS - 1 : slot - 1;      // the slot of stage s - 1
         int d = 0;
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
+        for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-            for (int tn = 0; tn < 2; ++tn) {
-                // the small partial products first
+            for (int tn = 0; tn < TN; ++tn) {
                 if (!(X6_CUT & 2)) {
+                    // the small partial products first
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][1], bf[tn][1], acc[tm][tn], 0, 0, 0);
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][0], bf[tn][2], acc[tm][tn], 0, 0, 0);
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][2], bf[tn][0], acc[tm][tn], 0, 0, 0);
                 }
-                // the DMAs of stage s + 3 one at a time between the MFMA groups
-                if (d < 4 && !(X6_CUT & 1)) { dma_one(snext, slot_next, d); }
+                // the DMAs of stage s + NS - 1 one at a time between the MFMA groups
+                if (d < NDMA_MAX && !(X6_CUT & 1)) dma_nth(snext, slot_next, d);
                 ++d;
                 if (!(X6_CUT & 2)) {
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][0], bf[tn][1], acc[tm][tn], 0, 0, 0);
@@ -229,28 +231,30 @@ __global__ __launch_bounds__(512) void gemm_x6_kernel(const X6Args g) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-        if (wave < 4 && !(X6_CUT & 1)) dma_one(snext, slot_next, 4);
-        slot = slot == X6_NS - 1 ? 0 : slot + 1;
+#pragma unroll
+        for (int dd = TM * TN; dd < NDMA_MAX; ++dd)
+            if (!(X6_CUT & 1)) dma_nth(snext, slot_next, dd);
+        slot = slot == NS - 1 ? 0 : slot + 1;
     }
 
     // ---- C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     const int li = lane & 31, lk = lane >> 5;
     const bool slabbed = g.slab != nullptr;
-    float* const sl = slabbed ? g.slab + ((long)split * g.ntile_launch + ltile) * (X6_BM * X6_BN) : nullptr;
+    float* const sl = slabbed ? g.slab + ((long)split * g.ntile_launch + ltile) * (X6_BM * BN) : nullptr;
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-        const int lcol = 64 * wn + 32 * tn + li, col = X6_BN * nt + lcol;
+    for (int tn = 0; tn < TN; ++tn) {
+        const int lcol = 32 * (TN * wn + tn) + li, col = BN * nt + lcol;
         if (col >= g.N) continue;
         const int cw = col >= g.csplit ? 1 : 0;
         const float bvc = (!slabbed && g.bias[cw]) ? g.bias[cw][col - cw * g.csplit] : 0.f;
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
+        for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int lrow = 64 * wm + 32 * tm + (r & 3) + 8 * (r >> 2) + 4 * lk, row = X6_BM * mt + lrow;
+                const int lrow = 32 * (TM * wm + tm) + (r & 3) + 8 * (r >> 2) + 4 * lk, row = X6_BM * mt + lrow;
                 if (row < g.M) {
                     if (slabbed) {
-                        sl[lrow * X6_BN + lcol] = acc[tm][tn][r];
+                        sl[lrow * BN + lcol] = acc[tm][tn][r];
                     } else {
                         const int rw = row >= g.rsplit ? 1 : 0, which = cw | rw;
                         float v = acc[tm][tn][r] + bvc;
@@ -263,18 +267,21 @@ __global__ __launch_bounds__(512) void gemm_x6_kernel(const X6Args g) {
 }
 
 // the tiles of a K-cut launch: C = sum over the splits' slabs in split order (+ bias)(relu)
+template <int NCT>
 __global__ __launch_bounds__(256) void gemm_x6_reduce_kernel(const X6Args g) {
-    const int ltile = blockIdx.x / 32, part = blockIdx.x % 32;                   // 32 workgroups per 256 x 128 tile: 8 rows each
+    constexpr int BN = 32 * NCT, RPW = 256 / BN * 4;                             // rows per workgroup: 8 (BN = 128) or 4
+    const int parts = X6_BM / RPW;
+    const int ltile = blockIdx.x / parts, part = blockIdx.x % parts;
     const int t = g.tile0 + ltile, nt = t % g.ntiles, mt = t / g.ntiles;
-    const int lcol = threadIdx.x & 127, col = X6_BN * nt + lcol;
+    const int lcol = threadIdx.x % BN, col = BN * nt + lcol;
     if (col >= g.N) return;
     const int cw = col >= g.csplit ? 1 : 0;
     const float bv = g.bias[cw] ? g.bias[cw][col - cw * g.csplit] : 0.f;
-    for (int rr = threadIdx.x >> 7; rr < 8; rr += 2) {
-        const int lrow = 8 * part + rr, row = X6_BM * mt + lrow;
+    for (int rr = threadIdx.x / BN; rr < RPW; rr += 256 / BN) {
+        const int lrow = RPW * part + rr, row = X6_BM * mt + lrow;
         if (row >= g.M) continue;
         float v = 0.f;
-        for (int s = 0; s < g.ksplit; ++s) v += g.slab[((long)s * g.ntile_launch + ltile) * (X6_BM * X6_BN) + lrow * X6_BN + lcol];
+        for (int s = 0; s < g.ksplit; ++s) v += g.slab[((long)s * g.ntile_launch + ltile) * (X6_BM * BN) + lrow * BN + lcol];
         v += bv;
         if (g.relu) v = fmaxf(v, 0.f);
         const int rw = row >= g.rsplit ? 1 : 0, which = cw | rw;
@@ -322,9 +329,52 @@ extern "C" int vocr_gemm_x6_split(const float* x, const float* x2, int seg, int 
 
 extern "C" size_t vocr_gemm_x6_workspace_bytes(int m, int n, int k) {
     if (m <= 0 || n <= 0 || k <= 0) return 0;
-    // at most one round of workgroups writes slabs: CU count tiles of 256 x 128
-    return (size_t)(x6_cu_count() + 8) * X6_BM * X6_BN * sizeof(float);
+    // at most one round of workgroups writes slabs: CU count tiles of 256 x 256
+    return (size_t)(x6_cu_count() + 8) * X6_BM * 256 * sizeof(float);
 }
+
+namespace {
+struct X6Plan { int nct, ntiles, tiles, full, rem, ks; double cost; };
+// whole rounds of one workgroup per CU run their tiles over the full K; what is left of the last round - when it would leave at least half of
+// the chip idle - is cut along K into slabs, so that it takes 1 / ks of a round (294 x 8 tiles of the data gradient: 1 + 1/6 rounds instead of 2).
+// Cost in units of one 256 x 128 tile over the full K; the narrow tile pays ~12 % for twice the DMA instructions per MFMA (measured).
+X6Plan x6_plan(int nct, int m, int n, int nkk, int ncu, bool can_cut) {
+    X6Plan p;
+    p.nct = nct;
+    p.ntiles = vocr_cdiv(n, 32 * nct);
+    p.tiles = vocr_cdiv(m, X6_BM) * p.ntiles;
+    p.full = (p.tiles / ncu) * ncu;
+    p.rem = p.tiles - p.full;
+    p.ks = 1;
+    if (p.rem > 0 && p.rem * 2 <= ncu && nkk >= 32 && can_cut) {
+        p.ks = ncu / p.rem;
+        if (p.ks > 8) p.ks = 8;
+        if (p.ks > nkk / 8) p.ks = nkk / 8;
+        if (p.ks < 1) p.ks = 1;
+    }
+    const double per_tile = nct == 8 ? 2.0 : 1.12;
+    p.cost = (p.full / ncu + (p.rem > 0 ? 1.0 / p.ks + (p.ks > 1 ? 0.03 : 0.0) : 0.0)) * per_tile;
+    return p;
+}
+
+template <int NCT>
+void x6_launch(X6Args g, const X6Plan& p, void* workspace, hipStream_t s) {
+    g.ntiles = p.ntiles;
+    const int main_tiles = p.ks > 1 ? p.full : p.tiles;
+    if (main_tiles > 0) {
+        g.tile0 = 0; g.ntile_launch = main_tiles; g.ksplit = 1; g.stages_per_split = g.nkk; g.slab = nullptr;
+        gemm_x6_kernel<NCT><<<main_tiles, 512, X6_LDS, s>>>(g);
+    }
+    if (p.ks > 1) {
+        g.tile0 = p.full; g.ntile_launch = p.rem;
+        g.stages_per_split = vocr_cdiv(g.nkk, p.ks);
+        g.ksplit = vocr_cdiv(g.nkk, g.stages_per_split);
+        g.slab = (float*)workspace;
+        gemm_x6_kernel<NCT><<<p.rem * g.ksplit, 512, X6_LDS, s>>>(g);
+        gemm_x6_reduce_kernel<NCT><<<p.rem * (NCT == 4 ? 32 : 64), 256, 0, s>>>(g);
+    }
+}
+}  // namespace
 
 // C[m][n] = A . B^T (+ bias)(relu) from split planes.  A: rows a_row0 .. + m and k16 steps a_kk0 .. + k/16 of a plane set written for
 // (a_rows, a_k); B likewise (rows = output columns).  Two outputs: columns >= csplit go to c1 at col - csplit, or rows >= rsplit to c1 at
@@ -344,48 +394,30 @@ extern "C" int vocr_gemm_x6(const void* a_planes, int a_rows, int a_k, int a_row
     g.M = m; g.N = n; g.nkk = k / 16;
     g.RTa = x6_rt(a_rows); g.KKa = x6_kk(a_k); g.RTb = x6_rt(b_rows); g.KKb = x6_kk(b_k);
     g.a_rt0 = a_row0 / 32; g.a_kk0 = a_kk0; g.b_rt0 = b_row0 / 32; g.b_kk0 = b_kk0;
-    g.mtiles = vocr_cdiv(m, X6_BM); g.ntiles = vocr_cdiv(n, X6_BN);
-    // a tile reads whole 256-row / 128-column blocks of fragments: they must exist in the plane sets (zero padding or later rows)
-    VOCR_CHECK_ARG(g.a_rt0 + 8 * g.mtiles <= g.RTa && g.b_rt0 + 4 * g.ntiles <= g.RTb && g.a_kk0 + g.nkk <= g.KKa && g.b_kk0 + g.nkk <= g.KKb,
-                   "vocr_gemm_x6: the view leaves its plane set");
+    g.mtiles = vocr_cdiv(m, X6_BM);
     g.csplit = csplit > 0 ? csplit : (1 << 30);
     g.rsplit = rsplit > 0 ? rsplit : (1 << 30);
     g.ldc = ldc;
     g.relu = relu;
+    const int ncu = x6_cu_count();
+    const X6Plan p4 = x6_plan(4, m, n, g.nkk, ncu, workspace != nullptr), p8 = x6_plan(8, m, n, g.nkk, ncu, workspace != nullptr);
+    // the wide tile reads whole blocks of 8 column tiles: they must exist in B's plane set (rows padded to 256: always, unless a view starts late)
+    const bool wide_ok = g.b_rt0 + 8 * p8.ntiles <= g.RTb;
+    const X6Plan& p = (wide_ok && p8.cost < p4.cost) ? p8 : p4;
+    // a tile reads whole 256-row / (32 NCT)-column blocks of fragments: they must exist in the plane sets (zero padding or later rows)
+    VOCR_CHECK_ARG(g.a_rt0 + 8 * g.mtiles <= g.RTa && g.b_rt0 + p.nct * p.ntiles <= g.RTb && g.a_kk0 + g.nkk <= g.KKa && g.b_kk0 + g.nkk <= g.KKb,
+                   "vocr_gemm_x6: the view leaves its plane set");
     static bool lds_ok = false;
     if (!lds_ok) {
-        if (hipFuncSetAttribute((const void*)gemm_x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, X6_NS * X6_STAGE) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)gemm_x6_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)gemm_x6_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS) != hipSuccess) {
             vocr_set_error("vocr_gemm_x6: hipFuncSetAttribute failed");
             return VOCR_ELAUNCH;
         }
         lds_ok = true;
     }
-    hipStream_t s = (hipStream_t)stream;
-    const int tiles = g.mtiles * g.ntiles, ncu = x6_cu_count();
-    // whole rounds of one workgroup per CU run their tiles over the full K; what is left of the last round - when it would leave more than
-    // half of the chip idle - is cut along K into slabs, so that it takes 1 / ksplit of a round (294 x 8 tiles of the data gradient: 1 + 1/6
-    // rounds instead of 2)
-    const int full = (tiles / ncu) * ncu, rem = tiles - full;
-    int ks = 1;
-    if (rem > 0 && rem * 2 <= ncu && g.nkk >= 32 && workspace) {
-        ks = ncu / rem;
-        if (ks > 8) ks = 8;
-        if (ks > g.nkk / 8) ks = g.nkk / 8;
-        if (ks < 1) ks = 1;
-    }
-    const int main_tiles = ks > 1 ? full : tiles;
-    if (main_tiles > 0) {
-        g.tile0 = 0; g.ntile_launch = main_tiles; g.ksplit = 1; g.stages_per_split = g.nkk; g.slab = nullptr;
-        gemm_x6_kernel<<<main_tiles, 512, X6_NS * X6_STAGE, s>>>(g);
-    }
-    if (ks > 1) {
-        g.tile0 = full; g.ntile_launch = rem;
-        g.stages_per_split = vocr_cdiv(g.nkk, ks);
-        g.ksplit = vocr_cdiv(g.nkk, g.stages_per_split);
-        g.slab = (float*)workspace;
-        gemm_x6_kernel<<<rem * g.ksplit, 512, X6_NS * X6_STAGE, s>>>(g);
-        gemm_x6_reduce_kernel<<<rem * 32, 256, 0, s>>>(g);
-    }
+    if (p.nct == 8) x6_launch<8>(g, p, workspace, (hipStream_t)stream);
+    else x6_launch<4>(g, p, workspace, (hipStream_t)stream);
     VOCR_CHECK_LAUNCH("vocr_gemm_x6");
     return VOCR_OK;
 }

@@ -240,7 +240,7 @@ class CnnOcrModel(nn.Module):
         follow_w = [(self.lstm.layer(l, "")[0], self.lstm.layer(l, "_reverse")[0]) for l in range(1, self.num_lstm_layers)]
         may_follow = ops.lstm_follow_ok(x.shape[0], H, 2 * H, H)
         x6_w = [(self.lstm.layer(l, "")[0], self.lstm.layer(l, "_reverse")[0]) for l in range(self.num_lstm_layers)] \
-            if ops.x6_layer_ok(1 << 20, x.shape[0], H, 0) else []
+            if ops.x6_layer_ok(1 << 10, x.shape[0], H, 0) else []
         prep = ops.forward_prep(convs, layers, torch.is_grad_enabled(), f16, follow_w if may_follow else (), x6_w)
         a = x
         for i in range(self.num_rds_layers):

@@ -696,8 +696,9 @@ _GEMM_X6 = _exp("VOCR_GEMM_X6", "1") == "1"
 
 
 def x6_layer_ok(T, B, H, rows):
-    """The BiLSTM layer's GEMMs run as bf16x6 products: dense rows whose time shift (B rows) is a whole number of k16 steps."""
-    return _GEMM_X6 and not rows and B % 16 == 0 and (4 * H) % 128 == 0 and T * B >= 256
+    """The BiLSTM layer's large GEMMs run as bf16x6 products (any row layout; the recurrent weight gradient joins them when its time shift -
+    B rows dense, 4 packed - is a whole number of k16 steps)."""
+    return _GEMM_X6 and (4 * H) % 128 == 0 and (rows if rows else T * B) >= 256
 
 
 def x6_planes(x, rows, k, k_contiguous, ld, x2=None, seg=0, axis=0, mask=None):
@@ -1077,15 +1078,24 @@ class BiLstmLayerFn(torch.autograd.Function):
             dwi_f, dwh_f, dbi_f, dbh_f, dwi_r, dwh_r, dbi_r, dbh_r = outs
             if parts:
                 call("vocr_lstm_bias_from_parts", _p(dbias), _p(ws), T, B, H, _stream())
-            if ctx.x6 and T > 1:
-                # bf16x6: the gate gradients of both directions as ONE transposed plane set (rows = gate columns, k = the frames); the input's and
-                # the output's transposes; the recurrent product's time shift (B rows = B / 16 k16 steps) is a k window of the same planes
+            sh = 4 if rows else B                        # rows between consecutive time steps of a sequence
+            if ctx.x6:
+                # bf16x6: the gate gradients of both directions as ONE transposed plane set (rows = gate columns, k = the frames; K is padded
+                # with zeros to whole k16 steps) and the input's transpose
+                k16 = (R + 15) // 16 * 16
                 dgt = x6_planes(dg[0], 2 * G, R, False, G, x2=dg[1], seg=G, axis=1)
                 xt = x6_planes(x, din, R, False, din)
-                gemm_x6(dgt, 2 * G, R, xt, din, R, 2 * G, din, R, dwi_f, din, c1=dwi_r, rsplit=G)
-                yt = x6_planes(y, 2 * H, R, False, 2 * H)
-                gemm_x6(dgt, 2 * G, R, yt, 2 * H, R, G, H, R - B, dwh_f, H, a_row0=0, a_kk0=B // 16, b_row0=0, b_kk0=0)
-                gemm_x6(dgt, 2 * G, R, yt, 2 * H, R, G, H, R - B, dwh_r, H, a_row0=G, a_kk0=0, b_row0=H, b_kk0=B // 16)
+                gemm_x6(dgt, 2 * G, R, xt, din, R, 2 * G, din, k16, dwi_f, din, c1=dwi_r, rsplit=G)
+                if T > 1 and sh % 16 == 0 and (R - sh) % 16 == 0:
+                    # the recurrent product's time shift (sh rows = sh / 16 k16 steps) is a k window of the same planes and of the output's transpose
+                    yt = x6_planes(y, 2 * H, R, False, 2 * H)
+                    gemm_x6(dgt, 2 * G, R, yt, 2 * H, R, G, H, R - sh, dwh_f, H, a_row0=0, a_kk0=sh // 16, b_row0=0, b_kk0=0)
+                    gemm_x6(dgt, 2 * G, R, yt, 2 * H, R, G, H, R - sh, dwh_r, H, a_row0=G, a_kk0=0, b_row0=H, b_kk0=sh // 16)
+                elif T > 1:
+                    gemm_pair(co, 1, 0, G, H, R - sh, dg[0][sh:], dg[1], G, y, y[sh:, H:], 2 * H, dwh_f, dwh_r, H)
+                else:
+                    dwh_f.zero_()
+                    dwh_r.zero_()
                 dbi_f.copy_(dbias[0])
                 dbi_r.copy_(dbias[1])
                 dbh_f.copy_(dbias[0])
@@ -1095,7 +1105,6 @@ class BiLstmLayerFn(torch.autograd.Function):
             if T > 1:
                 # forward dir: h_{t-1} = y[t-1, :, :H];   reverse dir: h_{t+1} = y[t+1, :, H:]  (zero past the length).  Dense rows:
                 # consecutive time steps are B rows apart; packed rows: 4 (the chain's groups), with an all-zero group on either side
-                sh = 4 if rows else B
                 m = R - sh
                 gemm_pair(co, 1, 0, G, H, m, dg[0][sh:], dg[1], G, y, y[sh:, H:], 2 * H, dwh_f, dwh_r, H)
             else:
