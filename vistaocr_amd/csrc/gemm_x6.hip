@@ -127,6 +127,22 @@ struct X6Args {
     int relu;
 };
 
+// Which tile a workgroup takes.  The dispatcher deals workgroups to the eight XCDs in turn (blockIdx % 8 - up to a rotation), each with its own
+// L2: XCD x takes a CONTIGUOUS range of the launch's (K split, tile) sequence, and the tile sequence runs through panels of four row tiles
+// column by column, so that the 32 workgroups an XCD runs at a time cover 4 row tiles x 8 column tiles and their k16 stages of A and B come
+// out of that L2 (consecutive tiles on consecutive XCDs made every XCD stream all of A: 8 x 231 MB through the fabric for the data gradient).
+constexpr int X6_PANEL = 4;
+__device__ __forceinline__ void x6_tile_of(int t, int mtiles, int ntiles, int& mt, int& nt) {
+    const int panel = t / (X6_PANEL * ntiles), within = t - panel * X6_PANEL * ntiles;
+    const int rows = min(X6_PANEL, mtiles - panel * X6_PANEL);
+    nt = within / rows;
+    mt = panel * X6_PANEL + within - nt * rows;
+}
+__device__ __forceinline__ int x6_xcd_chunked(int i, int n) {
+    const int xcd = i & 7, j = i >> 3, c = n >> 3, rr = n & 7;
+    return xcd * c + min(xcd, rr) + j;
+}
+
 // NCT = column tiles of 32 per workgroup tile: 4 (256 x 128: eight waves as 4 x 2 with 64 x 64 wave tiles, 36-KB stages, four ring slots) or 8
 // (256 x 256: 2 x 4 waves with 128 x 64 wave tiles - 128 accumulator registers -, 48-KB stages, three slots: half the DMA instructions per MFMA)
 template <int NCT>
@@ -141,10 +157,10 @@ __global__ __launch_bounds__(512) void gemm_x6_kernel(const X6Args g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = NCT == 4 ? (wave & 3) : (wave & 1), wn = NCT == 4 ? (wave >> 2) : (wave >> 1);
-    // tile order: column tiles fastest, so that consecutive workgroups (one XCD takes every eighth) share A rows
-    const int ltile = blockIdx.x % g.ntile_launch, split = blockIdx.x / g.ntile_launch;
-    const int t = g.tile0 + ltile;
-    const int nt = t % g.ntiles, mt = t / g.ntiles;
+    const int v = x6_xcd_chunked(blockIdx.x, gridDim.x);
+    const int ltile = v % g.ntile_launch, split = v / g.ntile_launch;
+    int mt, nt;
+    x6_tile_of(g.tile0 + ltile, g.mtiles, g.ntiles, mt, nt);
     const int s_beg = split * g.stages_per_split, s_end = min(g.nkk, s_beg + g.stages_per_split);      // K16 stages
     if (s_beg >= s_end) return;
 
@@ -272,7 +288,8 @@ __global__ __launch_bounds__(256) void gemm_x6_reduce_kernel(const X6Args g) {
     constexpr int BN = 32 * NCT, RPW = 256 / BN * 4;                             // rows per workgroup: 8 (BN = 128) or 4
     const int parts = X6_BM / RPW;
     const int ltile = blockIdx.x / parts, part = blockIdx.x % parts;
-    const int t = g.tile0 + ltile, nt = t % g.ntiles, mt = t / g.ntiles;
+    int mt, nt;
+    x6_tile_of(g.tile0 + ltile, g.mtiles, g.ntiles, mt, nt);
     const int lcol = threadIdx.x % BN, col = BN * nt + lcol;
     if (col >= g.N) return;
     const int cw = col >= g.csplit ? 1 : 0;
