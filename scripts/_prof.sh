@@ -9,10 +9,11 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/$T/f
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/$T/write -- python3 bench.py --config $CFG --steps 2 --warmup 1 --no-cpu-baseline --no-gemm-alone > /dev/null 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/$T/sq -- python3 scripts/one_conv.py > /dev/null 2>&1
 rocprofv3 --pmc SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/$T/sq2 -- python3 scripts/one_conv.py > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/$T/sq3 -- python3 scripts/one_conv.py > /dev/null 2>&1
 F=$(find gpurun_out/$T/fetch -name "*counter_collection.csv" | head -1); W=$(find gpurun_out/$T/write -name "*counter_collection.csv" | head -1)
 python scripts/pmc_summary.py traffic $F $W > gpurun_out/$T/pmc_hbm_traffic.txt 2>&1
 python scripts/pmc_summary.py traffic_json $F $W gpurun_out/$T/kernel_traffic.json >> gpurun_out/$T/pmc_hbm_traffic.txt 2>&1
-python scripts/pmc_summary.py busy $(find gpurun_out/$T/sq -name "*counter_collection.csv") $(find gpurun_out/$T/sq2 -name "*counter_collection.csv") > gpurun_out/$T/mfma_busy.txt 2>&1
+python scripts/pmc_summary.py busy $(find gpurun_out/$T/sq -name "*counter_collection.csv") $(find gpurun_out/$T/sq2 -name "*counter_collection.csv") $(find gpurun_out/$T/sq3 -name "*counter_collection.csv") > gpurun_out/$T/mfma_busy.txt 2>&1
 python scripts/timeline.py $(find gpurun_out/$T/trace -name "*kernel_trace.csv" | head -1) 3 > gpurun_out/$T/timeline.txt 2>&1
 cp $(find gpurun_out/$T/trace -name "*kernel_stats.csv" | head -1) gpurun_out/$T/kernel_stats.csv
 VOCR_ROCTX=1 rocprofv3 --kernel-trace --marker-trace --output-format csv -d gpurun_out/$T/marker -- python3 bench.py --config $CFG --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2>&1

@@ -20,6 +20,14 @@ dx = torch.empty(9408, 1024, device=dev)
 for _ in range(5): ops.gemm_pair(1, 0, 0, 9408, 1024, 2048, dg0, dg1, 2048, w0, w1, 1024, dx, None, 1024)
 dw0 = torch.empty(2048, 1024, device=dev); dw1 = torch.empty(2048, 1024, device=dev)
 for _ in range(5): ops.gemm_pair(0, 1, 0, 2048, 1024, 9408, dg0, dg1, 2048, a, a, 1024, dw0, dw1, 1024)
+# round 6: the same three products as bf16x6 (vocr_gemm_x6 on split planes): x-projection (256 x 256 tiles), data gradient (256 x 128), weight gradient (K cut)
+g6 = lambda t, rows, k, kc, ld, **kw: ops.x6_planes(t, rows, k, kc, ld, **kw)
+xa = g6(a, 9408, 1024, True, 1024); wb = g6(b, 4096, 1024, True, 1024, x2=b1, seg=2048, axis=1)
+for _ in range(5): ops.gemm_x6(xa, 9408, 1024, wb, 4096, 1024, 9408, 4096, 1024, c, c1=c1, csplit=2048, ldc=2048)
+da = g6(dg0, 9408, 4096, True, 2048, x2=dg1, seg=2048, axis=0); wt6 = g6(w0, 1024, 4096, False, 1024, x2=w1, seg=2048, axis=0)
+for _ in range(5): ops.gemm_x6(da, 9408, 4096, wt6, 1024, 4096, 9408, 1024, 4096, dx, ldc=1024)
+dgt = g6(dg0, 4096, 9408, False, 2048, x2=dg1, seg=2048, axis=1); xt = g6(a, 1024, 9408, False, 1024)
+for _ in range(5): ops.gemm_x6(dgt, 4096, 9408, xt, 1024, 9408, 4096, 1024, 9408, dw0, c1=dw1, rsplit=2048, ldc=1024)
 # round 5: the fp16-operand kernels (configs[4]) and one LSTM layer's two sweeps at the bench shape
 x_nhwc, x16p = ops.f16_layouts(x, True, True)
 dy16p = ops.f16_layouts(dy, False, True)[1]

@@ -62,6 +62,7 @@ def busy(paths):
                 else "fp16-operand conv forward (%s)" % k.split("<")[0] if k.startswith("conv3x3_h16_kernel") \
                 else "fp16-operand conv weight gradient (%s)" % k.split("<")[0] if k.startswith("conv3x3_wgrad_h16_kernel") \
                 else "LSTM sweep (%s)" % k.split("<")[0] if (k.startswith("lstm_fwd_chain4w") or k.startswith("lstm_bwd_chain4w")) \
+                else "bf16x6 GEMM (%s)" % k[:40] if k.startswith("gemm_x6_kernel") \
                 else "GEMM tile kernel (%s)" % k[:60] if k.startswith("gemm_f32_kernel") \
                 else "GEMM panel kernel (%s)" % k[:60] if k.startswith("gemm_dma_kernel") else None
             if key is None:
@@ -98,6 +99,9 @@ FAMILIES = (      # bench.py's FAMILY names -> kernel-name prefixes
     ("conv3x3 with fp16 operands, fp32 accumulate (conv3x3_h16_kernel on NHWC fp16 activations: forward + data gradient; conv3x3_wgrad_h16_kernel on "
      "channel-major fp16 copies: weight gradient; the register-staged kernels where the channel counts do not fit; v_mfma_f32_32x32x16_f16)",
      ("conv3x3_h16_kernel", "conv3x3_wgrad_h16_kernel", "conv3x3_f16_kernel", "conv3x3_wgrad_f16_kernel")),
+    ("dense fp32 GEMMs on the bf16 matrix pipe (gemm_x6_kernel behind vocr_gemm_x6: every fp32 operand split EXACTLY into three bf16 planes, six "
+     "v_mfma_f32_32x32x16_bf16 per fp32 product, fp32 accumulate, error below the f32-MFMA kernels' against fp64 - the LSTM projections and their "
+     "dX / dW; FLOPs counted as the fp32 products they replace, peak = the bf16 MFMA peak / 6 = 416.7 TFLOP/s)", ("gemm_x6_kernel",)),
 )
 
 
