@@ -168,7 +168,7 @@ def gemm_x6_flops(args):
     return 2.0 * m * n * k
 
 
-FLOPS_OF = {"vocr_gemm_x6": gemm_x6_flops, "vocr_conv3x3_fwd": conv_flops, "vocr_conv3x3_wino_fwd": conv_flops, "vocr_conv3x3_wgrad": conv_flops,
+FLOPS_OF = {"vocr_gemm_x6": gemm_x6_flops, "vocr_gemm_h3": gemm_x6_flops, "vocr_conv3x3_fwd": conv_flops, "vocr_conv3x3_wino_fwd": conv_flops, "vocr_conv3x3_wgrad": conv_flops,
             "vocr_conv3x3_wgrad_wino": conv_flops, "vocr_conv3x3_f16_fwd": conv_flops, "vocr_conv3x3_wgrad_f16": conv_flops,
             "vocr_conv3x3_h16_fwd": conv_flops, "vocr_conv3x3_wgrad_h16": conv_flops,
             "vocr_gemm": gemm_flops, "vocr_gemm_pair": gemm_pair_flops,
@@ -181,9 +181,14 @@ _X6_GEMM = ("dense fp32 GEMMs on the bf16 matrix pipe (gemm_x6_kernel behind voc
             "v_mfma_f32_32x32x16_bf16 per fp32 product, fp32 accumulate, error below the f32-MFMA kernels' against fp64 - the LSTM projections and their "
             "dX / dW; FLOPs counted as the fp32 products they replace, peak = the bf16 MFMA peak / 6 = 416.7 TFLOP/s)")
 X6_EQUIV_PEAK_TFLOPS = F16_MFMA_PEAK_TFLOPS / 6.0      # six bf16 MFMAs per fp32 product
+# the opt-in split (VOCR_LSTM_GEMM=fp16x3 / ops.set_lstm_gemm): not what the headline line runs
+_H3_GEMM = ("dense GEMMs as fp16x3 products (gemm_x6_kernel<., 2> behind vocr_gemm_h3: every fp32 operand as two fp16 planes with per-row power-of-two scales, "
+            "three v_mfma_f32_32x32x16_f16 per product, fp32 accumulate - a norm-wise fp32-grade approximation, OPT-IN; FLOPs counted as the products they "
+            "replace, peak = the fp16 MFMA peak / 3 = 833.3 TFLOP/s)")
+H3_EQUIV_PEAK_TFLOPS = F16_MFMA_PEAK_TFLOPS / 3.0
 # a family's own roofline where it is not the f32 matrix pipe
-FAMILY_PEAK = {_F16_CONV: F16_MFMA_PEAK_TFLOPS, _X6_GEMM: X6_EQUIV_PEAK_TFLOPS}
-FAMILY = {"vocr_gemm_x6": _X6_GEMM, "vocr_conv3x3_fwd": "conv3x3 forward + data gradient (conv3x3_wino4 / conv3x3_wino2 kernels: F(4,3) / F(2,3) along the row)",
+FAMILY_PEAK = {_F16_CONV: F16_MFMA_PEAK_TFLOPS, _X6_GEMM: X6_EQUIV_PEAK_TFLOPS, _H3_GEMM: H3_EQUIV_PEAK_TFLOPS}
+FAMILY = {"vocr_gemm_x6": _X6_GEMM, "vocr_gemm_h3": _H3_GEMM, "vocr_conv3x3_fwd": "conv3x3 forward + data gradient (conv3x3_wino4 / conv3x3_wino2 kernels: F(4,3) / F(2,3) along the row)",
           "vocr_conv3x3_wino_fwd": "conv3x3 forward + data gradient (conv3x3_wino4 / conv3x3_wino2 kernels: F(4,3) / F(2,3) along the row)",
           "vocr_conv3x3_wgrad": "conv3x3 weight gradient (conv3x3_wgrad_wino2d_kernel: F(3,2) along the row and across row pairs, piece stream)",
           "vocr_conv3x3_wgrad_wino": "conv3x3 weight gradient (conv3x3_wgrad_wino2d_kernel: F(3,2) along the row and across row pairs, piece stream)",
@@ -197,7 +202,12 @@ FAMILY = {"vocr_gemm_x6": _X6_GEMM, "vocr_conv3x3_fwd": "conv3x3 forward + data 
 
 def ops_x6_on():
     from vistaocr_amd import ops
-    return bool(ops._GEMM_X6)
+    return ops.lstm_gemm() != "f32"
+
+
+def lstm_gemm_mode():
+    from vistaocr_amd import ops
+    return ops.lstm_gemm()
 
 
 def gemm_alone(hidden, din=128):
@@ -209,7 +219,7 @@ def gemm_alone(hidden, din=128):
     dev = torch.device("cuda", torch.cuda.current_device())
     M, G, H = 294 * B, 4 * hidden, hidden
     x6 = ops_x6_on()
-    peak = X6_EQUIV_PEAK_TFLOPS if x6 else F32_MFMA_PEAK_TFLOPS
+    peak = {"bf16x6": X6_EQUIV_PEAK_TFLOPS, "fp16x3": H3_EQUIV_PEAK_TFLOPS, "f32": F32_MFMA_PEAK_TFLOPS}[lstm_gemm_mode()]
 
     def timed(fn, n=20):
         for _ in range(8):
@@ -514,7 +524,7 @@ def run_rank(args):
         torch.cuda.synchronize()
 
     MFMA_NAMES = ["vocr_conv3x3_fwd", "vocr_conv3x3_wino_fwd", "vocr_conv3x3_wgrad", "vocr_conv3x3_wgrad_wino", "vocr_conv3x3_f16_fwd",
-                  "vocr_conv3x3_wgrad_f16", "vocr_conv3x3_h16_fwd", "vocr_conv3x3_wgrad_h16", "vocr_gemm", "vocr_gemm_pair", "vocr_gemm_x6", "vocr_lstm_fwd", "vocr_lstm_fwd_range", "vocr_lstm_bwd_bias",
+                  "vocr_conv3x3_wgrad_f16", "vocr_conv3x3_h16_fwd", "vocr_conv3x3_wgrad_h16", "vocr_gemm", "vocr_gemm_pair", "vocr_gemm_x6", "vocr_gemm_h3", "vocr_lstm_fwd", "vocr_lstm_fwd_range", "vocr_lstm_bwd_bias",
                   "vocr_lstm_fwd_packed", "vocr_lstm_bwd_packed"]
 
     rank_dt = [0.0, 0.0]          # [min, max] over ranks of the last timed loop's wall time
@@ -566,7 +576,7 @@ def run_rank(args):
                           "vocr_bn_train_relu_fracpool2x2_fwd", "vocr_bn_relu_bwd",
                           "vocr_fracpool2x2_bwd", "vocr_bn_relu_fracpool2x2_bwd", "vocr_ctc_loss_grad", "vocr_clamp_adam", "vocr_bchw_to_wbch", "vocr_wbch_to_bchw",
                           "vocr_relu_maxpool2_fwd", "vocr_relu_maxpool2_bwd", "vocr_gather_rows", "vocr_dropout_fwd", "vocr_mul", "vocr_f32_to_f16_layouts", "vocr_conv3x3_c1_fwd", "vocr_conv3x3_c1_wgrad",
-                          "vocr_gemm_x6_split"]
+                          "vocr_gemm_x6_split", "vocr_gemm_h3_split"]
     _lib.enable_timing(names)
     for _ in range(PROFILE_STEPS):
         va.train(batch_dev, model, crit, opt)
@@ -663,8 +673,11 @@ def run_rank(args):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32" if conv_dtype == "fp32" else "f32 with fp16 conv operands (fp32 accumulate)") +
-                     (" (the LSTM's large GEMMs as bf16x6 products: fp32 operands split exactly into three bf16 planes, six bf16 MFMAs per fp32 "
-                      "product, fp32 accumulate; ops.VOCR_GEMM_X6=0 restores the f32-MFMA kernels)" if ops_x6_on() else ""), "data": "synthetic",
+                     {"bf16x6": " (the LSTM's large GEMMs as bf16x6 products: fp32 operands split exactly into three bf16 planes, six bf16 MFMAs per fp32 "
+                                "product, fp32 accumulate; VOCR_LSTM_GEMM=f32 restores the f32-MFMA kernels)",
+                      "fp16x3": " - OPT-IN MODE, NOT THE HEADLINE CONFIGURATION: the LSTM's large GEMMs as fp16x3 products (VOCR_LSTM_GEMM=fp16x3: operands "
+                                "approximated by two fp16 planes with per-row scales, three fp16 MFMAs per product, fp32 accumulate)",
+                      "f32": ""}[lstm_gemm_mode()], "data": "synthetic",
             "config": {"workload": wl["what"] + ", 3xBiLSTM-%d, train() = H2D of the batch + fwd+CTC+bwd+allreduce+clamp+Adam, loss returned as a float" % args.hidden,
                        "name": args.config, "widths": "%d .. %d px, mean %.0f" % (min(wl["widths"]), max(wl["widths"]), sum(wl["widths"]) / float(B)),
                        "conv_dtype": conv_dtype,

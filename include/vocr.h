@@ -318,6 +318,24 @@ int vocr_gemm_x6(const void* a_planes, int a_rows, int a_k, int a_row0, int a_kk
                  int m, int n, int k, float* c0, float* c1, int csplit, int rsplit, int ldc, const float* bias0, const float* bias1, int relu,
                  void* workspace, void* stream);
 
+/* ---- the same products from TWO fp16 planes per operand and three partial products ("fp16x3") - OPT-IN, not what CnnOcrModel runs by default ---- */
+/* a s = h0 + h1 with h0 = fp16(a s), h1 = fp16(a s - h0), s = the power of two that brings the ROW's largest magnitude into [2^14, 2^15): 22 - 23 of
+ * fp32's 24 significant bits per element (elements more than 2^17 below their row's maximum lose low bits to fp16's exponent range: absolute error
+ * <= 2^-40 of the row's maximum); a b ~ h0 g1 + h1 g0 + h0 g0, the dropped term <= 2^-24 |a b|; fp32 accumulate; both rows' scales undone exactly in
+ * the epilogue.  Half the matrix instructions and 2/3 of the operand bytes of bf16x6 for a NORM-WISE error bound (<= 2^-22 sum |a||b| + K 2^-39
+ * max|a| max|b| per dot product) instead of bf16x6's per-product one: measured against fp64 it stays below the f32-MFMA kernels' own error on the
+ * training step's shapes (tests/test_x6_gpu.py), but it is an approximation of the operands, which bf16x6 is not.  Same contracts as the three entry
+ * points above; a plane set is vocr_gemm_h3_planes_bytes(rows, k) bytes (the rows' maxima ride behind the planes) and is not interchangeable with a
+ * bf16x6 one.  The split takes the maxima in a pass of its own (order-free integer maximum: deterministic). */
+size_t vocr_gemm_h3_planes_bytes(int rows, int k);
+/* bound > 0: the caller's bound on every |element| (after the mask) stands in for the rows' maxima - no pass over the source for them (an LSTM
+ * output lies inside (-1, 1)); an element above the bound overflows fp16 and poisons its row, as an Inf in the source would.  bound = 0: measured. */
+int vocr_gemm_h3_split(const float* x, const float* x2, int seg, int seg_axis, const float* mask, long ld, int rows, int k, int k_contiguous,
+                       float bound, void* planes, void* stream);
+int vocr_gemm_h3(const void* a_planes, int a_rows, int a_k, int a_row0, int a_kk0, const void* b_planes, int b_rows, int b_k, int b_row0, int b_kk0,
+                 int m, int n, int k, float* c0, float* c1, int csplit, int rsplit, int ldc, const float* bias0, const float* bias1, int relu,
+                 void* workspace, void* stream);
+
 /* ---- the same recurrence without the padding: pack_padded_sequence's economy — src/models/cnnlstm.py:285-290 ---------- */
 /* The reference packs the length-sorted batch before nn.LSTM, so cuDNN never computes a padded frame.  Here the rows of every
  * sequence-side tensor (bridge output, xproj, y, gates, cell, dy, dgates) can be kept in a PACKED, chain-major order instead of

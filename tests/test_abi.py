@@ -124,6 +124,11 @@ def test_argument_validation_without_gpu():
     assert x6(256, 128, 40, one, None, 0, 0, 128, None, None, 0, None, None) == -1 and b"k % 16" in lib.vocr_last_error()
     assert x6(256, 128, 64, one, None, 64, 0, 128, None, None, 0, None, None) == -1               # a cut without a second output
     assert lib.vocr_gemm_x6(one, 256, 64, 0, 2, one, 128, 64, 0, 0, 256, 128, 64, one, None, 0, 0, 128, None, None, 0, None, None) == -1   # view leaves its planes
+    # the opt-in fp16x3 split: two planes + the rows' maxima (fp32) behind them; the same validation in front of any launch
+    assert lib.vocr_gemm_h3_planes_bytes(9408, 1024) == 2 * (37 * 8) * (32 * 2) * 1024 + 37 * 8 * 32 * 4 and lib.vocr_gemm_h3_planes_bytes(0, 8) == 0
+    assert lib.vocr_gemm_h3_split(one, None, 8, 0, None, 64, 32, 64, 1, 0.0, one, None) == -1 and b"second piece" in lib.vocr_last_error()
+    assert lib.vocr_gemm_h3_split(one, None, 0, 0, None, 64, 32, 64, 1, -1.0, one, None) == -1 and b"bound" in lib.vocr_last_error()
+    assert lib.vocr_gemm_h3(one, 256, 64, 0, 0, one, 128, 64, 0, 0, 256, 128, 40, one, None, 0, 0, 128, None, None, 0, None, None) == -1 and b"vocr_gemm_h3" in lib.vocr_last_error()
 
 
 def test_product_never_imports_oracle():

@@ -312,6 +312,7 @@ class CnnOcrModel(nn.Module):
         drop = self.lstm.training and self.p_lstm_dropout > 0      # nn.LSTM reads its own .training flag
         following = may_follow and 16 < b <= 32
         pre = None
+        x_bound = 0.0          # a bound on |hseq| where one is known: an LSTM layer's output lies in [-1, 1], times the drawn dropout's scale (fp16x3 splits use it)
         for l in range(self.num_lstm_layers):
             f = self.lstm.layer(l, "")
             r = self.lstm.layer(l, "_reverse")
@@ -343,7 +344,10 @@ class CnnOcrModel(nn.Module):
                 with prof_range("model.lstm.l%d" % l):
                     dp, ds = (self.p_lstm_dropout, self.dropout_seed + self._dropout_calls) if draw and mk is None else (0.0, 0)
                     hseq = ops.BiLstmLayerFn.apply(hseq, lens_dev, T, b, f[0], f[1], f[2], f[3], r[0], r[1], r[2], r[3], prep, True, dp, ds, rows,
-                                                   pre, fol, mk)
+                                                   pre, fol, mk, x_bound)
+                    # what the next layer reads: this layer's output, times 1 / (1 - p) where a mask we drew ourselves was applied (an explicit mask: unknown)
+                    x_bound = 0.0 if (mk is not None and self.dropout_masks is not None) else \
+                        (1.0 / (1.0 - self.p_lstm_dropout) if (dp > 0 or mk is not None) else 1.0)
                 pre = fol["out"][0] if fol is not None else None
                 continue
             with prof_range("model.lstm.l%d" % l):

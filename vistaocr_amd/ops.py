@@ -691,29 +691,61 @@ def gemm_pair(mode, ta, tb, m, n, k, a0, a1, lda, b0, b1, ldb, c0, c1, ldc, bias
          _p(bias0), _p(bias1), int(relu), _p(ws), nb, _stream())
 
 
-# ---- fp32 GEMM on the bf16 matrix pipe by exact operand splitting (include/vocr.h: vocr_gemm_x6*): the LSTM projections and their gradients
+# ---- fp32 GEMM on the 16-bit matrix pipe by operand splitting (include/vocr.h: vocr_gemm_x6* / vocr_gemm_h3*): the LSTM projections and their gradients
 _GEMM_X6 = _exp("VOCR_GEMM_X6", "1") == "1"
+# which split the large LSTM products use: "bf16x6" (default: three bf16 planes that sum to the operand EXACTLY, six products), "fp16x3" (opt-in: two fp16
+# planes with per-row power-of-two scales, three products - half the matrix instructions, a norm-wise instead of a per-product error bound), "f32" (the
+# f32-MFMA kernels).  VOCR_LSTM_GEMM in the environment or set_lstm_gemm() before the first forward pass.
+LSTM_GEMM_MODES = ("bf16x6", "fp16x3", "f32")
+_LSTM_GEMM = _os.environ.get("VOCR_LSTM_GEMM", "bf16x6")
+if _LSTM_GEMM not in LSTM_GEMM_MODES:
+    raise ValueError("VOCR_LSTM_GEMM=%r: one of %s" % (_LSTM_GEMM, ", ".join(LSTM_GEMM_MODES)))
+_X6_ENTRY = {"bf16x6": ("vocr_gemm_x6_planes_bytes", "vocr_gemm_x6_split", "vocr_gemm_x6"),
+             "fp16x3": ("vocr_gemm_h3_planes_bytes", "vocr_gemm_h3_split", "vocr_gemm_h3")}
+
+
+def set_lstm_gemm(mode):
+    """Select the arithmetic of the BiLSTM stack's large GEMMs for this process (see LSTM_GEMM_MODES); returns the previous mode."""
+    global _LSTM_GEMM
+    if mode not in LSTM_GEMM_MODES:
+        raise ValueError("lstm gemm mode %r: one of %s" % (mode, ", ".join(LSTM_GEMM_MODES)))
+    prev, _LSTM_GEMM = _LSTM_GEMM, mode
+    return prev
+
+
+def lstm_gemm():
+    return _LSTM_GEMM if _GEMM_X6 else "f32"
 
 
 def x6_layer_ok(T, B, H, rows):
-    """The BiLSTM layer's large GEMMs run as bf16x6 products (any row layout; the recurrent weight gradient joins them when its time shift -
+    """The BiLSTM layer's large GEMMs run as split products (any row layout; the recurrent weight gradient joins them when its time shift -
     B rows dense, 4 packed - is a whole number of k16 steps)."""
-    return _GEMM_X6 and (4 * H) % 128 == 0 and (rows if rows else T * B) >= 256
+    return lstm_gemm() != "f32" and (4 * H) % 128 == 0 and (rows if rows else T * B) >= 256
 
 
-def x6_planes(x, rows, k, k_contiguous, ld, x2=None, seg=0, axis=0, mask=None):
-    """The three bf16 planes of an fp32 operand in MFMA-fragment order (one pass over x; a torch.bfloat16 buffer)."""
+def x6_planes(x, rows, k, k_contiguous, ld, x2=None, seg=0, axis=0, mask=None, scheme=None, bound=0.0):
+    """The 16-bit planes of an fp32 operand in MFMA-fragment order (one pass over x; fp16x3: one more for the rows' maxima unless the caller
+    knows a `bound` of every |element| after the mask - an LSTM output lies inside (-1, 1))."""
+    scheme = scheme or lstm_gemm()
+    nbytes, split, _ = _X6_ENTRY[scheme]
     lib = _lib.load()
-    buf = torch.empty(lib.vocr_gemm_x6_planes_bytes(int(rows), int(k)) // 2, dtype=torch.bfloat16, device=x.device)
-    call("vocr_gemm_x6_split", _p(x), _p(x2), int(seg), int(axis), _p(mask), int(ld), int(rows), int(k), int(bool(k_contiguous)), _p(buf), _stream())
+    buf = torch.empty(getattr(lib, nbytes)(int(rows), int(k)) // 2, dtype=torch.int16, device=x.device)
+    if scheme == "fp16x3":
+        call(split, _p(x), _p(x2), int(seg), int(axis), _p(mask), int(ld), int(rows), int(k), int(bool(k_contiguous)), float(bound), _p(buf), _stream())
+    else:
+        call(split, _p(x), _p(x2), int(seg), int(axis), _p(mask), int(ld), int(rows), int(k), int(bool(k_contiguous)), _p(buf), _stream())
+    buf.x6_scheme = scheme
     return buf
 
 
 def gemm_x6(a, a_rows, a_k, b, b_rows, b_k, m, n, k, c0, ldc, c1=None, csplit=0, rsplit=0, bias0=None, bias1=None, a_row0=0, a_kk0=0, b_row0=0,
             b_kk0=0, relu=False):
     """c = A . B^T from split planes (views: row / k16 offsets into plane sets written for (a_rows, a_k) and (b_rows, b_k))."""
+    scheme = getattr(a, "x6_scheme", None)
+    if scheme is None or scheme != getattr(b, "x6_scheme", None):
+        raise RuntimeError("gemm_x6: operands from different splits (%r, %r)" % (scheme, getattr(b, "x6_scheme", None)))
     ws = _ws(_lib.load().vocr_gemm_x6_workspace_bytes(m, n, k), c0.device)
-    call("vocr_gemm_x6", _p(a), int(a_rows), int(a_k), int(a_row0), int(a_kk0), _p(b), int(b_rows), int(b_k), int(b_row0), int(b_kk0), int(m), int(n),
+    call(_X6_ENTRY[scheme][2], _p(a), int(a_rows), int(a_k), int(a_row0), int(a_kk0), _p(b), int(b_rows), int(b_k), int(b_row0), int(b_kk0), int(m), int(n),
          int(k), _p(c0), _p(c1), int(csplit), int(rsplit), int(ldc), _p(bias0), _p(bias1), int(relu), _p(ws), _stream())
 
 
@@ -929,7 +961,7 @@ class BiLstmLayerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, lens_dev, T, B, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r, prep=None, direct_grads=True,
-                drop_p=0.0, drop_seed=0, rows=0, pre=None, follow=None, drop_mask=None):
+                drop_p=0.0, drop_seed=0, rows=0, pre=None, follow=None, drop_mask=None, x_bound=0.0):
         """drop_p > 0: nn.LSTM's inter-layer dropout on this layer's OUTPUT (counter-based mask of vocr_dropout_fwd, as DropoutFn) -
         here so that its backward can ride on the backward sweep's read of dy instead of being a pass of its own.  drop_mask: the same
         with a mask that already exists ([R, 2H], pre-scaled; explicit test masks, or vocr_dropout_mask's draw made ahead of the sweep).
@@ -971,7 +1003,7 @@ class BiLstmLayerFn(torch.autograd.Function):
                 wk, ctx.x6_wt = prep.x6w[w_ih_f.data_ptr()]
             else:
                 wk, ctx.x6_wt = x6_weight_planes(w_ih_f, w_ih_r, torch.is_grad_enabled())
-            xa = x6_planes(x, R, din, True, din)
+            xa = x6_planes(x, R, din, True, din, bound=x_bound)
             gemm_x6(xa, R, din, wk, 2 * G, din, R, 2 * G, din, xproj[0], G, c1=xproj[1], csplit=G, bias0=bsum[0], bias1=bsum[1])
         elif pre is None:
             # both directions' x-projections in one launch: 2 x (columns / 128) panels x row groups == the CU count
@@ -1002,6 +1034,7 @@ class BiLstmLayerFn(torch.autograd.Function):
             call("vocr_lstm_fwd", _p(xproj), _p(w_hh_f), _p(w_hh_r), _p(lens_dev), _p(y), _p(gates), _p(cell), _p(ws), T, B, H,
                  _p(health(dev)), _stream())
         ctx.dims = (T, B, H, din, int(rows))
+        ctx.x_bound = float(x_bound)                # > 0: the caller's bound on |x| (the layer below's output, times its dropout scale): fp16x3 splits of x skip their maxima pass
         ctx.direct_grads = bool(direct_grads)       # False: the layer runs as several batch tiles, autograd adds their weight gradients
         ctx.b_refs = (b_ih_f, b_hh_f, b_ih_r, b_hh_r)
         out = y
@@ -1084,11 +1117,11 @@ class BiLstmLayerFn(torch.autograd.Function):
                 # with zeros to whole k16 steps) and the input's transpose
                 k16 = (R + 15) // 16 * 16
                 dgt = x6_planes(dg[0], 2 * G, R, False, G, x2=dg[1], seg=G, axis=1)
-                xt = x6_planes(x, din, R, False, din)
+                xt = x6_planes(x, din, R, False, din, bound=ctx.x_bound)
                 gemm_x6(dgt, 2 * G, R, xt, din, R, 2 * G, din, k16, dwi_f, din, c1=dwi_r, rsplit=G)
                 if T > 1 and sh % 16 == 0 and (R - sh) % 16 == 0:
                     # the recurrent product's time shift (sh rows = sh / 16 k16 steps) is a k window of the same planes and of the output's transpose
-                    yt = x6_planes(y, 2 * H, R, False, 2 * H)
+                    yt = x6_planes(y, 2 * H, R, False, 2 * H, bound=1.0)       # |h| = |o tanh(c)| <= 1
                     gemm_x6(dgt, 2 * G, R, yt, 2 * H, R, G, H, R - sh, dwh_f, H, a_row0=0, a_kk0=sh // 16, b_row0=0, b_kk0=0)
                     gemm_x6(dgt, 2 * G, R, yt, 2 * H, R, G, H, R - sh, dwh_r, H, a_row0=G, a_kk0=0, b_row0=H, b_kk0=sh // 16)
                 elif T > 1:
@@ -1123,13 +1156,13 @@ class BiLstmLayerFn(torch.autograd.Function):
             with torch.cuda.stream(side):
                 weight_grads(sinks)                 # under the next layer's persistent sweep
             mark_side_pending()
-            return (dx, None, None, None) + (None,) * 16
+            return (dx, None, None, None) + (None,) * 17
         if direct:
             weight_grads(sinks)
-            return (dx, None, None, None) + (None,) * 16
+            return (dx, None, None, None) + (None,) * 17
         outs = [torch.empty_like(p) for p in params]
         weight_grads(outs)
-        return (dx, None, None, None) + tuple(outs) + (None,) * 8
+        return (dx, None, None, None) + tuple(outs) + (None,) * 9
 
 
 # ------------------------------------------------------------------------------------------------ CTC
