@@ -168,7 +168,8 @@ def gemm_x6_flops(args):
     return 2.0 * m * n * k
 
 
-FLOPS_OF = {"vocr_gemm_x6": gemm_x6_flops, "vocr_gemm_h3": gemm_x6_flops, "vocr_conv3x3_fwd": conv_flops, "vocr_conv3x3_wino_fwd": conv_flops, "vocr_conv3x3_wgrad": conv_flops,
+FLOPS_OF = {"vocr_gemm_x6": gemm_x6_flops, "vocr_gemm_h3": gemm_x6_flops,
+            "vocr_gemm_x6_two_views": lambda a: 2.0 * a[7] * a[8] * a[9], "vocr_gemm_h3_two_views": lambda a: 2.0 * a[7] * a[8] * a[9], "vocr_conv3x3_fwd": conv_flops, "vocr_conv3x3_wino_fwd": conv_flops, "vocr_conv3x3_wgrad": conv_flops,
             "vocr_conv3x3_wgrad_wino": conv_flops, "vocr_conv3x3_f16_fwd": conv_flops, "vocr_conv3x3_wgrad_f16": conv_flops,
             "vocr_conv3x3_h16_fwd": conv_flops, "vocr_conv3x3_wgrad_h16": conv_flops,
             "vocr_gemm": gemm_flops, "vocr_gemm_pair": gemm_pair_flops,
@@ -188,7 +189,7 @@ _H3_GEMM = ("dense GEMMs as fp16x3 products (gemm_x6_kernel<., 2> behind vocr_ge
 H3_EQUIV_PEAK_TFLOPS = F16_MFMA_PEAK_TFLOPS / 3.0
 # a family's own roofline where it is not the f32 matrix pipe
 FAMILY_PEAK = {_F16_CONV: F16_MFMA_PEAK_TFLOPS, _X6_GEMM: X6_EQUIV_PEAK_TFLOPS, _H3_GEMM: H3_EQUIV_PEAK_TFLOPS}
-FAMILY = {"vocr_gemm_x6": _X6_GEMM, "vocr_gemm_h3": _H3_GEMM, "vocr_conv3x3_fwd": "conv3x3 forward + data gradient (conv3x3_wino4 / conv3x3_wino2 kernels: F(4,3) / F(2,3) along the row)",
+FAMILY = {"vocr_gemm_x6": _X6_GEMM, "vocr_gemm_h3": _H3_GEMM, "vocr_gemm_x6_two_views": _X6_GEMM, "vocr_gemm_h3_two_views": _H3_GEMM, "vocr_conv3x3_fwd": "conv3x3 forward + data gradient (conv3x3_wino4 / conv3x3_wino2 kernels: F(4,3) / F(2,3) along the row)",
           "vocr_conv3x3_wino_fwd": "conv3x3 forward + data gradient (conv3x3_wino4 / conv3x3_wino2 kernels: F(4,3) / F(2,3) along the row)",
           "vocr_conv3x3_wgrad": "conv3x3 weight gradient (conv3x3_wgrad_wino2d_kernel: F(3,2) along the row and across row pairs, piece stream)",
           "vocr_conv3x3_wgrad_wino": "conv3x3 weight gradient (conv3x3_wgrad_wino2d_kernel: F(3,2) along the row and across row pairs, piece stream)",
@@ -524,7 +525,7 @@ def run_rank(args):
         torch.cuda.synchronize()
 
     MFMA_NAMES = ["vocr_conv3x3_fwd", "vocr_conv3x3_wino_fwd", "vocr_conv3x3_wgrad", "vocr_conv3x3_wgrad_wino", "vocr_conv3x3_f16_fwd",
-                  "vocr_conv3x3_wgrad_f16", "vocr_conv3x3_h16_fwd", "vocr_conv3x3_wgrad_h16", "vocr_gemm", "vocr_gemm_pair", "vocr_gemm_x6", "vocr_gemm_h3", "vocr_lstm_fwd", "vocr_lstm_fwd_range", "vocr_lstm_bwd_bias",
+                  "vocr_conv3x3_wgrad_f16", "vocr_conv3x3_h16_fwd", "vocr_conv3x3_wgrad_h16", "vocr_gemm", "vocr_gemm_pair", "vocr_gemm_x6", "vocr_gemm_h3", "vocr_gemm_x6_two_views", "vocr_gemm_h3_two_views", "vocr_lstm_fwd", "vocr_lstm_fwd_range", "vocr_lstm_bwd_bias",
                   "vocr_lstm_fwd_packed", "vocr_lstm_bwd_packed"]
 
     rank_dt = [0.0, 0.0]          # [min, max] over ranks of the last timed loop's wall time

@@ -318,6 +318,14 @@ int vocr_gemm_x6(const void* a_planes, int a_rows, int a_k, int a_row0, int a_kk
                  int m, int n, int k, float* c0, float* c1, int csplit, int rsplit, int ldc, const float* bias0, const float* bias1, int relu,
                  void* workspace, void* stream);
 
+/* Two products of one shape from ONE pair of plane sets in one launch: rows < rsplit (a multiple of 256) of the m x n result read the views
+ * (a_row0, a_kk0 | b_row0, b_kk0) and go to c0; rows >= rsplit read (a_row0 + rsplit .., a_kk0_2 | b_row0_2, b_kk0_2) and go to c1 at row - rsplit.
+ * The recurrent weight gradients of both directions - each a time-shifted k window of the gate gradients' and the layer outputs' transposed planes -
+ * with half the K-cut slabs of two launches. */
+int vocr_gemm_x6_two_views(const void* a_planes, int a_rows, int a_k, int a_row0, const void* b_planes, int b_rows, int b_k, int m, int n, int k,
+                           int rsplit, int a_kk0, int b_row0, int b_kk0, int a_kk0_2, int b_row0_2, int b_kk0_2, float* c0, float* c1, int ldc,
+                           void* workspace, void* stream);
+
 /* ---- the same products from TWO fp16 planes per operand and three partial products ("fp16x3") - OPT-IN, not what CnnOcrModel runs by default ---- */
 /* a s = h0 + h1 with h0 = fp16(a s), h1 = fp16(a s - h0), s = the power of two that brings the ROW's largest magnitude into [2^14, 2^15): 22 - 23 of
  * fp32's 24 significant bits per element (elements more than 2^17 below their row's maximum lose low bits to fp16's exponent range: absolute error
@@ -335,6 +343,9 @@ int vocr_gemm_h3_split(const float* x, const float* x2, int seg, int seg_axis, c
 int vocr_gemm_h3(const void* a_planes, int a_rows, int a_k, int a_row0, int a_kk0, const void* b_planes, int b_rows, int b_k, int b_row0, int b_kk0,
                  int m, int n, int k, float* c0, float* c1, int csplit, int rsplit, int ldc, const float* bias0, const float* bias1, int relu,
                  void* workspace, void* stream);
+int vocr_gemm_h3_two_views(const void* a_planes, int a_rows, int a_k, int a_row0, const void* b_planes, int b_rows, int b_k, int m, int n, int k,
+                           int rsplit, int a_kk0, int b_row0, int b_kk0, int a_kk0_2, int b_row0_2, int b_kk0_2, float* c0, float* c1, int ldc,
+                           void* workspace, void* stream);
 
 /* ---- the same recurrence without the padding: pack_padded_sequence's economy — src/models/cnnlstm.py:285-290 ---------- */
 /* The reference packs the length-sorted batch before nn.LSTM, so cuDNN never computes a padded frame.  Here the rows of every

@@ -124,6 +124,9 @@ def test_argument_validation_without_gpu():
     assert x6(256, 128, 40, one, None, 0, 0, 128, None, None, 0, None, None) == -1 and b"k % 16" in lib.vocr_last_error()
     assert x6(256, 128, 64, one, None, 64, 0, 128, None, None, 0, None, None) == -1               # a cut without a second output
     assert lib.vocr_gemm_x6(one, 256, 64, 0, 2, one, 128, 64, 0, 0, 256, 128, 64, one, None, 0, 0, 128, None, None, 0, None, None) == -1   # view leaves its planes
+    tv = lambda fn, *a: fn(one, 512, 64, 0, one, 128, 64, 512, 128, 64, *a)
+    assert tv(lib.vocr_gemm_x6_two_views, 100, 0, 0, 0, 0, 0, 0, one, one, 128, None, None) == -1 and b"256-row tile" in lib.vocr_last_error()
+    assert tv(lib.vocr_gemm_h3_two_views, 256, 0, 0, 0, 9, 0, 0, one, one, 128, None, None) == -1 and b"second view" in lib.vocr_last_error()
     # the opt-in fp16x3 split: two planes + the rows' maxima (fp32) behind them; the same validation in front of any launch
     assert lib.vocr_gemm_h3_planes_bytes(9408, 1024) == 2 * (37 * 8) * (32 * 2) * 1024 + 37 * 8 * 32 * 4 and lib.vocr_gemm_h3_planes_bytes(0, 8) == 0
     assert lib.vocr_gemm_h3_split(one, None, 8, 0, None, 64, 32, 64, 1, 0.0, one, None) == -1 and b"second piece" in lib.vocr_last_error()

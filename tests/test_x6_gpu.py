@@ -189,6 +189,11 @@ def test_two_piece_sources_mask_cuts_and_views(dev, scheme):
     ex1 = dg[1][:R - sh].double().T @ y[sh:, Hh:].double()
     assert float((dwh[0].double() - ex0).abs().max()) <= 3e-6 * float(ex0.abs().max())
     assert float((dwh[1].double() - ex1).abs().max()) <= 3e-6 * float(ex1.abs().max())
+    # the same two products as ONE launch with two view sets (rows >= G4 of the stacked result: the reverse direction's views)
+    dw2 = torch.full((2, G4, Hh), float("nan"), device=dev)
+    ops.gemm_x6_two_views(dgt, 2 * G4, R, yt, 2 * Hh, R, 2 * G4, Hh, R - sh, G4, (sh // 16, 0, 0), (0, Hh, sh // 16), dw2[0], dw2[1], Hh)
+    assert float((dw2[0].double() - ex0).abs().max()) <= 3e-6 * float(ex0.abs().max())
+    assert float((dw2[1].double() - ex1).abs().max()) <= 3e-6 * float(ex1.abs().max())
 
 
 _LAYER_CODE = r'''

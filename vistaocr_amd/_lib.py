@@ -67,6 +67,8 @@ SIGNATURES = {
     "vocr_gemm_x6_split": (I, [P, P, I, I, P, ctypes.c_long, I, I, I, P, P]),
     "vocr_gemm_x6_workspace_bytes": (Z, [I, I, I]),
     "vocr_gemm_x6": (I, [P, I, I, I, I, P, I, I, I, I, I, I, I, P, P, I, I, I, P, P, I, P, P]),
+    "vocr_gemm_x6_two_views": (I, [P, I, I, I, P, I, I, I, I, I, I, I, I, I, I, I, I, P, P, I, P, P]),
+    "vocr_gemm_h3_two_views": (I, [P, I, I, I, P, I, I, I, I, I, I, I, I, I, I, I, I, P, P, I, P, P]),
     "vocr_gemm_h3_planes_bytes": (Z, [I, I]),
     "vocr_gemm_h3_split": (I, [P, P, I, I, P, ctypes.c_long, I, I, I, ctypes.c_float, P, P]),
     "vocr_gemm_h3": (I, [P, I, I, I, I, P, I, I, I, I, I, I, I, P, P, I, I, I, P, P, I, P, P]),

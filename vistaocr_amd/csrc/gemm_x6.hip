@@ -238,6 +238,7 @@ struct X6Args {
     int M, N, nkk;           // rows, columns, k16 steps of the product
     int RTa, RTb, KKa, KKb;  // padded row tiles and k16 steps of the two plane sets (their strides)
     int a_rt0, a_kk0, b_rt0, b_kk0;      // where the product's operands start inside the plane sets (views: shifted rows / k windows)
+    int alt_mt, a_kk0_alt, b_rt0_alt, b_kk0_alt;     // row tiles >= alt_mt (256-row tiles) read these views instead: two products of one shape in one launch
     int csplit, rsplit, ldc;
     int mtiles, ntiles, tile0, ntile_launch, ksplit, stages_per_split;
     int relu;
@@ -286,6 +287,8 @@ __global__ __launch_bounds__(512) void gemm_x6_kernel(const X6Args g) {
     if (s_beg >= s_end) return;
 
     const long pa = (long)g.RTa * g.KKa * 1024, pb = (long)g.RTb * g.KKb * 1024;       // plane strides in bytes
+    const bool alt = mt >= g.alt_mt;
+    const int a_kk0 = alt ? g.a_kk0_alt : g.a_kk0, b_kk0 = alt ? g.b_kk0_alt : g.b_kk0, b_rt0 = alt ? g.b_rt0_alt : g.b_rt0;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)g.a, 0, (int)(NP * pa), 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)g.b, 0, (int)(NP * pb), 0x00020000);
     const int voff = lane * 16;
@@ -300,11 +303,11 @@ __global__ __launch_bounds__(512) void gemm_x6_kernel(const X6Args g) {
         s = s_beg;                                            // diagnostic: every stage re-reads the first one (L2 hits)
 #endif
         if (f < NA) {
-            const long off = (f >> 3) * pa + ((long)(g.a_rt0 + 8 * mt + (f & 7)) * g.KKa + g.a_kk0 + s) * 1024;
+            const long off = (f >> 3) * pa + ((long)(g.a_rt0 + 8 * mt + (f & 7)) * g.KKa + a_kk0 + s) * 1024;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, X6_LDS_PTR(dst), 16, live ? voff : -16, live ? (int)off : 0, 0, 0);
         } else {
             const int fb = f - NA;
-            const long off = (fb / NCT) * pb + ((long)(g.b_rt0 + NCT * nt + (fb % NCT)) * g.KKb + g.b_kk0 + s) * 1024;
+            const long off = (fb / NCT) * pb + ((long)(b_rt0 + NCT * nt + (fb % NCT)) * g.KKb + b_kk0 + s) * 1024;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, X6_LDS_PTR(dst), 16, live ? voff : -16, live ? (int)off : 0, 0, 0);
         }
     };
@@ -397,7 +400,7 @@ __global__ __launch_bounds__(512) void gemm_x6_kernel(const X6Args g) {
         const int cw = col >= g.csplit ? 1 : 0;
         const float bvc = (!slabbed && g.bias[cw]) ? g.bias[cw][col - cw * g.csplit] : 0.f;
         float ib = 1.f;
-        if constexpr (NP == 2) ib = h3_inv_scale(g.sb[32 * g.b_rt0 + col]);
+        if constexpr (NP == 2) ib = h3_inv_scale(g.sb[32 * b_rt0 + col]);
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -568,10 +571,11 @@ void x6_launch(X6Args g, const X6Plan& p, void* workspace, hipStream_t s) {
 // C[m][n] = A . B^T (+ bias)(relu) from split planes.  A: rows a_row0 .. + m and k16 steps a_kk0 .. + k/16 of a plane set written for
 // (a_rows, a_k); B likewise (rows = output columns).  Two outputs: columns >= csplit go to c1 at col - csplit, or rows >= rsplit to c1 at
 // row - rsplit (0: no cut); a_row0 / b_row0 multiples of 32, k a multiple of 16.
+struct X6AltViews { int a_kk0, b_row0, b_kk0; };          // the views of the rows >= rsplit of a two-view product
 template <int NP>
 static int x6_gemm_impl(const char* name, const void* a_planes, int a_rows, int a_k, int a_row0, int a_kk0, const void* b_planes, int b_rows, int b_k,
                         int b_row0, int b_kk0, int m, int n, int k, float* c0, float* c1, int csplit, int rsplit, int ldc, const float* bias0,
-                        const float* bias1, int relu, void* workspace, void* stream) {
+                        const float* bias1, int relu, void* workspace, void* stream, const X6AltViews* alt = nullptr) {
     VOCR_CHECK_ARG(a_planes && b_planes && c0, "%s: null pointer", name);
     VOCR_CHECK_ARG(m > 0 && n > 0 && k > 0 && ldc > 0 && k % 16 == 0, "%s: bad shape (k %% 16 == 0)", name);
     VOCR_CHECK_ARG(a_row0 % 32 == 0 && b_row0 % 32 == 0 && a_row0 >= 0 && b_row0 >= 0 && a_kk0 >= 0 && b_kk0 >= 0, "%s: views start on tile boundaries", name);
@@ -584,6 +588,12 @@ static int x6_gemm_impl(const char* name, const void* a_planes, int a_rows, int 
     g.M = m; g.N = n; g.nkk = k / 16;
     g.RTa = x6_rt(a_rows); g.KKa = x6_kk(a_k); g.RTb = x6_rt(b_rows); g.KKb = x6_kk(b_k);
     g.a_rt0 = a_row0 / 32; g.a_kk0 = a_kk0; g.b_rt0 = b_row0 / 32; g.b_kk0 = b_kk0;
+    g.alt_mt = 1 << 30; g.a_kk0_alt = a_kk0; g.b_rt0_alt = g.b_rt0; g.b_kk0_alt = b_kk0;
+    if (alt) {
+        VOCR_CHECK_ARG(rsplit > 0 && rsplit % X6_BM == 0 && alt->b_row0 % 32 == 0 && alt->b_row0 >= 0 && alt->a_kk0 >= 0 && alt->b_kk0 >= 0,
+                       "%s: a second view set needs a row cut on a 256-row tile boundary and views on tile boundaries", name);
+        g.alt_mt = rsplit / X6_BM; g.a_kk0_alt = alt->a_kk0; g.b_rt0_alt = alt->b_row0 / 32; g.b_kk0_alt = alt->b_kk0;
+    }
     g.mtiles = vocr_cdiv(m, X6_BM);
     g.csplit = csplit > 0 ? csplit : (1 << 30);
     g.rsplit = rsplit > 0 ? rsplit : (1 << 30);
@@ -595,11 +605,13 @@ static int x6_gemm_impl(const char* name, const void* a_planes, int a_rows, int 
     const int ncu = x6_cu_count();
     const X6Plan p4 = x6_plan(4, m, n, g.nkk, ncu, workspace != nullptr), p8 = x6_plan(8, m, n, g.nkk, ncu, workspace != nullptr);
     // the wide tile reads whole blocks of 8 column tiles: they must exist in B's plane set (rows padded to 256: always, unless a view starts late)
-    const bool wide_ok = g.b_rt0 + 8 * p8.ntiles <= g.RTb;
+    const bool wide_ok = g.b_rt0 + 8 * p8.ntiles <= g.RTb && g.b_rt0_alt + 8 * p8.ntiles <= g.RTb;
     const X6Plan& p = (wide_ok && p8.cost < p4.cost) ? p8 : p4;
     // a tile reads whole 256-row / (32 NCT)-column blocks of fragments: they must exist in the plane sets (zero padding or later rows)
     VOCR_CHECK_ARG(g.a_rt0 + 8 * g.mtiles <= g.RTa && g.b_rt0 + p.nct * p.ntiles <= g.RTb && g.a_kk0 + g.nkk <= g.KKa && g.b_kk0 + g.nkk <= g.KKb,
                    "%s: the view leaves its plane set", name);
+    VOCR_CHECK_ARG(g.b_rt0_alt + p.nct * p.ntiles <= g.RTb && g.a_kk0_alt + g.nkk <= g.KKa && g.b_kk0_alt + g.nkk <= g.KKb,
+                   "%s: the second view leaves its plane set", name);
     static bool lds_ok = false;
     if (!lds_ok) {
         if (hipFuncSetAttribute((const void*)gemm_x6_kernel<4, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS) != hipSuccess ||
@@ -627,4 +639,22 @@ extern "C" int vocr_gemm_h3(const void* a_planes, int a_rows, int a_k, int a_row
                             const float* bias1, int relu, void* workspace, void* stream) {
     return x6_gemm_impl<2>("vocr_gemm_h3", a_planes, a_rows, a_k, a_row0, a_kk0, b_planes, b_rows, b_k, b_row0, b_kk0, m, n, k, c0, c1, csplit, rsplit, ldc,
                            bias0, bias1, relu, workspace, stream);
+}
+
+// Two products of one shape from ONE pair of plane sets in one launch: rows < rsplit (a multiple of 256) of C = A[a_row0 ..][a_kk0 ..] . B[b_row0 ..][b_kk0 ..]^T
+// go to c0, rows >= rsplit read the views (a_kk0_2, b_row0_2, b_kk0_2) and go to c1 at row - rsplit: the recurrent weight gradients of both directions
+// (each a time-shifted k window of the gate gradients' and the outputs' transposed planes) - half the K-cut slabs of two launches.
+extern "C" int vocr_gemm_x6_two_views(const void* a_planes, int a_rows, int a_k, int a_row0, const void* b_planes, int b_rows, int b_k, int m, int n, int k,
+                                      int rsplit, int a_kk0, int b_row0, int b_kk0, int a_kk0_2, int b_row0_2, int b_kk0_2, float* c0, float* c1, int ldc,
+                                      void* workspace, void* stream) {
+    const X6AltViews alt = {a_kk0_2, b_row0_2, b_kk0_2};
+    return x6_gemm_impl<3>("vocr_gemm_x6_two_views", a_planes, a_rows, a_k, a_row0, a_kk0, b_planes, b_rows, b_k, b_row0, b_kk0, m, n, k, c0, c1, 0, rsplit, ldc,
+                           nullptr, nullptr, 0, workspace, stream, &alt);
+}
+extern "C" int vocr_gemm_h3_two_views(const void* a_planes, int a_rows, int a_k, int a_row0, const void* b_planes, int b_rows, int b_k, int m, int n, int k,
+                                      int rsplit, int a_kk0, int b_row0, int b_kk0, int a_kk0_2, int b_row0_2, int b_kk0_2, float* c0, float* c1, int ldc,
+                                      void* workspace, void* stream) {
+    const X6AltViews alt = {a_kk0_2, b_row0_2, b_kk0_2};
+    return x6_gemm_impl<2>("vocr_gemm_h3_two_views", a_planes, a_rows, a_k, a_row0, a_kk0, b_planes, b_rows, b_k, b_row0, b_kk0, m, n, k, c0, c1, 0, rsplit, ldc,
+                           nullptr, nullptr, 0, workspace, stream, &alt);
 }

@@ -693,6 +693,7 @@ def gemm_pair(mode, ta, tb, m, n, k, a0, a1, lda, b0, b1, ldb, c0, c1, ldc, bias
 
 # ---- fp32 GEMM on the 16-bit matrix pipe by operand splitting (include/vocr.h: vocr_gemm_x6* / vocr_gemm_h3*): the LSTM projections and their gradients
 _GEMM_X6 = _exp("VOCR_GEMM_X6", "1") == "1"
+_X6_TWO_VIEWS = _exp("VOCR_X6_TWO_VIEWS", "1") == "1"          # the recurrent weight gradients of both directions as one launch
 # which split the large LSTM products use: "bf16x6" (default: three bf16 planes that sum to the operand EXACTLY, six products), "fp16x3" (opt-in: two fp16
 # planes with per-row power-of-two scales, three products - half the matrix instructions, a norm-wise instead of a per-product error bound), "f32" (the
 # f32-MFMA kernels).  VOCR_LSTM_GEMM in the environment or set_lstm_gemm() before the first forward pass.
@@ -700,8 +701,8 @@ LSTM_GEMM_MODES = ("bf16x6", "fp16x3", "f32")
 _LSTM_GEMM = _os.environ.get("VOCR_LSTM_GEMM", "bf16x6")
 if _LSTM_GEMM not in LSTM_GEMM_MODES:
     raise ValueError("VOCR_LSTM_GEMM=%r: one of %s" % (_LSTM_GEMM, ", ".join(LSTM_GEMM_MODES)))
-_X6_ENTRY = {"bf16x6": ("vocr_gemm_x6_planes_bytes", "vocr_gemm_x6_split", "vocr_gemm_x6"),
-             "fp16x3": ("vocr_gemm_h3_planes_bytes", "vocr_gemm_h3_split", "vocr_gemm_h3")}
+_X6_ENTRY = {"bf16x6": ("vocr_gemm_x6_planes_bytes", "vocr_gemm_x6_split", "vocr_gemm_x6", "vocr_gemm_x6_two_views"),
+             "fp16x3": ("vocr_gemm_h3_planes_bytes", "vocr_gemm_h3_split", "vocr_gemm_h3", "vocr_gemm_h3_two_views")}
 
 
 def set_lstm_gemm(mode):
@@ -727,7 +728,7 @@ def x6_planes(x, rows, k, k_contiguous, ld, x2=None, seg=0, axis=0, mask=None, s
     """The 16-bit planes of an fp32 operand in MFMA-fragment order (one pass over x; fp16x3: one more for the rows' maxima unless the caller
     knows a `bound` of every |element| after the mask - an LSTM output lies inside (-1, 1))."""
     scheme = scheme or lstm_gemm()
-    nbytes, split, _ = _X6_ENTRY[scheme]
+    nbytes, split = _X6_ENTRY[scheme][:2]
     lib = _lib.load()
     buf = torch.empty(getattr(lib, nbytes)(int(rows), int(k)) // 2, dtype=torch.int16, device=x.device)
     if scheme == "fp16x3":
@@ -747,6 +748,17 @@ def gemm_x6(a, a_rows, a_k, b, b_rows, b_k, m, n, k, c0, ldc, c1=None, csplit=0,
     ws = _ws(_lib.load().vocr_gemm_x6_workspace_bytes(m, n, k), c0.device)
     call(_X6_ENTRY[scheme][2], _p(a), int(a_rows), int(a_k), int(a_row0), int(a_kk0), _p(b), int(b_rows), int(b_k), int(b_row0), int(b_kk0), int(m), int(n),
          int(k), _p(c0), _p(c1), int(csplit), int(rsplit), int(ldc), _p(bias0), _p(bias1), int(relu), _p(ws), _stream())
+
+
+def gemm_x6_two_views(a, a_rows, a_k, b, b_rows, b_k, m, n, k, rsplit, views0, views1, c0, c1, ldc, a_row0=0):
+    """Two products of one shape in one launch (include/vocr.h: vocr_gemm_x6_two_views): rows < rsplit with views0 = (a_kk0, b_row0, b_kk0) into c0,
+    rows >= rsplit with views1 into c1."""
+    scheme = getattr(a, "x6_scheme", None)
+    if scheme is None or scheme != getattr(b, "x6_scheme", None):
+        raise RuntimeError("gemm_x6_two_views: operands from different splits (%r, %r)" % (scheme, getattr(b, "x6_scheme", None)))
+    ws = _ws(_lib.load().vocr_gemm_x6_workspace_bytes(m, n, k), c0.device)
+    call(_X6_ENTRY[scheme][3], _p(a), int(a_rows), int(a_k), int(a_row0), _p(b), int(b_rows), int(b_k), int(m), int(n), int(k), int(rsplit),
+         int(views0[0]), int(views0[1]), int(views0[2]), int(views1[0]), int(views1[1]), int(views1[2]), _p(c0), _p(c1), int(ldc), _p(ws), _stream())
 
 
 def colsum(x2d, out=None):
@@ -1122,8 +1134,12 @@ class BiLstmLayerFn(torch.autograd.Function):
                 if T > 1 and sh % 16 == 0 and (R - sh) % 16 == 0:
                     # the recurrent product's time shift (sh rows = sh / 16 k16 steps) is a k window of the same planes and of the output's transpose
                     yt = x6_planes(y, 2 * H, R, False, 2 * H, bound=1.0)       # |h| = |o tanh(c)| <= 1
-                    gemm_x6(dgt, 2 * G, R, yt, 2 * H, R, G, H, R - sh, dwh_f, H, a_row0=0, a_kk0=sh // 16, b_row0=0, b_kk0=0)
-                    gemm_x6(dgt, 2 * G, R, yt, 2 * H, R, G, H, R - sh, dwh_r, H, a_row0=G, a_kk0=0, b_row0=H, b_kk0=sh // 16)
+                    if G % 256 == 0 and _X6_TWO_VIEWS:
+                        # both directions in one launch: forward rows = dg_f[sh:]^T . y[:-sh, :H], reverse rows = dg_r[:-sh]^T . y[sh:, H:]
+                        gemm_x6_two_views(dgt, 2 * G, R, yt, 2 * H, R, 2 * G, H, R - sh, G, (sh // 16, 0, 0), (0, H, sh // 16), dwh_f, dwh_r, H)
+                    else:
+                        gemm_x6(dgt, 2 * G, R, yt, 2 * H, R, G, H, R - sh, dwh_f, H, a_row0=0, a_kk0=sh // 16, b_row0=0, b_kk0=0)
+                        gemm_x6(dgt, 2 * G, R, yt, 2 * H, R, G, H, R - sh, dwh_r, H, a_row0=G, a_kk0=0, b_row0=H, b_kk0=sh // 16)
                 elif T > 1:
                     gemm_pair(co, 1, 0, G, H, R - sh, dg[0][sh:], dg[1], G, y, y[sh:, H:], 2 * H, dwh_f, dwh_r, H)
                 else:
