@@ -7,7 +7,7 @@ from vistaocr_amd import ops, _lib
 from vistaocr_amd._lib import call
 dev = torch.device("cuda:0"); lib = _lib.load()
 SCH = os.environ.get("X6_SCHEME", "bf16x6")            # or fp16x3: the opt-in split (vocr_gemm_h3*)
-NB, SPLIT, GEMM = ops._X6_ENTRY[SCH]
+NB, SPLIT, GEMM = ops._X6_ENTRY[SCH][:3]
 print("split:", SCH)
 s = torch.cuda.current_stream().cuda_stream
 P = lambda t: t.data_ptr() if t is not None else None

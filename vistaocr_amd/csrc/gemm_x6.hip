@@ -540,7 +540,7 @@ X6Plan x6_plan(int nct, int m, int n, int nkk, int ncu, bool can_cut) {
     p.ks = 1;
     if (p.rem > 0 && p.rem * 2 <= ncu && nkk >= 32 && can_cut) {
         p.ks = ncu / p.rem;
-        if (p.ks > 8) p.ks = 8;
+        if (p.ks > 16) p.ks = 16;
         if (p.ks > nkk / 8) p.ks = nkk / 8;
         if (p.ks < 1) p.ks = 1;
     }
