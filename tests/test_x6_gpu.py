@@ -117,7 +117,8 @@ def test_fp16x3_split_with_a_callers_bound(dev, kc):
 
 @pytest.mark.parametrize("scheme", SCHEMES)
 @pytest.mark.parametrize("m,n,k,kc_a,kc_b", [(300, 200, 80, True, True), (1000, 384, 1024, True, False), (2048, 1024, 2000, False, False),
-                                             (9408, 1024, 512, True, True), (520, 4096, 256, True, True), (4096, 512, 4704, False, False)])
+                                             (9408, 1024, 512, True, True), (520, 4096, 256, True, True), (4096, 512, 4704, False, False),
+                                             (1024, 128, 4704, False, False)])          # the last one: four tiles, K cut sixteen ways
 def test_products_against_fp64(dev, m, n, k, kc_a, kc_b, scheme):
     from vistaocr_amd import ops
     g = torch.Generator().manual_seed(m + n + k)
