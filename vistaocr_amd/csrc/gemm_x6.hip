@@ -11,10 +11,13 @@
 // conflict-free ds_read_b128 per lane.  Rows are padded to 256, K to 32 (zeros).  The source may be K-contiguous ([row][k], vocr_gemm_x6_split_rk) or
 // K-strided ([k][row], _split_kr: the transposed operands of the weight gradients); the product kernel is the same for every transpose form.
 //
-// gemm_x6_kernel: workgroup tile 256 x 128, eight waves as 4 (rows) x 2 (columns) with 64 x 64 wave tiles (4 accumulator tiles, 64 VGPRs),
-// stages of one k16 step (36 fragments of 1 KB: five or four DMA instructions per wave), a ring of four LDS slots: the DMAs of stage s + 3 are
-// issued one at a time between the MFMA groups of stage s (24 MFMAs per wave = 1536 matrix-pipe cycles per SIMD), one barrier per stage.  Long-K products with few tiles are cut along K into
-// slabs that gemm_x6_reduce_kernel adds in a fixed order.
+// gemm_x6_kernel<NCT, NP>: workgroup tile 256 x 32 NCT - 256 x 128 (eight waves as 4 x 2, 64 x 64 wave tiles) or 256 x 256 (2 x 4 waves, 128 x 64 wave tiles,
+// 128 accumulator registers) -, stages of one k16 step of all planes (NP (8 + NCT) fragments of 1 KB, moved by LDS-DMA, NFRAG / 8 instructions per wave), a
+// ring of 144 KB / stage slots: the DMAs of stage s + NS - 1 are issued one at a time between the MFMA groups of stage s, one barrier per stage.  Whole rounds
+// of one workgroup per CU run the full K; what is left of the last round is cut along K into slabs that gemm_x6_reduce_kernel adds in a fixed order.  Tiles are
+// dealt to the XCDs in contiguous ranges of 4 x 8-tile blocks (x6_tile_of / x6_xcd_chunked).  A launch may carry a second set of views for the rows past a
+// cut (two products of one shape: the recurrent weight gradients of both directions).  The kernel is bound by the board's power limit.
+// NP = 3 is bf16x6 as above; NP = 2 is the opt-in fp16x3 split further down (two fp16 planes with per-row scales, three products).
 #include "vocr_common.h"
 
 namespace {
